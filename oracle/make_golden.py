@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE (/root/reference/mtn.py) on CPU.
+
+Runs only in the build container (the reference never travels to the GPU box).  The
+reference is imported, never copied: two shims are needed —
+  * ``torchtext`` is absent and only used by dead code  -> stub modules;
+  * ``Batch.__init__`` hard-codes ``.cuda()``             -> build the batch as a namespace
+    with the same fields using the reference's own static ``Batch.make_std_mask`` and the
+    feature-mask expression of data_utils.py:29.
+Weights and inputs come from oracle/fixtures.py (deterministic formulas); only reference
+OUTPUTS are stored.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+"""
+import os
+import sys
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle.fixtures import GOLDEN_CONFIGS, PAD, UNK, SOS, EOS, det_batch, det_state_dict  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference():
+    tt = types.ModuleType("torchtext")
+    tt_data = types.ModuleType("torchtext.data")
+    tt_ds = types.ModuleType("torchtext.datasets")
+
+    class Iterator:  # placeholder base class for the unused MyIterator
+        pass
+
+    tt_data.Iterator = Iterator
+    tt_data.batch = lambda *a, **k: None
+    tt.data, tt.datasets = tt_data, tt_ds
+    sys.modules.update({"torchtext": tt, "torchtext.data": tt_data, "torchtext.datasets": tt_ds})
+    sys.path.insert(0, REF)
+    import mtn as ref_mtn                # noqa
+    import data_utils as ref_du          # noqa
+    import label_smoothing as ref_ls     # noqa
+    return ref_mtn, ref_du, ref_ls
+
+
+def ref_batch(ref_du, raw):
+    b = types.SimpleNamespace()
+    t = lambda a: torch.from_numpy(a)
+    b.query, b.his, b.cap, b.trg, b.trg_y = t(raw["query"]), t(raw["his"]), t(raw["cap"]), t(raw["trg"]), t(raw["trg_y"])
+    fts = [t(f) for f in raw["fts"]]                     # already (B,V,F): the permute of data_utils.py:28 done
+    b.fts_mask = [(torch.sum(f != 1, dim=2) != 0).unsqueeze(-2) for f in fts]
+    b.fts = [f * b.fts_mask[i].squeeze().unsqueeze(-1).expand_as(f).float() for i, f in enumerate(fts)]
+    b.query_mask = (b.query != PAD).unsqueeze(-2)
+    b.his_mask = (b.his != PAD).unsqueeze(-2)
+    b.cap_mask = (b.cap != PAD).unsqueeze(-2)
+    b.trg_mask = ref_du.Batch.make_std_mask(b.trg, PAD)
+    b.ntokens = (b.trg_y != PAD).data.sum()
+    b.his_st = None
+    return b
+
+
+def build_ref_model(ref_mtn, c, seed=0):
+    m = ref_mtn.make_model(c["vocab"], c["vocab"], N=c["N"], d_model=c["d_model"], d_ff=c["d_ff"], h=c["h"],
+                           dropout=0.0, ft_sizes=c["ft_sizes"], diff_encoder=c["diff_encoder"],
+                           diff_embed=c["diff_embed"], diff_gen=c["diff_gen"], auto_encoder_ft=c["auto_encoder_ft"])
+    sd = m.state_dict()
+    new = det_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed)
+    for k in sd:
+        if k not in new:
+            new[k] = sd[k]
+    m.load_state_dict(new)
+    return m
+
+
+def run_config(name, c, ref_mtn, ref_du, ref_ls):
+    out = {}
+    torch.manual_seed(0)
+    m = build_ref_model(ref_mtn, c)
+    m.eval()
+    raw = det_batch(c["vocab"], c["B"], c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=1)
+    b = ref_batch(ref_du, raw)
+
+    # -- encode outputs
+    q, v, cp, hs, ae = m.encode(b.query, b.query_mask, b.his, b.his_mask, b.cap, b.cap_mask, b.fts, b.fts_mask)
+    out["enc.q"], out["enc.cap"], out["enc.his"] = q, cp, hs
+    for i, x in enumerate(v):
+        out[f"enc.vid.{i}"] = x
+    if ae is not None:
+        for i, x in enumerate(ae):
+            out[f"enc.ae.{i}"] = x
+
+    # -- per-sublayer outputs of decoder layer 0 (forward hooks on SublayerConnection)
+    hooks = []
+    for k, sl in enumerate(m.decoder.layers[0].sublayer):
+        hooks.append(sl.register_forward_hook(lambda mod, inp, o, k=k: out.__setitem__(f"layer0.sublayer.{k}", o.detach().clone())))
+    y, ae_out = m.forward(b)
+    for h in hooks:
+        h.remove()
+    out["out"] = y
+    for i, x in enumerate(ae_out):
+        out[f"ae_out.{i}"] = x
+    out["logp"] = m.generator(y)
+
+    # -- loss + grads (SimpleLossCompute without optimiser, then .backward() by hand)
+    crit = ref_ls.LabelSmoothing(size=c["vocab"], padding_idx=PAD, smoothing=0.1)
+    ae_y = b.cap if c["auto_encoder_ft"] in ("caption", "summary") else b.query
+    ae_norm = (ae_y != PAD).data.sum()
+    m.zero_grad()
+    y, ae_out = m.forward(b)
+    gen = m.generator
+    loss = crit(gen(y).contiguous().view(-1, c["vocab"]), b.trg_y.contiguous().view(-1)) / b.ntokens.float()
+    for i, a in enumerate(ae_out):
+        g = m.auto_encoder_generator[i] if m.auto_encoder_generator is not None else gen
+        loss = loss + 1.0 * crit(g(a).contiguous().view(-1, c["vocab"]), ae_y.contiguous().view(-1)) / ae_norm.float()
+    out["loss"] = loss.detach()
+    loss.backward()
+    gnames, gnorms = [], []
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        gnames.append(k)
+        gnorms.append(float(p.grad.double().norm()))
+        if p.grad.numel() <= 4096:
+            out["grad." + k] = p.grad.detach().clone()
+        else:
+            out["gradhead." + k] = p.grad.detach().reshape(-1)[:256].clone()
+    out["grad_names"] = np.array(gnames)
+    out["grad_norms"] = np.array(gnorms, dtype=np.float64)
+
+    # -- two optimiser steps exactly as train.py:190 + data_utils.py:123-156.  Kept in eval(): make_model
+    #    builds MultiHeadedAttention(h, d_model) WITHOUT forwarding its dropout argument (mtn.py:339 vs :234),
+    #    so attention-probability dropout is p=0.1 in train() whatever --dropout says, and is not reproducible.
+    m.eval()
+    m.zero_grad()
+    opt = ref_du.NoamOpt(c["d_model"], 1, 10, torch.optim.Adam(m.parameters(), lr=0, betas=(0.9, 0.98), eps=1e-9))
+    lc = ref_du.SimpleLossCompute(m.generator, m.auto_encoder_generator, crit, opt=opt, l=1.0)
+    step_losses = []
+    for _ in range(2):
+        y, ae_out = m.forward(b)
+        step_losses.append(float(lc(y, b.trg_y, b.ntokens, ae_out, ae_y, ae_norm)))
+    out["step_losses"] = np.array(step_losses, dtype=np.float64)
+    sd = m.state_dict()
+    for k in ["decoder.layers.0.self_attn.linears.0.bias", "decoder.layers.0.sublayer.0.norm.a_2",
+              "decoder.norm.b_2", "generator.proj.bias", "decoder.layers.0.feed_forward.w_2.bias"]:
+        out["after2." + k] = sd[k].detach().clone()
+    out["after2head.decoder.layers.0.his_attn.linears.1.weight"] = sd["decoder.layers.0.his_attn.linears.1.weight"].reshape(-1)[:256].clone()
+    out["after2head.query_embed.0.lut.weight"] = sd["query_embed.0.lut.weight"].reshape(-1)[:256].clone()
+
+    # -- beam search (data_utils.py:188) on the first dialogue, reference defaults beam=5,penalty=1,nbest=5
+    m = build_ref_model(ref_mtn, c)
+    m.eval()
+    raw1 = det_batch(c["vocab"], 1, c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=2, ragged=False)
+    b1 = ref_batch(ref_du, raw1)
+    with torch.no_grad():
+        nbest, best = ref_du.beam_search_decode(m, b1, 8, SOS, UNK, EOS, PAD)
+    out["beam.n"] = np.array(len(nbest))
+    for i, (toks, score) in enumerate(nbest):
+        out[f"beam.tokens.{i}"] = np.array([int(t) for t in toks], dtype=np.int64)
+        out[f"beam.score.{i}"] = np.array(float(score), dtype=np.float64)
+    out["beam.best"] = np.array(float(best), dtype=np.float64)
+
+    npz = {}
+    for k, v in out.items():
+        npz[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **npz)
+    print(f"{name}: {len(npz)} arrays, loss={float(out['loss']):.6f}, {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def main():
+    ref_mtn, ref_du, ref_ls = import_reference()
+    torch.set_num_threads(8)
+    for name, c in GOLDEN_CONFIGS.items():
+        run_config(name, c, ref_mtn, ref_du, ref_ls)
+
+
+if __name__ == "__main__":
+    main()
