@@ -1,0 +1,225 @@
+/*
+ * mtn_hip.h — C ABI of libmtn_hip.so: MI355X (gfx950) kernels for the MTN transformer hot path.
+ *
+ * The reference (henryhungle/MTN) has no FFI: its operator boundary is the Python nn.Module call
+ * surface in mtn.py.  Each entry point below replaces the op sequence of one reference operator
+ * (file:line cited per function) and is what a ctypes binding in the reference would call
+ * (INTEGRATION.md shows the stub).  Conventions:
+ *   - extern "C", plain pointers and sizes, no exceptions cross the boundary;
+ *   - every function returns 0 on success, nonzero on error; mtn_last_error() gives the text;
+ *   - all tensors are BORROWED device pointers, row-major, innermost dimension contiguous;
+ *     the caller allocates outputs / saved-for-backward buffers and owns their lifetime;
+ *   - kernels are enqueued on the hipStream_t passed in (void*), never synchronise, keep no
+ *     global mutable state: re-entrant per stream, capturable into a hipGraph;
+ *   - "lowp" buffers hold the compute element type selected by `dtype`:
+ *       MTN_F32  : float   (exact-fp32 MFMA path, parity mode)
+ *       MTN_BF16 : bfloat16 (fp32 accumulate; throughput mode)
+ *     residual streams, LayerNorm / softmax statistics, biases, LN gains and all gradients of
+ *     parameters are always float.
+ */
+#ifndef MTN_HIP_H
+#define MTN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTN_F32 0
+#define MTN_BF16 1
+
+#define MTN_OK 0
+#define MTN_ERR_ARG 1
+#define MTN_ERR_LAUNCH 2
+
+/* Library / error reporting. */
+const char* mtn_last_error(void);
+int mtn_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dropout stream: keep-mask bit for element `idx` of site `salt` is a pure function of
+ * (*seed, salt, idx), so backward regenerates it.  `seed` is a DEVICE pointer (a replayed
+ * hipGraph sees a fresh value each step).  p == 0 or seed == NULL disables dropout.
+ * (reference: nn.Dropout at mtn.py:123,230,246,277)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float p;
+    uint32_t salt;
+    const uint64_t* seed;
+} mtn_dropout;
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM (building block of every Linear on the path: mtn.py:243-244,256-258,267,273-280).
+ *   C[i][j] = epilogue( sum_k opA(i,k) * opB(j,k) )          i<M, j<N, k<K
+ *   a_trans == 0 : opA(i,k) = A[i*lda + k]      a_trans == 1 : opA(i,k) = A[k*lda + i]
+ *   b_trans == 0 : opB(j,k) = B[j*ldb + k]      b_trans == 1 : opB(j,k) = B[k*ldb + j]
+ *   epilogue(v) : v += bias[j]; relu; dropout; gate (v = gate[i][j] > 0 ? v*gate_scale : 0);
+ *                 v += residual[i*ldr + j]; then stored to out_f32 and/or out_lp (row stride ldc).
+ *   rowsum_out (optional): rowsum_out[i] = sum_k opA(i,k)   (bias gradients ride on the dW GEMM).
+ * Forward Linear: y = x W^T  -> A=x, B=W (both non-trans).  dX = dY W -> A=dY, B=W with b_trans.
+ * dW = dY^T X -> A=dY with a_trans, B=X with b_trans.
+ * Constraints: A,B are lowp of `dtype`; K, lda, ldb multiples of 8; 16-byte aligned bases.
+ * Up to MTN_GEMM_MAX_GROUP independent problems are executed by ONE launch.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* A;
+    const void* B;
+    int lda, ldb;
+    int M, N, K;
+    int a_trans, b_trans;
+    const float* bias;
+    int relu;
+    mtn_dropout drop;
+    const void* gate; /* lowp [M,N], row stride ldc */
+    float gate_scale;
+    const float* residual;
+    int ldr;
+    float* out_f32;
+    void* out_lp;
+    int ldc;
+    float* rowsum_out;
+} mtn_gemm_problem;
+
+#define MTN_GEMM_MAX_GROUP 8
+int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems /* host array */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm, MTN variant (mtn.py:103-114): y = a2 * (x-mean) / (std_unbiased + eps) + b2.
+ * fwd: x [rows,d] float.  Optional outputs: y_f32, y_lp (lowp), mean[rows], rstd[rows]
+ *      with rstd = 1/(std+eps).
+ * bwd: g = dL/dy [rows,d] float; dres (optional) = gradient arriving on the residual branch,
+ *      added to dx.  dx [rows,d] float (may alias dres).  da2/db2 [d] float are WRITTEN
+ *      (not accumulated); `partial` is caller scratch of mtn_layernorm_bwd_partial_floats().
+ * ------------------------------------------------------------------------------------------ */
+int mtn_layernorm_fwd(int dtype, int rows, int d, float eps, const float* x, const float* a2, const float* b2,
+                      float* y_f32, void* y_lp, float* mean, float* rstd, void* stream);
+long mtn_layernorm_bwd_partial_floats(int rows, int d);
+int mtn_layernorm_bwd(int rows, int d, float eps, const float* x, const float* a2, const float* mean,
+                      const float* rstd, const float* g, const float* dres, float* dx, float* da2, float* db2,
+                      float* partial, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scaled-dot-product attention core (mtn.py:221-231) for all heads of all batch rows.
+ *   q  : lowp, element (b,i,h,c) at q[(b*a+i)*ldq + h*dk + c]      i<a
+ *   k,v: lowp, element (b,j,h,c) at k[(b*m+j)*ldkv + h*dk + c]     j<m
+ *   mask: uint8, element (b,i,j) at mask[b*mask_sb + i*mask_sq + j]; 0 => score := -1e9
+ *         (mask_sq == 0 broadcasts over query rows; mask == NULL => nothing masked)
+ *   o  : lowp [(b*a+i)*ldo + h*dk + c];  lse: float [(b*h + hh)*a + i] = max + log(sum exp)
+ * bwd: d_o lowp (same layout as o) -> dq (ldq layout), dk/dv (ldkv layout), all lowp.
+ *      Gradient does not flow through masked scores (masked_fill).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, h, a, m, dk;
+    const void *q, *k, *v;
+    int ldq, ldkv;
+    const uint8_t* mask;
+    long mask_sb, mask_sq;
+    mtn_dropout drop;
+    void* o;
+    int ldo;
+    float* lse;
+    /* backward only */
+    const void* d_o;
+    void *dq, *dk_out, *dv_out;
+} mtn_attn_args;
+int mtn_attention_fwd(int dtype, const mtn_attn_args* args, void* stream);
+int mtn_attention_bwd(int dtype, const mtn_attn_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused sublayers: SublayerConnection.forward (mtn.py:125-127) around MultiHeadedAttention
+ * (mtn.py:248-267) or PositionwiseFeedForward (mtn.py:279-280):
+ *     y = x + dropout( f( LayerNorm(x) ) )
+ * Weight layout: w_qkv is the three input Linears stacked [3d,d] (q,k,v order = linears[0..2]),
+ * b_qkv [3d]; w_o/b_o = linears[3].  Self-attention (kv source = LayerNorm(x)) runs one packed
+ * QKV projection; cross-attention projects q from LayerNorm(x) and k,v from `mem` [B,m,d] lowp.
+ * Saved-for-backward buffers are caller-allocated (sizes in comments).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, a, m, d, h;
+    int self_attn;
+    float ln_eps;
+    mtn_dropout drop_attn; /* on softmax probabilities (mtn.py:230) */
+    mtn_dropout drop_out;  /* on the sublayer output (mtn.py:127)   */
+    const float* x;        /* [B,a,d] */
+    const void* mem;       /* lowp [B,m,d]; unused when self_attn */
+    const uint8_t* mask;
+    long mask_sb, mask_sq;
+    const float *ln_a, *ln_b;
+    const void* w_qkv; /* lowp [3d,d] */
+    const float* b_qkv;
+    const void* w_o; /* lowp [d,d] */
+    const float* b_o;
+    float* y;    /* [B,a,d] */
+    void* xn;    /* lowp [B*a,d]  saved */
+    float* mean; /* [B*a]         saved */
+    float* rstd; /* [B*a]         saved */
+    void* qkv;   /* lowp: self [B*a,3d]; cross [B*a,d] (q only)   saved */
+    void* kv;    /* lowp cross only [B*m,2d]                      saved */
+    void* o;     /* lowp [B*a,d]  saved */
+    float* lse;  /* [B*h*a]       saved */
+    /* ---- backward (mtn_mha_sublayer_bwd) ---- */
+    const float* dy; /* [B,a,d] */
+    float* dx;       /* [B,a,d] written */
+    float* dmem;     /* [B,m,d] float gradient of mem (cross only; NULL = not needed) */
+    int dmem_accumulate; /* 0: dmem is written; 1: dmem += (memory shared by several sublayers) */
+    float *d_ln_a, *d_ln_b;                   /* [d] written */
+    float *d_w_qkv, *d_b_qkv, *d_w_o, *d_b_o; /* written */
+    void* ws_lp;   /* lowp scratch: mtn_mha_bwd_ws_lp_elems() elements */
+    float* ws_f32; /* float scratch: mtn_mha_bwd_ws_f32_floats() */
+} mtn_mha_args;
+int mtn_mha_sublayer_fwd(int dtype, const mtn_mha_args* args, void* stream);
+int mtn_mha_sublayer_bwd(int dtype, const mtn_mha_args* args, void* stream);
+long mtn_mha_bwd_ws_lp_elems(int B, int a, int m, int d, int self_attn);
+long mtn_mha_bwd_ws_f32_floats(int B, int a, int m, int d);
+
+typedef struct {
+    int rows, d, d_ff;
+    float ln_eps;
+    mtn_dropout drop_hidden; /* mtn.py:280 */
+    mtn_dropout drop_out;    /* mtn.py:127 */
+    const float* x;          /* [rows,d] */
+    const float *ln_a, *ln_b;
+    const void* w1; /* lowp [d_ff,d] */
+    const float* b1;
+    const void* w2; /* lowp [d,d_ff] */
+    const float* b2;
+    float* y;    /* [rows,d] */
+    void* xn;    /* lowp [rows,d]    saved */
+    float* mean; /* saved */
+    float* rstd; /* saved */
+    void* hid;   /* lowp [rows,d_ff] saved (post-ReLU, post-dropout) */
+    /* ---- backward ---- */
+    const float* dy;
+    float* dx;
+    float *d_ln_a, *d_ln_b, *d_w1, *d_b1, *d_w2, *d_b2;
+    void* ws_lp;   /* lowp scratch: rows*d + rows*d_ff elements */
+    float* ws_f32; /* float scratch: mtn_ffn_bwd_ws_f32_floats() */
+} mtn_ffn_args;
+int mtn_ffn_sublayer_fwd(int dtype, const mtn_ffn_args* args, void* stream);
+int mtn_ffn_sublayer_bwd(int dtype, const mtn_ffn_args* args, void* stream);
+long mtn_ffn_bwd_ws_f32_floats(int rows, int d, int d_ff);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise helpers on the path.
+ * ------------------------------------------------------------------------------------------ */
+/* dst(lowp) = cast(src float); n elements. */
+int mtn_cast_f32_to_lp(int dtype, long n, const float* src, void* dst, void* stream);
+/* dst(lowp)[i] = src[i] * keep(i)/(1-p): gradient entering a dropped-out branch (mtn.py:127). */
+int mtn_dropout_bwd_to_lp(int dtype, long n, const float* src, mtn_dropout drop, void* dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser: Adam(betas=(0.9,0.98), eps=1e-9) under the Noam schedule
+ * (train.py:190, data_utils.py:92-117), fused over ONE flat parameter buffer.
+ *   state (device, 8 floats): [0]=step [1]=lr [2]=1-b1^t [3]=1-b2^t  (updated by mtn_noam_tick)
+ *   mtn_adam_step: g *= grad_scale (optional float device scalar, e.g. 1/global_ntokens);
+ *     m,v updated, p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps); p_lp (optional) = cast(p).
+ * ------------------------------------------------------------------------------------------ */
+int mtn_noam_tick(float* state, float factor, int model_size, int warmup, float beta1, float beta2, void* stream);
+int mtn_adam_step(int dtype, long n, float* p, const float* g, float* m, float* v, void* p_lp, const float* state,
+                  const float* grad_scale, float beta1, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTN_HIP_H */

@@ -1,0 +1,368 @@
+// attention.hip — scaled-dot-product attention core (mtn.py:221-231), forward and backward.
+// One workgroup per (batch row, head).  K/V tiles are staged through LDS (fp32, rows padded to dk+4 so that
+// 16-byte reads of 16 consecutive rows hit distinct banks), scores are tiled over keys with an online
+// softmax (running row max / sum, wave-shuffle reductions), masked scores take the reference's -1e9
+// (a fully masked row is uniform, not NaN), probabilities are dropped out with the counter-based mask.
+// Query lengths on this path are short (T,Q <= ~54 in DSTC7; 20 in the bench configs), so the contraction
+// runs on the VALU with 4x-register-tiled LDS reads; the d_model x d_model projections around it are MFMA.
+#include "common.h"
+
+static constexpr int AQ = 32;       // query rows per forward workgroup
+static constexpr int MT_F = 64;     // keys per forward tile
+static constexpr int MT_B = 32;     // keys per backward tile
+static constexpr int AMAX_B = 64;   // max query rows in backward (whole query block lives in LDS)
+
+template <typename T> __device__ __forceinline__ float4 load4(const T* p);
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    uint2 u = *(const uint2*)p;
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, float4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) { *(float4*)p = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *(uint2*)p = u;
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+// ------------------------------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const mtn_attn_args A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int dk = A.dk, ldr = dk + 4, a = A.a, m = A.m;
+    float* Qs = sm;                    // [AQ][ldr]  (pre-scaled by 1/sqrt(dk))
+    float* Os = Qs + AQ * ldr;         // [AQ][ldr]
+    float* Ks = Os + AQ * ldr;         // [MT_F][ldr]
+    float* Vs = Ks + MT_F * ldr;       // [MT_F][ldr]
+    float* Ss = Vs + MT_F * ldr;       // [AQ][MT_F+4]
+    float* mrow = Ss + AQ * (MT_F + 4);
+    float* lrow = mrow + AQ;
+    float* arow = lrow + AQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / A.h, hh = blockIdx.x % A.h, q0 = blockIdx.y * AQ;
+    const int dk4 = dk >> 2;
+    const float scale = rsqrtf((float)dk);
+    const T* qg = (const T*)A.q + (size_t)b * a * A.ldq + hh * dk;
+    const T* kg = (const T*)A.k + (size_t)b * m * A.ldkv + hh * dk;
+    const T* vg = (const T*)A.v + (size_t)b * m * A.ldkv + hh * dk;
+    const DropState ds = drop_init(A.drop);
+
+    for (int idx = tid; idx < AQ * dk4; idx += 256) {
+        int i = idx / dk4, c = (idx % dk4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 + i < a) {
+            v = load4<T>(qg + (size_t)(q0 + i) * A.ldq + c);
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        }
+        *(float4*)(Qs + i * ldr + c) = v;
+        *(float4*)(Os + i * ldr + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < AQ) { mrow[tid] = -INFINITY; lrow[tid] = 0.f; arow[tid] = 0.f; }
+
+    for (int j0 = 0; j0 < m; j0 += MT_F) {
+        __syncthreads();
+        for (int idx = tid; idx < MT_F * dk4; idx += 256) {
+            int j = idx / dk4, c = (idx % dk4) * 4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (j0 + j < m) {
+                kv = load4<T>(kg + (size_t)(j0 + j) * A.ldkv + c);
+                vv = load4<T>(vg + (size_t)(j0 + j) * A.ldkv + c);
+            }
+            *(float4*)(Ks + j * ldr + c) = kv;
+            *(float4*)(Vs + j * ldr + c) = vv;
+        }
+        __syncthreads();
+        // scores: task = (block of 4 query rows, key j); 8*64 = 512 tasks
+        for (int task = tid; task < (AQ / 4) * MT_F; task += 256) {
+            const int j = task % MT_F, i0 = (task / MT_F) * 4;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            const float* kp = Ks + j * ldr;
+            const float* qp = Qs + i0 * ldr;
+#pragma unroll 2
+            for (int c = 0; c < dk; c += 4) {
+                float4 kv = *(const float4*)(kp + c);
+                s0 += dot4(*(const float4*)(qp + c), kv);
+                s1 += dot4(*(const float4*)(qp + ldr + c), kv);
+                s2 += dot4(*(const float4*)(qp + 2 * ldr + c), kv);
+                s3 += dot4(*(const float4*)(qp + 3 * ldr + c), kv);
+            }
+            float sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = q0 + i0 + r;
+                float s = sv[r];
+                if (j0 + j >= m || qi >= a) s = -INFINITY;  // tile padding: excluded from the softmax
+                else if (A.mask && A.mask[(size_t)b * A.mask_sb + (size_t)qi * A.mask_sq + j0 + j] == 0) s = -1e9f;
+                Ss[(i0 + r) * (MT_F + 4) + j] = s;
+            }
+        }
+        __syncthreads();
+        // online softmax: each wave owns rows wave, wave+4, ...; lane = key within the tile
+        for (int i = wave; i < AQ; i += 4) {
+            const float s = Ss[i * (MT_F + 4) + lane];
+            const float mo = mrow[i];
+            const float mn = fmaxf(mo, wave_max(s));
+            float p = (mn == -INFINITY) ? 0.f : __expf(s - mn);
+            const float psum = wave_sum(p);
+            const float alpha = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+            if (ds.on) {
+                const uint64_t idx = ((uint64_t)(b * A.h + hh) * a + (q0 + i)) * (uint64_t)m + (j0 + lane);
+                p = drop_keep(ds, idx) ? p * ds.scale : 0.f;
+            }
+            Ss[i * (MT_F + 4) + lane] = p;
+            if (lane == 0) { mrow[i] = mn; lrow[i] = lrow[i] * alpha + psum; arow[i] = alpha; }
+        }
+        __syncthreads();
+        // O = alpha*O + P V : task = (block of 4 rows, 4 columns)
+        for (int task = tid; task < (AQ / 4) * dk4; task += 256) {
+            const int c = (task % dk4) * 4, i0 = (task / dk4) * 4;
+            float4 acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float4 o = *(const float4*)(Os + (i0 + r) * ldr + c);
+                const float al = arow[i0 + r];
+                acc[r] = make_float4(o.x * al, o.y * al, o.z * al, o.w * al);
+            }
+#pragma unroll 2
+            for (int j = 0; j < MT_F; j += 4) {
+                float4 v0 = *(const float4*)(Vs + j * ldr + c), v1 = *(const float4*)(Vs + (j + 1) * ldr + c);
+                float4 v2 = *(const float4*)(Vs + (j + 2) * ldr + c), v3 = *(const float4*)(Vs + (j + 3) * ldr + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float4 p = *(const float4*)(Ss + (i0 + r) * (MT_F + 4) + j);
+                    acc[r].x += p.x * v0.x + p.y * v1.x + p.z * v2.x + p.w * v3.x;
+                    acc[r].y += p.x * v0.y + p.y * v1.y + p.z * v2.y + p.w * v3.y;
+                    acc[r].z += p.x * v0.z + p.y * v1.z + p.z * v2.z + p.w * v3.z;
+                    acc[r].w += p.x * v0.w + p.y * v1.w + p.z * v2.w + p.w * v3.w;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *(float4*)(Os + (i0 + r) * ldr + c) = acc[r];
+        }
+    }
+    __syncthreads();
+    T* og = (T*)A.o + (size_t)b * a * A.ldo + hh * dk;
+    for (int idx = tid; idx < AQ * dk4; idx += 256) {
+        int i = idx / dk4, c = (idx % dk4) * 4;
+        if (q0 + i < a) {
+            const float inv = 1.0f / lrow[i];
+            float4 o = *(const float4*)(Os + i * ldr + c);
+            store4<T>(og + (size_t)(q0 + i) * A.ldo + c, make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv));
+        }
+    }
+    if (A.lse && tid < AQ && q0 + tid < a) A.lse[(size_t)(b * A.h + hh) * a + q0 + tid] = mrow[tid] + __logf(lrow[tid]);
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// P_ij = exp(S_ij - lse_i); dP = dO V^T (through the same dropout mask); D_i = sum_c dO_ic O_ic;
+// dS = P*(dP - D), zero where the score was masked; dV = Pdrop^T dO; dQ = scale * dS K; dK = dS^T (scale*Q).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const mtn_attn_args A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int dk = A.dk, ldr = dk + 4, a = A.a, m = A.m;
+    const int ap = (a + 3) & ~3;
+    float* Qs = sm;                  // [ap][ldr] pre-scaled
+    float* dOs = Qs + ap * ldr;      // [ap][ldr]
+    float* dQs = dOs + ap * ldr;     // [ap][ldr]
+    float* Ks = dQs + ap * ldr;      // [MT_B][ldr]
+    float* Vs = Ks + MT_B * ldr;     // [MT_B][ldr]
+    float* Ps = Vs + MT_B * ldr;     // [ap][MT_B+4]  dropped-out probabilities
+    float* dSs = Ps + ap * (MT_B + 4);  // [ap][MT_B+4]
+    float* Dr = dSs + ap * (MT_B + 4);  // [ap]
+    float* Ls = Dr + ap;                // [ap]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / A.h, hh = blockIdx.x % A.h;
+    const int dk4 = dk >> 2;
+    const float scale = rsqrtf((float)dk);
+    const T* qg = (const T*)A.q + (size_t)b * a * A.ldq + hh * dk;
+    const T* kg = (const T*)A.k + (size_t)b * m * A.ldkv + hh * dk;
+    const T* vg = (const T*)A.v + (size_t)b * m * A.ldkv + hh * dk;
+    const T* og = (const T*)A.o + (size_t)b * a * A.ldo + hh * dk;
+    const T* dog = (const T*)A.d_o + (size_t)b * a * A.ldo + hh * dk;
+    const DropState ds = drop_init(A.drop);
+
+    for (int idx = tid; idx < ap * dk4; idx += 256) {
+        int i = idx / dk4, c = (idx % dk4) * 4;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), dv = qv;
+        if (i < a) {
+            qv = load4<T>(qg + (size_t)i * A.ldq + c);
+            qv.x *= scale; qv.y *= scale; qv.z *= scale; qv.w *= scale;
+            dv = load4<T>(dog + (size_t)i * A.ldo + c);
+        }
+        *(float4*)(Qs + i * ldr + c) = qv;
+        *(float4*)(dOs + i * ldr + c) = dv;
+        *(float4*)(dQs + i * ldr + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = wave; i < ap; i += 4) {  // D_i = sum_c dO*O, one wave per row
+        float s = 0.f;
+        if (i < a)
+            for (int c = lane; c < dk; c += 64)
+                s += LP<T>::to_f32(dog[(size_t)i * A.ldo + c]) * LP<T>::to_f32(og[(size_t)i * A.ldo + c]);
+        s = wave_sum(s);
+        if (lane == 0) { Dr[i] = s; Ls[i] = (i < a) ? A.lse[(size_t)(b * A.h + hh) * a + i] : 0.f; }
+    }
+
+    T* dqg = (T*)A.dq + (size_t)b * a * A.ldq + hh * dk;
+    T* dkg = (T*)A.dk_out + (size_t)b * m * A.ldkv + hh * dk;
+    T* dvg = (T*)A.dv_out + (size_t)b * m * A.ldkv + hh * dk;
+
+    for (int j0 = 0; j0 < m; j0 += MT_B) {
+        __syncthreads();
+        for (int idx = tid; idx < MT_B * dk4; idx += 256) {
+            int j = idx / dk4, c = (idx % dk4) * 4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (j0 + j < m) {
+                kv = load4<T>(kg + (size_t)(j0 + j) * A.ldkv + c);
+                vv = load4<T>(vg + (size_t)(j0 + j) * A.ldkv + c);
+            }
+            *(float4*)(Ks + j * ldr + c) = kv;
+            *(float4*)(Vs + j * ldr + c) = vv;
+        }
+        __syncthreads();
+        // P and dS for the tile: task = (block of 4 query rows, key j)
+        for (int task = tid; task < (ap / 4) * MT_B; task += 256) {
+            const int j = task % MT_B, i0 = (task / MT_B) * 4;
+            float s[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* kp = Ks + j * ldr;
+            const float* vp = Vs + j * ldr;
+#pragma unroll 2
+            for (int c = 0; c < dk; c += 4) {
+                float4 kv = *(const float4*)(kp + c), vv = *(const float4*)(vp + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[r] += dot4(*(const float4*)(Qs + (i0 + r) * ldr + c), kv);
+                    dp[r] += dot4(*(const float4*)(dOs + (i0 + r) * ldr + c), vv);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = i0 + r;
+                float pd = 0.f, dsv = 0.f;
+                if (j0 + j < m && qi < a) {
+                    const bool keep_score = !(A.mask && A.mask[(size_t)b * A.mask_sb + (size_t)qi * A.mask_sq + j0 + j] == 0);
+                    const float sc = keep_score ? s[r] : -1e9f;
+                    const float p = __expf(sc - Ls[qi]);
+                    float dpd = dp[r];
+                    pd = p;
+                    if (ds.on) {
+                        const uint64_t idx = ((uint64_t)(b * A.h + hh) * a + qi) * (uint64_t)m + (j0 + j);
+                        const bool kp_ = drop_keep(ds, idx);
+                        pd = kp_ ? p * ds.scale : 0.f;
+                        dpd = kp_ ? dpd * ds.scale : 0.f;
+                    }
+                    dsv = keep_score ? p * (dpd - Dr[qi]) : 0.f;
+                }
+                Ps[qi * (MT_B + 4) + j] = pd;
+                dSs[qi * (MT_B + 4) + j] = dsv;
+            }
+        }
+        __syncthreads();
+        // dV[j] = sum_i Pd[i][j] dO[i],  dK[j] = sum_i dS[i][j] Qs[i]   : task = (key j, 4 columns)
+        for (int task = tid; task < MT_B * dk4; task += 256) {
+            const int c = (task % dk4) * 4, j = task / dk4;
+            if (j0 + j < m) {
+                float4 av = make_float4(0.f, 0.f, 0.f, 0.f), ak = av;
+#pragma unroll 4
+                for (int i = 0; i < ap; ++i) {
+                    const float p = Ps[i * (MT_B + 4) + j], d = dSs[i * (MT_B + 4) + j];
+                    float4 dv = *(const float4*)(dOs + i * ldr + c), qv = *(const float4*)(Qs + i * ldr + c);
+                    av.x += p * dv.x; av.y += p * dv.y; av.z += p * dv.z; av.w += p * dv.w;
+                    ak.x += d * qv.x; ak.y += d * qv.y; ak.z += d * qv.z; ak.w += d * qv.w;
+                }
+                store4<T>(dvg + (size_t)(j0 + j) * A.ldkv + c, av);
+                store4<T>(dkg + (size_t)(j0 + j) * A.ldkv + c, ak);
+            }
+        }
+        // dQ[i] += sum_j dS[i][j] K[j]   : task = (row i, 4 columns)
+        for (int task = tid; task < ap * dk4; task += 256) {
+            const int c = (task % dk4) * 4, i = task / dk4;
+            float4 acc = *(const float4*)(dQs + i * ldr + c);
+#pragma unroll 2
+            for (int j = 0; j < MT_B; j += 4) {
+                float4 d = *(const float4*)(dSs + i * (MT_B + 4) + j);
+                float4 k0 = *(const float4*)(Ks + j * ldr + c), k1 = *(const float4*)(Ks + (j + 1) * ldr + c);
+                float4 k2 = *(const float4*)(Ks + (j + 2) * ldr + c), k3 = *(const float4*)(Ks + (j + 3) * ldr + c);
+                acc.x += d.x * k0.x + d.y * k1.x + d.z * k2.x + d.w * k3.x;
+                acc.y += d.x * k0.y + d.y * k1.y + d.z * k2.y + d.w * k3.y;
+                acc.z += d.x * k0.z + d.y * k1.z + d.z * k2.z + d.w * k3.z;
+                acc.w += d.x * k0.w + d.y * k1.w + d.z * k2.w + d.w * k3.w;
+            }
+            *(float4*)(dQs + i * ldr + c) = acc;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ap * dk4; idx += 256) {
+        int i = idx / dk4, c = (idx % dk4) * 4;
+        if (i < a) {
+            float4 v = *(const float4*)(dQs + i * ldr + c);
+            store4<T>(dqg + (size_t)i * A.ldq + c, make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static size_t fwd_lds_bytes(int dk) { return sizeof(float) * ((size_t)(2 * AQ + 2 * MT_F) * (dk + 4) + (size_t)AQ * (MT_F + 4) + 3 * AQ); }
+static size_t bwd_lds_bytes(int a, int dk) {
+    size_t ap = (a + 3) & ~3;
+    return sizeof(float) * ((3 * ap + 2 * MT_B) * (size_t)(dk + 4) + 2 * ap * (MT_B + 4) + 2 * ap);
+}
+
+static int check_attn(const mtn_attn_args* A, bool bwd) {
+    MTN_CHECK_ARG(A, "null args");
+    MTN_CHECK_ARG(A->B > 0 && A->h > 0 && A->a > 0 && A->m > 0, "empty attention problem");
+    MTN_CHECK_ARG(A->dk >= 4 && A->dk % 4 == 0 && A->dk <= 128, "dk must be a multiple of 4, <= 128");
+    MTN_CHECK_ARG(A->ldq % 4 == 0 && A->ldkv % 4 == 0 && A->ldo % 4 == 0, "row strides must be multiples of 4");
+    MTN_CHECK_ARG(A->q && A->k && A->v && A->o, "null tensor");
+    if (bwd) {
+        MTN_CHECK_ARG(A->d_o && A->dq && A->dk_out && A->dv_out && A->lse, "null backward tensor");
+        MTN_CHECK_ARG(A->a <= AMAX_B, "attention backward supports at most 64 query rows per sequence");
+    }
+    return MTN_OK;
+}
+
+template <typename K> static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { mtn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
+    }
+    return MTN_OK;
+}
+
+extern "C" int mtn_attention_fwd(int dtype, const mtn_attn_args* A, void* stream) {
+    MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
+    if (int rc = check_attn(A, false)) return rc;
+    const size_t lds = fwd_lds_bytes(A->dk);
+    dim3 grid(A->B * A->h, (A->a + AQ - 1) / AQ), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTN_BF16) {
+        if (int rc = set_lds(attn_fwd_kernel<bf16_t>, lds)) return rc;
+        hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, block, lds, s, *A);
+    } else {
+        if (int rc = set_lds(attn_fwd_kernel<float>, lds)) return rc;
+        hipLaunchKernelGGL((attn_fwd_kernel<float>), grid, block, lds, s, *A);
+    }
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}
+
+extern "C" int mtn_attention_bwd(int dtype, const mtn_attn_args* A, void* stream) {
+    MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
+    if (int rc = check_attn(A, true)) return rc;
+    const size_t lds = bwd_lds_bytes(A->a, A->dk);
+    MTN_CHECK_ARG(lds <= 160 * 1024, "attention backward tile does not fit LDS");
+    dim3 grid(A->B * A->h), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTN_BF16) {
+        if (int rc = set_lds(attn_bwd_kernel<bf16_t>, lds)) return rc;
+        hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), grid, block, lds, s, *A);
+    } else {
+        if (int rc = set_lds(attn_bwd_kernel<float>, lds)) return rc;
+        hipLaunchKernelGGL((attn_bwd_kernel<float>), grid, block, lds, s, *A);
+    }
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}

@@ -1,0 +1,111 @@
+// common.h — shared device/host helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mtn_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---------------------------------------------------------------- error plumbing (host)
+void mtn_set_error(const char* fmt, ...);
+#define MTN_CHECK_ARG(cond, msg)                         \
+    do {                                                 \
+        if (!(cond)) {                                   \
+            mtn_set_error("%s: %s", __func__, msg);      \
+            return MTN_ERR_ARG;                          \
+        }                                                \
+    } while (0)
+#define MTN_CHECK_LAUNCH()                                                        \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            mtn_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return MTN_ERR_LAUNCH;                                                \
+        }                                                                         \
+    } while (0)
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct LP;  // low-precision element traits
+template <> struct LP<float> {
+    static constexpr int EPV = 4;     // elements per 16-byte vector
+    static constexpr int KSTEP = 16;  // contraction elements consumed by one 16-byte fragment pair
+    __device__ static __forceinline__ float to_f32(float v) { return v; }
+    __device__ static __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct LP<bf16_t> {
+    static constexpr int EPV = 8;
+    static constexpr int KSTEP = 32;
+    __device__ static __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+    __device__ static __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
+};
+
+// One 16-byte fragment pair -> 16x16 accumulator.  A fragment lane l holds row (l&15), contraction slots
+// (l>>4)*EPV .. +EPV-1 of the KSTEP-wide step; B likewise for column (l&15).  The slot->k map is the same
+// permutation on both operands, so any k-order inside the 16 bytes is fine.
+template <typename T> __device__ __forceinline__ void mma16(f32x4_t& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void mma16<bf16_t>(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&b, acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4_t& acc, const uint4& a, const uint4& b) {
+    // exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): lane group g supplies k = g per instruction
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------- dropout keep-mask
+// Counter-based: keep(idx) is a pure function of (seed, salt, idx).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+struct DropState {
+    uint32_t k0, k1, thresh;  // thresh = p * 2^24
+    float scale;              // 1/(1-p)
+    bool on;
+};
+__device__ __forceinline__ DropState drop_init(const mtn_dropout& d) {
+    DropState s;
+    s.on = (d.p > 0.f) && (d.seed != nullptr);
+    s.k0 = s.k1 = s.thresh = 0; s.scale = 1.f;
+    if (s.on) {
+        uint64_t sd = *d.seed;
+        s.k0 = mix32((uint32_t)sd ^ (d.salt * 0x9E3779B9u));
+        s.k1 = mix32((uint32_t)(sd >> 32) + d.salt * 0x85EBCA6Bu + 0x165667B1u);
+        s.thresh = (uint32_t)(d.p * 16777216.0f);
+        s.scale = 1.0f / (1.0f - d.p);
+    }
+    return s;
+}
+__device__ __forceinline__ bool drop_keep(const DropState& s, uint64_t idx) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t r = mix32(lo ^ s.k0) ^ mix32(hi + s.k1);
+    r = mix32(r + s.k1);
+    return (r >> 8) >= s.thresh;
+}
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

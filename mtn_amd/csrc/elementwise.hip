@@ -1,0 +1,138 @@
+// elementwise.hip — HBM-bound helpers on the path: casts, dropout-backward, fused Adam/Noam
+// (train.py:190, data_utils.py:92-117).  16-byte vector accesses, grid-stride loops.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ---------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+void mtn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mtn_last_error(void) { return g_err; }
+extern "C" int mtn_version(void) { return 100; }
+
+static inline int grid_for(long n_vec) {
+    long b = (n_vec + 255) / 256;
+    if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------- cast / dropout-backward
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(long n, const float* __restrict__ src, T* __restrict__ dst, const mtn_dropout drop) {
+    const DropState ds = drop_init(drop);
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = *(const float4*)(src + i * 4);
+        if (ds.on) {
+            v.x = drop_keep(ds, (uint64_t)(i * 4 + 0)) ? v.x * ds.scale : 0.f;
+            v.y = drop_keep(ds, (uint64_t)(i * 4 + 1)) ? v.y * ds.scale : 0.f;
+            v.z = drop_keep(ds, (uint64_t)(i * 4 + 2)) ? v.z * ds.scale : 0.f;
+            v.w = drop_keep(ds, (uint64_t)(i * 4 + 3)) ? v.w * ds.scale : 0.f;
+        }
+        if constexpr (sizeof(T) == 2) {
+            uint2 u;
+            u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+            u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+            *(uint2*)(dst + i * 4) = u;
+        } else {
+            *(float4*)(dst + i * 4) = v;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
+        long i = (n4 << 2) + threadIdx.x;
+        float v = src[i];
+        if (ds.on) v = drop_keep(ds, (uint64_t)i) ? v * ds.scale : 0.f;
+        dst[i] = LP<T>::from_f32(v);
+    }
+}
+
+static int launch_cast(int dtype, long n, const float* src, void* dst, mtn_dropout drop, void* stream) {
+    MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
+    MTN_CHECK_ARG(n > 0 && src && dst, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTN_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t>), dim3(grid_for(n >> 2)), dim3(256), 0, s, n, src, (bf16_t*)dst, drop);
+    else hipLaunchKernelGGL((cast_kernel<float>), dim3(grid_for(n >> 2)), dim3(256), 0, s, n, src, (float*)dst, drop);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}
+
+extern "C" int mtn_cast_f32_to_lp(int dtype, long n, const float* src, void* dst, void* stream) {
+    mtn_dropout none = {0.f, 0u, nullptr};
+    return launch_cast(dtype, n, src, dst, none, stream);
+}
+extern "C" int mtn_dropout_bwd_to_lp(int dtype, long n, const float* src, mtn_dropout drop, void* dst, void* stream) {
+    return launch_cast(dtype, n, src, dst, drop, stream);
+}
+
+// ---------------------------------------------------------------- Noam schedule + Adam
+__global__ void noam_tick_kernel(float* state, float factor, float model_size, float warmup, float beta1, float beta2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float step = state[0] + 1.0f;
+        state[0] = step;
+        state[1] = factor * rsqrtf(model_size) * fminf(rsqrtf(step), step * powf(warmup, -1.5f));  // data_utils.py:111-117
+        state[2] = 1.0f - powf(beta1, step);
+        state[3] = 1.0f - powf(beta2, step);
+    }
+}
+extern "C" int mtn_noam_tick(float* state, float factor, int model_size, int warmup, float beta1, float beta2, void* stream) {
+    MTN_CHECK_ARG(state && model_size > 0 && warmup > 0, "bad arguments");
+    hipLaunchKernelGGL(noam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, factor, (float)model_size, (float)warmup, beta1, beta2);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}
+
+// torch.optim.Adam semantics: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  38 B/param of HBM traffic with the bf16 copy.
+template <typename T>
+__global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, T* __restrict__ p_lp, const float* __restrict__ state,
+                                                   const float* __restrict__ grad_scale, float beta1, float beta2, float eps) {
+    const float lr = state[1], bc1 = state[2], bc2 = state[3];
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    const float gs = grad_scale ? *grad_scale : 1.0f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 pv = *(const float4*)(p + i * 4), gv = *(const float4*)(g + i * 4);
+        float4 mv = *(const float4*)(m + i * 4), vv = *(const float4*)(v + i * 4);
+        float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gp[k] * gs;
+            mp[k] = beta1 * mp[k] + (1.0f - beta1) * gk;
+            vp[k] = beta2 * vp[k] + (1.0f - beta2) * gk * gk;
+            pp[k] -= step_size * mp[k] / (sqrtf(vp[k]) * inv_sqrt_bc2 + eps);
+        }
+        *(float4*)(p + i * 4) = pv;
+        *(float4*)(m + i * 4) = mv;
+        *(float4*)(v + i * 4) = vv;
+        if (p_lp) {
+            if constexpr (sizeof(T) == 2) {
+                uint2 u;
+                u.x = (uint32_t)f32_to_bf16(pv.x) | ((uint32_t)f32_to_bf16(pv.y) << 16);
+                u.y = (uint32_t)f32_to_bf16(pv.z) | ((uint32_t)f32_to_bf16(pv.w) << 16);
+                *(uint2*)(p_lp + i * 4) = u;
+            } else {
+                *(float4*)(p_lp + i * 4) = pv;
+            }
+        }
+    }
+}
+
+extern "C" int mtn_adam_step(int dtype, long n, float* p, const float* g, float* m, float* v, void* p_lp, const float* state,
+                             const float* grad_scale, float beta1, float beta2, float eps, void* stream) {
+    MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
+    MTN_CHECK_ARG(n > 0 && n % 4 == 0 && p && g && m && v && state, "n must be a positive multiple of 4; buffers non-null");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTN_BF16)
+        hipLaunchKernelGGL((adam_kernel<bf16_t>), dim3(grid_for(n >> 2)), dim3(256), 0, s, n, p, g, m, v, (bf16_t*)p_lp, state, grad_scale, beta1, beta2, eps);
+    else
+        hipLaunchKernelGGL((adam_kernel<float>), dim3(grid_for(n >> 2)), dim3(256), 0, s, n, p, g, m, v, (float*)p_lp, state, grad_scale, beta1, beta2, eps);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}

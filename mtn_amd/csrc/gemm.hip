@@ -1,0 +1,234 @@
+// gemm.hip — grouped MFMA GEMM for every Linear on the MTN path (mtn.py:243-244,256-258,267,273-280)
+// and their backward contractions.  One launch executes up to MTN_GEMM_MAX_GROUP independent problems
+// (independent sublayers of one DecoderLayer share a launch so that the grid fills 256 CUs).
+//
+// Tile: 64x64 outputs per 256-thread workgroup (4 waves, each a 32x32 quadrant = 2x2 MFMA 16x16 tiles),
+// depth 128 bytes per row per step (64 bf16 / 32 fp32).  Operands are staged global -> registers -> LDS
+// (next tile's loads are in flight during the MFMAs of the current one); a "transposed" operand (stored
+// contraction-major, e.g. dY and X in dW = dY^T X) is transposed in registers in 4x4 blocks on the way to
+// LDS, so the MFMA fragment reads are always 16-byte, contraction-contiguous.
+// LDS rows are padded to 144 bytes: the 16 rows of a fragment read land on 16 distinct 16-byte slots.
+#include "common.h"
+
+struct GemmGroup {
+    int count;
+    int tile_start[MTN_GEMM_MAX_GROUP + 1];
+    mtn_gemm_problem p[MTN_GEMM_MAX_GROUP];
+};
+
+static constexpr int TILE = 64;
+static constexpr int LDSROW = 144;  // bytes per LDS tile row (128 data + 16 pad)
+
+// ---- staging of one 64-row x 128-byte operand tile -------------------------------------------------
+template <typename T, bool TR> struct Stage {
+    uint4 r[(TR && sizeof(T) == 4) ? 4 : 2];
+
+    __device__ __forceinline__ void load(const T* __restrict__ base, int ld, int R, int K, int row0, int k0, int tid) {
+        constexpr int EPV = LP<T>::EPV;
+        if constexpr (!TR) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int c = tid + 256 * j;
+                int gr = row0 + (c >> 3), gk = k0 + (c & 7) * EPV;
+                r[j] = (gr < R && gk < K) ? *(const uint4*)(base + (size_t)gr * ld + gk) : make_uint4(0, 0, 0, 0);
+            }
+        } else if constexpr (sizeof(T) == 2) {  // 64 k x 64 rows, 4x4 blocks, one per thread
+            int kb = tid >> 4, rb = tid & 15;
+            int gr = row0 + rb * 4;
+            uint2 v[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                int gk = k0 + kb * 4 + kk;
+                v[kk] = (gk < K && gr < R) ? *(const uint2*)(base + (size_t)gk * ld + gr) : make_uint2(0, 0);
+            }
+            // 4x4 transpose of 16-bit elements: v[k] = rows r0..r3 at k  ->  out[r] = k0..k3 at row r
+            r[0].x = (v[0].x & 0xffffu) | (v[1].x << 16);        r[0].y = (v[2].x & 0xffffu) | (v[3].x << 16);
+            r[0].z = (v[0].x >> 16) | (v[1].x & 0xffff0000u);    r[0].w = (v[2].x >> 16) | (v[3].x & 0xffff0000u);
+            r[1].x = (v[0].y & 0xffffu) | (v[1].y << 16);        r[1].y = (v[2].y & 0xffffu) | (v[3].y << 16);
+            r[1].z = (v[0].y >> 16) | (v[1].y & 0xffff0000u);    r[1].w = (v[2].y >> 16) | (v[3].y & 0xffff0000u);
+        } else {  // fp32: 32 k x 64 rows, 128 blocks of 4x4; threads 128..255 idle
+            if (tid < 128) {
+                int kb = tid >> 4, rb = tid & 15;
+                int gr = row0 + rb * 4;
+                uint4 v[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    int gk = k0 + kb * 4 + kk;
+                    v[kk] = (gk < K && gr < R) ? *(const uint4*)(base + (size_t)gk * ld + gr) : make_uint4(0, 0, 0, 0);
+                }
+                r[0] = make_uint4(v[0].x, v[1].x, v[2].x, v[3].x);
+                r[1] = make_uint4(v[0].y, v[1].y, v[2].y, v[3].y);
+                r[2] = make_uint4(v[0].z, v[1].z, v[2].z, v[3].z);
+                r[3] = make_uint4(v[0].w, v[1].w, v[2].w, v[3].w);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(unsigned char* s, int tid) const {
+        if constexpr (!TR) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int c = tid + 256 * j;
+                *(uint4*)(s + (c >> 3) * LDSROW + (c & 7) * 16) = r[j];
+            }
+        } else if constexpr (sizeof(T) == 2) {
+            int kb = tid >> 4, rb = tid & 15;
+            unsigned char* p = s + (rb * 4) * LDSROW + kb * 8;
+            *(uint2*)(p) = make_uint2(r[0].x, r[0].y);
+            *(uint2*)(p + LDSROW) = make_uint2(r[0].z, r[0].w);
+            *(uint2*)(p + 2 * LDSROW) = make_uint2(r[1].x, r[1].y);
+            *(uint2*)(p + 3 * LDSROW) = make_uint2(r[1].z, r[1].w);
+        } else {
+            if (tid < 128) {
+                int kb = tid >> 4, rb = tid & 15;
+                unsigned char* p = s + (rb * 4) * LDSROW + kb * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(uint4*)(p + q * LDSROW) = r[q];
+            }
+        }
+    }
+};
+
+template <typename T, bool A_T, bool B_T>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE * LDSROW];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + TILE * LDSROW;
+
+    const int tid = threadIdx.x;
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
+    const mtn_gemm_problem& P = grp.p[g];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = (N + TILE - 1) / TILE;
+    const int t = (int)blockIdx.x - grp.tile_start[g];
+    const int row0 = (t / tiles_n) * TILE, col0 = (t % tiles_n) * TILE;
+    const T* __restrict__ A = (const T*)P.A;
+    const T* __restrict__ B = (const T*)P.B;
+    const bool do_rowsum = (P.rowsum_out != nullptr) && (col0 == 0);
+
+    const int lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1, lg = lane >> 4, l15 = lane & 15;
+
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float rsum = 0.f;
+
+    Stage<T, A_T> stA;
+    Stage<T, B_T> stB;
+    stA.load(A, P.lda, M, K, row0, 0, tid);
+    stB.load(B, P.ldb, N, K, col0, 0, tid);
+
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        stA.store(sA, tid);
+        stB.store(sB, tid);
+        __syncthreads();
+        if (k0 + BK < K) {  // next tile's global loads fly during the MFMAs below
+            stA.load(A, P.lda, M, K, row0, k0 + BK, tid);
+            stB.load(B, P.ldb, N, K, col0, k0 + BK, tid);
+        }
+        if (do_rowsum && tid < TILE) {
+            const uint4* rp = (const uint4*)(sA + tid * LDSROW);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                uint4 u = rp[q];
+                if constexpr (sizeof(T) == 2) {
+                    rsum += __uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u) + __uint_as_float(u.y << 16) +
+                            __uint_as_float(u.y & 0xffff0000u) + __uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u) +
+                            __uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u);
+                } else {
+                    rsum += __uint_as_float(u.x) + __uint_as_float(u.y) + __uint_as_float(u.z) + __uint_as_float(u.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *(const uint4*)(sA + (wr * 32 + i * 16 + l15) * LDSROW + ks * 64 + lg * 16);
+                b[i] = *(const uint4*)(sB + (wc * 32 + i * 16 + l15) * LDSROW + ks * 64 + lg * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma16<T>(acc[i][j], a[i], b[j]);
+        }
+        __syncthreads();
+    }
+
+    if (do_rowsum && tid < TILE && row0 + tid < M) P.rowsum_out[row0 + tid] = rsum;
+
+    // ---- epilogue: lane holds C[row = 4*lg + r][col = l15] of each 16x16 tile
+    const DropState ds = drop_init(P.drop);
+    const float* __restrict__ bias = P.bias;
+    const float* __restrict__ res = P.residual;
+    const T* __restrict__ gate = (const T*)P.gate;
+    float* __restrict__ of = P.out_f32;
+    T* __restrict__ ol = (T*)P.out_lp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wc * 32 + j * 16 + l15;
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wr * 32 + i * 16 + lg * 4 + r;
+                if (row >= M) continue;
+                float v = acc[i][j][r] + bv;
+                if (P.relu) v = fmaxf(v, 0.f);
+                if (ds.on) v = drop_keep(ds, (uint64_t)row * (uint64_t)N + col) ? v * ds.scale : 0.f;
+                const size_t o = (size_t)row * P.ldc + col;
+                if (gate) v = (LP<T>::to_f32(gate[o]) > 0.f) ? v * P.gate_scale : 0.f;
+                if (res) v += res[(size_t)row * P.ldr + col];
+                if (of) of[o] = v;
+                if (ol) ol[o] = LP<T>::from_f32(v);
+            }
+        }
+}
+
+template <typename T>
+static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, hipStream_t s) {
+    dim3 grid(total_tiles), block(256);
+    if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp);
+    else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp);
+    else if (at && bt) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, s, grp);
+    else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, s, grp);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}
+
+extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, void* stream) {
+    MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
+    MTN_CHECK_ARG(count >= 1 && count <= MTN_GEMM_MAX_GROUP && problems, "bad problem count");
+    GemmGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    grp.count = count;
+    int tiles = 0;
+    const int align = (dtype == MTN_BF16) ? 8 : 4;
+    for (int i = 0; i < count; ++i) {
+        const mtn_gemm_problem& p = problems[i];
+        MTN_CHECK_ARG(p.A && p.B && (p.out_f32 || p.out_lp), "null operand/output");
+        MTN_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty problem");
+        MTN_CHECK_ARG(p.a_trans == problems[0].a_trans && p.b_trans == problems[0].b_trans, "mixed layouts in one group");
+        MTN_CHECK_ARG(p.lda % align == 0 && p.ldb % align == 0, "lda/ldb must be multiples of 16 bytes");
+        MTN_CHECK_ARG(p.a_trans || p.K % align == 0, "K must be a multiple of 16 bytes for a row-major A");
+        MTN_CHECK_ARG(p.b_trans || p.K % align == 0, "K must be a multiple of 16 bytes for a row-major B");
+        MTN_CHECK_ARG(!p.a_trans || p.M % 4 == 0, "M must be a multiple of 4 for a transposed A");
+        MTN_CHECK_ARG(!p.b_trans || p.N % 4 == 0, "N must be a multiple of 4 for a transposed B");
+        MTN_CHECK_ARG((((uintptr_t)p.A) & 15) == 0 && (((uintptr_t)p.B) & 15) == 0, "A/B must be 16-byte aligned");
+        grp.tile_start[i] = tiles;
+        tiles += ((p.M + TILE - 1) / TILE) * ((p.N + TILE - 1) / TILE);
+        grp.p[i] = p;
+    }
+    for (int i = count; i <= MTN_GEMM_MAX_GROUP; ++i) grp.tile_start[i] = tiles;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTN_BF16) return launch_gemm<bf16_t>(grp, tiles, problems[0].a_trans, problems[0].b_trans, s);
+    return launch_gemm<float>(grp, tiles, problems[0].a_trans, problems[0].b_trans, s);
+}

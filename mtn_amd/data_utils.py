@@ -1,0 +1,170 @@
+"""Batch / masks / optimiser / loss harness around the model — the surface of the reference's
+data_utils.py + label_smoothing.py that train.py's batch loop drives (SURVEY.md §2 "IN as harness").
+
+Differences that matter on MI355X: nothing here forces a host sync inside the step (the reference's
+``loss.item()`` at data_utils.py:156 is optional), the optimiser is one fused Adam kernel over the flat
+parameter buffer with the Noam rate computed on device (so a whole step can be captured in a hipGraph), and
+tensors stay on whatever device they were created on (no hard-coded ``.cuda()``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+
+
+def subsequent_mask(size: int, device=None) -> torch.Tensor:
+    """(1,size,size) bool, True where a position may be attended (data_utils.py:10-14)."""
+    return torch.ones(1, size, size, dtype=torch.bool, device=device).tril_()
+
+
+class Batch:
+    """Holds one mini-batch with its masks (data_utils.py:21-54).  ``fts`` are (B,V,F) float tensors (already
+    batch-first, on the target device) or (V,B,F) numpy arrays as data_handler.make_batch produces them."""
+
+    def __init__(self, query, his, his_st=None, fts=None, cap=None, trg=None, trg_y=None, pad=0, device=None):
+        dev = device if device is not None else query.device
+        self.query, self.his, self.his_st = query.to(dev), his.to(dev), his_st
+        if fts is not None:
+            cleaned, masks = [], []
+            for ft in fts:
+                if not torch.is_tensor(ft):
+                    ft = torch.from_numpy(ft).float().permute(1, 0, 2)          # data_utils.py:28
+                ft = ft.to(dev)
+                mask = ((ft != 1).sum(dim=2) != 0).unsqueeze(-2)                # frames padded with 1.0 (data_handler.py:236)
+                cleaned.append(ft * mask.squeeze(-2).unsqueeze(-1).to(ft.dtype))
+                masks.append(mask)
+            self.fts, self.fts_mask = cleaned, masks
+        else:
+            self.fts = self.fts_mask = None
+        self.query_mask = (self.query != pad).unsqueeze(-2)
+        self.his_mask = (self.his != pad).unsqueeze(-2)
+        if cap is not None:
+            self.cap = cap.to(dev)
+            self.cap_mask = (self.cap != pad).unsqueeze(-2)
+        else:
+            self.cap = self.cap_mask = None
+        if trg is not None:
+            self.trg, self.trg_y = trg.to(dev), trg_y.to(dev)
+            self.trg_mask = self.make_std_mask(self.trg, pad)
+            self.ntokens = (self.trg_y != pad).sum()
+
+    @staticmethod
+    def make_std_mask(tgt, pad):
+        """pad mask AND causal mask (data_utils.py:48-54)."""
+        return (tgt != pad).unsqueeze(-2) & subsequent_mask(tgt.size(-1), tgt.device)
+
+
+class LabelSmoothing(nn.Module):
+    """KLDivLoss(sum) against the smoothed target distribution (label_smoothing.py:9-32), computed in closed
+    form without materialising the (rows, vocab) target matrix twice.  The reference's quirk is kept: rows
+    whose target is <pad> are zeroed only if the SUM OF THEIR INDICES is > 0 (label_smoothing.py:29)."""
+
+    def __init__(self, size: int, padding_idx: int, smoothing: float = 0.0):
+        super().__init__()
+        self.size, self.padding_idx, self.smoothing = size, padding_idx, smoothing
+        self.confidence = 1.0 - smoothing
+
+    def forward(self, x, target):
+        assert x.size(1) == self.size
+        eps = self.smoothing / (self.size - 2)
+        true_dist = torch.full_like(x, eps)
+        true_dist.scatter_(1, target.unsqueeze(1), self.confidence)
+        true_dist[:, self.padding_idx] = 0
+        pad_rows = target == self.padding_idx
+        idx_sum = (torch.arange(target.numel(), device=target.device) * pad_rows).sum()
+        zero_rows = pad_rows & (idx_sum > 0)                      # device-side form of the reference's host test
+        true_dist = true_dist * (~zero_rows).unsqueeze(1).to(x.dtype)
+        pos = true_dist > 0
+        safe = torch.where(pos, true_dist, torch.ones_like(true_dist))
+        return (true_dist * (safe.log() - x)).sum()
+
+
+class FusedAdam:
+    """Adam(betas=(0.9,0.98), eps=1e-9) (train.py:190) over the model's flat buffers in ONE kernel, with the Noam
+    learning rate (data_utils.py:111-117) advanced on device.  Writes the compute-dtype weight copy in the same pass."""
+
+    def __init__(self, model, betas=(0.9, 0.98), eps=1e-9):
+        self.model = model
+        self.betas, self.eps = betas, eps
+        flat, _, _ = model.flat_buffers()
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.state = torch.zeros(8, device=flat.device, dtype=torch.float32)   # step, lr, 1-b1^t, 1-b2^t
+        self.param_groups = [{"lr": 0.0, "params": list(model.parameters())}]
+        self.grad_scale: Optional[torch.Tensor] = None                        # device scalar multiplied into every gradient
+
+    def tick(self, factor: float, model_size: int, warmup: int):
+        L.check(L.load().mtn_noam_tick(self.state.data_ptr(), factor, model_size, warmup, self.betas[0], self.betas[1], L.stream_ptr()))
+
+    def step(self):
+        flat, flat_lp, grad = self.model.flat_buffers()
+        if self.m.data_ptr() == 0 or self.m.numel() != flat.numel() or self.m.device != flat.device:
+            raise L.MtnHipError("model was re-flattened after the optimiser was built")
+        lp_ptr = None if flat_lp is flat else flat_lp.data_ptr()
+        L.check(L.load().mtn_adam_step(L.dtype_code(self.model.compute_dtype), flat.numel(), flat.data_ptr(), grad.data_ptr(),
+                                       self.m.data_ptr(), self.v.data_ptr(), lp_ptr, self.state.data_ptr(),
+                                       L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.zero_glue_grads()
+
+
+class NoamOpt:
+    """Optimiser wrapper with the reference's interface (data_utils.py:92-117): ``step()``, ``rate()``,
+    ``.optimizer.zero_grad()``.  The schedule itself runs on device inside FusedAdam.tick()."""
+
+    def __init__(self, model_size, factor, warmup, optimizer: FusedAdam):
+        self.optimizer = optimizer
+        self._step = 0
+        self.warmup, self.factor, self.model_size = warmup, factor, model_size
+        self._rate = 0
+
+    def step(self):
+        self._step += 1
+        self.optimizer.tick(self.factor, self.model_size, self.warmup)
+        self.optimizer.step()
+
+    def rate(self, step=None):
+        if step is None:
+            step = self._step
+        return self.factor * (self.model_size ** (-0.5) * min(step ** (-0.5), step * self.warmup ** (-1.5)))
+
+
+class SimpleLossCompute:
+    """generator -> label-smoothed KL (+ lambda * auto-encoder losses) -> backward -> optimiser step
+    (data_utils.py:123-156).  ``sync=False`` returns the device tensor instead of ``loss.item()*norm`` so that the
+    step contains no host synchronisation; ``grad_sync`` (optional callable) runs between backward and the
+    optimiser step — that is where data-parallel gradient all-reduce goes."""
+
+    def __init__(self, generator, ae_generator, criterion, opt=None, l=1.0, sync=True, grad_sync=None):
+        self.generator, self.ae_generator, self.criterion = generator, ae_generator, criterion
+        self.opt, self.l, self.sync, self.grad_sync = opt, l, sync, grad_sync
+
+    def loss(self, x, y, norm, ae_x=None, ae_y=None, ae_norm=None):
+        out = self.generator(x)
+        loss = self.criterion(out.reshape(-1, out.size(-1)), y.reshape(-1)) / norm.float()
+        if ae_x is not None:
+            xs = ae_x if isinstance(ae_x, (list, tuple)) else [ae_x]
+            for i, ae_in in enumerate(xs):
+                if self.ae_generator is not None:
+                    gen = self.ae_generator[i] if isinstance(ae_x, (list, tuple)) else self.ae_generator
+                else:
+                    gen = self.generator
+                ae_out = gen(ae_in)
+                loss = loss + self.l * self.criterion(ae_out.reshape(-1, ae_out.size(-1)), ae_y.reshape(-1)) / ae_norm.float()
+        return loss
+
+    def __call__(self, x, y, norm, ae_x=None, ae_y=None, ae_norm=None):
+        loss = self.loss(x, y, norm, ae_x, ae_y, ae_norm)
+        if self.opt is not None:
+            loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync()
+            self.opt.step()
+            self.opt.optimizer.zero_grad()
+        out = loss.detach() * norm.float()
+        return out.item() if self.sync else out

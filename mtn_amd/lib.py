@@ -1,0 +1,131 @@
+"""ctypes binding of libmtn_hip.so (C ABI in include/mtn_hip.h).
+
+The HIP library is the product path: if it is missing this module raises — there is no
+CPU or PyTorch fallback behind these calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtn_hip.so")
+
+MTN_F32, MTN_BF16 = 0, 1
+
+
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("salt", C.c_uint32), ("seed", C.c_void_p)]
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("lda", C.c_int), ("ldb", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_trans", C.c_int), ("b_trans", C.c_int),
+                ("bias", C.c_void_p), ("relu", C.c_int), ("drop", Dropout),
+                ("gate", C.c_void_p), ("gate_scale", C.c_float),
+                ("residual", C.c_void_p), ("ldr", C.c_int),
+                ("out_f32", C.c_void_p), ("out_lp", C.c_void_p), ("ldc", C.c_int), ("rowsum_out", C.c_void_p)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("h", C.c_int), ("a", C.c_int), ("m", C.c_int), ("dk", C.c_int),
+                ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("ldq", C.c_int), ("ldkv", C.c_int),
+                ("mask", C.c_void_p), ("mask_sb", C.c_long), ("mask_sq", C.c_long), ("drop", Dropout),
+                ("o", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p),
+                ("d_o", C.c_void_p), ("dq", C.c_void_p), ("dk_out", C.c_void_p), ("dv_out", C.c_void_p)]
+
+
+class MhaArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("a", C.c_int), ("m", C.c_int), ("d", C.c_int), ("h", C.c_int),
+                ("self_attn", C.c_int), ("ln_eps", C.c_float), ("drop_attn", Dropout), ("drop_out", Dropout),
+                ("x", C.c_void_p), ("mem", C.c_void_p), ("mask", C.c_void_p), ("mask_sb", C.c_long), ("mask_sq", C.c_long),
+                ("ln_a", C.c_void_p), ("ln_b", C.c_void_p), ("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p),
+                ("w_o", C.c_void_p), ("b_o", C.c_void_p),
+                ("y", C.c_void_p), ("xn", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("qkv", C.c_void_p), ("kv", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+                ("dy", C.c_void_p), ("dx", C.c_void_p), ("dmem", C.c_void_p), ("dmem_accumulate", C.c_int),
+                ("d_ln_a", C.c_void_p), ("d_ln_b", C.c_void_p),
+                ("d_w_qkv", C.c_void_p), ("d_b_qkv", C.c_void_p), ("d_w_o", C.c_void_p), ("d_b_o", C.c_void_p),
+                ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p)]
+
+
+class FfnArgs(C.Structure):
+    _fields_ = [("rows", C.c_int), ("d", C.c_int), ("d_ff", C.c_int), ("ln_eps", C.c_float),
+                ("drop_hidden", Dropout), ("drop_out", Dropout),
+                ("x", C.c_void_p), ("ln_a", C.c_void_p), ("ln_b", C.c_void_p),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("y", C.c_void_p), ("xn", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("hid", C.c_void_p),
+                ("dy", C.c_void_p), ("dx", C.c_void_p),
+                ("d_ln_a", C.c_void_p), ("d_ln_b", C.c_void_p), ("d_w1", C.c_void_p), ("d_b1", C.c_void_p),
+                ("d_w2", C.c_void_p), ("d_b2", C.c_void_p),
+                ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p)]
+
+
+# every symbol include/mtn_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "mtn_last_error": (C.c_char_p, []),
+    "mtn_version": (C.c_int, []),
+    "mtn_gemm": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
+    "mtn_layernorm_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mtn_layernorm_bwd_partial_floats": (C.c_long, [C.c_int, C.c_int]),
+    "mtn_layernorm_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mtn_attention_fwd": (C.c_int, [C.c_int, C.POINTER(AttnArgs), _P]),
+    "mtn_attention_bwd": (C.c_int, [C.c_int, C.POINTER(AttnArgs), _P]),
+    "mtn_mha_sublayer_fwd": (C.c_int, [C.c_int, C.POINTER(MhaArgs), _P]),
+    "mtn_mha_sublayer_bwd": (C.c_int, [C.c_int, C.POINTER(MhaArgs), _P]),
+    "mtn_mha_bwd_ws_lp_elems": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mtn_mha_bwd_ws_f32_floats": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mtn_ffn_sublayer_fwd": (C.c_int, [C.c_int, C.POINTER(FfnArgs), _P]),
+    "mtn_ffn_sublayer_bwd": (C.c_int, [C.c_int, C.POINTER(FfnArgs), _P]),
+    "mtn_ffn_bwd_ws_f32_floats": (C.c_long, [C.c_int, C.c_int, C.c_int]),
+    "mtn_cast_f32_to_lp": (C.c_int, [C.c_int, C.c_long, _P, _P, _P]),
+    "mtn_dropout_bwd_to_lp": (C.c_int, [C.c_int, C.c_long, _P, Dropout, _P, _P]),
+    "mtn_noam_tick": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
+    "mtn_adam_step": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
+}
+
+_lib = None
+
+
+class MtnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library or raise.  No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MtnHipError(f"{LIB_PATH} is missing: build it with `python -m mtn_amd.build` "
+                          "(hipcc --offload-arch=gfx950).  mtn_amd has no CPU/PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)             # AttributeError here = ABI drift: fail loudly
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise MtnHipError(f"libmtn_hip error {rc}: {load().mtn_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return MTN_F32
+    if dt == torch.bfloat16:
+        return MTN_BF16
+    raise ValueError(f"unsupported compute dtype {dt}")

@@ -1,0 +1,529 @@
+"""MTN model on MI355X: same ``make_model()`` / module-tree / ``state_dict`` surface as the reference's
+mtn.py, with the decoder hot path executed by fused HIP sublayer kernels (mtn_amd.ops).
+
+What is kept from the reference (so that run.sh / train.py / generate.py-style callers drop in):
+  * ``make_model(src_vocab, tgt_vocab, N, d_model, d_ff, h, dropout, separate_his_embed, separate_cap_embed,
+    ft_sizes, diff_encoder, diff_embed, diff_gen, auto_encoder_ft, auto_encoder_attn)``  (mtn.py:332-337)
+  * ``EncoderDecoder.forward(b) / encode(...) / decode(...) / vid_encode(...)``, ``.generator``,
+    ``.auto_encoder_generator``                                                         (mtn.py:28-60)
+  * the state_dict key schema, so reference checkpoints load with ``load_state_dict``.
+What is different: parameters live in ONE flat fp32 buffer (plus a flat compute-dtype copy and a flat
+gradient buffer) laid out so that the q/k/v Linears of every attention are one [3d,d] matrix; sublayers run as
+LayerNorm -> MFMA GEMM -> attention -> GEMM(+bias,+dropout,+residual) kernel chains; backward writes
+parameter gradients straight into the flat gradient buffer (what the RCCL all-reduce and the fused Adam
+consume).  Embedding lookup, positional encoding, the feature Linear and the generator are plain
+PyTorch-ROCm ops (glue, <5 % of FLOPs).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import lib as L
+from . import ops
+
+ATTN_DROPOUT_DEFAULT = 0.1   # mtn.py:339 builds MultiHeadedAttention(h, d_model) without forwarding `dropout`
+
+
+# ------------------------------------------------------------------------------------------ leaf modules
+class LayerNorm(nn.Module):
+    """a_2 * (x - mean) / (std_unbiased + eps) + b_2  (mtn.py:103-114) on the HIP kernel."""
+
+    def __init__(self, features: int, eps: float = 1e-6):
+        super().__init__()
+        self.a_2 = nn.Parameter(torch.ones(features))
+        self.b_2 = nn.Parameter(torch.zeros(features))
+        self.eps = eps
+        self._grads = None          # (flat-grad views) once the owner model is flattened
+        self._lp_dtype = None
+
+    def forward_lp(self, x):
+        ga, gb = self._grads if self._grads is not None else (None, None)
+        return ops.layer_norm(x, self.a_2, self.b_2, self.eps, self._lp_dtype, ga, gb)
+
+    def forward(self, x):
+        return self.forward_lp(x)[0]
+
+
+class MultiHeadedAttention(nn.Module):
+    """Parameter container + standalone operator for mtn.py:233-267.  ``linears[0..2]`` = q,k,v input
+    projections, ``linears[3]`` = output projection."""
+
+    def __init__(self, h: int, d_model: int, dropout: float = ATTN_DROPOUT_DEFAULT):
+        super().__init__()
+        assert d_model % h == 0
+        self.d_k = d_model // h
+        self.h = h
+        self.linears = nn.ModuleList([nn.Linear(d_model, d_model) for _ in range(4)])
+        self.attn = None
+        self.p = dropout
+        self._fused = None          # dict of fused views, set by EncoderDecoder._flatten
+
+    def fused(self):
+        if self._fused is None:     # stand-alone use (tests): build packed weights on the fly, grads via autograd
+            w = torch.cat([self.linears[i].weight for i in range(3)], 0)
+            b = torch.cat([self.linears[i].bias for i in range(3)], 0)
+            return dict(w_qkv=w, b_qkv=b, w_o=self.linears[3].weight, b_o=self.linears[3].bias,
+                        w_qkv_lp=None, w_o_lp=None, grads=None)
+        return self._fused
+
+    def forward(self, query, key, value, mask=None):
+        """Un-fused operator form (projections + attention core + output projection), no residual/LayerNorm."""
+        lp = torch.bfloat16 if self._fused is None else self._fused["lp_dtype"]
+        f = self.fused()
+        B, a, d = query.shape
+        wq, wk, wv = f["w_qkv"][:d], f["w_qkv"][d:2 * d], f["w_qkv"][2 * d:]
+        bq, bk, bv = f["b_qkv"][:d], f["b_qkv"][d:2 * d], f["b_qkv"][2 * d:]
+        q = ops.linear(query, wq, bq, lp)
+        k = ops.linear(key, wk, bk, lp)
+        v = ops.linear(value, wv, bv, lp)
+        o = ops.AttentionCoreFn.apply(q, k, v, mask, self.h, self.p if self.training else 0.0, None, 0)
+        return ops.linear(o, f["w_o"], f["b_o"], lp, out_f32=True)
+
+
+class PositionwiseFeedForward(nn.Module):
+    """Parameter container for mtn.py:269-280."""
+
+    def __init__(self, d_model: int, d_ff: int, dropout: float = 0.1):
+        super().__init__()
+        self.w_1 = nn.Linear(d_model, d_ff)
+        self.w_2 = nn.Linear(d_ff, d_model)
+        self.p = dropout
+        self._fused = None
+
+    def fused(self):
+        if self._fused is None:
+            return dict(w1=self.w_1.weight, b1=self.w_1.bias, w2=self.w_2.weight, b2=self.w_2.bias,
+                        w1_lp=None, w2_lp=None, grads=None)
+        return self._fused
+
+    def forward(self, x):
+        lp = torch.bfloat16 if self._fused is None else self._fused["lp_dtype"]
+        f = self.fused()
+        hdn = ops.linear(x, f["w1"], f["b1"], lp, relu=True)
+        if self.training and self.p > 0:
+            hdn = F.dropout(hdn, self.p)
+        return ops.linear(hdn, f["w2"], f["b2"], lp, out_f32=True)
+
+
+class SublayerConnection(nn.Module):
+    """x + dropout(sublayer(norm(x)))  (mtn.py:116-127).  ``attend`` / ``feed`` are the fused fast paths the
+    DecoderLayer uses; ``forward(x, sublayer)`` keeps the reference's generic callable form."""
+
+    def __init__(self, size: int, dropout: float):
+        super().__init__()
+        self.norm = LayerNorm(size)
+        self.p = dropout
+        self.salt = 0
+        self._owner = None          # EncoderDecoder (for compute dtype / dropout seed); set at flatten
+
+    def _ctx(self):
+        o = self._owner
+        if o is None:
+            return torch.bfloat16, None
+        return o.compute_dtype, (o._seed if self.training else None)
+
+    def attend(self, x, attn: MultiHeadedAttention, mem, mask):
+        lp, seed = self._ctx()
+        f = attn.fused()
+        g = None
+        if f["grads"] is not None and self.norm._grads is not None:
+            g = dict(f["grads"], ln_a=self.norm._grads[0], ln_b=self.norm._grads[1])
+        cfg = ops.MhaConfig(heads=attn.h, eps=self.norm.eps,
+                            p_attn=attn.p if self.training else 0.0, p_out=self.p if self.training else 0.0,
+                            salt=self.salt, seed=seed, lp_dtype=lp, w_qkv_lp=f["w_qkv_lp"], w_o_lp=f["w_o_lp"], grads=g)
+        mem_lp = getattr(mem, "_mtn_lp", None) if mem is not None else None
+        if mem_lp is not None and mem_lp.dtype != lp:
+            mem_lp = None
+        return ops.MHASublayerFn.apply(x, mem, mem_lp, mask, self.norm.a_2, self.norm.b_2,
+                                       f["w_qkv"], f["b_qkv"], f["w_o"], f["b_o"], cfg)
+
+    def feed(self, x, ff: PositionwiseFeedForward):
+        lp, seed = self._ctx()
+        f = ff.fused()
+        g = None
+        if f["grads"] is not None and self.norm._grads is not None:
+            g = dict(f["grads"], ln_a=self.norm._grads[0], ln_b=self.norm._grads[1])
+        cfg = ops.FfnConfig(eps=self.norm.eps, p_hidden=ff.p if self.training else 0.0,
+                            p_out=self.p if self.training else 0.0, salt=self.salt, seed=seed, lp_dtype=lp,
+                            w1_lp=f["w1_lp"], w2_lp=f["w2_lp"], grads=g)
+        return ops.FFNSublayerFn.apply(x, self.norm.a_2, self.norm.b_2, f["w1"], f["b1"], f["w2"], f["b2"], cfg)
+
+    def forward(self, x, sublayer, mem=None, mask=None, self_attention=False):
+        """``sublayer`` is a MultiHeadedAttention (with ``mem``/``mask``; ``self_attention`` -> key=value=norm(x)), a
+        PositionwiseFeedForward (as the reference passes it, mtn.py:213,218) or any callable (generic, un-fused)."""
+        if isinstance(sublayer, MultiHeadedAttention):
+            return self.attend(x, sublayer, None if self_attention else mem, mask)
+        if isinstance(sublayer, PositionwiseFeedForward):
+            return self.feed(x, sublayer)
+        y = sublayer(self.norm(x))
+        if self.training and self.p > 0:
+            y = F.dropout(y, self.p)
+        return x + y
+
+
+class DecoderLayer(nn.Module):
+    """One MTN block (mtn.py:166-218): 4 text attentions, per-modality query-aware auto-encoder
+    (self-attn, attend-to-video, FFN) + attend-to-auto-encoder, final FFN: 5+4F fused sublayers."""
+
+    def __init__(self, size, self_attn, cap_attn, his_attn, q_attn, auto_encoder_self_attn, auto_encoder_vid_attn,
+                 auto_encoder_attn, feed_forward, auto_encoder_feed_forward, dropout):
+        super().__init__()
+        self.size = size
+        self.self_attn = self_attn
+        self.src_attn = q_attn
+        self.feed_forward = feed_forward
+        self.his_attn = his_attn
+        self.cap_attn = cap_attn
+        self.auto_encoder_attn = auto_encoder_attn
+        self.auto_encoder_self_attn = auto_encoder_self_attn
+        self.auto_encoder_vid_attn = auto_encoder_vid_attn
+        self.auto_encoder_feed_forward = auto_encoder_feed_forward
+        self.sublayer = nn.ModuleList([SublayerConnection(size, dropout) for _ in range(5 + 4 * len(auto_encoder_vid_attn))])
+
+    def forward(self, x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask,
+                ae_fts, ae_features):
+        sl = self.sublayer
+        x = sl[0](x, self.self_attn, None, tgt_mask, True)
+        x = sl[1](x, self.his_attn, his_memory, his_mask)
+        if ae_features in ("caption", "summary"):
+            x = sl[2](x, self.src_attn, q_memory, q_mask)
+            x = sl[3](x, self.cap_attn, cap_memory, cap_mask)
+            if ae_fts is None:
+                ae_fts = cap_memory
+            ae_mask = cap_mask
+        elif ae_features == "query":
+            x = sl[2](x, self.cap_attn, cap_memory, cap_mask)
+            x = sl[3](x, self.src_attn, q_memory, q_mask)
+            if ae_fts is None:
+                ae_fts = q_memory
+            ae_mask = q_mask
+        else:
+            raise ValueError("auto_encoder_ft must be 'query', 'caption' or 'summary' (reference: mtn.py:187-202)")
+        k = 4
+        out_ae = []
+        for i, vid_ft in enumerate(vid_fts):
+            ae = ae_fts[i] if isinstance(ae_fts, (list, tuple)) else ae_fts
+            ae = sl[k](ae, self.auto_encoder_self_attn[i], None, ae_mask, True); k += 1
+            ae = sl[k](ae, self.auto_encoder_vid_attn[i], vid_ft, vid_mask[i]); k += 1
+            ae = sl[k](ae, self.auto_encoder_feed_forward[i]); k += 1
+            x = sl[k](x, self.auto_encoder_attn[i], ae, ae_mask); k += 1
+            out_ae.append(ae)
+        return sl[k](x, self.feed_forward), out_ae
+
+
+class Decoder(nn.Module):
+    """N DecoderLayers + final LayerNorms (mtn.py:149-164)."""
+
+    def __init__(self, make_layer, N: int, ft_sizes: Sequence[int]):
+        super().__init__()
+        self.layers = nn.ModuleList([make_layer() for _ in range(N)])
+        size = self.layers[0].size
+        self.norm = LayerNorm(size)
+        self.ae_norm = nn.ModuleList([LayerNorm(size) for _ in ft_sizes])
+
+    def forward(self, vid_ft, vid_mask, x, his_memory, his_mask, cap_memory, cap_mask, query_memory, query_mask, tgt_mask,
+                auto_encoded_ft, auto_encoded_features):
+        for layer in self.layers:
+            x, auto_encoded_ft = layer(x, cap_memory, cap_mask, his_memory, his_mask, query_memory, query_mask, tgt_mask,
+                                       vid_ft, vid_mask, auto_encoded_ft, auto_encoded_features)
+        return self.norm(x), [self.ae_norm[i](ft) for i, ft in enumerate(auto_encoded_ft)]
+
+
+class Encoder(nn.Module):
+    """Bank of LayerNorms applied to the (possibly nested) input streams in order (mtn.py:75-101).
+    Each output carries its compute-dtype copy (``._mtn_lp``) for use as attention memory."""
+
+    def __init__(self, size: int, nb_layers: int):
+        super().__init__()
+        self.norm = nn.ModuleList([LayerNorm(size) for _ in range(nb_layers)])
+        self.nb_layers = nb_layers
+
+    def _apply_norm(self, i, x):
+        y, y_lp = self.norm[i].forward_lp(x)
+        y._mtn_lp = y_lp
+        return y
+
+    def forward(self, *seqs):
+        out, i = [], 0
+        for s in seqs:
+            if i >= self.nb_layers:
+                break
+            if isinstance(s, (list, tuple)):
+                ys = []
+                for t in s:
+                    ys.append(self._apply_norm(i, t)); i += 1
+                out.append(ys)
+            else:
+                out.append(self._apply_norm(i, s)); i += 1
+        return out
+
+
+class Embeddings(nn.Module):
+    def __init__(self, d_model: int, vocab: int):
+        super().__init__()
+        self.lut = nn.Embedding(vocab, d_model)
+        self.d_model = d_model
+
+    def forward(self, x):                      # mtn.py:288-289
+        return self.lut(x) * math.sqrt(self.d_model)
+
+
+class PositionalEncoding(nn.Module):
+    def __init__(self, d_model: int, dropout: float, max_len: int = 5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pos = torch.arange(0.0, max_len).unsqueeze(1)
+        div = torch.exp(torch.arange(0.0, d_model, 2) * -(math.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, d_model)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def forward(self, x):                      # mtn.py:307-309
+        return self.dropout(x + self.pe[:, : x.size(1)])
+
+
+class Generator(nn.Module):
+    def __init__(self, d_model: int, vocab: int):
+        super().__init__()
+        self.proj = nn.Linear(d_model, vocab)
+
+    def forward(self, x):                      # mtn.py:68-69
+        return F.log_softmax(self.proj(x), dim=-1)
+
+
+# ------------------------------------------------------------------------------------------ top level
+class EncoderDecoder(nn.Module):
+    def __init__(self, query_encoder, his_encoder, cap_encoder, vid_encoder, decoder, query_embed, his_embed, cap_embed,
+                 tgt_embed, generator, diff_encoder=False, auto_encoder_embed=None, auto_encoder_ft=None,
+                 auto_encoder_generator=None, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.query_encoder = query_encoder
+        self.his_encoder = his_encoder
+        self.cap_encoder = cap_encoder
+        self.vid_encoder = vid_encoder
+        self.decoder = decoder
+        self.query_embed = query_embed
+        self.his_embed = his_embed
+        self.cap_embed = cap_embed
+        self.tgt_embed = tgt_embed
+        self.generator = generator
+        self.diff_encoder = diff_encoder
+        self.auto_encoder_embed = auto_encoder_embed
+        self.auto_encoder_ft = auto_encoder_ft
+        self.auto_encoder_generator = auto_encoder_generator
+        self.compute_dtype = compute_dtype
+        self._flat = self._flat_lp = self._flat_grad = None
+        self._flat_version = -1
+        self._glue_numel = 0
+        self._layer_slices = []
+        self._seed = None
+
+    # ---- flat parameter storage ------------------------------------------------------------------
+    def _ordered_params(self):
+        """(glue params, path params) in flat-buffer order.  q/k/v weights (then biases) of every attention adjacent."""
+        seen, glue, path = set(), [], []
+
+        def add(lst, p):
+            if p is not None and id(p) not in seen:
+                seen.add(id(p)); lst.append(p)
+
+        def add_mha(m: MultiHeadedAttention):
+            for i in range(3):
+                add(path, m.linears[i].weight)
+            for i in range(3):
+                add(path, m.linears[i].bias)
+            add(path, m.linears[3].weight); add(path, m.linears[3].bias)
+
+        def add_ffn(f: PositionwiseFeedForward):
+            for p in (f.w_1.weight, f.w_1.bias, f.w_2.weight, f.w_2.bias):
+                add(path, p)
+
+        layer_marks = []
+        for n in self.query_encoder.norm:
+            add(path, n.a_2); add(path, n.b_2)
+        for layer in self.decoder.layers:
+            start = len(path)
+            for m in (layer.self_attn, layer.his_attn, layer.cap_attn, layer.src_attn):
+                add_mha(m)
+            for i in range(len(layer.auto_encoder_vid_attn)):
+                add_mha(layer.auto_encoder_self_attn[i]); add_mha(layer.auto_encoder_vid_attn[i])
+                add_ffn(layer.auto_encoder_feed_forward[i]); add_mha(layer.auto_encoder_attn[i])
+            add_ffn(layer.feed_forward)
+            for s in layer.sublayer:
+                add(path, s.norm.a_2); add(path, s.norm.b_2)
+            layer_marks.append((start, len(path)))
+        for n in [self.decoder.norm] + list(self.decoder.ae_norm):
+            add(path, n.a_2); add(path, n.b_2)
+        for p in self.parameters():            # everything else = glue (embeddings, feature Linear, generator)
+            if id(p) not in seen:
+                add(glue, p)
+        return glue, path, layer_marks
+
+    def _flatten(self):
+        """(Re)build the flat fp32 / compute-dtype / gradient buffers on the parameters' current device."""
+        glue, path, layer_marks = self._ordered_params()
+        params = glue + path
+        dev = params[0].device
+        pad = lambda n: (n + 7) // 8 * 8
+        offs, total = [], 0
+        for p in params:
+            offs.append(total); total += pad(p.numel())
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        for p, o in zip(params, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1).float())
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            p.grad = grad[o:o + p.numel()].view(p.shape)
+        self._flat, self._flat_grad = flat, grad
+        self._glue_numel = offs[len(glue)] if path else total
+        path_off = {id(p): o for p, o in zip(params, offs)}
+        self._layer_slices = [(path_off[id(path[s])], path_off[id(path[e - 1])] + pad(path[e - 1].numel())) for s, e in layer_marks]
+        lp = self.compute_dtype
+        self._flat_lp = torch.empty(total, device=dev, dtype=lp) if lp != torch.float32 else flat
+        self._flat_version = -1
+        if dev.type == "cuda":
+            if self._seed is None or self._seed.device != dev:
+                self._seed = torch.full((1,), torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, device=dev, dtype=torch.int64)
+
+        def views(p):
+            o = path_off[id(p)]
+            return flat[o:o + p.numel()].view(p.shape), self._flat_lp[o:o + p.numel()].view(p.shape), grad[o:o + p.numel()].view(p.shape)
+
+        def span(ps, shape):
+            o = path_off[id(ps[0])]
+            n = sum(p.numel() for p in ps)
+            assert all(path_off[id(ps[i + 1])] == path_off[id(ps[i])] + ps[i].numel() for i in range(len(ps) - 1)), "fused span not contiguous"
+            return flat[o:o + n].view(shape), self._flat_lp[o:o + n].view(shape), grad[o:o + n].view(shape)
+
+        for m in self.modules():
+            if isinstance(m, MultiHeadedAttention) and id(m.linears[0].weight) in path_off:
+                d = m.linears[0].weight.size(1)
+                w, wl, gw = span([m.linears[i].weight for i in range(3)], (3 * d, d))
+                b, _, gb = span([m.linears[i].bias for i in range(3)], (3 * d,))
+                wo, wol, gwo = views(m.linears[3].weight)
+                bo, _, gbo = views(m.linears[3].bias)
+                m._fused = dict(w_qkv=w, b_qkv=b, w_o=wo, b_o=bo, w_qkv_lp=wl, w_o_lp=wol, lp_dtype=lp,
+                                grads=dict(w_qkv=gw, b_qkv=gb, w_o=gwo, b_o=gbo))
+            elif isinstance(m, PositionwiseFeedForward) and id(m.w_1.weight) in path_off:
+                w1, w1l, g1 = views(m.w_1.weight); b1, _, gb1 = views(m.w_1.bias)
+                w2, w2l, g2 = views(m.w_2.weight); b2, _, gb2 = views(m.w_2.bias)
+                m._fused = dict(w1=w1, b1=b1, w2=w2, b2=b2, w1_lp=w1l, w2_lp=w2l, lp_dtype=lp,
+                                grads=dict(w1=g1, b1=gb1, w2=g2, b2=gb2))
+            elif isinstance(m, LayerNorm) and id(m.a_2) in path_off:
+                m._grads = (views(m.a_2)[2], views(m.b_2)[2])
+                m._lp_dtype = lp
+        for n, layer in enumerate(self.decoder.layers):
+            for k, s in enumerate(layer.sublayer):
+                object.__setattr__(s, "_owner", self)      # plain attribute: not a registered submodule
+                s.salt = n * 64 + k + 1
+
+    def _apply(self, fn, *a, **kw):             # .cuda()/.to(): parameters are re-created -> re-flatten
+        super()._apply(fn, *a, **kw)
+        self._flat = None
+        return self
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(dtype, dtype)
+        self._flat = None
+        return self
+
+    def prepare(self):
+        """Make flat buffers current: flatten if needed, refresh the compute-dtype weight copy if the fp32
+        master was modified by anything other than the fused optimiser (load_state_dict, a torch optimiser)."""
+        if self._flat is None:
+            self._flatten()
+        if self._flat_lp is not self._flat and self._flat._version != self._flat_version:
+            L.check(L.load().mtn_cast_f32_to_lp(L.dtype_code(self.compute_dtype), self._flat.numel(), self._flat.data_ptr(),
+                                                self._flat_lp.data_ptr(), L.stream_ptr()))
+            self._flat_version = self._flat._version
+        return self
+
+    def flat_buffers(self):
+        self.prepare()
+        return self._flat, self._flat_lp, self._flat_grad
+
+    def zero_glue_grads(self):
+        """Gradients of path parameters are overwritten by the kernels every step; only the autograd-accumulated
+        glue parameters (embeddings, feature Linear, generator) need zeroing."""
+        self._flat_grad[: self._glue_numel].zero_()
+
+    def advance_dropout_seed(self):
+        if self._seed is not None:
+            self._seed.add_(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF)
+
+    # ---- reference API ---------------------------------------------------------------------------
+    def forward(self, b):                      # mtn.py:28-30
+        q, v, cp, hs, ae = self.encode(b.query, b.query_mask, b.his, b.his_mask, b.cap, b.cap_mask, b.fts, b.fts_mask)
+        return self.decode(v, hs, cp, q, b.fts_mask, b.his_mask, b.cap_mask, b.query_mask, b.trg, b.trg_mask, ae)
+
+    def vid_encode(self, video_features, video_features_mask=None, encoded_query=None):   # mtn.py:32-36
+        return [self.vid_encoder[i](ft) for i, ft in enumerate(video_features)]
+
+    def encode(self, query, query_mask, his=None, his_mask=None, cap=None, cap_mask=None, vid=None, vid_mask=None):
+        """mtn.py:38-56 — every text stream goes through ``query_embed``; returns
+        [q_mem, [vid_mem], cap_mem, his_mem, ae] with ae = list of auto-encoder seeds or None."""
+        self.prepare()
+        if self.training:
+            self.advance_dropout_seed()
+        streams = [self.query_embed(query), self.vid_encode(vid, vid_mask), self.query_embed(cap), self.query_embed(his)]
+        if not self.diff_encoder:
+            out = self.query_encoder(*streams)
+            out.append(None)
+            return out
+        ft = cap if self.auto_encoder_ft in ("caption", "summary") else query
+        if self.auto_encoder_embed is not None:
+            ae = [self.auto_encoder_embed[i](ft) for i in range(len(vid))]
+        else:
+            ae = [self.query_embed(ft) for _ in range(len(vid))]
+        return self.query_encoder(*streams, ae)
+
+    def decode(self, encoded_vid_features, his_memory, cap_memory, query_memory, vid_features_mask, his_mask, cap_mask,
+               query_mask, tgt, tgt_mask, auto_encoded_ft):          # mtn.py:58-60
+        self.prepare()
+        return self.decoder(encoded_vid_features, vid_features_mask, self.tgt_embed(tgt), his_memory, his_mask, cap_memory,
+                            cap_mask, query_memory, query_mask, tgt_mask, auto_encoded_ft, self.auto_encoder_ft)
+
+
+def make_model(src_vocab, tgt_vocab, N=6, d_model=512, d_ff=2048, h=8, dropout=0.1, separate_his_embed=False,
+               separate_cap_embed=False, ft_sizes=None, diff_encoder=False, diff_embed=False, diff_gen=False,
+               auto_encoder_ft=None, auto_encoder_attn=False, compute_dtype="bf16", attn_dropout=ATTN_DROPOUT_DEFAULT):
+    """Same signature and defaults as mtn.py:332-337 (+ ``compute_dtype``: 'bf16' | 'fp32', and
+    ``attn_dropout`` exposing the reference's hard-wired attention-probability dropout of 0.1).
+    Xavier-uniform on every parameter with dim > 1, nn.Linear defaults for biases (mtn.py:410-412)."""
+    ft_sizes = list(ft_sizes or [])
+    F_ = len(ft_sizes)
+    attn = lambda: MultiHeadedAttention(h, d_model, attn_dropout)
+    ff = lambda: PositionwiseFeedForward(d_model, d_ff, dropout)
+    pos = lambda: PositionalEncoding(d_model, dropout)
+    embed = lambda vocab: nn.Sequential(Embeddings(d_model, vocab), pos())
+    query_embed, tgt_embed = embed(src_vocab), embed(tgt_vocab)
+    his_embed = embed(src_vocab) if separate_his_embed else None
+    cap_embed = embed(src_vocab) if separate_cap_embed else None
+    auto_encoder_embed = nn.ModuleList([embed(src_vocab) for _ in ft_sizes]) if diff_embed else None
+    query_encoder = Encoder(d_model, nb_layers=3 + (2 * F_ if diff_encoder else F_))
+    vid_encoder = nn.ModuleList([nn.Sequential(nn.Linear(fs, d_model), nn.ReLU(), pos()) for fs in ft_sizes])
+    generator = Generator(d_model, tgt_vocab)
+    auto_encoder_generator = nn.ModuleList([Generator(d_model, tgt_vocab) for _ in ft_sizes]) if diff_gen else None
+
+    def make_layer():
+        return DecoderLayer(d_model, attn(), attn(), attn(), attn(),
+                            nn.ModuleList([attn() for _ in ft_sizes]), nn.ModuleList([attn() for _ in ft_sizes]),
+                            nn.ModuleList([attn() for _ in ft_sizes]), ff(), nn.ModuleList([ff() for _ in ft_sizes]), dropout)
+
+    decoder = Decoder(make_layer, N, ft_sizes)
+    cd = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(compute_dtype, compute_dtype)
+    model = EncoderDecoder(query_encoder=query_encoder, his_encoder=None, cap_encoder=None, vid_encoder=vid_encoder,
+                           decoder=decoder, query_embed=query_embed, his_embed=his_embed, cap_embed=cap_embed,
+                           tgt_embed=tgt_embed, generator=generator, auto_encoder_generator=auto_encoder_generator,
+                           auto_encoder_embed=auto_encoder_embed, diff_encoder=diff_encoder, auto_encoder_ft=auto_encoder_ft,
+                           compute_dtype=cd)
+    for p in model.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+    return model

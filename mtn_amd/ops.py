@@ -1,0 +1,409 @@
+"""Operators of the MTN hot path, backed by libmtn_hip.so.
+
+Mirrors the reference's operator surface (mtn.py): ``LayerNorm.forward`` (:111-114),
+``SublayerConnection.forward`` ∘ ``MultiHeadedAttention.forward`` (:125-127, :248-267, :221-231) and
+``SublayerConnection.forward`` ∘ ``PositionwiseFeedForward.forward`` (:125-127, :279-280), each as one
+``torch.autograd.Function`` whose forward/backward enqueue the fused HIP kernel chains.  PyTorch is used
+for device memory, streams and autograd bookkeeping only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def _drop(p: float, salt: int, seed: Optional[torch.Tensor]) -> L.Dropout:
+    if p > 0.0 and seed is not None:
+        return L.Dropout(float(p), int(salt) & 0xFFFFFFFF, seed.data_ptr())
+    return L.Dropout(0.0, 0, None)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.MtnHipError("mtn_amd operators run on the GPU only (HIP kernels); got a CPU tensor")
+
+
+def _mask_u8(mask: Optional[torch.Tensor], B: int, a: int, m: int):
+    """Reference masks are bool (B|1, 1|a, m) (data_utils.py:34-53).  -> (uint8 tensor, batch stride, row stride)."""
+    if mask is None:
+        return None, 0, 0
+    if mask.dim() != 3 or mask.size(-1) != m:
+        raise ValueError(f"mask must be (B|1, 1|{a}, {m}); got {tuple(mask.shape)}")
+    mu = mask.to(torch.uint8).contiguous()
+    sb = 0 if mu.size(0) == 1 else mu.size(1) * m
+    sq = 0 if mu.size(1) == 1 else m
+    if mu.size(0) not in (1, B) or mu.size(1) not in (1, a):
+        raise ValueError(f"mask {tuple(mask.shape)} does not broadcast to ({B},{a},{m})")
+    return mu, sb, sq
+
+
+def gemm(dtype: int, problems):
+    """problems: list of lib.GemmProblem -> one grouped launch."""
+    arr = (L.GemmProblem * len(problems))(*problems)
+    L.check(L.load().mtn_gemm(dtype, len(problems), arr, L.stream_ptr()))
+
+
+def cast_to_lp(x: torch.Tensor, lp_dtype: torch.dtype) -> torch.Tensor:
+    _require_cuda(x)
+    if lp_dtype == torch.float32:
+        return x.contiguous()
+    x = x.contiguous()
+    out = torch.empty_like(x, dtype=lp_dtype)
+    L.check(L.load().mtn_cast_f32_to_lp(L.dtype_code(lp_dtype), x.numel(), x.data_ptr(), out.data_ptr(), L.stream_ptr()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+class LayerNormFn(torch.autograd.Function):
+    """mtn.py:111-114.  Returns (y_f32, y_lp); y_lp (compute dtype copy for GEMM operands) is non-differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, a2, b2, eps, lp_dtype, grad_a, grad_b):
+        _require_cuda(x, a2, b2)
+        x = x.contiguous()
+        d = x.size(-1)
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        want_lp = lp_dtype is not None and lp_dtype != torch.float32
+        y_lp = torch.empty_like(x, dtype=lp_dtype) if want_lp else None
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        code = L.dtype_code(lp_dtype) if want_lp else L.MTN_F32
+        L.check(L.load().mtn_layernorm_fwd(code, rows, d, eps, x.data_ptr(), a2.data_ptr(), b2.data_ptr(), y.data_ptr(),
+                                           L.ptr(y_lp), mean.data_ptr(), rstd.data_ptr(), L.stream_ptr()))
+        ctx.save_for_backward(x, a2, mean, rstd)
+        ctx.eps, ctx.grad_a, ctx.grad_b = eps, grad_a, grad_b
+        if y_lp is None:
+            y_lp = torch.empty(0, device=x.device, dtype=torch.float32)   # placeholder second output
+        ctx.mark_non_differentiable(y_lp)
+        return y, y_lp
+
+    @staticmethod
+    def backward(ctx, g, _g_lp):
+        x, a2, mean, rstd = ctx.saved_tensors
+        d = x.size(-1)
+        rows = x.numel() // d
+        g = g.contiguous()
+        lib = L.load()
+        dx = torch.empty_like(x)
+        da = ctx.grad_a if ctx.grad_a is not None else torch.empty_like(a2)
+        db = ctx.grad_b if ctx.grad_b is not None else torch.empty_like(a2)
+        partial = torch.empty(lib.mtn_layernorm_bwd_partial_floats(rows, d), device=x.device, dtype=torch.float32)
+        L.check(lib.mtn_layernorm_bwd(rows, d, ctx.eps, x.data_ptr(), a2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      g.data_ptr(), None, dx.data_ptr(), da.data_ptr(), db.data_ptr(), partial.data_ptr(),
+                                      L.stream_ptr()))
+        ret_a = None if ctx.grad_a is not None else da
+        ret_b = None if ctx.grad_b is not None else db
+        return dx, ret_a, ret_b, None, None, None, None
+
+
+def layer_norm(x, a2, b2, eps=1e-6, lp_dtype=None, grad_a=None, grad_b=None):
+    """-> (y fp32, y in the compute dtype).  grad_a/grad_b: optional fp32 destinations for da2/db2."""
+    y, y_lp = LayerNormFn.apply(x, a2, b2, eps, lp_dtype, grad_a, grad_b)
+    if y_lp.numel() == 0 and y.numel() != 0:
+        y_lp = y.detach()
+    return y, y_lp
+
+
+# ------------------------------------------------------------------------------------------ sublayers
+@dataclass
+class MhaConfig:
+    heads: int
+    eps: float = 1e-6
+    p_attn: float = 0.0           # dropout on softmax probabilities (mtn.py:230)
+    p_out: float = 0.0            # dropout on the sublayer output (mtn.py:127)
+    salt: int = 0                 # unique per sublayer: sites salt*4+{0,1}
+    seed: Optional[torch.Tensor] = None          # device int64[1], advanced once per step
+    lp_dtype: torch.dtype = torch.bfloat16
+    w_qkv_lp: Optional[torch.Tensor] = None      # compute-dtype copies of the weights ([3d,d], [d,d])
+    w_o_lp: Optional[torch.Tensor] = None
+    grads: Optional[dict] = None                 # fp32 destinations: ln_a ln_b w_qkv b_qkv w_o b_o (flat-grad views)
+
+
+class MHASublayerFn(torch.autograd.Function):
+    """y = x + dropout(MHA(LN(x), mem, mem, mask)).  mem=None -> self-attention (key=value=LN(x), mtn.py:183,209)."""
+
+    @staticmethod
+    def forward(ctx, x, mem, mem_lp, mask, ln_a, ln_b, w_qkv, b_qkv, w_o, b_o, cfg: MhaConfig):
+        _require_cuda(x, mem, ln_a, w_qkv)
+        lib = L.load()
+        x = x.contiguous()
+        B, a, d = x.shape
+        self_attn = mem is None
+        m = a if self_attn else mem.size(1)
+        lp = cfg.lp_dtype
+        code = L.dtype_code(lp)
+        dev = x.device
+        if not self_attn and mem_lp is None:
+            mem_lp = cast_to_lp(mem, lp)
+        w_qkv_lp = cfg.w_qkv_lp if cfg.w_qkv_lp is not None else cast_to_lp(w_qkv, lp)
+        w_o_lp = cfg.w_o_lp if cfg.w_o_lp is not None else cast_to_lp(w_o, lp)
+        mask_u8, sb, sq = _mask_u8(mask, B, a, m)
+        y = torch.empty_like(x)
+        xn = torch.empty(B * a, d, device=dev, dtype=lp)
+        mean = torch.empty(B * a, device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        qkv = torch.empty(B * a, 3 * d if self_attn else d, device=dev, dtype=lp)
+        kv = None if self_attn else torch.empty(B * m, 2 * d, device=dev, dtype=lp)
+        o = torch.empty(B * a, d, device=dev, dtype=lp)
+        lse = torch.empty(B * cfg.heads * a, device=dev, dtype=torch.float32)
+        args = L.MhaArgs()
+        args.B, args.a, args.m, args.d, args.h = B, a, m, d, cfg.heads
+        args.self_attn, args.ln_eps = int(self_attn), cfg.eps
+        args.drop_attn = _drop(cfg.p_attn, cfg.salt * 4 + 0, cfg.seed)
+        args.drop_out = _drop(cfg.p_out, cfg.salt * 4 + 1, cfg.seed)
+        args.x, args.mem = x.data_ptr(), L.ptr(mem_lp)
+        args.mask, args.mask_sb, args.mask_sq = L.ptr(mask_u8), sb, sq
+        args.ln_a, args.ln_b = ln_a.data_ptr(), ln_b.data_ptr()
+        args.w_qkv, args.b_qkv, args.w_o, args.b_o = w_qkv_lp.data_ptr(), b_qkv.data_ptr(), w_o_lp.data_ptr(), b_o.data_ptr()
+        args.y, args.xn, args.mean, args.rstd = y.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        args.qkv, args.kv, args.o, args.lse = qkv.data_ptr(), L.ptr(kv), o.data_ptr(), lse.data_ptr()
+        L.check(lib.mtn_mha_sublayer_fwd(code, C.byref(args), L.stream_ptr()))
+        ctx.save_for_backward(x, mem_lp, mask_u8, ln_a, ln_b, w_qkv_lp, b_qkv, w_o_lp, b_o, xn, mean, rstd, qkv, kv, o, lse)
+        ctx.cfg, ctx.dims, ctx.mask_strides = cfg, (B, a, m, d, self_attn), (sb, sq)
+        ctx.need_dmem = (not self_attn) and mem.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mem_lp, mask_u8, ln_a, ln_b, w_qkv_lp, b_qkv, w_o_lp, b_o, xn, mean, rstd, qkv, kv, o, lse = ctx.saved_tensors
+        cfg: MhaConfig = ctx.cfg
+        B, a, m, d, self_attn = ctx.dims
+        lib = L.load()
+        code = L.dtype_code(cfg.lp_dtype)
+        dev = x.device
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dmem = torch.empty(B, m, d, device=dev, dtype=torch.float32) if ctx.need_dmem else None
+        g = cfg.grads
+
+        def dst(name, like):
+            return g[name] if g is not None else torch.empty(like.shape, device=dev, dtype=torch.float32)
+
+        d_ln_a, d_ln_b = dst("ln_a", ln_a), dst("ln_b", ln_b)
+        d_w_qkv, d_b_qkv = dst("w_qkv", w_qkv_lp), dst("b_qkv", b_qkv)
+        d_w_o, d_b_o = dst("w_o", w_o_lp), dst("b_o", b_o)
+        ws_lp = torch.empty(lib.mtn_mha_bwd_ws_lp_elems(B, a, m, d, int(self_attn)), device=dev, dtype=cfg.lp_dtype)
+        ws_f32 = torch.empty(lib.mtn_mha_bwd_ws_f32_floats(B, a, m, d), device=dev, dtype=torch.float32)
+        args = L.MhaArgs()
+        args.B, args.a, args.m, args.d, args.h = B, a, m, d, cfg.heads
+        args.self_attn, args.ln_eps = int(self_attn), cfg.eps
+        args.drop_attn = _drop(cfg.p_attn, cfg.salt * 4 + 0, cfg.seed)
+        args.drop_out = _drop(cfg.p_out, cfg.salt * 4 + 1, cfg.seed)
+        args.x, args.mem = x.data_ptr(), L.ptr(mem_lp)
+        args.mask, args.mask_sb, args.mask_sq = L.ptr(mask_u8), ctx.mask_strides[0], ctx.mask_strides[1]
+        args.ln_a, args.ln_b = ln_a.data_ptr(), ln_b.data_ptr()
+        args.w_qkv, args.b_qkv, args.w_o, args.b_o = w_qkv_lp.data_ptr(), b_qkv.data_ptr(), w_o_lp.data_ptr(), b_o.data_ptr()
+        args.xn, args.mean, args.rstd = xn.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        args.qkv, args.kv, args.o, args.lse = qkv.data_ptr(), L.ptr(kv), o.data_ptr(), lse.data_ptr()
+        args.dy, args.dx, args.dmem, args.dmem_accumulate = dy.data_ptr(), dx.data_ptr(), L.ptr(dmem), 0
+        args.d_ln_a, args.d_ln_b = d_ln_a.data_ptr(), d_ln_b.data_ptr()
+        args.d_w_qkv, args.d_b_qkv, args.d_w_o, args.d_b_o = d_w_qkv.data_ptr(), d_b_qkv.data_ptr(), d_w_o.data_ptr(), d_b_o.data_ptr()
+        args.ws_lp, args.ws_f32 = ws_lp.data_ptr(), ws_f32.data_ptr()
+        L.check(lib.mtn_mha_sublayer_bwd(code, C.byref(args), L.stream_ptr()))
+        if g is not None:
+            return dx, dmem, None, None, None, None, None, None, None, None, None
+        return dx, dmem, None, None, d_ln_a, d_ln_b, d_w_qkv, d_b_qkv, d_w_o, d_b_o, None
+
+
+@dataclass
+class FfnConfig:
+    eps: float = 1e-6
+    p_hidden: float = 0.0         # mtn.py:280
+    p_out: float = 0.0            # mtn.py:127
+    salt: int = 0
+    seed: Optional[torch.Tensor] = None
+    lp_dtype: torch.dtype = torch.bfloat16
+    w1_lp: Optional[torch.Tensor] = None
+    w2_lp: Optional[torch.Tensor] = None
+    grads: Optional[dict] = None  # ln_a ln_b w1 b1 w2 b2
+
+
+class FFNSublayerFn(torch.autograd.Function):
+    """y = x + dropout(w_2(dropout(relu(w_1 LN(x)))))."""
+
+    @staticmethod
+    def forward(ctx, x, ln_a, ln_b, w1, b1, w2, b2, cfg: FfnConfig):
+        _require_cuda(x, ln_a, w1)
+        lib = L.load()
+        x = x.contiguous()
+        d = x.size(-1)
+        rows = x.numel() // d
+        ff = w1.size(0)
+        lp = cfg.lp_dtype
+        code = L.dtype_code(lp)
+        dev = x.device
+        w1_lp = cfg.w1_lp if cfg.w1_lp is not None else cast_to_lp(w1, lp)
+        w2_lp = cfg.w2_lp if cfg.w2_lp is not None else cast_to_lp(w2, lp)
+        y = torch.empty_like(x)
+        xn = torch.empty(rows, d, device=dev, dtype=lp)
+        mean = torch.empty(rows, device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        hid = torch.empty(rows, ff, device=dev, dtype=lp)
+        args = L.FfnArgs()
+        args.rows, args.d, args.d_ff, args.ln_eps = rows, d, ff, cfg.eps
+        args.drop_hidden = _drop(cfg.p_hidden, cfg.salt * 4 + 2, cfg.seed)
+        args.drop_out = _drop(cfg.p_out, cfg.salt * 4 + 1, cfg.seed)
+        args.x, args.ln_a, args.ln_b = x.data_ptr(), ln_a.data_ptr(), ln_b.data_ptr()
+        args.w1, args.b1, args.w2, args.b2 = w1_lp.data_ptr(), b1.data_ptr(), w2_lp.data_ptr(), b2.data_ptr()
+        args.y, args.xn, args.mean, args.rstd, args.hid = y.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), hid.data_ptr()
+        L.check(lib.mtn_ffn_sublayer_fwd(code, C.byref(args), L.stream_ptr()))
+        ctx.save_for_backward(x, ln_a, ln_b, w1_lp, b1, w2_lp, b2, xn, mean, rstd, hid)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ln_a, ln_b, w1_lp, b1, w2_lp, b2, xn, mean, rstd, hid = ctx.saved_tensors
+        cfg: FfnConfig = ctx.cfg
+        lib = L.load()
+        code = L.dtype_code(cfg.lp_dtype)
+        dev = x.device
+        d = x.size(-1)
+        rows = x.numel() // d
+        ff = w1_lp.size(0)
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        g = cfg.grads
+
+        def dst(name, like):
+            return g[name] if g is not None else torch.empty(like.shape, device=dev, dtype=torch.float32)
+
+        d_ln_a, d_ln_b = dst("ln_a", ln_a), dst("ln_b", ln_b)
+        d_w1, d_b1, d_w2, d_b2 = dst("w1", w1_lp), dst("b1", b1), dst("w2", w2_lp), dst("b2", b2)
+        ws_lp = torch.empty(rows * d + rows * ff, device=dev, dtype=cfg.lp_dtype)
+        ws_f32 = torch.empty(lib.mtn_ffn_bwd_ws_f32_floats(rows, d, ff), device=dev, dtype=torch.float32)
+        args = L.FfnArgs()
+        args.rows, args.d, args.d_ff, args.ln_eps = rows, d, ff, cfg.eps
+        args.drop_hidden = _drop(cfg.p_hidden, cfg.salt * 4 + 2, cfg.seed)
+        args.drop_out = _drop(cfg.p_out, cfg.salt * 4 + 1, cfg.seed)
+        args.x, args.ln_a, args.ln_b = x.data_ptr(), ln_a.data_ptr(), ln_b.data_ptr()
+        args.w1, args.b1, args.w2, args.b2 = w1_lp.data_ptr(), b1.data_ptr(), w2_lp.data_ptr(), b2.data_ptr()
+        args.xn, args.mean, args.rstd, args.hid = xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), hid.data_ptr()
+        args.dy, args.dx = dy.data_ptr(), dx.data_ptr()
+        args.d_ln_a, args.d_ln_b = d_ln_a.data_ptr(), d_ln_b.data_ptr()
+        args.d_w1, args.d_b1, args.d_w2, args.d_b2 = d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr()
+        args.ws_lp, args.ws_f32 = ws_lp.data_ptr(), ws_f32.data_ptr()
+        L.check(lib.mtn_ffn_sublayer_bwd(code, C.byref(args), L.stream_ptr()))
+        if g is not None:
+            return dx, None, None, None, None, None, None, None
+        return dx, d_ln_a, d_ln_b, d_w1, d_b1, d_w2, d_b2, None
+
+
+# ------------------------------------------------------------------------------------------ attention core (tests / decode)
+def attention(q, k, v, mask, heads: int, p_drop: float = 0.0, seed=None, salt: int = 0):
+    """mtn.py:221-231 on packed-head layouts: q (B,a,d), k/v (B,m,d) of the compute dtype.  Returns (o, lse)."""
+    _require_cuda(q, k, v)
+    B, a, d = q.shape
+    m = k.size(1)
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    o = torch.empty_like(q)
+    lse = torch.empty(B * heads * a, device=q.device, dtype=torch.float32)
+    mask_u8, sb, sq = _mask_u8(mask, B, a, m)
+    args = L.AttnArgs()
+    args.B, args.h, args.a, args.m, args.dk = B, heads, a, m, d // heads
+    args.q, args.k, args.v, args.ldq, args.ldkv = q.data_ptr(), k.data_ptr(), v.data_ptr(), d, d
+    args.mask, args.mask_sb, args.mask_sq = L.ptr(mask_u8), sb, sq
+    args.drop = _drop(p_drop, salt, seed)
+    args.o, args.ldo, args.lse = o.data_ptr(), d, lse.data_ptr()
+    L.check(L.load().mtn_attention_fwd(L.dtype_code(q.dtype), C.byref(args), L.stream_ptr()))
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, lse, d_o, mask, heads: int, p_drop: float = 0.0, seed=None, salt: int = 0):
+    B, a, d = q.shape
+    m = k.size(1)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    mask_u8, sb, sq = _mask_u8(mask, B, a, m)
+    args = L.AttnArgs()
+    args.B, args.h, args.a, args.m, args.dk = B, heads, a, m, d // heads
+    args.q, args.k, args.v, args.ldq, args.ldkv = q.data_ptr(), k.data_ptr(), v.data_ptr(), d, d
+    args.mask, args.mask_sb, args.mask_sq = L.ptr(mask_u8), sb, sq
+    args.drop = _drop(p_drop, salt, seed)
+    args.o, args.ldo, args.lse = o.data_ptr(), d, lse.data_ptr()
+    args.d_o, args.dq, args.dk_out, args.dv_out = d_o.contiguous().data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    L.check(L.load().mtn_attention_bwd(L.dtype_code(q.dtype), C.byref(args), L.stream_ptr()))
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------ un-fused operator forms
+class AttentionCoreFn(torch.autograd.Function):
+    """attention() of mtn.py:221-231 with autograd, on (B,L,d) packed-head tensors of the compute dtype."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, heads, p_drop, seed, salt):
+        o, lse = attention(q, k, v, mask, heads, p_drop, seed, salt)
+        ctx.save_for_backward(q.contiguous(), k.contiguous(), v.contiguous(), o, lse)
+        ctx.meta = (mask, heads, p_drop, seed, salt)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse = ctx.saved_tensors
+        mask, heads, p_drop, seed, salt = ctx.meta
+        dq, dk, dv = attention_bwd(q, k, v, o, lse, d_o.to(q.dtype), mask, heads, p_drop, seed, salt)
+        return dq, dk, dv, None, None, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = [relu](x W^T + b) on the MFMA GEMM (nn.Linear as used at mtn.py:243-244,273-276,378)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, lp_dtype, relu, out_f32):
+        _require_cuda(x, w)
+        code = L.dtype_code(lp_dtype)
+        K, N = w.size(1), w.size(0)
+        x2 = x.reshape(-1, K)
+        x_lp = x2.contiguous() if x2.dtype == lp_dtype else cast_to_lp(x2.float(), lp_dtype)
+        w_lp = w.contiguous() if w.dtype == lp_dtype else cast_to_lp(w.float(), lp_dtype)
+        M = x_lp.size(0)
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32 if out_f32 else lp_dtype)
+        p = L.GemmProblem()
+        p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K = x_lp.data_ptr(), w_lp.data_ptr(), K, K, M, N, K
+        p.bias, p.relu, p.gate_scale, p.ldc = L.ptr(b), int(relu), 1.0, N
+        if out.dtype == torch.float32:
+            p.out_f32 = out.data_ptr()
+        else:
+            p.out_lp = out.data_ptr()
+        gemm(code, [p])
+        ctx.save_for_backward(x_lp, w_lp, out if relu else None)
+        ctx.meta = (lp_dtype, relu, x.shape, x.dtype, b is not None)
+        return out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_lp, w_lp, out = ctx.saved_tensors
+        lp_dtype, relu, xshape, xdtype, has_b = ctx.meta
+        code = L.dtype_code(lp_dtype)
+        M, K = x_lp.shape
+        N = w_lp.size(0)
+        dy2 = dy.reshape(M, N)
+        if relu:
+            dy2 = dy2 * (out > 0).to(dy2.dtype)
+        dy_lp = dy2.contiguous() if dy2.dtype == lp_dtype else cast_to_lp(dy2.float(), lp_dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            p = L.GemmProblem()
+            p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K, p.b_trans = dy_lp.data_ptr(), w_lp.data_ptr(), N, K, M, K, N, 1
+            p.gate_scale, p.out_f32, p.ldc = 1.0, dx.data_ptr(), K
+            gemm(code, [p])
+            dx = dx.view(xshape).to(xdtype)
+        dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+        db = torch.empty(N, device=dy.device, dtype=torch.float32)
+        p = L.GemmProblem()
+        p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K, p.a_trans, p.b_trans = dy_lp.data_ptr(), x_lp.data_ptr(), N, K, N, K, M, 1, 1
+        p.gate_scale, p.out_f32, p.ldc, p.rowsum_out = 1.0, dw.data_ptr(), K, db.data_ptr()
+        gemm(code, [p])
+        return dx, dw, (db if has_b else None), None, None, None
+
+
+def linear(x, w, b, lp_dtype=torch.bfloat16, relu=False, out_f32=False):
+    return LinearFn.apply(x, w, b, lp_dtype, relu, out_f32)

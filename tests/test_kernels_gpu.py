@@ -1,0 +1,187 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against the CPU oracle's leaf functions
+(oracle/mtn_oracle.py, pinned to the reference by tests/test_oracle_golden.py) on the same seeded inputs."""
+import math
+
+import pytest
+import torch
+
+from tests.util import DTYPES, TOL, absmax, lp_round, relmax
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def _gemm_problem(L, A, B, M, N, K, at, bt, lda, ldb):
+    p = L.GemmProblem()
+    p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K, p.a_trans, p.b_trans, p.gate_scale = A.data_ptr(), B.data_ptr(), lda, ldb, M, N, K, at, bt, 1.0
+    return p
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (100, 72, 136), (640, 512, 512), (20, 1536, 128), (384, 128, 1000)])
+def test_gemm_layouts(dev, dtype, at, bt, M, N, K):
+    """Asymmetric random operands (catches row/col swaps of the MFMA fragment maps), ragged M/N/K."""
+    from mtn_amd import lib as L, ops
+    if at and M % 4: pytest.skip("transposed A needs M%4==0")
+    if bt and N % 4: pytest.skip("transposed B needs N%4==0")
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + at * 2 + bt)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g) * torch.linspace(0.5, 1.5, N).unsqueeze(1)
+    ref = lp_round(a, dtype).double() @ lp_round(b, dtype).double().t()
+    A = (a.t().contiguous() if at else a).to(dev, dtype)
+    B = (b.t().contiguous() if bt else b).to(dev, dtype)
+    out = torch.full((M, N), float("nan"), device=dev)
+    p = _gemm_problem(L, A, B, M, N, K, at, bt, A.size(1), B.size(1))
+    p.out_f32, p.ldc = out.data_ptr(), N
+    ops.gemm(L.dtype_code(dtype), [p])
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 1e-5      # operands pre-rounded: only accumulation order differs
+    assert relmax(out, ref) < tol * math.sqrt(K)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogue_and_group(dev, dtype):
+    """bias + relu + gate + residual + both outputs + row sums, three problems in one launch."""
+    from mtn_amd import lib as L, ops
+    g = torch.Generator().manual_seed(5)
+    probs, checks = [], []
+    for (M, N, K) in [(96, 128, 64), (33, 64, 256), (200, 192, 128)]:
+        a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        gate = torch.randn(M, N, generator=g)
+        A, B = a.to(dev, dtype), b.to(dev, dtype)
+        Bias, Res, Gate = bias.to(dev), res.to(dev), gate.to(dev, dtype)
+        of = torch.empty(M, N, device=dev)
+        ol = torch.empty(M, N, device=dev, dtype=dtype)
+        rs = torch.empty(M, device=dev)
+        p = _gemm_problem(L, A, B, M, N, K, 0, 0, K, K)
+        p.bias, p.relu, p.gate, p.gate_scale = Bias.data_ptr(), 1, Gate.data_ptr(), 1.25
+        p.residual, p.ldr, p.out_f32, p.out_lp, p.ldc, p.rowsum_out = Res.data_ptr(), N, of.data_ptr(), ol.data_ptr(), N, rs.data_ptr()
+        probs.append(p)
+        ar, br = lp_round(a, dtype).double(), lp_round(b, dtype).double()
+        v = torch.relu(ar @ br.t() + bias.double())
+        v = torch.where(lp_round(gate, dtype).double() > 0, v * 1.25, torch.zeros_like(v)) + res.double()
+        checks.append((of, ol, rs, v, ar.sum(1), (A, B, Bias, Res, Gate)))
+    ops.gemm(L.dtype_code(dtype), probs)
+    torch.cuda.synchronize()
+    for of, ol, rs, v, rsum, _keep in checks:
+        assert relmax(of, v) < 2e-4
+        assert relmax(ol.float(), v) < (1e-5 if dtype == torch.float32 else 1e-2)
+        assert relmax(rs, rsum) < 1e-4
+
+
+def test_gemm_rejects_misaligned(dev):
+    from mtn_amd import lib as L, ops
+    A = torch.zeros(64, 70, device=dev, dtype=torch.bfloat16)
+    p = _gemm_problem(L, A, A, 64, 64, 70, 0, 0, 70, 70)
+    out = torch.empty(64, 64, device=dev)
+    p.out_f32, p.ldc = out.data_ptr(), 64
+    with pytest.raises(L.MtnHipError):
+        ops.gemm(L.MTN_BF16, [p])
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,d", [(1, 64), (37, 128), (640, 512), (130, 2048)])
+def test_layernorm_fwd_bwd(dev, rows, d):
+    from mtn_amd import ops
+    from oracle.mtn_oracle import layer_norm as ref_ln
+    g = torch.Generator().manual_seed(rows + d)
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.3)
+    a2, b2 = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    gy = torch.randn(rows, d, generator=g)
+    xr, ar, br = x.clone().requires_grad_(), a2.clone().requires_grad_(), b2.clone().requires_grad_()
+    yr = ref_ln(xr, ar, br, 1e-6)
+    yr.backward(gy)
+    xd, ad, bd = x.to(dev).requires_grad_(), a2.to(dev).requires_grad_(), b2.to(dev).requires_grad_()
+    y, y_lp = ops.layer_norm(xd, ad, bd, 1e-6, torch.bfloat16)
+    y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    assert absmax(y, yr) < 1e-4
+    assert relmax(y_lp.float(), yr) < 1e-2
+    assert relmax(xd.grad, xr.grad) < 1e-4
+    assert relmax(ad.grad, ar.grad) < 1e-4
+    assert relmax(bd.grad, br.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ attention core
+def _attn_ref(q, k, v, mask, h):
+    from oracle.mtn_oracle import scaled_dot_attention
+    B, a, d = q.shape
+    sp = lambda t: t.reshape(B, -1, h, d // h).transpose(1, 2)
+    o, p = scaled_dot_attention(sp(q), sp(k), sp(v), None if mask is None else mask.unsqueeze(1))
+    return o.transpose(1, 2).reshape(B, a, d), p
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,h,a,m,dk,kind", [
+    (2, 4, 20, 20, 32, "causal"), (3, 8, 20, 128, 64, "pad"), (2, 2, 7, 37, 16, "pad"), (1, 4, 20, 300, 64, "pad"),
+    (2, 4, 33, 70, 64, "none"), (2, 8, 54, 54, 64, "causal")])
+def test_attention_fwd_bwd(dev, dtype, B, h, a, m, dk, kind):
+    """Causal / key-padding / absent masks, a fully masked row (uniform attention, zero score-gradient), key counts that
+    are not multiples of the 64/32-key tiles, multi-tile online softmax."""
+    from mtn_amd import ops
+    d = h * dk
+    g = torch.Generator().manual_seed(B * 100 + a + m)
+    q, k, v = (lp_round(torch.randn(B, L, d, generator=g), dtype) for L in (a, m, m))
+    go = lp_round(torch.randn(B, a, d, generator=g), dtype)
+    if kind == "causal":
+        mask = torch.tril(torch.ones(1, a, m, dtype=torch.bool)).expand(B, a, m).clone()
+        mask[0, :, -3:] = False
+    elif kind == "pad":
+        lens = torch.randint(1, m + 1, (B,), generator=g)
+        mask = (torch.arange(m).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(1)
+        mask[B - 1] = False                      # an empty memory: every score masked -> uniform attention
+    else:
+        mask = None
+    qr, kr, vr = q.clone().requires_grad_(), k.clone().requires_grad_(), v.clone().requires_grad_()
+    orf, _ = _attn_ref(qr, kr, vr, mask, h)
+    orf.backward(go)
+    qd, kd, vd = (t.to(dev, dtype) for t in (q, k, v))
+    md = None if mask is None else mask.to(dev)
+    o, lse = ops.attention(qd, kd, vd, md, h)
+    dq, dk_, dv = ops.attention_bwd(qd, kd, vd, o, lse, go.to(dev, dtype), md, h)
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert relmax(o.float(), orf) < tol
+    assert relmax(dq.float(), qr.grad) < tol * 2
+    assert relmax(dk_.float(), kr.grad) < tol * 2
+    assert relmax(dv.float(), vr.grad) < tol * 2
+
+
+def test_attention_dropout_statistics_and_consistency(dev):
+    """Keep-rate of the counter-based mask, and backward uses the same mask as forward: with V = identity-like
+    probes the dropped entries of P are visible in O, and dV must vanish exactly where P was dropped."""
+    from mtn_amd import ops
+    B, h, a, m, dk = 2, 2, 16, 64, 64
+    d = h * dk
+    seed = torch.tensor([12345], device=dev, dtype=torch.int64)
+    q = torch.zeros(B, a, d, device=dev)                      # uniform attention: P = 1/m everywhere
+    k = torch.randn(B, m, d, device=dev)
+    v = torch.zeros(B, m, d, device=dev)
+    for hh in range(h):
+        v[:, :, hh * dk:(hh + 1) * dk] = torch.eye(m, dk, device=dev)        # O[i, j] = Pdrop[i, j] for j < dk
+    o, lse = ops.attention(q, k, v, None, h, p_drop=0.25, seed=seed, salt=3)
+    kept = (o != 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.03
+    nz = o[o != 0]
+    assert torch.allclose(nz, torch.full_like(nz, (1.0 / m) / 0.75), rtol=1e-4)
+    o2, _ = ops.attention(q, k, v, None, h, p_drop=0.25, seed=seed, salt=3)
+    assert torch.equal(o, o2)                                  # pure function of (seed, salt, index)
+    o3, _ = ops.attention(q, k, v, None, h, p_drop=0.25, seed=seed + 1, salt=3)
+    assert not torch.equal(o, o3)
+    go = torch.zeros_like(o)
+    go[:, 0, :] = 1.0                                          # only query row 0 of every head sends gradient
+    _, _, dv = ops.attention_bwd(q, k, v, o, lse, go, None, h, p_drop=0.25, seed=seed, salt=3)
+    torch.cuda.synchronize()
+    for b in range(B):
+        for hh in range(h):
+            p_row0 = o[b, 0, hh * dk:(hh + 1) * dk]            # = Pdrop[0, j]
+            dv_col = dv[b, :dk, hh * dk]                       # dV[j, c] = Pdrop[0, j] * go[0, c]
+            assert torch.allclose(dv_col, p_row0, rtol=1e-4, atol=1e-7)

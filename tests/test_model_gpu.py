@@ -1,0 +1,258 @@
+"""GPU parity of the fused sublayers and of the whole model (forward, loss, gradients, optimiser steps, DP math)
+against the CPU oracle and the committed golden outputs of the reference (tests/golden, made by oracle/make_golden.py).
+
+Tolerances (BASELINE.json north_star): 1e-3 in fp32 mode, 1e-2 in bf16 mode, both as max|err| / max|ref| per tensor."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import mtn_oracle as orc
+from tests.util import DTYPES, TOL, absmax, relmax
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def build_model(c, dtype, dev, dropout=0.0, attn_dropout=0.0, seed=0):
+    """mtn_amd model loaded with the deterministic fixture weights."""
+    from mtn_amd import make_model
+    m = make_model(c["vocab"], c["vocab"], N=c["N"], d_model=c["d_model"], d_ff=c["d_ff"], h=c["h"], dropout=dropout,
+                   ft_sizes=c["ft_sizes"], diff_encoder=c["diff_encoder"], diff_embed=c["diff_embed"], diff_gen=c["diff_gen"],
+                   auto_encoder_ft=c["auto_encoder_ft"], compute_dtype=dtype, attn_dropout=attn_dropout)
+    sd = fx.det_state_dict(fx.state_shapes(**c), seed)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith(".pe") for k in missing), (missing, unexpected)
+    return m.to(dev)
+
+
+def dev_batch(raw, dev):
+    from mtn_amd import Batch
+    t = torch.from_numpy
+    return Batch(t(raw["query"]), t(raw["his"]), None, [t(f) for f in raw["fts"]], t(raw["cap"]), t(raw["trg"]), t(raw["trg_y"]),
+                 pad=fx.PAD, device=dev)
+
+
+def raw_batch(c, seed=1, **kw):
+    return fx.det_batch(c["vocab"], c["B"], c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=seed, **kw)
+
+
+# ------------------------------------------------------------------------------------------ fused sublayers
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cross", [False, True])
+def test_mha_sublayer_fwd_bwd(dev, dtype, cross):
+    from mtn_amd import ops
+    B, a, m, d, h = 3, 20, 37 if cross else 20, 128, 4
+    g = torch.Generator().manual_seed(11 + cross)
+    x = torch.randn(B, a, d, generator=g)
+    mem = torch.randn(B, m, d, generator=g) if cross else None
+    ln_a, ln_b = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    w = [torch.randn(d, d, generator=g) * d ** -0.5 for _ in range(4)]
+    b = [0.1 * torch.randn(d, generator=g) for _ in range(4)]
+    gy = torch.randn(B, a, d, generator=g)
+    if cross:
+        lens = torch.randint(1, m + 1, (B,), generator=g)
+        mask = (torch.arange(m).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(1)
+        mask[1] = False
+    else:
+        mask = orc.make_std_mask(torch.randint(0, 3, (B, a), generator=g), 1)
+    # oracle
+    leaves = [t.clone().requires_grad_() for t in [x, ln_a, ln_b] + w + b + ([mem] if cross else [])]
+    xr, ar, br = leaves[:3]
+    wr, bbr = leaves[3:7], leaves[7:11]
+    xn = orc.layer_norm(xr, ar, br)
+    kv = leaves[11] if cross else xn
+    yr = xr + orc.multi_head_attention(xn, kv, kv, mask, wr, bbr, h)
+    yr.backward(gy)
+    # HIP
+    D = lambda t: t.to(dev).requires_grad_()
+    xd, ad, bd = D(x), D(ln_a), D(ln_b)
+    wqkv, bqkv = D(torch.cat(w[:3], 0)), D(torch.cat(b[:3], 0))
+    wo, bo = D(w[3]), D(b[3])
+    memd = D(mem) if cross else None
+    cfg = ops.MhaConfig(heads=h, lp_dtype=dtype)
+    y = ops.MHASublayerFn.apply(xd, memd, None, mask.to(dev), ad, bd, wqkv, bqkv, wo, bo, cfg)
+    y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert relmax(y, yr) < tol
+    assert relmax(xd.grad, xr.grad) < tol * 2
+    assert relmax(ad.grad, ar.grad) < tol * 2 and relmax(bd.grad, br.grad) < tol * 2
+    assert relmax(wqkv.grad, torch.cat([t.grad for t in wr[:3]], 0)) < tol * 2
+    assert relmax(bqkv.grad, torch.cat([t.grad for t in bbr[:3]], 0)) < tol * 2
+    assert relmax(wo.grad, wr[3].grad) < tol * 2 and relmax(bo.grad, bbr[3].grad) < tol * 2
+    if cross:
+        assert relmax(memd.grad, leaves[11].grad) < tol * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ffn_sublayer_fwd_bwd(dev, dtype):
+    from mtn_amd import ops
+    rows, d, ff = 70, 128, 512
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, rows // 2, d, generator=g)
+    ln_a, ln_b = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    w1, b1 = torch.randn(ff, d, generator=g) * d ** -0.5, 0.1 * torch.randn(ff, generator=g)
+    w2, b2 = torch.randn(d, ff, generator=g) * ff ** -0.5, 0.1 * torch.randn(d, generator=g)
+    gy = torch.randn_like(x)
+    leaves = [t.clone().requires_grad_() for t in (x, ln_a, ln_b, w1, b1, w2, b2)]
+    yr = leaves[0] + orc.feed_forward(orc.layer_norm(leaves[0], leaves[1], leaves[2]), *leaves[3:])
+    yr.backward(gy)
+    dl = [t.to(dev).requires_grad_() for t in (x, ln_a, ln_b, w1, b1, w2, b2)]
+    y = ops.FFNSublayerFn.apply(*dl, ops.FfnConfig(lp_dtype=dtype))
+    y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert relmax(y, yr) < tol
+    for t, r in zip(dl, leaves):
+        assert relmax(t.grad, r.grad) < tol * 2
+
+
+# ------------------------------------------------------------------------------------------ whole model vs golden
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", list(fx.GOLDEN_CONFIGS))
+def test_model_forward_matches_reference_golden(dev, dtype, name):
+    """encode outputs, every sublayer output of layer 0, final (out, [ae]) and generator log-probs against the outputs the
+    REFERENCE produced for the same weights/inputs (ragged batch: padded tails, empty history row, padded frames)."""
+    c = fx.GOLDEN_CONFIGS[name]
+    g = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    model = build_model(c, dtype, dev).eval()
+    b = dev_batch(raw_batch(c), dev)
+    taps = {}
+    hooks = [sl.register_forward_hook(lambda mod, inp, out, k=k: taps.__setitem__(k, out.detach()))
+             for k, sl in enumerate(model.decoder.layers[0].sublayer)]
+    with torch.no_grad():
+        q, v, cp, hs, ae = model.encode(b.query, b.query_mask, b.his, b.his_mask, b.cap, b.cap_mask, b.fts, b.fts_mask)
+        out, ae_out = model.forward(b)
+        logp = model.generator(out)
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    T = lambda k: torch.from_numpy(g[k])
+    tol = TOL[dtype]
+    assert relmax(q, T("enc.q")) < tol and relmax(cp, T("enc.cap")) < tol and relmax(hs, T("enc.his")) < tol
+    for i, x in enumerate(v):
+        assert relmax(x, T(f"enc.vid.{i}")) < tol
+    for k in range(5 + 4 * len(c["ft_sizes"])):
+        assert relmax(taps[k], T(f"layer0.sublayer.{k}")) < tol, k
+    assert relmax(out, T("out")) < tol
+    for i, a in enumerate(ae_out):
+        assert relmax(a, T(f"ae_out.{i}")) < tol
+    assert relmax(logp, T("logp")) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", ["cfg1_query", "small_shared", "small_diffall"])
+def test_model_loss_and_grads_match_reference_golden(dev, dtype, name):
+    from mtn_amd import LabelSmoothing, SimpleLossCompute
+    c = fx.GOLDEN_CONFIGS[name]
+    g = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    model = build_model(c, dtype, dev).eval()        # eval(): dropout off, as in the golden run
+    b = dev_batch(raw_batch(c), dev)
+    crit = LabelSmoothing(c["vocab"], fx.PAD, 0.1)
+    lc = SimpleLossCompute(model.generator, model.auto_encoder_generator, crit, opt=None)
+    ae_y = b.cap if c["auto_encoder_ft"] in ("caption", "summary") else b.query
+    model.prepare(); model.zero_glue_grads()
+    out, ae_out = model.forward(b)
+    loss = lc.loss(out, b.trg_y, b.ntokens, ae_out, ae_y, (ae_y != fx.PAD).sum())
+    loss.backward()
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert abs(float(loss) - float(g["loss"])) < tol * max(1.0, abs(float(g["loss"])))
+    norms = dict(zip([str(s) for s in g["grad_names"]], g["grad_norms"]))
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for k, n in norms.items():
+        gr = params[k].grad
+        assert gr is not None, k
+        if "grad." + k in g:
+            e = relmax(gr, torch.from_numpy(g["grad." + k]))
+        else:
+            e = relmax(gr.reshape(-1)[:256], torch.from_numpy(g["gradhead." + k]))
+        gn = float(gr.double().norm())
+        e = max(e, abs(gn - n) / max(n, 1e-6)) if n > 1e-4 else e
+        worst = max(worst, e)
+        assert e < tol * 3, (k, e)
+    print(f"{name} {dtype}: worst grad rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_two_fused_adam_steps_match_reference_golden(dev, dtype):
+    """forward -> loss -> backward -> fused Noam/Adam step, twice, vs the reference's NoamOpt(Adam) (train.py:190)."""
+    from mtn_amd import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
+    name = "cfg1_query"
+    c = fx.GOLDEN_CONFIGS[name]
+    g = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    model = build_model(c, dtype, dev).eval()
+    b = dev_batch(raw_batch(c), dev)
+    opt = NoamOpt(c["d_model"], 1, 10, FusedAdam(model))
+    lc = SimpleLossCompute(model.generator, model.auto_encoder_generator, LabelSmoothing(c["vocab"], fx.PAD, 0.1), opt=opt)
+    losses = []
+    for _ in range(2):
+        out, ae_out = model.forward(b)
+        losses.append(lc(out, b.trg_y, b.ntokens, ae_out, b.query, (b.query != fx.PAD).sum()))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    np.testing.assert_allclose(losses, g["step_losses"], rtol=tol * 2)
+    sd = model.state_dict()
+    for k in g:
+        if k.startswith("after2."):
+            assert relmax(sd[k[7:]], torch.from_numpy(g[k])) < tol * 3, k
+        elif k.startswith("after2head."):
+            assert relmax(sd[k[11:]].reshape(-1)[:256], torch.from_numpy(g[k])) < tol * 3, k
+
+
+def test_dropout_training_step_runs_and_is_seed_deterministic(dev):
+    """train() mode: in-kernel dropout on attention probabilities, FFN hidden and sublayer outputs.  Same seed -> same
+    loss and gradients; advancing the seed changes them; gradients stay finite."""
+    from mtn_amd import LabelSmoothing, SimpleLossCompute
+    c = fx.GOLDEN_CONFIGS["cfg1_query"]
+    model = build_model(c, torch.bfloat16, dev, dropout=0.1, attn_dropout=0.1).train()
+    for mod in model.modules():                 # keep the PyTorch-side (glue) dropout out of the determinism check
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    b = dev_batch(raw_batch(c), dev)
+    lc = SimpleLossCompute(model.generator, None, LabelSmoothing(c["vocab"], fx.PAD, 0.1), opt=None)
+
+    def run(seed_val):
+        model.prepare(); model.zero_glue_grads()
+        model._seed.fill_(seed_val - (0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF))   # encode() advances it by this
+        out, ae_out = model.forward(b)
+        loss = lc.loss(out, b.trg_y, b.ntokens, ae_out, b.query, (b.query != fx.PAD).sum())
+        loss.backward()
+        return float(loss), model._flat_grad.clone()
+
+    l1, g1 = run(1000)
+    l2, g2 = run(1000)
+    l3, g3 = run(2000)
+    assert l1 == l2 and torch.equal(g1, g2)
+    assert l1 != l3
+    assert torch.isfinite(g1).all() and torch.isfinite(g3).all()
+    model.eval()
+    with torch.no_grad():
+        e1 = model.forward(b)[0]
+        e2 = model.forward(b)[0]
+    assert torch.equal(e1, e2)
+
+
+def test_state_dict_roundtrip_and_lowp_refresh(dev):
+    """load_state_dict into the flat buffers refreshes the compute-dtype weight copy (version-counter check)."""
+    c = fx.GOLDEN_CONFIGS["small_shared"]
+    m1 = build_model(c, torch.bfloat16, dev, seed=0).eval()
+    m2 = build_model(c, torch.bfloat16, dev, seed=1).eval()
+    b = dev_batch(raw_batch(c), dev)
+    with torch.no_grad():
+        o1 = m1.forward(b)[0]
+        o2 = m2.forward(b)[0]
+        assert relmax(o1, o2) > 1e-2
+        m2.load_state_dict(m1.state_dict())
+        o3 = m2.forward(b)[0]
+    assert torch.equal(o1, o3)
