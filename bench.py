@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py — train-step throughput of the MTN hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the reference's batch loop body (train.py:29-40 + data_utils.py:133-156) over one synthetic
+batch already resident in HBM: forward -> generator + label-smoothed loss (main + 2 auto-encoder terms) -> backward ->
+[RCCL all-reduce of the flat gradient] -> Adam/Noam update.  Workload at every N: BASELINE.json configs[1] shapes
+(d_model=512, 6 layers, 8 heads, d_ff=2048, |V|=3000, Q/H/C/T=20/128/40/20, 32 I3D(2048)+32 VGGish(128) frames), 32
+samples PER GPU (weak scaling), bf16 compute with fp32 master weights / residual stream / statistics, dropout 0.1 on
+(in-kernel), random-init weights, synthetic data.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+SURVEY_GFLOP_PER_SAMPLE = {"cfg2": 15.90, "cfg4": 33.22, "cfg1": 0.315}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg4"])
+    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--bf16-grad-allreduce", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(model, cfg, B, steps):
+    """The CPU oracle (PyTorch-CPU fp32 restatement of the reference, oracle/mtn_oracle.py) running the same step on
+    the host cores of this box: forward -> loss -> backward -> Adam/Noam.  Bounded sample: 1 warm-up + `steps` steps."""
+    from oracle import fixtures as fx
+    from oracle.mtn_oracle import OracleConfig, OracleMTN, noam_rate
+    ocfg = OracleConfig(vocab=cfg["vocab"], n_layers=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], heads=cfg["h"],
+                        ft_sizes=tuple(cfg["ft_sizes"]), diff_encoder=True, auto_encoder_ft="query")
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items() if not k.endswith(".pe")}
+    om = OracleMTN(ocfg, sd)
+    raw = fx.det_batch(cfg["vocab"], B, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], seed=1, ragged=False)
+    ob = fx.oracle_batch(raw)
+    opt = torch.optim.Adam(list(sd.values()), lr=0.0, betas=(0.9, 0.98), eps=1e-9)
+    times = []
+    for s in range(steps + 1):
+        t0 = time.perf_counter()
+        out, ae = om.forward(ob)
+        loss = om.loss(ob, out, ae)
+        opt.zero_grad()
+        loss.backward()
+        for gparam in opt.param_groups:
+            gparam["lr"] = noam_rate(s + 1, cfg["d_model"], 4000)
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} train steps (after 1 warm-up) of the same workload, batch {B}, fp32, dropout off; median step {med:.3f} s; nproc={os.cpu_count()}"}
+
+
+def gemm_kernel_roofline(dev, dtype_code, lp_dtype):
+    """Live HIP-event timing of the dominant kernel (grouped MFMA GEMM, forward layout) at the largest shape of the
+    step: the history K/V projection [B*H=4096, 2d=1024] x K=512.  Algorithmic FLOPs = 2*M*N*K per launch."""
+    from mtn_amd import lib as L, ops
+    M, N, K = 4096, 1024, 512
+    A = torch.randn(M, K, device=dev).to(lp_dtype)
+    W = torch.randn(N, K, device=dev).to(lp_dtype)
+    bias = torch.zeros(N, device=dev)
+    out = torch.empty(M, N, device=dev, dtype=lp_dtype)
+    p = L.GemmProblem()
+    p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K, p.gate_scale = A.data_ptr(), W.data_ptr(), K, K, M, N, K, 1.0
+    p.bias, p.out_lp, p.ldc = bias.data_ptr(), out.data_ptr(), N
+    for _ in range(5):
+        ops.gemm(dtype_code, [p])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 50
+    e0.record()
+    for _ in range(n):
+        ops.gemm(dtype_code, [p])
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
+    return {"kernel": "gemm_kernel<bf16,N,N> 64x64 tile", "shape": [M, N, K], "us_per_launch": round(us, 2), "achieved": round(tf, 1)}
+
+
+def main():
+    args = parse()
+    from mtn_amd import dp, lib, make_model
+    from mtn_amd.synthetic import CONFIGS, flops_per_sample, synthetic_batch
+    from mtn_amd.train_step import TrainStep
+
+    rank, world, local = dp.init_distributed()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib.load()
+    cfg = dict(CONFIGS[args.workload])
+    B = args.batch_per_gpu or cfg["B"]
+    lp = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(0)                       # identical replicas: same seed -> same make_model init on every rank
+    model = make_model(cfg["vocab"], cfg["vocab"], N=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"],
+                       dropout=args.dropout, ft_sizes=cfg["ft_sizes"], diff_encoder=True, diff_embed=False, diff_gen=False,
+                       auto_encoder_ft="query", compute_dtype=lp, attn_dropout=0.1 if args.dropout > 0 else 0.0)
+    model.to(dev).train()
+    model.prepare()
+    sync = None
+    if world > 1:
+        sync = dp.GradSync(lambda: model.flat_buffers()[2], compress_bf16=args.bf16_grad_allreduce)
+        sync.broadcast_(model._flat)
+        model._flat_version = -1
+        model.prepare()
+    batch = synthetic_batch(cfg["vocab"], B, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"],
+                            device=dev, seed=1 + rank, ragged=False)
+    step = TrainStep(model, batch, cfg["vocab"], pad=1, warmup=4000, grad_sync=sync, use_graph=not args.no_graph)
+
+    for _ in range(max(1, args.warmup)):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        loss = step()
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss_val = float(loss.item()) / float(batch.ntokens)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        gflop = SURVEY_GFLOP_PER_SAMPLE.get(args.workload) if (args.workload != "cfg2" or True) else None
+        gflop_formula = flops_per_sample(**cfg) / 1e9
+        step_tf = value * gflop / 1e3                                 # whole job
+        peak = (PEAK_BF16_TFLOPS if lp == torch.bfloat16 else PEAK_FP32_TFLOPS) * world
+        ev_ms = e0.elapsed_time(e1) / args.steps
+        roof = {"bound": "mfma", "achieved": round(step_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(step_tf / peak, 5),
+                "traffic": None,
+                "what": "whole captured train step (one hipGraph launch = one step): algorithmic GFLOP/sample x samples per "
+                        "launch / HIP-event time per launch on the launch stream",
+                "gflop_per_sample": gflop, "gflop_per_sample_closed_form": round(gflop_formula, 3),
+                "hip_event_ms_per_step": round(ev_ms, 4),
+                "hbm_floor": {"bytes_per_step": 38 * sum(p.numel() for p in model.parameters()),
+                              "achieved_GBps": round(38 * sum(p.numel() for p in model.parameters()) / (ms * 1e-3) / 1e9, 1),
+                              "peak_GBps": PEAK_HBM_GBS}}
+        try:
+            roof["dominant_kernel"] = gemm_kernel_roofline(dev, lib.dtype_code(lp), lp)
+            roof["dominant_kernel"]["frac"] = round(roof["dominant_kernel"]["achieved"] / (peak / world), 4)
+        except Exception as e:  # pragma: no cover
+            roof["dominant_kernel"] = {"error": str(e)}
+        line = {"metric": "train-step samples/sec (d_model=512, 6L MTN)", "value": round(value, 2), "unit": "samples/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"{args.workload}: d_model={cfg['d_model']} N={cfg['N']} h={cfg['h']} d_ff={cfg['d_ff']} |V|={cfg['vocab']} "
+                                       f"Q/H/C/T={cfg['Q']}/{cfg['H']}/{cfg['C']}/{cfg['T']} frames={cfg['frames']} ft={cfg['ft_sizes']}",
+                           "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                           "dropout": args.dropout, "attn_dropout": 0.1 if args.dropout > 0 else 0.0,
+                           "hip_graph": not args.no_graph, "weights": "random-init (xavier), fp32 master + bf16 compute copy",
+                           "loss_per_token_last_step": round(loss_val, 4)},
+                "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(model, cfg, B, args.cpu_steps)
+            except Exception as e:  # pragma: no cover
+                line["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

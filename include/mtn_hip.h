@@ -105,7 +105,8 @@ int mtn_layernorm_bwd(int rows, int d, float eps, const float* x, const float* a
  *   k,v: lowp, element (b,j,h,c) at k[(b*m+j)*ldkv + h*dk + c]     j<m
  *   mask: uint8, element (b,i,j) at mask[b*mask_sb + i*mask_sq + j]; 0 => score := -1e9
  *         (mask_sq == 0 broadcasts over query rows; mask == NULL => nothing masked)
- *   o  : lowp [(b*a+i)*ldo + h*dk + c];  lse: float [(b*h + hh)*a + i] = max + log(sum exp)
+ *   o  : lowp [(b*a+i)*ldo + h*dk + c];  lse: float2 per (b,head,i) at lse[2*((b*h+hh)*a+i)] = {row max, 1/row sum}
+ *        (kept apart: a fully masked row has max = -1e9, where max + log(sum) would lose log(sum))
  * bwd: d_o lowp (same layout as o) -> dq (ldq layout), dk/dv (ldkv layout), all lowp.
  *      Gradient does not flow through masked scores (masked_fill).
  * ------------------------------------------------------------------------------------------ */
@@ -157,7 +158,7 @@ typedef struct {
     void* qkv;   /* lowp: self [B*a,3d]; cross [B*a,d] (q only)   saved */
     void* kv;    /* lowp cross only [B*m,2d]                      saved */
     void* o;     /* lowp [B*a,d]  saved */
-    float* lse;  /* [B*h*a]       saved */
+    float* lse;  /* [2*B*h*a]     saved */
     /* ---- backward (mtn_mha_sublayer_bwd) ---- */
     const float* dy; /* [B,a,d] */
     float* dx;       /* [B,a,d] written */

@@ -154,7 +154,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtn_attn_args A) {
             store4<T>(og + (size_t)(q0 + i) * A.ldo + c, make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv));
         }
     }
-    if (A.lse && tid < AQ && q0 + tid < a) A.lse[(size_t)(b * A.h + hh) * a + q0 + tid] = mrow[tid] + __logf(lrow[tid]);
+    if (A.lse && tid < AQ && q0 + tid < a) {   // row max and row sum kept apart: max may be -1e9 (fully masked row)
+        float* st = A.lse + 2 * ((size_t)(b * A.h + hh) * a + q0 + tid);
+        st[0] = mrow[tid];
+        st[1] = 1.0f / lrow[tid];
+    }
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -173,7 +177,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const mtn_attn_args A) {
     float* Ps = Vs + MT_B * ldr;     // [ap][MT_B+4]  dropped-out probabilities
     float* dSs = Ps + ap * (MT_B + 4);  // [ap][MT_B+4]
     float* Dr = dSs + ap * (MT_B + 4);  // [ap]
-    float* Ls = Dr + ap;                // [ap]
+    float* Ls = Dr + ap;                // [ap] row max
+    float* Li = Ls + ap;                // [ap] 1/row sum
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / A.h, hh = blockIdx.x % A.h;
     const int dk4 = dk >> 2;
@@ -203,7 +208,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const mtn_attn_args A) {
             for (int c = lane; c < dk; c += 64)
                 s += LP<T>::to_f32(dog[(size_t)i * A.ldo + c]) * LP<T>::to_f32(og[(size_t)i * A.ldo + c]);
         s = wave_sum(s);
-        if (lane == 0) { Dr[i] = s; Ls[i] = (i < a) ? A.lse[(size_t)(b * A.h + hh) * a + i] : 0.f; }
+        if (lane == 0) {
+            Dr[i] = s;
+            const float* st = A.lse + 2 * ((size_t)(b * A.h + hh) * a + i);
+            Ls[i] = (i < a) ? st[0] : 0.f;
+            Li[i] = (i < a) ? st[1] : 0.f;
+        }
     }
 
     T* dqg = (T*)A.dq + (size_t)b * a * A.ldq + hh * dk;
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const mtn_attn_args A) {
                 if (j0 + j < m && qi < a) {
                     const bool keep_score = !(A.mask && A.mask[(size_t)b * A.mask_sb + (size_t)qi * A.mask_sq + j0 + j] == 0);
                     const float sc = keep_score ? s[r] : -1e9f;
-                    const float p = __expf(sc - Ls[qi]);
+                    const float p = __expf(sc - Ls[qi]) * Li[qi];
                     float dpd = dp[r];
                     pd = p;
                     if (ds.on) {
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const mtn_attn_args A) {
 static size_t fwd_lds_bytes(int dk) { return sizeof(float) * ((size_t)(2 * AQ + 2 * MT_F) * (dk + 4) + (size_t)AQ * (MT_F + 4) + 3 * AQ); }
 static size_t bwd_lds_bytes(int a, int dk) {
     size_t ap = (a + 3) & ~3;
-    return sizeof(float) * ((3 * ap + 2 * MT_B) * (size_t)(dk + 4) + 2 * ap * (MT_B + 4) + 2 * ap);
+    return sizeof(float) * ((3 * ap + 2 * MT_B) * (size_t)(dk + 4) + 2 * ap * (MT_B + 4) + 3 * ap);
 }
 
 static int check_attn(const mtn_attn_args* A, bool bwd) {

@@ -381,6 +381,7 @@ class EncoderDecoder(nn.Module):
             p.data = flat[o:o + p.numel()].view(p.shape)
             p.grad = grad[o:o + p.numel()].view(p.shape)
         self._flat, self._flat_grad = flat, grad
+        self._flat_params = params
         self._glue_numel = offs[len(glue)] if path else total
         path_off = {id(p): o for p, o in zip(params, offs)}
         self._layer_slices = [(path_off[id(path[s])], path_off[id(path[e - 1])] + pad(path[e - 1].numel())) for s, e in layer_marks]
@@ -438,10 +439,11 @@ class EncoderDecoder(nn.Module):
         master was modified by anything other than the fused optimiser (load_state_dict, a torch optimiser)."""
         if self._flat is None:
             self._flatten()
-        if self._flat_lp is not self._flat and self._flat._version != self._flat_version:
+        ver = sum(p._version for p in self._flat_params)     # `.data = view` gives every parameter its own counter
+        if self._flat_lp is not self._flat and ver != self._flat_version:
             L.check(L.load().mtn_cast_f32_to_lp(L.dtype_code(self.compute_dtype), self._flat.numel(), self._flat.data_ptr(),
                                                 self._flat_lp.data_ptr(), L.stream_ptr()))
-            self._flat_version = self._flat._version
+            self._flat_version = ver
         return self
 
     def flat_buffers(self):

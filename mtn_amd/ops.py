@@ -153,7 +153,7 @@ class MHASublayerFn(torch.autograd.Function):
         qkv = torch.empty(B * a, 3 * d if self_attn else d, device=dev, dtype=lp)
         kv = None if self_attn else torch.empty(B * m, 2 * d, device=dev, dtype=lp)
         o = torch.empty(B * a, d, device=dev, dtype=lp)
-        lse = torch.empty(B * cfg.heads * a, device=dev, dtype=torch.float32)
+        lse = torch.empty(2 * B * cfg.heads * a, device=dev, dtype=torch.float32)
         args = L.MhaArgs()
         args.B, args.a, args.m, args.d, args.h = B, a, m, d, cfg.heads
         args.self_attn, args.ln_eps = int(self_attn), cfg.eps
@@ -305,7 +305,7 @@ def attention(q, k, v, mask, heads: int, p_drop: float = 0.0, seed=None, salt: i
     m = k.size(1)
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     o = torch.empty_like(q)
-    lse = torch.empty(B * heads * a, device=q.device, dtype=torch.float32)
+    lse = torch.empty(2 * B * heads * a, device=q.device, dtype=torch.float32)
     mask_u8, sb, sq = _mask_u8(mask, B, a, m)
     args = L.AttnArgs()
     args.B, args.h, args.a, args.m, args.dk = B, heads, a, m, d // heads

