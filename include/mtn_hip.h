@@ -81,7 +81,7 @@ typedef struct {
     float* rowsum_out;
 } mtn_gemm_problem;
 
-#define MTN_GEMM_MAX_GROUP 8
+#define MTN_GEMM_MAX_GROUP 16
 int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems /* host array */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -92,9 +92,38 @@ int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems /* host arra
  *      added to dx.  dx [rows,d] float (may alias dres).  da2/db2 [d] float are WRITTEN
  *      (not accumulated); `partial` is caller scratch of mtn_layernorm_bwd_partial_floats().
  * ------------------------------------------------------------------------------------------ */
+#define MTN_LN_MAX_GROUP 8
+typedef struct {
+    int rows, d;
+    float eps;
+    const float *x, *a2, *b2;
+    float* y_f32;
+    void* y_lp;
+    float *mean, *rstd;
+} mtn_ln_fwd_desc;
+typedef struct {
+    int rows, d;
+    float eps;
+    const float *x, *a2, *mean, *rstd, *g, *dres;
+    float* dx;
+    float* partial; /* NULL: dx only */
+} mtn_ln_bwd_desc;
+/* Grouped forms: up to MTN_LN_MAX_GROUP independent row streams per launch. */
+int mtn_layernorm_fwd_group(int dtype, int count, const mtn_ln_fwd_desc* descs /* host array */, void* stream);
+int mtn_layernorm_bwd_group(int count, const mtn_ln_bwd_desc* descs /* host array */, void* stream);
 int mtn_layernorm_fwd(int dtype, int rows, int d, float eps, const float* x, const float* a2, const float* b2,
                       float* y_f32, void* y_lp, float* mean, float* rstd, void* stream);
 long mtn_layernorm_bwd_partial_floats(int rows, int d);
+int mtn_layernorm_bwd_nparts(int rows);
+/* da2/db2 == NULL: only dx is produced now and `partial` is left for a later grouped mtn_layernorm_bwd_finalize()
+ * (many LayerNorms per launch, off the critical path of backward).  partial == NULL: dx only, no parameter gradients. */
+typedef struct {
+    const float* partial; /* [nparts][2*d] as written by mtn_layernorm_bwd */
+    int nparts, d;
+    float *da2, *db2;
+} mtn_ln_finalize_desc;
+#define MTN_LN_FINALIZE_MAX_GROUP 64
+int mtn_layernorm_bwd_finalize(int count, const mtn_ln_finalize_desc* descs /* host array */, void* stream);
 int mtn_layernorm_bwd(int rows, int d, float eps, const float* x, const float* a2, const float* mean,
                       const float* rstd, const float* g, const float* dres, float* dx, float* da2, float* db2,
                       float* partial, void* stream);
@@ -124,6 +153,10 @@ typedef struct {
     const void* d_o;
     void *dq, *dk_out, *dv_out;
 } mtn_attn_args;
+#define MTN_ATTN_MAX_GROUP 4
+/* Grouped forms: up to MTN_ATTN_MAX_GROUP independent attention problems (different shapes allowed) per launch. */
+int mtn_attention_fwd_group(int dtype, int count, const mtn_attn_args* args /* host array */, void* stream);
+int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args* args /* host array */, void* stream);
 int mtn_attention_fwd(int dtype, const mtn_attn_args* args, void* stream);
 int mtn_attention_bwd(int dtype, const mtn_attn_args* args, void* stream);
 
@@ -151,6 +184,8 @@ typedef struct {
     const float* b_qkv;
     const void* w_o; /* lowp [d,d] */
     const float* b_o;
+    const void* w_qkv_t; /* lowp [d,3d] = w_qkv^T, optional (backward: NULL -> slower transposing GEMM path) */
+    const void* w_o_t;   /* lowp [d,d]  = w_o^T,  optional */
     float* y;    /* [B,a,d] */
     void* xn;    /* lowp [B*a,d]  saved */
     float* mean; /* [B*a]         saved */
@@ -168,9 +203,15 @@ typedef struct {
     float *d_w_qkv, *d_b_qkv, *d_w_o, *d_b_o; /* written */
     void* ws_lp;   /* lowp scratch: mtn_mha_bwd_ws_lp_elems() elements */
     float* ws_f32; /* float scratch: mtn_mha_bwd_ws_f32_floats() */
+    int defer_param_grads; /* 1: backward skips the dW/db GEMMs and the LayerNorm finalize; the caller batches them
+                              later from mtn_mha_param_grad_work() (ws_lp/ws_f32 and saved buffers must stay alive) */
 } mtn_mha_args;
 int mtn_mha_sublayer_fwd(int dtype, const mtn_mha_args* args, void* stream);
 int mtn_mha_sublayer_bwd(int dtype, const mtn_mha_args* args, void* stream);
+/* Deferred parameter-gradient work of one sublayer backward: fills up to 3 GEMM problems (host structs, nothing is
+ * launched) and one LayerNorm finalize descriptor; returns the number of GEMM problems.  Feed them to mtn_gemm()
+ * (any grouping) and mtn_layernorm_bwd_finalize() once the sublayer's backward has been enqueued. */
+int mtn_mha_param_grad_work(int dtype, const mtn_mha_args* args, mtn_gemm_problem* out3, mtn_ln_finalize_desc* out_ln);
 long mtn_mha_bwd_ws_lp_elems(int B, int a, int m, int d, int self_attn);
 long mtn_mha_bwd_ws_f32_floats(int B, int a, int m, int d);
 
@@ -185,6 +226,8 @@ typedef struct {
     const float* b1;
     const void* w2; /* lowp [d,d_ff] */
     const float* b2;
+    const void* w1_t; /* lowp [d,d_ff] = w1^T, optional (backward) */
+    const void* w2_t; /* lowp [d_ff,d] = w2^T, optional (backward) */
     float* y;    /* [rows,d] */
     void* xn;    /* lowp [rows,d]    saved */
     float* mean; /* saved */
@@ -196,18 +239,53 @@ typedef struct {
     float *d_ln_a, *d_ln_b, *d_w1, *d_b1, *d_w2, *d_b2;
     void* ws_lp;   /* lowp scratch: rows*d + rows*d_ff elements */
     float* ws_f32; /* float scratch: mtn_ffn_bwd_ws_f32_floats() */
+    int defer_param_grads;
 } mtn_ffn_args;
 int mtn_ffn_sublayer_fwd(int dtype, const mtn_ffn_args* args, void* stream);
 int mtn_ffn_sublayer_bwd(int dtype, const mtn_ffn_args* args, void* stream);
 long mtn_ffn_bwd_ws_f32_floats(int rows, int d, int d_ff);
+int mtn_ffn_param_grad_work(int dtype, const mtn_ffn_args* args, mtn_gemm_problem* out2, mtn_ln_finalize_desc* out_ln);
+
+/* ------------------------------------------------------------------------------------------
+ * Lockstep sublayer groups.  The sublayers of one DecoderLayer that do not depend on each other (x's text attention,
+ * the two auto-encoder chains) share every kernel launch: stage 1 one grouped LayerNorm, stage 2 one grouped GEMM
+ * (QKV / Q+KV / FFN-1), stage 3 one grouped attention (attention members only), stage 4 one grouped GEMM (output
+ * projection / FFN-2 with bias+dropout+residual).  Backward mirrors it in 5 grouped stages.  Launch count per group is
+ * 4 (5) whatever the number of members; up to MTN_SUBLAYER_MAX_GROUP attention + as many FFN members.
+ * Backward always defers parameter gradients (see mtn_*_param_grad_work).
+ * ------------------------------------------------------------------------------------------ */
+#define MTN_SUBLAYER_MAX_GROUP 4
+int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
+int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise helpers on the path.
  * ------------------------------------------------------------------------------------------ */
 /* dst(lowp) = cast(src float); n elements. */
 int mtn_cast_f32_to_lp(int dtype, long n, const float* src, void* dst, void* stream);
+typedef struct {
+    long n;
+    const float* src;
+    void* dst;
+    mtn_dropout drop;
+} mtn_cast_desc;
+#define MTN_CAST_MAX_GROUP 8
+/* Grouped cast / dropout-backward: dst_g(lowp)[i] = src_g[i] * keep_g(i)/(1-p_g). */
+int mtn_cast_group(int dtype, int count, const mtn_cast_desc* descs /* host array */, void* stream);
 /* dst(lowp)[i] = src[i] * keep(i)/(1-p): gradient entering a dropped-out branch (mtn.py:127). */
 int mtn_dropout_bwd_to_lp(int dtype, long n, const float* src, mtn_dropout drop, void* dst, void* stream);
+
+/* Transposed compute-dtype weight copies (operand of dX = dY W on the LDS-DMA GEMM path): for each descriptor the
+ * [rows, cols] matrix at src+off is written as [cols, rows] at dst+off.  `descs_device` is a DEVICE array (built once),
+ * tile_start = running sum of ceil(rows/64)*ceil(cols/64), total_tiles = the final sum. */
+typedef struct {
+    long off;       /* element offset of the matrix in both flat buffers */
+    int rows, cols;
+    int tile_start;
+    int reserved;
+} mtn_transpose_desc;
+int mtn_transpose_group(int dtype, const void* src, void* dst, const mtn_transpose_desc* descs_device, int count,
+                        int total_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser: Adam(betas=(0.9,0.98), eps=1e-9) under the Noam schedule

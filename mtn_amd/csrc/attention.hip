@@ -30,9 +30,16 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4 v) 
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
 // ------------------------------------------------------------------------------------------ forward
+struct AttnGroup {
+    int count;
+    mtn_attn_args a[MTN_ATTN_MAX_GROUP];
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const mtn_attn_args A) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnGroup G) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mtn_attn_args& A = G.a[blockIdx.z];
+    if ((int)blockIdx.x >= A.B * A.h || (int)blockIdx.y * AQ >= A.a) return;
     const int dk = A.dk, ldr = dk + 4, a = A.a, m = A.m;
     float* Qs = sm;                    // [AQ][ldr]  (pre-scaled by 1/sqrt(dk))
     float* Os = Qs + AQ * ldr;         // [AQ][ldr]
@@ -165,8 +172,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtn_attn_args A) {
 // P_ij = exp(S_ij - lse_i); dP = dO V^T (through the same dropout mask); D_i = sum_c dO_ic O_ic;
 // dS = P*(dP - D), zero where the score was masked; dV = Pdrop^T dO; dQ = scale * dS K; dK = dS^T (scale*Q).
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const mtn_attn_args A) {
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnGroup G) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mtn_attn_args& A = G.a[blockIdx.z];
+    if ((int)blockIdx.x >= A.B * A.h) return;
     const int dk = A.dk, ldr = dk + 4, a = A.a, m = A.m;
     const int ap = (a + 3) & ~3;
     float* Qs = sm;                  // [ap][ldr] pre-scaled
@@ -342,37 +351,63 @@ template <typename K> static int set_lds(K kernel, size_t bytes) {
     return MTN_OK;
 }
 
-extern "C" int mtn_attention_fwd(int dtype, const mtn_attn_args* A, void* stream) {
+extern "C" int mtn_attention_fwd_group(int dtype, int count, const mtn_attn_args* args, void* stream) {
     MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
-    if (int rc = check_attn(A, false)) return rc;
-    const size_t lds = fwd_lds_bytes(A->dk);
-    dim3 grid(A->B * A->h, (A->a + AQ - 1) / AQ), block(256);
+    MTN_CHECK_ARG(count >= 1 && count <= MTN_ATTN_MAX_GROUP && args, "bad group");
+    AttnGroup G;
+    memset(&G, 0, sizeof(G));
+    G.count = count;
+    size_t lds = 0;
+    int gx = 0, gy = 0;
+    for (int i = 0; i < count; ++i) {
+        if (int rc = check_attn(&args[i], false)) return rc;
+        G.a[i] = args[i];
+        size_t l = fwd_lds_bytes(args[i].dk);
+        if (l > lds) lds = l;
+        if (args[i].B * args[i].h > gx) gx = args[i].B * args[i].h;
+        if ((args[i].a + AQ - 1) / AQ > gy) gy = (args[i].a + AQ - 1) / AQ;
+    }
+    dim3 grid(gx, gy, count), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MTN_BF16) {
         if (int rc = set_lds(attn_fwd_kernel<bf16_t>, lds)) return rc;
-        hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, block, lds, s, *A);
+        hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, block, lds, s, G);
     } else {
         if (int rc = set_lds(attn_fwd_kernel<float>, lds)) return rc;
-        hipLaunchKernelGGL((attn_fwd_kernel<float>), grid, block, lds, s, *A);
+        hipLaunchKernelGGL((attn_fwd_kernel<float>), grid, block, lds, s, G);
     }
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
 
-extern "C" int mtn_attention_bwd(int dtype, const mtn_attn_args* A, void* stream) {
+extern "C" int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args* args, void* stream) {
     MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
-    if (int rc = check_attn(A, true)) return rc;
-    const size_t lds = bwd_lds_bytes(A->a, A->dk);
+    MTN_CHECK_ARG(count >= 1 && count <= MTN_ATTN_MAX_GROUP && args, "bad group");
+    AttnGroup G;
+    memset(&G, 0, sizeof(G));
+    G.count = count;
+    size_t lds = 0;
+    int gx = 0;
+    for (int i = 0; i < count; ++i) {
+        if (int rc = check_attn(&args[i], true)) return rc;
+        G.a[i] = args[i];
+        size_t l = bwd_lds_bytes(args[i].a, args[i].dk);
+        if (l > lds) lds = l;
+        if (args[i].B * args[i].h > gx) gx = args[i].B * args[i].h;
+    }
     MTN_CHECK_ARG(lds <= 160 * 1024, "attention backward tile does not fit LDS");
-    dim3 grid(A->B * A->h), block(256);
+    dim3 grid(gx, 1, count), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == MTN_BF16) {
         if (int rc = set_lds(attn_bwd_kernel<bf16_t>, lds)) return rc;
-        hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), grid, block, lds, s, *A);
+        hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), grid, block, lds, s, G);
     } else {
         if (int rc = set_lds(attn_bwd_kernel<float>, lds)) return rc;
-        hipLaunchKernelGGL((attn_bwd_kernel<float>), grid, block, lds, s, *A);
+        hipLaunchKernelGGL((attn_bwd_kernel<float>), grid, block, lds, s, G);
     }
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
+
+extern "C" int mtn_attention_fwd(int dtype, const mtn_attn_args* A, void* stream) { return mtn_attention_fwd_group(dtype, 1, A, stream); }
+extern "C" int mtn_attention_bwd(int dtype, const mtn_attn_args* A, void* stream) { return mtn_attention_bwd_group(dtype, 1, A, stream); }

@@ -23,9 +23,18 @@ static inline int grid_for(long n_vec) {
 }
 
 // ---------------------------------------------------------------- cast / dropout-backward
+struct CastGroup {
+    int count;
+    mtn_cast_desc d[MTN_CAST_MAX_GROUP];
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void cast_kernel(long n, const float* __restrict__ src, T* __restrict__ dst, const mtn_dropout drop) {
-    const DropState ds = drop_init(drop);
+__global__ __launch_bounds__(256) void cast_kernel(const CastGroup grp) {
+    const mtn_cast_desc& D = grp.d[blockIdx.y];
+    const long n = D.n;
+    const float* __restrict__ src = D.src;
+    T* __restrict__ dst = (T*)D.dst;
+    const DropState ds = drop_init(D.drop);
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 v = *(const float4*)(src + i * 4);
@@ -52,14 +61,29 @@ __global__ __launch_bounds__(256) void cast_kernel(long n, const float* __restri
     }
 }
 
-static int launch_cast(int dtype, long n, const float* src, void* dst, mtn_dropout drop, void* stream) {
+extern "C" int mtn_cast_group(int dtype, int count, const mtn_cast_desc* descs, void* stream) {
     MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
-    MTN_CHECK_ARG(n > 0 && src && dst, "bad arguments");
+    MTN_CHECK_ARG(count >= 1 && count <= MTN_CAST_MAX_GROUP && descs, "bad group");
+    CastGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    grp.count = count;
+    long nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        MTN_CHECK_ARG(descs[i].n > 0 && descs[i].src && descs[i].dst, "bad cast descriptor");
+        grp.d[i] = descs[i];
+        if (descs[i].n > nmax) nmax = descs[i].n;
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MTN_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t>), dim3(grid_for(n >> 2)), dim3(256), 0, s, n, src, (bf16_t*)dst, drop);
-    else hipLaunchKernelGGL((cast_kernel<float>), dim3(grid_for(n >> 2)), dim3(256), 0, s, n, src, (float*)dst, drop);
+    dim3 grid(grid_for(nmax >> 2), count);
+    if (dtype == MTN_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t>), grid, dim3(256), 0, s, grp);
+    else hipLaunchKernelGGL((cast_kernel<float>), grid, dim3(256), 0, s, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
+}
+
+static int launch_cast(int dtype, long n, const float* src, void* dst, mtn_dropout drop, void* stream) {
+    mtn_cast_desc D = {n, src, dst, drop};
+    return mtn_cast_group(dtype, 1, &D, stream);
 }
 
 extern "C" int mtn_cast_f32_to_lp(int dtype, long n, const float* src, void* dst, void* stream) {
@@ -68,6 +92,54 @@ extern "C" int mtn_cast_f32_to_lp(int dtype, long n, const float* src, void* dst
 }
 extern "C" int mtn_dropout_bwd_to_lp(int dtype, long n, const float* src, mtn_dropout drop, void* dst, void* stream) {
     return launch_cast(dtype, n, src, dst, drop, stream);
+}
+
+// ---------------------------------------------------------------- transposed weight copies
+// dX = dY W needs W with the contraction index contiguous: every 2-D path weight [rows, cols] keeps a transposed
+// compute-dtype copy [cols, rows] at the same offset of a second flat buffer, refreshed once per optimiser step
+// (2 x 213 MB of HBM traffic for the 106.65 M-parameter model: ~0.1 ms, against ~150 small GEMMs that then run on the
+// LDS-DMA fast path).  One launch covers all matrices through a device-resident descriptor table.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_group_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                              const mtn_transpose_desc* __restrict__ descs, int count) {
+    __shared__ T tile[64][65];
+    int lo = 0, hi = count - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                       // last descriptor whose tile_start <= b
+        int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile_start <= b) lo = mid; else hi = mid - 1;
+    }
+    const mtn_transpose_desc D = descs[lo];
+    const int tiles_c = (D.cols + 63) >> 6;
+    const int t = b - D.tile_start;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const T* s = src + D.off;
+    T* d = dst + D.off;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        if (r < D.rows && c < D.cols) tile[ty + 4 * i][tx] = s[(size_t)r * D.cols + c];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (r < D.rows && c < D.cols) d[(size_t)c * D.rows + r] = tile[tx][ty + 4 * i];
+    }
+}
+
+extern "C" int mtn_transpose_group(int dtype, const void* src, void* dst, const mtn_transpose_desc* descs_device, int count,
+                                   int total_tiles, void* stream) {
+    MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
+    MTN_CHECK_ARG(src && dst && descs_device && count > 0 && total_tiles > 0, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTN_BF16)
+        hipLaunchKernelGGL((transpose_group_kernel<bf16_t>), dim3(total_tiles), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, descs_device, count);
+    else
+        hipLaunchKernelGGL((transpose_group_kernel<float>), dim3(total_tiles), dim3(256), 0, s, (const float*)src, (float*)dst, descs_device, count);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
 }
 
 // ---------------------------------------------------------------- Noam schedule + Adam

@@ -193,10 +193,160 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
         }
 }
 
+
+// ====================================================================================================================
+// Fast path for row-major x row-major problems (forward Linears, and dX = dY (W^T)^T through the transposed weight
+// copy): the problems on this path are SMALL (M = B*L = 640..4096 rows, K = 512..2048) and latency-bound, so the
+// kernel is built around memory-level parallelism rather than MFMA issue rate:
+//   * a K-chunk of 512 BYTES per row (256 bf16 / 128 fp32) per stage, two stages = 128 KiB of the CU's 160 KiB LDS;
+//     for K <= 2 chunks (every d_model=512 contraction) the WHOLE K extent of both operands is in flight at once;
+//   * operands go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction), no VGPR round
+//     trip; out-of-range K chunks are pushed past the buffer descriptor's bound and arrive as zeros;
+//   * LDS rows are 512 B, so 16 rows of a fragment read would share one 16-byte slot: the 16-byte chunk index is
+//     XOR-ed with (row & 15).  LDS-DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE address
+//     and again on the fragment read (same involution);
+//   * counted vmcnt + raw s_barrier: the next stage stays in flight across the barrier.
+// ====================================================================================================================
+static constexpr int DMA_ROWB = 512;                         // bytes per tile row per stage
+static constexpr int DMA_TILE_BYTES = TILE * DMA_ROWB;       // 32 KiB per operand per stage
+static constexpr int DMA_STAGE_BYTES = 2 * DMA_TILE_BYTES;   // A + B
+static constexpr int DMA_LDS_BYTES = 2 * DMA_STAGE_BYTES;    // two stages = 128 KiB
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
 template <typename T>
-static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, hipStream_t s) {
+__device__ __forceinline__ void dma_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_tile, int ld_bytes, int R,
+                                               int K, int row0, int k0, int wave, int lane) {
+    constexpr int EPV = LP<T>::EPV;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = j * 8 + wave * 2 + (lane >> 5);          // tile row written by this lane
+        const int c = (lane & 31) ^ (row & 15);                  // source 16-byte chunk that lands in slot (lane & 31)
+        const int gk = k0 + c * EPV;
+        int grow = row0 + row;
+        grow = grow < R ? grow : R - 1;                          // rows past the end only feed outputs that are never stored
+        unsigned voff = (gk < K) ? (unsigned)grow * (unsigned)ld_bytes + (unsigned)gk * (unsigned)sizeof(T) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + j * 4096 + wave * 1024), 16, voff, 0, 0, 0);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
+    constexpr int BK = DMA_ROWB / (int)sizeof(T);            // 256 bf16 / 128 fp32
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
+    const mtn_gemm_problem& P = grp.p[g];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = (N + TILE - 1) / TILE;
+    const int t = (int)blockIdx.x - grp.tile_start[g];
+    const int row0 = (t / tiles_n) * TILE, col0 = (t % tiles_n) * TILE;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
+    const int lda_b = P.lda * (int)sizeof(T), ldb_b = P.ldb * (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (M - 1) * lda_b + K * (int)sizeof(T), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (N - 1) * ldb_b + K * (int)sizeof(T), 0x00020000);
+
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nstages = (K + BK - 1) / BK;
+#ifdef MTN_DBG_EMPTY
+    if (P.out_lp) { ((T*)P.out_lp)[(size_t)(row0 + (tid >> 2)) * P.ldc + col0 + (tid & 3)] = 0; }
+    return;
+#endif
+#ifndef MTN_DBG_NO_LOAD
+    // prologue: up to two stages in flight (16 DMA instructions per wave per stage, always)
+    dma_issue_tile<T>(rA, smem, lda_b, M, K, row0, 0, wave, lane);
+    dma_issue_tile<T>(rB, smem + DMA_TILE_BYTES, ldb_b, N, K, col0, 0, wave, lane);
+    if (nstages > 1) {
+        dma_issue_tile<T>(rA, smem + DMA_STAGE_BYTES, lda_b, M, K, row0, BK, wave, lane);
+        dma_issue_tile<T>(rB, smem + DMA_STAGE_BYTES + DMA_TILE_BYTES, ldb_b, N, K, col0, BK, wave, lane);
+    }
+#endif
+    for (int s = 0; s < nstages; ++s) {
+        if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage s landed, stage s+1 still flying
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* sA = smem + (s & 1) * DMA_STAGE_BYTES;
+        const unsigned char* sB = sA + DMA_TILE_BYTES;
+        const int kleft = K - s * BK;
+        int ksteps = kleft >= BK ? 8 : (kleft * (int)sizeof(T) + 63) / 64;   // 64-byte contraction steps holding data
+#ifdef MTN_DBG_NO_COMPUTE
+        ksteps = 0;
+#endif
+#pragma unroll 2
+        for (int ks = 0; ks < ksteps; ++ks) {
+            uint4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = wr * 32 + i * 16 + l15, rb = wc * 32 + i * 16 + l15;
+                a[i] = *(const uint4*)(sA + ra * DMA_ROWB + (((ks * 4 + lg) ^ (ra & 15)) << 4));
+                b[i] = *(const uint4*)(sB + rb * DMA_ROWB + (((ks * 4 + lg) ^ (rb & 15)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma16<T>(acc[i][j], a[i], b[j]);
+        }
+#ifndef MTN_DBG_NO_LOAD
+        if (s + 2 < nstages) {           // refill this buffer with stage s+2 once every wave is done reading it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            unsigned char* dst = smem + (s & 1) * DMA_STAGE_BYTES;
+            dma_issue_tile<T>(rA, dst, lda_b, M, K, row0, (s + 2) * BK, wave, lane);
+            dma_issue_tile<T>(rB, dst + DMA_TILE_BYTES, ldb_b, N, K, col0, (s + 2) * BK, wave, lane);
+        }
+#endif
+    }
+
+    // ---- epilogue (same as gemm_kernel): lane holds C[row = 4*lg + r][col = l15] of each 16x16 tile
+    const DropState ds = drop_init(P.drop);
+    const float* __restrict__ bias = P.bias;
+    const float* __restrict__ res = P.residual;
+    const T* __restrict__ gate = (const T*)P.gate;
+    float* __restrict__ of = P.out_f32;
+    T* __restrict__ ol = (T*)P.out_lp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wc * 32 + j * 16 + l15;
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wr * 32 + i * 16 + lg * 4 + r;
+                if (row >= M) continue;
+                float v = acc[i][j][r] + bv;
+                if (P.relu) v = fmaxf(v, 0.f);
+                if (ds.on) v = drop_keep(ds, (uint64_t)row * (uint64_t)N + col) ? v * ds.scale : 0.f;
+                const size_t o = (size_t)row * P.ldc + col;
+                if (gate) v = (LP<T>::to_f32(gate[o]) > 0.f) ? v * P.gate_scale : 0.f;
+                if (res) v += res[(size_t)row * P.ldr + col];
+                if (of) of[o] = v;
+                if (ol) ol[o] = LP<T>::from_f32(v);
+            }
+        }
+}
+
+template <typename T>
+static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, bool dma_ok, hipStream_t s) {
     dim3 grid(total_tiles), block(256);
-    if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp);
+    if (!at && !bt && dma_ok) {
+        static bool attr_set = false;          // 128 KiB dynamic LDS needs the opt-in once per kernel
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
+            if (e != hipSuccess) { mtn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<T>), grid, block, DMA_LDS_BYTES, s, grp);
+    } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp);
     else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp);
     else if (at && bt) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, s, grp);
     else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, s, grp);
@@ -229,6 +379,15 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     }
     for (int i = count; i <= MTN_GEMM_MAX_GROUP; ++i) grp.tile_start[i] = tiles;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MTN_BF16) return launch_gemm<bf16_t>(grp, tiles, problems[0].a_trans, problems[0].b_trans, s);
-    return launch_gemm<float>(grp, tiles, problems[0].a_trans, problems[0].b_trans, s);
+    // LDS-DMA path: row-major operands below 2 GiB, no row-sum side output, and a grid that fits the chip in about two
+    // rounds (128 KiB of LDS = one workgroup per CU): large grids are throughput-bound and do better on the
+    // register-staged kernel at 5 workgroups per CU.
+    bool dma_ok = !problems[0].rowsum_out && tiles <= 640;
+    const long esz = (dtype == MTN_BF16) ? 2 : 4;
+    for (int i = 0; i < count; ++i) {
+        const mtn_gemm_problem& p = problems[i];
+        if (p.rowsum_out || (long)p.M * p.lda * esz >= (1L << 31) || (long)p.N * p.ldb * esz >= (1L << 31)) dma_ok = false;
+    }
+    if (dtype == MTN_BF16) return launch_gemm<bf16_t>(grp, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s);
+    return launch_gemm<float>(grp, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s);
 }

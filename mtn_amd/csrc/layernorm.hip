@@ -3,15 +3,24 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------ forward
+// Grouped: one launch normalises the rows of up to MTN_LN_MAX_GROUP independent streams (the lockstep sublayer groups of
+// a DecoderLayer: x and the two auto-encoder streams), each with its own gain/bias.
+struct LnFwdGroup {
+    int count;
+    int block_start[MTN_LN_MAX_GROUP + 1];
+    mtn_ln_fwd_desc d[MTN_LN_MAX_GROUP];
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, float eps, const float* __restrict__ x,
-                                                     const float* __restrict__ a2, const float* __restrict__ b2,
-                                                     float* __restrict__ y_f32, T* __restrict__ y_lp,
-                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp) {
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.block_start[g + 1]) ++g;
+    const mtn_ln_fwd_desc& D = grp.d[g];
+    const int d = D.d;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + (size_t)row * d;
+    const int row = ((int)blockIdx.x - grp.block_start[g]) * 4 + (threadIdx.x >> 6);
+    if (row >= D.rows) return;
+    const float* xr = D.x + (size_t)row * d;
     float s = 0.f;
     for (int c = lane * 4; c < d; c += 256) {
         float4 v = *(const float4*)(xr + c);
@@ -25,21 +34,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, float eps,
         q += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
     }
     const float std_u = sqrtf(wave_sum(q) / (float)(d - 1));
-    const float rstd = 1.0f / (std_u + eps);
+    const float rstd = 1.0f / (std_u + D.eps);
     if (lane == 0) {
-        if (mean_out) mean_out[row] = mean;
-        if (rstd_out) rstd_out[row] = rstd;
+        if (D.mean) D.mean[row] = mean;
+        if (D.rstd) D.rstd[row] = rstd;
     }
+    T* y_lp = (T*)D.y_lp;
     for (int c = lane * 4; c < d; c += 256) {
         float4 v = *(const float4*)(xr + c);
-        float4 g = *(const float4*)(a2 + c);
-        float4 b = *(const float4*)(b2 + c);
+        float4 ga = *(const float4*)(D.a2 + c);
+        float4 b = *(const float4*)(D.b2 + c);
         float4 o;
-        o.x = g.x * (v.x - mean) * rstd + b.x;
-        o.y = g.y * (v.y - mean) * rstd + b.y;
-        o.z = g.z * (v.z - mean) * rstd + b.z;
-        o.w = g.w * (v.w - mean) * rstd + b.w;
-        if (y_f32) *(float4*)(y_f32 + (size_t)row * d + c) = o;
+        o.x = ga.x * (v.x - mean) * rstd + b.x;
+        o.y = ga.y * (v.y - mean) * rstd + b.y;
+        o.z = ga.z * (v.z - mean) * rstd + b.z;
+        o.w = ga.w * (v.w - mean) * rstd + b.w;
+        if (D.y_f32) *(float4*)(D.y_f32 + (size_t)row * d + c) = o;
         if (y_lp) {
             T* yp = y_lp + (size_t)row * d + c;
             if constexpr (sizeof(T) == 2) {
@@ -54,42 +64,76 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, float eps,
     }
 }
 
-extern "C" int mtn_layernorm_fwd(int dtype, int rows, int d, float eps, const float* x, const float* a2, const float* b2,
-                                 float* y_f32, void* y_lp, float* mean, float* rstd, void* stream) {
+extern "C" int mtn_layernorm_fwd_group(int dtype, int count, const mtn_ln_fwd_desc* descs, void* stream) {
     MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
-    MTN_CHECK_ARG(rows > 0 && d >= 4 && d % 4 == 0, "rows>0 and d%4==0 required");
-    MTN_CHECK_ARG(x && a2 && b2, "null input");
-    dim3 grid((rows + 3) / 4), block(256);
+    MTN_CHECK_ARG(count >= 1 && count <= MTN_LN_MAX_GROUP && descs, "bad group");
+    LnFwdGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    grp.count = count;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const mtn_ln_fwd_desc& D = descs[i];
+        MTN_CHECK_ARG(D.rows > 0 && D.d >= 4 && D.d % 4 == 0, "rows>0 and d%4==0 required");
+        MTN_CHECK_ARG(D.x && D.a2 && D.b2, "null input");
+        grp.block_start[i] = blocks;
+        blocks += (D.rows + 3) / 4;
+        grp.d[i] = D;
+    }
+    for (int i = count; i <= MTN_LN_MAX_GROUP; ++i) grp.block_start[i] = blocks;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MTN_BF16)
-        hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), grid, block, 0, s, rows, d, eps, x, a2, b2, y_f32, (bf16_t*)y_lp, mean, rstd);
-    else
-        hipLaunchKernelGGL((ln_fwd_kernel<float>), grid, block, 0, s, rows, d, eps, x, a2, b2, y_f32, (float*)y_lp, mean, rstd);
+    if (dtype == MTN_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, grp);
+    else hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
+}
+
+extern "C" int mtn_layernorm_fwd(int dtype, int rows, int d, float eps, const float* x, const float* a2, const float* b2,
+                                 float* y_f32, void* y_lp, float* mean, float* rstd, void* stream) {
+    mtn_ln_fwd_desc D = {rows, d, eps, x, a2, b2, y_f32, y_lp, mean, rstd};
+    return mtn_layernorm_fwd_group(dtype, 1, &D, stream);
 }
 
 // ------------------------------------------------------------------------------------------ backward
 // With h_i = g_i*a2_i, xc_i = x_i-mean, r = 1/(std+eps), s1 = sum h, s2 = sum h*xc:
 //   dx_i = r*h_i - r*s1/d - s2*r^2/(std*(d-1)) * xc_i      (+ dres_i)
 //   da2_i = sum_rows g_i*xc_i*r        db2_i = sum_rows g_i
-// Parameter gradients: each wave accumulates its rows in registers (lane owns columns lane*4+256*j),
-// writes one partial row; ln_bwd_finalize sums the partials (deterministic, no atomics).
-static constexpr int LN_BWD_ROWS_PER_WAVE = 16;
+// dx is on the critical path of backward: 2 rows per wave, 8 rows per 256-thread workgroup, so a 640-row stream
+// fills 80 workgroups.  Parameter gradients are off the critical path: each workgroup reduces its rows through
+// LDS and writes ONE partial row [2d]; a grouped finalize kernel (many LayerNorms per launch, fixed summation
+// order => deterministic, no atomics) turns partials into da2/db2 — see mtn_layernorm_bwd_finalize().
+static constexpr int LN_BWD_ROWS_PER_WAVE = 2;
+static constexpr int LN_BWD_ROWS_PER_BLOCK = 4 * LN_BWD_ROWS_PER_WAVE;
 static constexpr int LN_MAXV = 8;  // float4 per lane -> d <= 2048
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, float eps, const float* __restrict__ x,
-                                                     const float* __restrict__ a2, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* __restrict__ g,
-                                                     const float* __restrict__ dres, float* __restrict__ dx,
-                                                     float* __restrict__ partial) {
-    const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int r0 = wave_global * LN_BWD_ROWS_PER_WAVE;
+struct LnBwdGroup {
+    int count;
+    int block_start[MTN_LN_MAX_GROUP + 1];
+    mtn_ln_bwd_desc d[MTN_LN_MAX_GROUP];
+};
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4 waves][2][d]
+    int gi = 0;
+    while (gi + 1 < grp.count && (int)blockIdx.x >= grp.block_start[gi + 1]) ++gi;
+    const mtn_ln_bwd_desc& D = grp.d[gi];
+    const int rows = D.rows, d = D.d;
+    const float eps = D.eps;
+    const float* __restrict__ x = D.x;
+    const float* __restrict__ a2 = D.a2;
+    const float* __restrict__ mean = D.mean;
+    const float* __restrict__ rstd = D.rstd;
+    const float* __restrict__ g = D.g;
+    const float* __restrict__ dres = D.dres;
+    float* __restrict__ dx = D.dx;
+    float* __restrict__ partial = D.partial;
+    const int blk = (int)blockIdx.x - grp.block_start[gi];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blk * LN_BWD_ROWS_PER_BLOCK + wave * LN_BWD_ROWS_PER_WAVE;
     float4 ga[LN_MAXV], gb[LN_MAXV];
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) ga[j] = gb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float inv_d = 1.0f / (float)d;
+#pragma unroll
     for (int rr = 0; rr < LN_BWD_ROWS_PER_WAVE; ++rr) {
         const int row = r0 + rr;
         if (row >= rows) break;
@@ -97,18 +141,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, float eps,
         const float std_u = fmaxf(1.0f / r - eps, 1e-30f);
         const float* xr = x + (size_t)row * d;
         const float* gr = g + (size_t)row * d;
+        float4 hv[LN_MAXV], ev[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < LN_MAXV; ++j) {
             const int c = lane * 4 + 256 * j;
             if (c < d) {
                 float4 xv = *(const float4*)(xr + c), gv = *(const float4*)(gr + c), av = *(const float4*)(a2 + c);
-                float h0 = gv.x * av.x, h1 = gv.y * av.y, h2 = gv.z * av.z, h3 = gv.w * av.w;
-                float e0 = xv.x - mu, e1 = xv.y - mu, e2 = xv.z - mu, e3 = xv.w - mu;
-                s1 += (h0 + h1) + (h2 + h3);
-                s2 += (h0 * e0 + h1 * e1) + (h2 * e2 + h3 * e3);
-                ga[j].x += gv.x * e0 * r; ga[j].y += gv.y * e1 * r; ga[j].z += gv.z * e2 * r; ga[j].w += gv.w * e3 * r;
+                float4 h = make_float4(gv.x * av.x, gv.y * av.y, gv.z * av.z, gv.w * av.w);
+                float4 e = make_float4(xv.x - mu, xv.y - mu, xv.z - mu, xv.w - mu);
+                s1 += (h.x + h.y) + (h.z + h.w);
+                s2 += (h.x * e.x + h.y * e.y) + (h.z * e.z + h.w * e.w);
+                ga[j].x += gv.x * e.x * r; ga[j].y += gv.y * e.y * r; ga[j].z += gv.z * e.z * r; ga[j].w += gv.w * e.w * r;
                 gb[j].x += gv.x; gb[j].y += gv.y; gb[j].z += gv.z; gb[j].w += gv.w;
+                hv[j] = h; ev[j] = e;
             }
         }
         s1 = wave_sum(s1);
@@ -119,12 +165,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, float eps,
         for (int j = 0; j < LN_MAXV; ++j) {
             const int c = lane * 4 + 256 * j;
             if (c < d) {
-                float4 xv = *(const float4*)(xr + c), gv = *(const float4*)(gr + c), av = *(const float4*)(a2 + c);
                 float4 o;
-                o.x = r * gv.x * av.x - c1 - c2 * (xv.x - mu);
-                o.y = r * gv.y * av.y - c1 - c2 * (xv.y - mu);
-                o.z = r * gv.z * av.z - c1 - c2 * (xv.z - mu);
-                o.w = r * gv.w * av.w - c1 - c2 * (xv.w - mu);
+                o.x = r * hv[j].x - c1 - c2 * ev[j].x;
+                o.y = r * hv[j].y - c1 - c2 * ev[j].y;
+                o.z = r * hv[j].z - c1 - c2 * ev[j].z;
+                o.w = r * hv[j].w - c1 - c2 * ev[j].w;
                 if (dres) {
                     float4 dv = *(const float4*)(dres + (size_t)row * d + c);
                     o.x += dv.x; o.y += dv.y; o.z += dv.z; o.w += dv.w;
@@ -133,47 +178,104 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, float eps,
             }
         }
     }
-    float* pa = partial + (size_t)wave_global * 2 * d;
-    float* pb = pa + d;
+    if (partial == nullptr) return;
+    float* sa = sm + (size_t)wave * 2 * d;
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) {
         const int c = lane * 4 + 256 * j;
         if (c < d) {
-            *(float4*)(pa + c) = ga[j];
-            *(float4*)(pb + c) = gb[j];
+            *(float4*)(sa + c) = ga[j];
+            *(float4*)(sa + d + c) = gb[j];
         }
+    }
+    __syncthreads();
+    float* pp = partial + (size_t)blk * 2 * d;
+    for (int c = threadIdx.x * 4; c < 2 * d; c += 1024) {
+        float4 a = *(const float4*)(sm + c), b = *(const float4*)(sm + 2 * d + c);
+        float4 e = *(const float4*)(sm + 4 * d + c), f = *(const float4*)(sm + 6 * d + c);
+        *(float4*)(pp + c) = make_float4((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y), (a.z + b.z) + (e.z + f.z), (a.w + b.w) + (e.w + f.w));
     }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_finalize(int nparts, int d, const float* __restrict__ partial,
-                                                       float* __restrict__ da2, float* __restrict__ db2) {
-    const int c = blockIdx.x * 256 + threadIdx.x;  // column over [0, 2d): first d -> da2, next d -> db2
+// Grouped finalize: blockIdx.y = LayerNorm index, blockIdx.x covers the 2d columns (first d -> da2, next d -> db2).
+struct LnFinalizeGroup {
+    int count;
+    mtn_ln_finalize_desc d[MTN_LN_FINALIZE_MAX_GROUP];
+};
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const LnFinalizeGroup grp) {
+    const mtn_ln_finalize_desc& D = grp.d[blockIdx.y];
+    const int d = D.d;
+    const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= 2 * d) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * 2 * d + c];
-    if (c < d) { if (da2) da2[c] = s; }
-    else if (db2) db2[c - d] = s;
+    const float* p = D.partial + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= D.nparts; i += 4) {
+        s0 += p[(size_t)(i + 0) * 2 * d]; s1 += p[(size_t)(i + 1) * 2 * d];
+        s2 += p[(size_t)(i + 2) * 2 * d]; s3 += p[(size_t)(i + 3) * 2 * d];
+    }
+    for (; i < D.nparts; ++i) s0 += p[(size_t)i * 2 * d];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (c < d) { if (D.da2) D.da2[c] = s; }
+    else if (D.db2) D.db2[c - d] = s;
 }
 
-static inline int ln_bwd_waves(int rows) { return (rows + LN_BWD_ROWS_PER_WAVE - 1) / LN_BWD_ROWS_PER_WAVE; }
+static inline int ln_bwd_blocks(int rows) { return (rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK; }
 
-extern "C" long mtn_layernorm_bwd_partial_floats(int rows, int d) {
-    int blocks = (ln_bwd_waves(rows) + 3) / 4;
-    return (long)blocks * 4 * 2 * d;
+extern "C" long mtn_layernorm_bwd_partial_floats(int rows, int d) { return (long)ln_bwd_blocks(rows) * 2 * d; }
+extern "C" int mtn_layernorm_bwd_nparts(int rows) { return ln_bwd_blocks(rows); }
+
+extern "C" int mtn_layernorm_bwd_finalize(int count, const mtn_ln_finalize_desc* descs, void* stream) {
+    MTN_CHECK_ARG(count >= 1 && descs, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < count; base += MTN_LN_FINALIZE_MAX_GROUP) {
+        LnFinalizeGroup grp;
+        grp.count = count - base < MTN_LN_FINALIZE_MAX_GROUP ? count - base : MTN_LN_FINALIZE_MAX_GROUP;
+        int dmax = 0;
+        for (int i = 0; i < grp.count; ++i) {
+            grp.d[i] = descs[base + i];
+            MTN_CHECK_ARG(grp.d[i].partial && grp.d[i].nparts > 0 && grp.d[i].d > 0, "bad finalize descriptor");
+            if (grp.d[i].d > dmax) dmax = grp.d[i].d;
+        }
+        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * dmax + 255) / 256, grp.count), dim3(256), 0, s, grp);
+        MTN_CHECK_LAUNCH();
+    }
+    return MTN_OK;
+}
+
+extern "C" int mtn_layernorm_bwd_group(int count, const mtn_ln_bwd_desc* descs, void* stream) {
+    MTN_CHECK_ARG(count >= 1 && count <= MTN_LN_MAX_GROUP && descs, "bad group");
+    LnBwdGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    grp.count = count;
+    int blocks = 0, dmax = 0;
+    bool any_partial = false;
+    for (int i = 0; i < count; ++i) {
+        const mtn_ln_bwd_desc& D = descs[i];
+        MTN_CHECK_ARG(D.rows > 0 && D.d >= 4 && D.d % 4 == 0 && D.d <= 256 * LN_MAXV, "rows>0, d%4==0, d<=2048 required");
+        MTN_CHECK_ARG(D.x && D.a2 && D.mean && D.rstd && D.g && D.dx, "null input");
+        grp.block_start[i] = blocks;
+        blocks += ln_bwd_blocks(D.rows);
+        grp.d[i] = D;
+        if (D.d > dmax) dmax = D.d;
+        any_partial |= (D.partial != nullptr);
+    }
+    for (int i = count; i <= MTN_LN_MAX_GROUP; ++i) grp.block_start[i] = blocks;
+    const size_t lds = any_partial ? sizeof(float) * 8 * (size_t)dmax : 0;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, grp);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
 }
 
 extern "C" int mtn_layernorm_bwd(int rows, int d, float eps, const float* x, const float* a2, const float* mean,
                                  const float* rstd, const float* g, const float* dres, float* dx, float* da2, float* db2,
                                  float* partial, void* stream) {
-    MTN_CHECK_ARG(rows > 0 && d >= 4 && d % 4 == 0 && d <= 256 * LN_MAXV, "rows>0, d%4==0, d<=2048 required");
-    MTN_CHECK_ARG(x && a2 && mean && rstd && g && dx && partial, "null input");
-    hipStream_t s = (hipStream_t)stream;
-    const int blocks = (ln_bwd_waves(rows) + 3) / 4;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, rows, d, eps, x, a2, mean, rstd, g, dres, dx, partial);
-    MTN_CHECK_LAUNCH();
-    if (da2 || db2) {
-        hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * d + 255) / 256), dim3(256), 0, s, blocks * 4, d, partial, da2, db2);
-        MTN_CHECK_LAUNCH();
+    MTN_CHECK_ARG(partial || (!da2 && !db2), "parameter gradients need the partial scratch buffer");
+    mtn_ln_bwd_desc D = {rows, d, eps, x, a2, mean, rstd, g, dres, dx, partial};
+    if (int rc = mtn_layernorm_bwd_group(1, &D, stream)) return rc;
+    if (da2 || db2) {   // immediate finalize; callers that batch many LayerNorms pass NULL here and call mtn_layernorm_bwd_finalize later
+        mtn_ln_finalize_desc F = {partial, ln_bwd_blocks(rows), d, da2, db2};
+        return mtn_layernorm_bwd_finalize(1, &F, stream);
     }
     return MTN_OK;
 }

@@ -3,9 +3,15 @@
 //                                                          (mtn.py:125-127, 248-267, 221-231)
 //   y = x + dropout(W2 dropout(relu(W1 LayerNorm(x))))     SublayerConnection ∘ PositionwiseFeedForward
 //                                                          (mtn.py:125-127, 279-280)
-// Each entry point enqueues a short fixed chain of kernels on the caller's stream (no syncs, no
-// allocation): LayerNorm -> grouped MFMA GEMM(s) -> attention core -> GEMM with bias/dropout/residual
-// epilogue.  Backward mirrors it and writes parameter gradients straight into the caller's buffers.
+// executed as LOCKSTEP GROUPS: sublayers that do not depend on each other (x's text attention and the two
+// auto-encoder chains of a DecoderLayer, mtn.py:183-215) share every launch —
+//   forward : grouped LayerNorm -> grouped GEMM (QKV | Q+KV | FFN-1) -> grouped attention -> grouped GEMM
+//             (output projection | FFN-2, + bias + dropout + residual)
+//   backward: grouped dropout-backward cast -> grouped GEMM (dO | dh) -> grouped attention backward ->
+//             grouped GEMM (dLN-out, + dmem) -> grouped LayerNorm backward (+ residual gradient)
+// so a group costs 4 (5) launches whatever its size, and every launch carries 2-3x the workgroups of a single
+// sublayer (these kernels are latency-bound at M = B*L = 640 rows).  Nothing synchronises, nothing allocates; parameter
+// gradients are written straight into the caller's buffers, immediately or deferred (mtn_*_param_grad_work).
 #include "common.h"
 
 static inline const char* lp_off(const void* p, long elems, int dtype) {
@@ -21,11 +27,23 @@ static mtn_gemm_problem gemm_init(const void* A, int lda, const void* B, int ldb
     return p;
 }
 
-#define RUN(expr)                     \
-    do {                              \
-        int rc__ = (expr);            \
+#define RUN(expr)                        \
+    do {                                 \
+        int rc__ = (expr);               \
         if (rc__ != MTN_OK) return rc__; \
     } while (0)
+
+// Problems of one stage may mix operand layouts (members with and without transposed weight copies): one launch per layout.
+static int run_gemms(int dtype, int n, const mtn_gemm_problem* p, void* stream) {
+    mtn_gemm_problem buf[MTN_GEMM_MAX_GROUP];
+    for (int bt = 0; bt < 2; ++bt) {
+        int k = 0;
+        for (int i = 0; i < n; ++i)
+            if (p[i].b_trans == bt) buf[k++] = p[i];
+        if (k) RUN(mtn_gemm(dtype, k, buf, stream));
+    }
+    return MTN_OK;
+}
 
 static int check_mha(const mtn_mha_args* a, bool bwd) {
     MTN_CHECK_ARG(a, "null args");
@@ -42,128 +60,6 @@ static int check_mha(const mtn_mha_args* a, bool bwd) {
     return MTN_OK;
 }
 
-extern "C" int mtn_mha_sublayer_fwd(int dtype, const mtn_mha_args* a, void* stream) {
-    MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
-    RUN(check_mha(a, false));
-    const int d = a->d, rows = a->B * a->a, m = a->self_attn ? a->a : a->m, rows_m = a->B * m;
-    // 1. LayerNorm(x) -> xn (lowp), row statistics saved for backward
-    RUN(mtn_layernorm_fwd(dtype, rows, d, a->ln_eps, a->x, a->ln_a, a->ln_b, nullptr, a->xn, a->mean, a->rstd, stream));
-    // 2. input projections (mtn.py:256-258): one launch
-    if (a->self_attn) {
-        mtn_gemm_problem p = gemm_init(a->xn, d, a->w_qkv, d, rows, 3 * d, d, 0, 0);
-        p.bias = a->b_qkv; p.out_lp = a->qkv; p.ldc = 3 * d;
-        RUN(mtn_gemm(dtype, 1, &p, stream));
-    } else {
-        mtn_gemm_problem p[2];
-        p[0] = gemm_init(a->xn, d, a->w_qkv, d, rows, d, d, 0, 0);
-        p[0].bias = a->b_qkv; p[0].out_lp = a->qkv; p[0].ldc = d;
-        p[1] = gemm_init(a->mem, d, lp_off(a->w_qkv, (long)d * d, dtype), d, rows_m, 2 * d, d, 0, 0);
-        p[1].bias = a->b_qkv + d; p[1].out_lp = a->kv; p[1].ldc = 2 * d;
-        RUN(mtn_gemm(dtype, 2, p, stream));
-    }
-    // 3. softmax(QK^T/sqrt(dk) masked) V per head (mtn.py:221-231)
-    mtn_attn_args t;
-    memset(&t, 0, sizeof(t));
-    t.B = a->B; t.h = a->h; t.a = a->a; t.m = m; t.dk = d / a->h;
-    if (a->self_attn) {
-        t.q = a->qkv; t.k = lp_off(a->qkv, d, dtype); t.v = lp_off(a->qkv, 2 * d, dtype); t.ldq = t.ldkv = 3 * d;
-    } else {
-        t.q = a->qkv; t.ldq = d; t.k = a->kv; t.v = lp_off(a->kv, d, dtype); t.ldkv = 2 * d;
-    }
-    t.mask = a->mask; t.mask_sb = a->mask_sb; t.mask_sq = a->mask_sq; t.drop = a->drop_attn;
-    t.o = a->o; t.ldo = d; t.lse = a->lse;
-    RUN(mtn_attention_fwd(dtype, &t, stream));
-    // 4. output projection + dropout + residual (mtn.py:267, 127)
-    mtn_gemm_problem po = gemm_init(a->o, d, a->w_o, d, rows, d, d, 0, 0);
-    po.bias = a->b_o; po.drop = a->drop_out; po.residual = a->x; po.ldr = d; po.out_f32 = a->y; po.ldc = d;
-    RUN(mtn_gemm(dtype, 1, &po, stream));
-    return MTN_OK;
-}
-
-extern "C" long mtn_mha_bwd_ws_lp_elems(int B, int a, int m, int d, int self_attn) {
-    long rows = (long)B * a, rows_m = (long)B * (self_attn ? a : m);
-    return 2 * rows * d + (self_attn ? 3 * rows * d : rows * d + 2 * rows_m * d);
-}
-extern "C" long mtn_mha_bwd_ws_f32_floats(int B, int a, int m, int d) {
-    (void)m;
-    long rows = (long)B * a;
-    return rows * d + mtn_layernorm_bwd_partial_floats((int)rows, d);
-}
-
-extern "C" int mtn_mha_sublayer_bwd(int dtype, const mtn_mha_args* a, void* stream) {
-    MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
-    RUN(check_mha(a, true));
-    const int d = a->d, rows = a->B * a->a, m = a->self_attn ? a->a : a->m, rows_m = a->B * m;
-    void* dyl = a->ws_lp;                                   // [rows,d]   dropout-backward of dy, lowp
-    void* dO = lp_off(a->ws_lp, (long)rows * d, dtype);     // [rows,d]
-    void* dqkv = lp_off(a->ws_lp, 2L * rows * d, dtype);    // self: [rows,3d]; cross: dq [rows,d] then dkv [rows_m,2d]
-    void* dkv = lp_off(dqkv, (long)rows * d, dtype);
-    float* dxn = a->ws_f32;                                 // [rows,d]
-    float* ln_partial = a->ws_f32 + (long)rows * d;
-
-    // 1. gradient entering the dropped-out branch
-    RUN(mtn_dropout_bwd_to_lp(dtype, (long)rows * d, a->dy, a->drop_out, dyl, stream));
-    // 2. dO = dyl @ Wo
-    {
-        mtn_gemm_problem p = gemm_init(dyl, d, a->w_o, d, rows, d, d, 0, 1);
-        p.out_lp = dO; p.ldc = d;
-        RUN(mtn_gemm(dtype, 1, &p, stream));
-    }
-    // 3. attention core backward -> dq, dk, dv
-    mtn_attn_args t;
-    memset(&t, 0, sizeof(t));
-    t.B = a->B; t.h = a->h; t.a = a->a; t.m = m; t.dk = d / a->h;
-    if (a->self_attn) {
-        t.q = a->qkv; t.k = lp_off(a->qkv, d, dtype); t.v = lp_off(a->qkv, 2 * d, dtype); t.ldq = t.ldkv = 3 * d;
-        t.dq = dqkv; t.dk_out = lp_off(dqkv, d, dtype); t.dv_out = lp_off(dqkv, 2 * d, dtype);
-    } else {
-        t.q = a->qkv; t.ldq = d; t.k = a->kv; t.v = lp_off(a->kv, d, dtype); t.ldkv = 2 * d;
-        t.dq = dqkv; t.dk_out = dkv; t.dv_out = lp_off(dkv, d, dtype);
-    }
-    t.mask = a->mask; t.mask_sb = a->mask_sb; t.mask_sq = a->mask_sq; t.drop = a->drop_attn;
-    t.o = a->o; t.ldo = d; t.lse = a->lse; t.d_o = dO;
-    RUN(mtn_attention_bwd(dtype, &t, stream));
-    // 4. gradients w.r.t. the projection inputs (one launch)
-    if (a->self_attn) {
-        mtn_gemm_problem p = gemm_init(dqkv, 3 * d, a->w_qkv, d, rows, d, 3 * d, 0, 1);
-        p.out_f32 = dxn; p.ldc = d;
-        RUN(mtn_gemm(dtype, 1, &p, stream));
-    } else {
-        mtn_gemm_problem p[2];
-        p[0] = gemm_init(dqkv, d, a->w_qkv, d, rows, d, d, 0, 1);
-        p[0].out_f32 = dxn; p[0].ldc = d;
-        int n = 1;
-        if (a->dmem) {
-            p[1] = gemm_init(dkv, 2 * d, lp_off(a->w_qkv, (long)d * d, dtype), d, rows_m, d, 2 * d, 0, 1);
-            if (a->dmem_accumulate) { p[1].residual = a->dmem; p[1].ldr = d; }
-            p[1].out_f32 = a->dmem; p[1].ldc = d;
-            n = 2;
-        }
-        RUN(mtn_gemm(dtype, n, p, stream));
-    }
-    // 5. parameter gradients (one launch): dWo = dyl^T O, dWqkv = dqkv^T xn (+ dkv^T mem); biases ride as row sums
-    {
-        mtn_gemm_problem p[3];
-        int n = 0;
-        p[n] = gemm_init(dyl, d, a->o, d, d, d, rows, 1, 1);
-        p[n].out_f32 = a->d_w_o; p[n].ldc = d; p[n].rowsum_out = a->d_b_o; ++n;
-        if (a->self_attn) {
-            p[n] = gemm_init(dqkv, 3 * d, a->xn, d, 3 * d, d, rows, 1, 1);
-            p[n].out_f32 = a->d_w_qkv; p[n].ldc = d; p[n].rowsum_out = a->d_b_qkv; ++n;
-        } else {
-            p[n] = gemm_init(dqkv, d, a->xn, d, d, d, rows, 1, 1);
-            p[n].out_f32 = a->d_w_qkv; p[n].ldc = d; p[n].rowsum_out = a->d_b_qkv; ++n;
-            p[n] = gemm_init(dkv, 2 * d, a->mem, d, 2 * d, d, rows_m, 1, 1);
-            p[n].out_f32 = a->d_w_qkv + (long)d * d; p[n].ldc = d; p[n].rowsum_out = a->d_b_qkv + d; ++n;
-        }
-        RUN(mtn_gemm(dtype, n, p, stream));
-    }
-    // 6. LayerNorm backward, fused with the residual-branch gradient
-    RUN(mtn_layernorm_bwd(rows, d, a->ln_eps, a->x, a->ln_a, a->mean, a->rstd, dxn, a->dy, a->dx, a->d_ln_a, a->d_ln_b, ln_partial, stream));
-    return MTN_OK;
-}
-
-// ------------------------------------------------------------------------------------------ FFN
 static int check_ffn(const mtn_ffn_args* a, bool bwd) {
     MTN_CHECK_ARG(a, "null args");
     MTN_CHECK_ARG(a->rows > 0 && a->d > 0 && a->d_ff > 0 && a->d % 8 == 0 && a->d_ff % 8 == 0, "bad shape");
@@ -177,54 +73,277 @@ static int check_ffn(const mtn_ffn_args* a, bool bwd) {
     return MTN_OK;
 }
 
-extern "C" int mtn_ffn_sublayer_fwd(int dtype, const mtn_ffn_args* a, void* stream) {
+static void attn_args_of(const mtn_mha_args* a, int dtype, mtn_attn_args* t) {
+    const int d = a->d, m = a->self_attn ? a->a : a->m;
+    memset(t, 0, sizeof(*t));
+    t->B = a->B; t->h = a->h; t->a = a->a; t->m = m; t->dk = d / a->h;
+    if (a->self_attn) {
+        t->q = a->qkv; t->k = lp_off(a->qkv, d, dtype); t->v = lp_off(a->qkv, 2 * d, dtype); t->ldq = t->ldkv = 3 * d;
+    } else {
+        t->q = a->qkv; t->ldq = d; t->k = a->kv; t->v = lp_off(a->kv, d, dtype); t->ldkv = 2 * d;
+    }
+    t->mask = a->mask; t->mask_sb = a->mask_sb; t->mask_sq = a->mask_sq; t->drop = a->drop_attn;
+    t->o = a->o; t->ldo = d; t->lse = a->lse;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+extern "C" int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream) {
     MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
-    RUN(check_ffn(a, false));
-    const int d = a->d, ff = a->d_ff, rows = a->rows;
-    RUN(mtn_layernorm_fwd(dtype, rows, d, a->ln_eps, a->x, a->ln_a, a->ln_b, nullptr, a->xn, a->mean, a->rstd, stream));
-    mtn_gemm_problem p1 = gemm_init(a->xn, d, a->w1, d, rows, ff, d, 0, 0);
-    p1.bias = a->b1; p1.relu = 1; p1.drop = a->drop_hidden; p1.out_lp = a->hid; p1.ldc = ff;
-    RUN(mtn_gemm(dtype, 1, &p1, stream));
-    mtn_gemm_problem p2 = gemm_init(a->hid, ff, a->w2, ff, rows, d, ff, 0, 0);
-    p2.bias = a->b2; p2.drop = a->drop_out; p2.residual = a->x; p2.ldr = d; p2.out_f32 = a->y; p2.ldc = d;
-    RUN(mtn_gemm(dtype, 1, &p2, stream));
+    MTN_CHECK_ARG(n_mha >= 0 && n_mha <= MTN_SUBLAYER_MAX_GROUP && n_ffn >= 0 && n_ffn <= MTN_SUBLAYER_MAX_GROUP && n_mha + n_ffn > 0, "bad group size");
+    for (int i = 0; i < n_mha; ++i) RUN(check_mha(&mha[i], false));
+    for (int i = 0; i < n_ffn; ++i) RUN(check_ffn(&ffn[i], false));
+    // 1. LayerNorm(x) -> xn (compute dtype); row statistics saved for backward
+    {
+        mtn_ln_fwd_desc L[2 * MTN_SUBLAYER_MAX_GROUP];
+        int n = 0;
+        for (int i = 0; i < n_mha; ++i) {
+            const mtn_mha_args* a = &mha[i];
+            L[n++] = mtn_ln_fwd_desc{a->B * a->a, a->d, a->ln_eps, a->x, a->ln_a, a->ln_b, nullptr, a->xn, a->mean, a->rstd};
+        }
+        for (int i = 0; i < n_ffn; ++i) {
+            const mtn_ffn_args* a = &ffn[i];
+            L[n++] = mtn_ln_fwd_desc{a->rows, a->d, a->ln_eps, a->x, a->ln_a, a->ln_b, nullptr, a->xn, a->mean, a->rstd};
+        }
+        RUN(mtn_layernorm_fwd_group(dtype, n, L, stream));
+    }
+    // 2. input projections (mtn.py:256-258) and FFN first Linear + ReLU + dropout (mtn.py:280)
+    {
+        mtn_gemm_problem p[3 * MTN_SUBLAYER_MAX_GROUP];
+        int n = 0;
+        for (int i = 0; i < n_mha; ++i) {
+            const mtn_mha_args* a = &mha[i];
+            const int d = a->d, rows = a->B * a->a;
+            if (a->self_attn) {
+                p[n] = gemm_init(a->xn, d, a->w_qkv, d, rows, 3 * d, d, 0, 0);
+                p[n].bias = a->b_qkv; p[n].out_lp = a->qkv; p[n].ldc = 3 * d; ++n;
+            } else {
+                p[n] = gemm_init(a->xn, d, a->w_qkv, d, rows, d, d, 0, 0);
+                p[n].bias = a->b_qkv; p[n].out_lp = a->qkv; p[n].ldc = d; ++n;
+                p[n] = gemm_init(a->mem, d, lp_off(a->w_qkv, (long)d * d, dtype), d, a->B * a->m, 2 * d, d, 0, 0);
+                p[n].bias = a->b_qkv + d; p[n].out_lp = a->kv; p[n].ldc = 2 * d; ++n;
+            }
+        }
+        for (int i = 0; i < n_ffn; ++i) {
+            const mtn_ffn_args* a = &ffn[i];
+            p[n] = gemm_init(a->xn, a->d, a->w1, a->d, a->rows, a->d_ff, a->d, 0, 0);
+            p[n].bias = a->b1; p[n].relu = 1; p[n].drop = a->drop_hidden; p[n].out_lp = a->hid; p[n].ldc = a->d_ff; ++n;
+        }
+        RUN(mtn_gemm(dtype, n, p, stream));
+    }
+    // 3. softmax(QK^T/sqrt(dk) masked) V per head (mtn.py:221-231)
+    if (n_mha) {
+        mtn_attn_args t[MTN_SUBLAYER_MAX_GROUP];
+        for (int i = 0; i < n_mha; ++i) attn_args_of(&mha[i], dtype, &t[i]);
+        RUN(mtn_attention_fwd_group(dtype, n_mha, t, stream));
+    }
+    // 4. output projection / FFN second Linear, + bias + dropout + residual (mtn.py:267, 280, 127)
+    {
+        mtn_gemm_problem p[2 * MTN_SUBLAYER_MAX_GROUP];
+        int n = 0;
+        for (int i = 0; i < n_mha; ++i) {
+            const mtn_mha_args* a = &mha[i];
+            const int d = a->d, rows = a->B * a->a;
+            p[n] = gemm_init(a->o, d, a->w_o, d, rows, d, d, 0, 0);
+            p[n].bias = a->b_o; p[n].drop = a->drop_out; p[n].residual = a->x; p[n].ldr = d; p[n].out_f32 = a->y; p[n].ldc = d; ++n;
+        }
+        for (int i = 0; i < n_ffn; ++i) {
+            const mtn_ffn_args* a = &ffn[i];
+            p[n] = gemm_init(a->hid, a->d_ff, a->w2, a->d_ff, a->rows, a->d, a->d_ff, 0, 0);
+            p[n].bias = a->b2; p[n].drop = a->drop_out; p[n].residual = a->x; p[n].ldr = a->d; p[n].out_f32 = a->y; p[n].ldc = a->d; ++n;
+        }
+        RUN(mtn_gemm(dtype, n, p, stream));
+    }
     return MTN_OK;
 }
 
+extern "C" int mtn_mha_sublayer_fwd(int dtype, const mtn_mha_args* a, void* stream) { return mtn_sublayer_group_fwd(dtype, 1, a, 0, nullptr, stream); }
+extern "C" int mtn_ffn_sublayer_fwd(int dtype, const mtn_ffn_args* a, void* stream) { return mtn_sublayer_group_fwd(dtype, 0, nullptr, 1, a, stream); }
+
+// ------------------------------------------------------------------------------------------ workspaces
+extern "C" long mtn_mha_bwd_ws_lp_elems(int B, int a, int m, int d, int self_attn) {
+    long rows = (long)B * a, rows_m = (long)B * (self_attn ? a : m);
+    return 2 * rows * d + (self_attn ? 3 * rows * d : rows * d + 2 * rows_m * d);
+}
+extern "C" long mtn_mha_bwd_ws_f32_floats(int B, int a, int m, int d) {
+    (void)m;
+    long rows = (long)B * a;
+    return rows * d + mtn_layernorm_bwd_partial_floats((int)rows, d);
+}
 extern "C" long mtn_ffn_bwd_ws_f32_floats(int rows, int d, int d_ff) {
     (void)d_ff;
     return (long)rows * d + mtn_layernorm_bwd_partial_floats(rows, d);
 }
 
-extern "C" int mtn_ffn_sublayer_bwd(int dtype, const mtn_ffn_args* a, void* stream) {
+// Workspace carving (same for the backward kernels and for the deferred parameter-gradient problems).
+struct MhaWs { void *dyl, *dO, *dqkv, *dkv; float *dxn, *ln_partial; };
+static MhaWs mha_ws(const mtn_mha_args* a, int dtype) {
+    const long rows = (long)a->B * a->a, d = a->d;
+    MhaWs w;
+    w.dyl = a->ws_lp;                                   // [rows,d]  dropout-backward of dy
+    w.dO = lp_off(a->ws_lp, rows * d, dtype);           // [rows,d]
+    w.dqkv = lp_off(a->ws_lp, 2 * rows * d, dtype);     // self: [rows,3d]; cross: dq [rows,d] then dkv [rows_m,2d]
+    w.dkv = lp_off(w.dqkv, rows * d, dtype);
+    w.dxn = a->ws_f32;                                  // [rows,d]
+    w.ln_partial = a->ws_f32 + rows * d;
+    return w;
+}
+struct FfnWs { void *dyl, *dh; float *dxn, *ln_partial; };
+static FfnWs ffn_ws(const mtn_ffn_args* a, int dtype) {
+    FfnWs w;
+    w.dyl = a->ws_lp;                                               // [rows,d]
+    w.dh = lp_off(a->ws_lp, (long)a->rows * a->d, dtype);           // [rows,d_ff]
+    w.dxn = a->ws_f32;
+    w.ln_partial = a->ws_f32 + (long)a->rows * a->d;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------ backward
+extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream) {
     MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
-    RUN(check_ffn(a, true));
-    const int d = a->d, ff = a->d_ff, rows = a->rows;
-    void* dyl = a->ws_lp;                                 // [rows,d]
-    void* dh = lp_off(a->ws_lp, (long)rows * d, dtype);   // [rows,d_ff]
-    float* dxn = a->ws_f32;
-    float* ln_partial = a->ws_f32 + (long)rows * d;
-    RUN(mtn_dropout_bwd_to_lp(dtype, (long)rows * d, a->dy, a->drop_out, dyl, stream));
-    {   // dh = (dyl @ W2) * relu'(h) * hidden-dropout mask  — both recovered from the saved hidden (hid > 0)
-        mtn_gemm_problem p = gemm_init(dyl, d, a->w2, ff, rows, ff, d, 0, 1);
-        p.gate = a->hid;
-        p.gate_scale = (a->drop_hidden.p > 0.f && a->drop_hidden.seed) ? 1.0f / (1.0f - a->drop_hidden.p) : 1.0f;
-        p.out_lp = dh; p.ldc = ff;
-        RUN(mtn_gemm(dtype, 1, &p, stream));
+    MTN_CHECK_ARG(n_mha >= 0 && n_mha <= MTN_SUBLAYER_MAX_GROUP && n_ffn >= 0 && n_ffn <= MTN_SUBLAYER_MAX_GROUP && n_mha + n_ffn > 0, "bad group size");
+    for (int i = 0; i < n_mha; ++i) RUN(check_mha(&mha[i], true));
+    for (int i = 0; i < n_ffn; ++i) RUN(check_ffn(&ffn[i], true));
+    // 1. gradient entering the dropped-out branch, in the compute dtype
+    {
+        mtn_cast_desc c[2 * MTN_SUBLAYER_MAX_GROUP];
+        int n = 0;
+        for (int i = 0; i < n_mha; ++i) c[n++] = mtn_cast_desc{(long)mha[i].B * mha[i].a * mha[i].d, mha[i].dy, mha_ws(&mha[i], dtype).dyl, mha[i].drop_out};
+        for (int i = 0; i < n_ffn; ++i) c[n++] = mtn_cast_desc{(long)ffn[i].rows * ffn[i].d, ffn[i].dy, ffn_ws(&ffn[i], dtype).dyl, ffn[i].drop_out};
+        RUN(mtn_cast_group(dtype, n, c, stream));
     }
-    {   // dxn = dh @ W1
-        mtn_gemm_problem p = gemm_init(dh, ff, a->w1, d, rows, d, ff, 0, 1);
-        p.out_f32 = dxn; p.ldc = d;
-        RUN(mtn_gemm(dtype, 1, &p, stream));
+    // 2. dO = dyl Wo ;  dh = (dyl W2) * relu'(h) * hidden-dropout mask (both recovered from the saved hidden: hid > 0)
+    {
+        mtn_gemm_problem p[2 * MTN_SUBLAYER_MAX_GROUP];
+        int n = 0;
+        for (int i = 0; i < n_mha; ++i) {
+            const mtn_mha_args* a = &mha[i];
+            const MhaWs w = mha_ws(a, dtype);
+            const int d = a->d, rows = a->B * a->a;
+            p[n] = a->w_o_t ? gemm_init(w.dyl, d, a->w_o_t, d, rows, d, d, 0, 0) : gemm_init(w.dyl, d, a->w_o, d, rows, d, d, 0, 1);
+            p[n].out_lp = w.dO; p[n].ldc = d; ++n;
+        }
+        for (int i = 0; i < n_ffn; ++i) {
+            const mtn_ffn_args* a = &ffn[i];
+            const FfnWs w = ffn_ws(a, dtype);
+            const int d = a->d, ff = a->d_ff;
+            p[n] = a->w2_t ? gemm_init(w.dyl, d, a->w2_t, d, a->rows, ff, d, 0, 0) : gemm_init(w.dyl, d, a->w2, ff, a->rows, ff, d, 0, 1);
+            p[n].gate = a->hid;
+            p[n].gate_scale = (a->drop_hidden.p > 0.f && a->drop_hidden.seed) ? 1.0f / (1.0f - a->drop_hidden.p) : 1.0f;
+            p[n].out_lp = w.dh; p[n].ldc = ff; ++n;
+        }
+        RUN(run_gemms(dtype, n, p, stream));
     }
-    {   // dW2 = dyl^T hid, dW1 = dh^T xn; bias gradients as row sums
-        mtn_gemm_problem p[2];
-        p[0] = gemm_init(dyl, d, a->hid, ff, d, ff, rows, 1, 1);
-        p[0].out_f32 = a->d_w2; p[0].ldc = ff; p[0].rowsum_out = a->d_b2;
-        p[1] = gemm_init(dh, ff, a->xn, d, ff, d, rows, 1, 1);
-        p[1].out_f32 = a->d_w1; p[1].ldc = d; p[1].rowsum_out = a->d_b1;
-        RUN(mtn_gemm(dtype, 2, p, stream));
+    // 3. attention core backward -> dq, dk, dv
+    if (n_mha) {
+        mtn_attn_args t[MTN_SUBLAYER_MAX_GROUP];
+        for (int i = 0; i < n_mha; ++i) {
+            const mtn_mha_args* a = &mha[i];
+            const MhaWs w = mha_ws(a, dtype);
+            attn_args_of(a, dtype, &t[i]);
+            t[i].d_o = w.dO;
+            if (a->self_attn) { t[i].dq = w.dqkv; t[i].dk_out = lp_off(w.dqkv, a->d, dtype); t[i].dv_out = lp_off(w.dqkv, 2 * a->d, dtype); }
+            else { t[i].dq = w.dqkv; t[i].dk_out = w.dkv; t[i].dv_out = lp_off(w.dkv, a->d, dtype); }
+        }
+        RUN(mtn_attention_bwd_group(dtype, n_mha, t, stream));
     }
-    RUN(mtn_layernorm_bwd(rows, d, a->ln_eps, a->x, a->ln_a, a->mean, a->rstd, dxn, a->dy, a->dx, a->d_ln_a, a->d_ln_b, ln_partial, stream));
+    // 4. gradients w.r.t. the LayerNorm output (and the attention memory): w_qkv^T is [d,3d] — columns 0..d-1 are
+    //    Wq^T, columns d..3d-1 are Wkv^T (row stride 3d)
+    {
+        mtn_gemm_problem p[3 * MTN_SUBLAYER_MAX_GROUP];
+        int n = 0;
+        for (int i = 0; i < n_mha; ++i) {
+            const mtn_mha_args* a = &mha[i];
+            const MhaWs w = mha_ws(a, dtype);
+            const int d = a->d, rows = a->B * a->a, rows_m = a->B * a->m;
+            if (a->self_attn) {
+                p[n] = a->w_qkv_t ? gemm_init(w.dqkv, 3 * d, a->w_qkv_t, 3 * d, rows, d, 3 * d, 0, 0) : gemm_init(w.dqkv, 3 * d, a->w_qkv, d, rows, d, 3 * d, 0, 1);
+                p[n].out_f32 = w.dxn; p[n].ldc = d; ++n;
+            } else {
+                p[n] = a->w_qkv_t ? gemm_init(w.dqkv, d, a->w_qkv_t, 3 * d, rows, d, d, 0, 0) : gemm_init(w.dqkv, d, a->w_qkv, d, rows, d, d, 0, 1);
+                p[n].out_f32 = w.dxn; p[n].ldc = d; ++n;
+                if (a->dmem) {
+                    p[n] = a->w_qkv_t ? gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv_t, d, dtype), 3 * d, rows_m, d, 2 * d, 0, 0)
+                                      : gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv, (long)d * d, dtype), d, rows_m, d, 2 * d, 0, 1);
+                    if (a->dmem_accumulate) { p[n].residual = a->dmem; p[n].ldr = d; }
+                    p[n].out_f32 = a->dmem; p[n].ldc = d; ++n;
+                }
+            }
+        }
+        for (int i = 0; i < n_ffn; ++i) {
+            const mtn_ffn_args* a = &ffn[i];
+            const FfnWs w = ffn_ws(a, dtype);
+            const int d = a->d, ff = a->d_ff;
+            p[n] = a->w1_t ? gemm_init(w.dh, ff, a->w1_t, ff, a->rows, d, ff, 0, 0) : gemm_init(w.dh, ff, a->w1, d, a->rows, d, ff, 0, 1);
+            p[n].out_f32 = w.dxn; p[n].ldc = d; ++n;
+        }
+        RUN(run_gemms(dtype, n, p, stream));
+    }
+    // 5. LayerNorm backward fused with the residual-branch gradient (critical path: dx only)
+    {
+        mtn_ln_bwd_desc L[2 * MTN_SUBLAYER_MAX_GROUP];
+        int n = 0;
+        for (int i = 0; i < n_mha; ++i) {
+            const mtn_mha_args* a = &mha[i];
+            const MhaWs w = mha_ws(a, dtype);
+            L[n++] = mtn_ln_bwd_desc{a->B * a->a, a->d, a->ln_eps, a->x, a->ln_a, a->mean, a->rstd, w.dxn, a->dy, a->dx, w.ln_partial};
+        }
+        for (int i = 0; i < n_ffn; ++i) {
+            const mtn_ffn_args* a = &ffn[i];
+            const FfnWs w = ffn_ws(a, dtype);
+            L[n++] = mtn_ln_bwd_desc{a->rows, a->d, a->ln_eps, a->x, a->ln_a, a->mean, a->rstd, w.dxn, a->dy, a->dx, w.ln_partial};
+        }
+        RUN(mtn_layernorm_bwd_group(n, L, stream));
+    }
+    // 6. parameter gradients (off the critical path): now, unless the caller batches them across sublayers
+    {
+        mtn_gemm_problem p[5 * MTN_SUBLAYER_MAX_GROUP];
+        mtn_ln_finalize_desc ln[2 * MTN_SUBLAYER_MAX_GROUP];
+        int n = 0, nl = 0;
+        for (int i = 0; i < n_mha; ++i)
+            if (!mha[i].defer_param_grads) n += mtn_mha_param_grad_work(dtype, &mha[i], p + n, &ln[nl++]);
+        for (int i = 0; i < n_ffn; ++i)
+            if (!ffn[i].defer_param_grads) n += mtn_ffn_param_grad_work(dtype, &ffn[i], p + n, &ln[nl++]);
+        for (int i = 0; i < n; i += MTN_GEMM_MAX_GROUP) RUN(mtn_gemm(dtype, n - i < MTN_GEMM_MAX_GROUP ? n - i : MTN_GEMM_MAX_GROUP, p + i, stream));
+        if (nl) RUN(mtn_layernorm_bwd_finalize(nl, ln, stream));
+    }
     return MTN_OK;
+}
+
+extern "C" int mtn_mha_sublayer_bwd(int dtype, const mtn_mha_args* a, void* stream) { return mtn_sublayer_group_bwd(dtype, 1, a, 0, nullptr, stream); }
+extern "C" int mtn_ffn_sublayer_bwd(int dtype, const mtn_ffn_args* a, void* stream) { return mtn_sublayer_group_bwd(dtype, 0, nullptr, 1, a, stream); }
+
+// dWo = dyl^T O, dWqkv = dqkv^T xn (+ dkv^T mem for cross attention); bias gradients ride as row sums of the A operand.
+extern "C" int mtn_mha_param_grad_work(int dtype, const mtn_mha_args* a, mtn_gemm_problem* p, mtn_ln_finalize_desc* ln) {
+    const int d = a->d, rows = a->B * a->a, m = a->self_attn ? a->a : a->m, rows_m = a->B * m;
+    const MhaWs w = mha_ws(a, dtype);
+    int n = 0;
+    p[n] = gemm_init(w.dyl, d, a->o, d, d, d, rows, 1, 1);
+    p[n].out_f32 = a->d_w_o; p[n].ldc = d; p[n].rowsum_out = a->d_b_o; ++n;
+    if (a->self_attn) {
+        p[n] = gemm_init(w.dqkv, 3 * d, a->xn, d, 3 * d, d, rows, 1, 1);
+        p[n].out_f32 = a->d_w_qkv; p[n].ldc = d; p[n].rowsum_out = a->d_b_qkv; ++n;
+    } else {
+        p[n] = gemm_init(w.dqkv, d, a->xn, d, d, d, rows, 1, 1);
+        p[n].out_f32 = a->d_w_qkv; p[n].ldc = d; p[n].rowsum_out = a->d_b_qkv; ++n;
+        p[n] = gemm_init(w.dkv, 2 * d, a->mem, d, 2 * d, d, rows_m, 1, 1);
+        p[n].out_f32 = a->d_w_qkv + (long)d * d; p[n].ldc = d; p[n].rowsum_out = a->d_b_qkv + d; ++n;
+    }
+    ln->partial = w.ln_partial;
+    ln->nparts = mtn_layernorm_bwd_nparts(rows);
+    ln->d = d; ln->da2 = a->d_ln_a; ln->db2 = a->d_ln_b;
+    return n;
+}
+
+// dW2 = dyl^T hid, dW1 = dh^T xn; bias gradients as row sums of the A operand.
+extern "C" int mtn_ffn_param_grad_work(int dtype, const mtn_ffn_args* a, mtn_gemm_problem* p, mtn_ln_finalize_desc* ln) {
+    const int d = a->d, ff = a->d_ff, rows = a->rows;
+    const FfnWs w = ffn_ws(a, dtype);
+    p[0] = gemm_init(w.dyl, d, a->hid, ff, d, ff, rows, 1, 1);
+    p[0].out_f32 = a->d_w2; p[0].ldc = ff; p[0].rowsum_out = a->d_b2;
+    p[1] = gemm_init(w.dh, ff, a->xn, d, ff, d, rows, 1, 1);
+    p[1].out_f32 = a->d_w1; p[1].ldc = d; p[1].rowsum_out = a->d_b1;
+    ln->partial = w.ln_partial;
+    ln->nparts = mtn_layernorm_bwd_nparts(rows);
+    ln->d = d; ln->da2 = a->d_ln_a; ln->db2 = a->d_ln_b;
+    return 2;
 }

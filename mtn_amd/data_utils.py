@@ -108,6 +108,7 @@ class FusedAdam:
         L.check(L.load().mtn_adam_step(L.dtype_code(self.model.compute_dtype), flat.numel(), flat.data_ptr(), grad.data_ptr(),
                                        self.m.data_ptr(), self.v.data_ptr(), lp_ptr, self.state.data_ptr(),
                                        L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
+        self.model.refresh_transposed()
 
     def zero_grad(self, set_to_none: bool = False):
         self.model.zero_glue_grads()

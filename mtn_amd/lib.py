@@ -42,13 +42,13 @@ class MhaArgs(C.Structure):
                 ("self_attn", C.c_int), ("ln_eps", C.c_float), ("drop_attn", Dropout), ("drop_out", Dropout),
                 ("x", C.c_void_p), ("mem", C.c_void_p), ("mask", C.c_void_p), ("mask_sb", C.c_long), ("mask_sq", C.c_long),
                 ("ln_a", C.c_void_p), ("ln_b", C.c_void_p), ("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p),
-                ("w_o", C.c_void_p), ("b_o", C.c_void_p),
+                ("w_o", C.c_void_p), ("b_o", C.c_void_p), ("w_qkv_t", C.c_void_p), ("w_o_t", C.c_void_p),
                 ("y", C.c_void_p), ("xn", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
                 ("qkv", C.c_void_p), ("kv", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
                 ("dy", C.c_void_p), ("dx", C.c_void_p), ("dmem", C.c_void_p), ("dmem_accumulate", C.c_int),
                 ("d_ln_a", C.c_void_p), ("d_ln_b", C.c_void_p),
                 ("d_w_qkv", C.c_void_p), ("d_b_qkv", C.c_void_p), ("d_w_o", C.c_void_p), ("d_b_o", C.c_void_p),
-                ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p)]
+                ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int)]
 
 
 class FfnArgs(C.Structure):
@@ -56,11 +56,37 @@ class FfnArgs(C.Structure):
                 ("drop_hidden", Dropout), ("drop_out", Dropout),
                 ("x", C.c_void_p), ("ln_a", C.c_void_p), ("ln_b", C.c_void_p),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("w1_t", C.c_void_p), ("w2_t", C.c_void_p),
                 ("y", C.c_void_p), ("xn", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("hid", C.c_void_p),
                 ("dy", C.c_void_p), ("dx", C.c_void_p),
                 ("d_ln_a", C.c_void_p), ("d_ln_b", C.c_void_p), ("d_w1", C.c_void_p), ("d_b1", C.c_void_p),
                 ("d_w2", C.c_void_p), ("d_b2", C.c_void_p),
-                ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p)]
+                ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int)]
+
+
+class TransposeDesc(C.Structure):
+    _fields_ = [("off", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("tile_start", C.c_int), ("reserved", C.c_int)]
+
+
+class LnFwdDesc(C.Structure):
+    _fields_ = [("rows", C.c_int), ("d", C.c_int), ("eps", C.c_float), ("x", C.c_void_p), ("a2", C.c_void_p), ("b2", C.c_void_p),
+                ("y_f32", C.c_void_p), ("y_lp", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p)]
+
+
+class LnBwdDesc(C.Structure):
+    _fields_ = [("rows", C.c_int), ("d", C.c_int), ("eps", C.c_float), ("x", C.c_void_p), ("a2", C.c_void_p), ("mean", C.c_void_p),
+                ("rstd", C.c_void_p), ("g", C.c_void_p), ("dres", C.c_void_p), ("dx", C.c_void_p), ("partial", C.c_void_p)]
+
+
+class CastDesc(C.Structure):
+    _fields_ = [("n", C.c_long), ("src", C.c_void_p), ("dst", C.c_void_p), ("drop", Dropout)]
+
+
+class LnFinalizeDesc(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("nparts", C.c_int), ("d", C.c_int), ("da2", C.c_void_p), ("db2", C.c_void_p)]
+
+
+GEMM_MAX_GROUP = 16
 
 
 # every symbol include/mtn_hip.h declares: name -> (restype, argtypes)
@@ -70,7 +96,18 @@ SYMBOLS = {
     "mtn_version": (C.c_int, []),
     "mtn_gemm": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
     "mtn_layernorm_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mtn_layernorm_fwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(LnFwdDesc), _P]),
+    "mtn_layernorm_bwd_group": (C.c_int, [C.c_int, C.POINTER(LnBwdDesc), _P]),
+    "mtn_attention_fwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(AttnArgs), _P]),
+    "mtn_attention_bwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(AttnArgs), _P]),
+    "mtn_cast_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(CastDesc), _P]),
+    "mtn_sublayer_group_fwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
+    "mtn_sublayer_group_bwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_layernorm_bwd_partial_floats": (C.c_long, [C.c_int, C.c_int]),
+    "mtn_layernorm_bwd_nparts": (C.c_int, [C.c_int]),
+    "mtn_layernorm_bwd_finalize": (C.c_int, [C.c_int, C.POINTER(LnFinalizeDesc), _P]),
+    "mtn_mha_param_grad_work": (C.c_int, [C.c_int, C.POINTER(MhaArgs), C.POINTER(GemmProblem), C.POINTER(LnFinalizeDesc)]),
+    "mtn_ffn_param_grad_work": (C.c_int, [C.c_int, C.POINTER(FfnArgs), C.POINTER(GemmProblem), C.POINTER(LnFinalizeDesc)]),
     "mtn_layernorm_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mtn_attention_fwd": (C.c_int, [C.c_int, C.POINTER(AttnArgs), _P]),
     "mtn_attention_bwd": (C.c_int, [C.c_int, C.POINTER(AttnArgs), _P]),
@@ -83,6 +120,7 @@ SYMBOLS = {
     "mtn_ffn_bwd_ws_f32_floats": (C.c_long, [C.c_int, C.c_int, C.c_int]),
     "mtn_cast_f32_to_lp": (C.c_int, [C.c_int, C.c_long, _P, _P, _P]),
     "mtn_dropout_bwd_to_lp": (C.c_int, [C.c_int, C.c_long, _P, Dropout, _P, _P]),
+    "mtn_transpose_group": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, _P]),
     "mtn_noam_tick": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     "mtn_adam_step": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
 }

@@ -40,10 +40,11 @@ class LayerNorm(nn.Module):
         self.eps = eps
         self._grads = None          # (flat-grad views) once the owner model is flattened
         self._lp_dtype = None
+        self._queue = None
 
     def forward_lp(self, x):
         ga, gb = self._grads if self._grads is not None else (None, None)
-        return ops.layer_norm(x, self.a_2, self.b_2, self.eps, self._lp_dtype, ga, gb)
+        return ops.layer_norm(x, self.a_2, self.b_2, self.eps, self._lp_dtype, ga, gb, self._queue)
 
     def forward(self, x):
         return self.forward_lp(x)[0]
@@ -124,33 +125,55 @@ class SublayerConnection(nn.Module):
     def _ctx(self):
         o = self._owner
         if o is None:
-            return torch.bfloat16, None
-        return o.compute_dtype, (o._seed if self.training else None)
+            return torch.bfloat16, None, None
+        return o.compute_dtype, (o._seed if self.training else None), o._queue
 
     def attend(self, x, attn: MultiHeadedAttention, mem, mask):
-        lp, seed = self._ctx()
+        lp, seed, queue = self._ctx()
         f = attn.fused()
         g = None
         if f["grads"] is not None and self.norm._grads is not None:
             g = dict(f["grads"], ln_a=self.norm._grads[0], ln_b=self.norm._grads[1])
         cfg = ops.MhaConfig(heads=attn.h, eps=self.norm.eps,
                             p_attn=attn.p if self.training else 0.0, p_out=self.p if self.training else 0.0,
-                            salt=self.salt, seed=seed, lp_dtype=lp, w_qkv_lp=f["w_qkv_lp"], w_o_lp=f["w_o_lp"], grads=g)
+                            salt=self.salt, seed=seed, lp_dtype=lp, w_qkv_lp=f["w_qkv_lp"], w_o_lp=f["w_o_lp"],
+                            w_qkv_lpT=f.get("w_qkv_lpT"), w_o_lpT=f.get("w_o_lpT"), grads=g,
+                            queue=queue if g is not None else None)
         mem_lp = getattr(mem, "_mtn_lp", None) if mem is not None else None
         if mem_lp is not None and mem_lp.dtype != lp:
             mem_lp = None
         return ops.MHASublayerFn.apply(x, mem, mem_lp, mask, self.norm.a_2, self.norm.b_2,
                                        f["w_qkv"], f["b_qkv"], f["w_o"], f["b_o"], cfg)
 
+    def member(self, sublayer, mem=None, mask=None):
+        """This sublayer as a member of a lockstep group (ops.SublayerGroupFn); needs the flattened model."""
+        lp, seed, queue = self._ctx()
+        f = sublayer.fused()
+        g = dict(f["grads"], ln_a=self.norm._grads[0], ln_b=self.norm._grads[1])
+        if isinstance(sublayer, MultiHeadedAttention):
+            cfg = ops.MhaConfig(heads=sublayer.h, eps=self.norm.eps, p_attn=sublayer.p if self.training else 0.0,
+                                p_out=self.p if self.training else 0.0, salt=self.salt, seed=seed, lp_dtype=lp,
+                                w_qkv_lp=f["w_qkv_lp"], w_o_lp=f["w_o_lp"], w_qkv_lpT=f.get("w_qkv_lpT"), w_o_lpT=f.get("w_o_lpT"),
+                                grads=g, queue=queue)
+            mem_lp = getattr(mem, "_mtn_lp", None) if mem is not None else None
+            if mem_lp is not None and mem_lp.dtype != lp:
+                mem_lp = None
+            return ops.GroupMember("mha", cfg, (self.norm.a_2, self.norm.b_2, f["b_qkv"], f["b_o"]), mask, mem_lp)
+        cfg = ops.FfnConfig(eps=self.norm.eps, p_hidden=sublayer.p if self.training else 0.0, p_out=self.p if self.training else 0.0,
+                            salt=self.salt, seed=seed, lp_dtype=lp, w1_lp=f["w1_lp"], w2_lp=f["w2_lp"], w1_lpT=f.get("w1_lpT"),
+                            w2_lpT=f.get("w2_lpT"), grads=g, queue=queue)
+        return ops.GroupMember("ffn", cfg, (self.norm.a_2, self.norm.b_2, f["b1"], f["b2"]))
+
     def feed(self, x, ff: PositionwiseFeedForward):
-        lp, seed = self._ctx()
+        lp, seed, queue = self._ctx()
         f = ff.fused()
         g = None
         if f["grads"] is not None and self.norm._grads is not None:
             g = dict(f["grads"], ln_a=self.norm._grads[0], ln_b=self.norm._grads[1])
         cfg = ops.FfnConfig(eps=self.norm.eps, p_hidden=ff.p if self.training else 0.0,
                             p_out=self.p if self.training else 0.0, salt=self.salt, seed=seed, lp_dtype=lp,
-                            w1_lp=f["w1_lp"], w2_lp=f["w2_lp"], grads=g)
+                            w1_lp=f["w1_lp"], w2_lp=f["w2_lp"], w1_lpT=f.get("w1_lpT"), w2_lpT=f.get("w2_lpT"), grads=g,
+                            queue=queue if g is not None else None)
         return ops.FFNSublayerFn.apply(x, self.norm.a_2, self.norm.b_2, f["w1"], f["b1"], f["w2"], f["b2"], cfg)
 
     def forward(self, x, sublayer, mem=None, mask=None, self_attention=False):
@@ -185,9 +208,66 @@ class DecoderLayer(nn.Module):
         self.auto_encoder_feed_forward = auto_encoder_feed_forward
         self.sublayer = nn.ModuleList([SublayerConnection(size, dropout) for _ in range(5 + 4 * len(auto_encoder_vid_attn))])
 
+    def _forward_lockstep(self, x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask,
+                          ae_fts, ae_features):
+        """Same arithmetic as forward(), scheduled as lockstep groups: the first three text attentions of x run in the same
+        launches as the three sublayers of each auto-encoder chain (they do not depend on each other, mtn.py:183-213)."""
+        sl = self.sublayer
+        if ae_features in ("caption", "summary"):
+            text = [(sl[0], self.self_attn, None, tgt_mask), (sl[1], self.his_attn, his_memory, his_mask),
+                    (sl[2], self.src_attn, q_memory, q_mask), (sl[3], self.cap_attn, cap_memory, cap_mask)]
+            seed_ae, ae_mask = cap_memory, cap_mask
+        elif ae_features == "query":
+            text = [(sl[0], self.self_attn, None, tgt_mask), (sl[1], self.his_attn, his_memory, his_mask),
+                    (sl[2], self.cap_attn, cap_memory, cap_mask), (sl[3], self.src_attn, q_memory, q_mask)]
+            seed_ae, ae_mask = q_memory, q_mask
+        else:
+            raise ValueError("auto_encoder_ft must be 'query', 'caption' or 'summary' (reference: mtn.py:187-202)")
+        if ae_fts is None:
+            ae_fts = seed_ae
+        nF = len(vid_fts)
+        aes = [ae_fts[i] if isinstance(ae_fts, (list, tuple)) else ae_fts for i in range(nF)]
+        chains = [[(sl[4 + 4 * i], self.auto_encoder_self_attn[i], None, ae_mask),
+                   (sl[5 + 4 * i], self.auto_encoder_vid_attn[i], vid_fts[i], vid_mask[i]),
+                   (sl[6 + 4 * i], self.auto_encoder_feed_forward[i], None, None)] for i in range(nF)]
+
+        def run(items):                      # items: [(sublayer_connection, module, mem, mask, input)]
+            members, tensors = [], []
+            for sc, mod, mem, mask, inp in items:
+                members.append(sc.member(mod, mem, mask))
+                tensors += [inp, mem if isinstance(mod, MultiHeadedAttention) else None]
+            # attention members first, then FFN members (the C side takes two arrays)
+            order = sorted(range(len(members)), key=lambda k: members[k].kind != "mha")
+            outs = ops.SublayerGroupFn.apply([members[k] for k in order], *[t for k in order for t in tensors[2 * k:2 * k + 2]])
+            res = [None] * len(members)
+            for pos, k in enumerate(order):
+                res[k] = outs[pos]
+            return res
+
+        for j in range(3):
+            items = [text[j] + (x,)] + [chains[i][j] + (aes[i],) for i in range(nF)]
+            outs = run(items)
+            x, aes = outs[0], list(outs[1:])
+        x = run([text[3] + (x,)])[0]
+        for i in range(nF):
+            x = run([(sl[7 + 4 * i], self.auto_encoder_attn[i], aes[i], ae_mask, x)])[0]
+        x = run([(sl[4 + 4 * nF], self.feed_forward, None, None, x)])[0]
+        return x, aes
+
     def forward(self, x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask,
                 ae_fts, ae_features):
+        owner = getattr(self, "_owner", None)
+        if (owner is not None and owner.lockstep and x.is_cuda and owner._flat is not None and len(vid_fts) + 1 <= 4
+                and not self._forward_hooks_on_sublayers()):
+            return self._forward_lockstep(x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts,
+                                          vid_mask, ae_fts, ae_features)
         sl = self.sublayer
+        streams = owner._streams if (owner is not None and x.is_cuda) else None
+        entry = None
+        if streams and getattr(self, "_layer_index", 0) == 0:
+            # first layer: the auto-encoder seeds and the video memories were produced on the current stream
+            entry = torch.cuda.Event()
+            entry.record(torch.cuda.current_stream())
         x = sl[0](x, self.self_attn, None, tgt_mask, True)
         x = sl[1](x, self.his_attn, his_memory, his_mask)
         if ae_features in ("caption", "summary"):
@@ -204,16 +284,43 @@ class DecoderLayer(nn.Module):
             ae_mask = q_mask
         else:
             raise ValueError("auto_encoder_ft must be 'query', 'caption' or 'summary' (reference: mtn.py:187-202)")
-        k = 4
-        out_ae = []
+        # The query-aware auto-encoder chains (self-attn -> attend-to-video -> FFN, one per modality) depend only on the
+        # previous layer's auto-encoder outputs, not on x: each runs on its own HIP stream, concurrently with the four
+        # text attentions of x above; x joins a chain right before it attends to that chain's output.  (Backward runs
+        # each node on its forward stream, so the concurrency carries over; graph capture records the fork/join.)
+        main = torch.cuda.current_stream() if streams else None
+        nF = len(vid_fts)
+        aes = []
         for i, vid_ft in enumerate(vid_fts):
             ae = ae_fts[i] if isinstance(ae_fts, (list, tuple)) else ae_fts
-            ae = sl[k](ae, self.auto_encoder_self_attn[i], None, ae_mask, True); k += 1
-            ae = sl[k](ae, self.auto_encoder_vid_attn[i], vid_ft, vid_mask[i]); k += 1
-            ae = sl[k](ae, self.auto_encoder_feed_forward[i]); k += 1
-            x = sl[k](x, self.auto_encoder_attn[i], ae, ae_mask); k += 1
-            out_ae.append(ae)
+            k = 4 + 4 * i
+            if streams:
+                side = streams[i]
+                if entry is not None:
+                    side.wait_event(entry)
+                with torch.cuda.stream(side):
+                    ae = sl[k](ae, self.auto_encoder_self_attn[i], None, ae_mask, True)
+                    ae = sl[k + 1](ae, self.auto_encoder_vid_attn[i], vid_ft, vid_mask[i])
+                    ae = sl[k + 2](ae, self.auto_encoder_feed_forward[i])
+                ae.record_stream(main)
+            else:
+                ae = sl[k](ae, self.auto_encoder_self_attn[i], None, ae_mask, True)
+                ae = sl[k + 1](ae, self.auto_encoder_vid_attn[i], vid_ft, vid_mask[i])
+                ae = sl[k + 2](ae, self.auto_encoder_feed_forward[i])
+            aes.append(ae)
+        out_ae = []
+        for i in range(nF):
+            if streams:
+                main.wait_stream(streams[i])
+            x = sl[4 + 4 * i + 3](x, self.auto_encoder_attn[i], aes[i], ae_mask)
+            out_ae.append(aes[i])
+        k = 4 + 4 * nF
         return sl[k](x, self.feed_forward), out_ae
+
+
+    def _forward_hooks_on_sublayers(self):
+        """Per-sublayer forward hooks (used to tap intermediate outputs) need the one-sublayer-at-a-time schedule."""
+        return any(len(s._forward_hooks) > 0 for s in self.sublayer)
 
 
 class Decoder(nn.Module):
@@ -228,6 +335,7 @@ class Decoder(nn.Module):
 
     def forward(self, vid_ft, vid_mask, x, his_memory, his_mask, cap_memory, cap_mask, query_memory, query_mask, tgt_mask,
                 auto_encoded_ft, auto_encoded_features):
+        ops.prepare_masks(tgt_mask, his_mask, cap_mask, query_mask, vid_mask)
         for layer in self.layers:
             x, auto_encoded_ft = layer(x, cap_memory, cap_mask, his_memory, his_mask, query_memory, query_mask, tgt_mask,
                                        vid_ft, vid_mask, auto_encoded_ft, auto_encoded_features)
@@ -323,6 +431,10 @@ class EncoderDecoder(nn.Module):
         self._glue_numel = 0
         self._layer_slices = []
         self._seed = None
+        self._queue = ops.ParamGradQueue()     # dW/db/LN-parameter work batched at the end of backward
+        self._streams = None                   # side streams for the two auto-encoder chains (sequential schedule only)
+        self.multi_stream = False
+        self.lockstep = True                   # independent sublayers of a layer share launches (ops.SublayerGroupFn)
 
     # ---- flat parameter storage ------------------------------------------------------------------
     def _ordered_params(self):
@@ -388,6 +500,8 @@ class EncoderDecoder(nn.Module):
         lp = self.compute_dtype
         self._flat_lp = torch.empty(total, device=dev, dtype=lp) if lp != torch.float32 else flat
         self._flat_version = -1
+        self._flat_lpT = torch.zeros(total, device=dev, dtype=lp) if dev.type == "cuda" else None
+        tdescs = []          # (offset, rows, cols) of every 2-D path weight that gets a transposed copy
         if dev.type == "cuda":
             if self._seed is None or self._seed.device != dev:
                 self._seed = torch.full((1,), torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, device=dev, dtype=torch.int64)
@@ -411,15 +525,46 @@ class EncoderDecoder(nn.Module):
                 bo, _, gbo = views(m.linears[3].bias)
                 m._fused = dict(w_qkv=w, b_qkv=b, w_o=wo, b_o=bo, w_qkv_lp=wl, w_o_lp=wol, lp_dtype=lp,
                                 grads=dict(w_qkv=gw, b_qkv=gb, w_o=gwo, b_o=gbo))
+                if self._flat_lpT is not None:
+                    oq, oo = path_off[id(m.linears[0].weight)], path_off[id(m.linears[3].weight)]
+                    m._fused["w_qkv_lpT"] = self._flat_lpT[oq:oq + 3 * d * d].view(d, 3 * d)
+                    m._fused["w_o_lpT"] = self._flat_lpT[oo:oo + d * d].view(d, d)
+                    tdescs += [(oq, 3 * d, d), (oo, d, d)]
             elif isinstance(m, PositionwiseFeedForward) and id(m.w_1.weight) in path_off:
                 w1, w1l, g1 = views(m.w_1.weight); b1, _, gb1 = views(m.w_1.bias)
                 w2, w2l, g2 = views(m.w_2.weight); b2, _, gb2 = views(m.w_2.bias)
                 m._fused = dict(w1=w1, b1=b1, w2=w2, b2=b2, w1_lp=w1l, w2_lp=w2l, lp_dtype=lp,
                                 grads=dict(w1=g1, b1=gb1, w2=g2, b2=gb2))
+                if self._flat_lpT is not None:
+                    o1, o2 = path_off[id(m.w_1.weight)], path_off[id(m.w_2.weight)]
+                    ffd, dm = m.w_1.weight.shape
+                    m._fused["w1_lpT"] = self._flat_lpT[o1:o1 + ffd * dm].view(dm, ffd)
+                    m._fused["w2_lpT"] = self._flat_lpT[o2:o2 + ffd * dm].view(ffd, dm)
+                    tdescs += [(o1, ffd, dm), (o2, dm, ffd)]
             elif isinstance(m, LayerNorm) and id(m.a_2) in path_off:
                 m._grads = (views(m.a_2)[2], views(m.b_2)[2])
                 m._lp_dtype = lp
+                m._queue = self._queue
+        self._tdesc = None
+        if tdescs:
+            import ctypes as C
+            arr = (L.TransposeDesc * len(tdescs))()
+            tiles = 0
+            for i, (o, r, c) in enumerate(tdescs):
+                arr[i].off, arr[i].rows, arr[i].cols, arr[i].tile_start = o, r, c, tiles
+                tiles += ((r + 63) // 64) * ((c + 63) // 64)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self._tdesc = (raw, len(tdescs), tiles)
+        if dev.type == "cuda" and self.multi_stream:
+            n_side = max(len(l.auto_encoder_vid_attn) for l in self.decoder.layers)
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(n_side)]
+            self._queue.side_streams = self._streams
+        else:
+            self._streams = None
+            self._queue.side_streams = []
         for n, layer in enumerate(self.decoder.layers):
+            object.__setattr__(layer, "_owner", self)
+            layer._layer_index = n
             for k, s in enumerate(layer.sublayer):
                 object.__setattr__(s, "_owner", self)      # plain attribute: not a registered submodule
                 s.salt = n * 64 + k + 1
@@ -444,7 +589,19 @@ class EncoderDecoder(nn.Module):
             L.check(L.load().mtn_cast_f32_to_lp(L.dtype_code(self.compute_dtype), self._flat.numel(), self._flat.data_ptr(),
                                                 self._flat_lp.data_ptr(), L.stream_ptr()))
             self._flat_version = ver
+            self.refresh_transposed()
+        elif self._flat_lp is self._flat and ver != self._flat_version:
+            self._flat_version = ver
+            self.refresh_transposed()
         return self
+
+    def refresh_transposed(self):
+        """Rewrite the transposed compute-dtype weight copies from the current weights (one grouped kernel)."""
+        if self._tdesc is None:
+            return
+        raw, n, tiles = self._tdesc
+        L.check(L.load().mtn_transpose_group(L.dtype_code(self.compute_dtype), self._flat_lp.data_ptr(), self._flat_lpT.data_ptr(),
+                                             raw.data_ptr(), n, tiles, L.stream_ptr()))
 
     def flat_buffers(self):
         self.prepare()

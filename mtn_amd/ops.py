@@ -31,17 +31,31 @@ def _require_cuda(*ts):
 
 
 def _mask_u8(mask: Optional[torch.Tensor], B: int, a: int, m: int):
-    """Reference masks are bool (B|1, 1|a, m) (data_utils.py:34-53).  -> (uint8 tensor, batch stride, row stride)."""
+    """Reference masks are bool (B|1, 1|a, m) (data_utils.py:34-53).  -> (uint8 tensor, batch stride, row stride).
+    The uint8 image is cached on the mask object: the same mask serves every layer (and several streams)."""
     if mask is None:
         return None, 0, 0
-    if mask.dim() != 3 or mask.size(-1) != m:
-        raise ValueError(f"mask must be (B|1, 1|{a}, {m}); got {tuple(mask.shape)}")
-    mu = mask.to(torch.uint8).contiguous()
-    sb = 0 if mu.size(0) == 1 else mu.size(1) * m
-    sq = 0 if mu.size(1) == 1 else m
-    if mu.size(0) not in (1, B) or mu.size(1) not in (1, a):
+    if mask.dim() != 3 or mask.size(-1) != m or mask.size(0) not in (1, B) or mask.size(1) not in (1, a):
         raise ValueError(f"mask {tuple(mask.shape)} does not broadcast to ({B},{a},{m})")
-    return mu, sb, sq
+    cached = getattr(mask, "_mtn_u8", None)
+    if cached is None:
+        cached = mask.to(torch.uint8).contiguous()
+        try:
+            mask._mtn_u8 = cached
+        except Exception:
+            pass
+    sb = 0 if cached.size(0) == 1 else cached.size(1) * m
+    sq = 0 if cached.size(1) == 1 else m
+    return cached, sb, sq
+
+
+def prepare_masks(*masks):
+    """Convert masks to their kernel form NOW (on the current stream), before other streams start using them."""
+    for mk in masks:
+        if isinstance(mk, (list, tuple)):
+            prepare_masks(*mk)
+        elif mk is not None and getattr(mk, "_mtn_u8", None) is None:
+            mk._mtn_u8 = mk.to(torch.uint8).contiguous()
 
 
 def gemm(dtype: int, problems):
@@ -60,12 +74,56 @@ def cast_to_lp(x: torch.Tensor, lp_dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
+# ------------------------------------------------------------------------------------------ deferred parameter gradients
+class ParamGradQueue:
+    """dW/db GEMMs and LayerNorm gain/bias reductions are off the critical path of backward.  Sublayer backwards
+    enqueue them here (problem structs built by the C side, nothing launched) and the queue launches them in a few
+    large grouped kernels when the backward pass ends (autograd engine callback) — hundreds of workgroups per launch
+    instead of ~250 small launches serialised behind the activation-gradient chain."""
+
+    def __init__(self):
+        self.gemm, self.ln, self.keep = [], [], []
+        self.dtype = None
+        self.side_streams = []
+        self._armed = False
+
+    def add(self, dtype, problems, ln_desc, keep):
+        assert self.dtype in (None, dtype)
+        self.dtype = dtype
+        self.gemm.extend(problems)
+        if ln_desc is not None:
+            self.ln.append(ln_desc)
+        self.keep.extend(keep)
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        self._armed = False
+        if not self.gemm and not self.ln:
+            return
+        lib = L.load()
+        cur = torch.cuda.current_stream()
+        for s in self.side_streams:
+            cur.wait_stream(s)
+        for t in self.keep:
+            t.record_stream(cur)
+        for i in range(0, len(self.gemm), L.GEMM_MAX_GROUP):
+            chunk = self.gemm[i:i + L.GEMM_MAX_GROUP]
+            arr = (L.GemmProblem * len(chunk))(*chunk)
+            L.check(lib.mtn_gemm(self.dtype, len(chunk), arr, cur.cuda_stream))
+        if self.ln:
+            arr = (L.LnFinalizeDesc * len(self.ln))(*self.ln)
+            L.check(lib.mtn_layernorm_bwd_finalize(len(self.ln), arr, cur.cuda_stream))
+        self.gemm, self.ln, self.keep = [], [], []
+
+
 # ------------------------------------------------------------------------------------------ LayerNorm
 class LayerNormFn(torch.autograd.Function):
     """mtn.py:111-114.  Returns (y_f32, y_lp); y_lp (compute dtype copy for GEMM operands) is non-differentiable."""
 
     @staticmethod
-    def forward(ctx, x, a2, b2, eps, lp_dtype, grad_a, grad_b):
+    def forward(ctx, x, a2, b2, eps, lp_dtype, grad_a, grad_b, queue=None):
         _require_cuda(x, a2, b2)
         x = x.contiguous()
         d = x.size(-1)
@@ -79,7 +137,7 @@ class LayerNormFn(torch.autograd.Function):
         L.check(L.load().mtn_layernorm_fwd(code, rows, d, eps, x.data_ptr(), a2.data_ptr(), b2.data_ptr(), y.data_ptr(),
                                            L.ptr(y_lp), mean.data_ptr(), rstd.data_ptr(), L.stream_ptr()))
         ctx.save_for_backward(x, a2, mean, rstd)
-        ctx.eps, ctx.grad_a, ctx.grad_b = eps, grad_a, grad_b
+        ctx.eps, ctx.grad_a, ctx.grad_b, ctx.queue = eps, grad_a, grad_b, queue
         if y_lp is None:
             y_lp = torch.empty(0, device=x.device, dtype=torch.float32)   # placeholder second output
         ctx.mark_non_differentiable(y_lp)
@@ -96,17 +154,21 @@ class LayerNormFn(torch.autograd.Function):
         da = ctx.grad_a if ctx.grad_a is not None else torch.empty_like(a2)
         db = ctx.grad_b if ctx.grad_b is not None else torch.empty_like(a2)
         partial = torch.empty(lib.mtn_layernorm_bwd_partial_floats(rows, d), device=x.device, dtype=torch.float32)
+        defer = ctx.queue is not None and ctx.grad_a is not None
         L.check(lib.mtn_layernorm_bwd(rows, d, ctx.eps, x.data_ptr(), a2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                      g.data_ptr(), None, dx.data_ptr(), da.data_ptr(), db.data_ptr(), partial.data_ptr(),
-                                      L.stream_ptr()))
+                                      g.data_ptr(), None, dx.data_ptr(), None if defer else da.data_ptr(),
+                                      None if defer else db.data_ptr(), partial.data_ptr(), L.stream_ptr()))
+        if defer:
+            desc = L.LnFinalizeDesc(partial.data_ptr(), lib.mtn_layernorm_bwd_nparts(rows), d, da.data_ptr(), db.data_ptr())
+            ctx.queue.add(None if ctx.queue.dtype is None else ctx.queue.dtype, [], desc, [partial])
         ret_a = None if ctx.grad_a is not None else da
         ret_b = None if ctx.grad_b is not None else db
-        return dx, ret_a, ret_b, None, None, None, None
+        return dx, ret_a, ret_b, None, None, None, None, None
 
 
-def layer_norm(x, a2, b2, eps=1e-6, lp_dtype=None, grad_a=None, grad_b=None):
+def layer_norm(x, a2, b2, eps=1e-6, lp_dtype=None, grad_a=None, grad_b=None, queue=None):
     """-> (y fp32, y in the compute dtype).  grad_a/grad_b: optional fp32 destinations for da2/db2."""
-    y, y_lp = LayerNormFn.apply(x, a2, b2, eps, lp_dtype, grad_a, grad_b)
+    y, y_lp = LayerNormFn.apply(x, a2, b2, eps, lp_dtype, grad_a, grad_b, queue)
     if y_lp.numel() == 0 and y.numel() != 0:
         y_lp = y.detach()
     return y, y_lp
@@ -124,7 +186,10 @@ class MhaConfig:
     lp_dtype: torch.dtype = torch.bfloat16
     w_qkv_lp: Optional[torch.Tensor] = None      # compute-dtype copies of the weights ([3d,d], [d,d])
     w_o_lp: Optional[torch.Tensor] = None
+    w_qkv_lpT: Optional[torch.Tensor] = None     # transposed compute-dtype copies (backward dX on the LDS-DMA GEMM path)
+    w_o_lpT: Optional[torch.Tensor] = None
     grads: Optional[dict] = None                 # fp32 destinations: ln_a ln_b w_qkv b_qkv w_o b_o (flat-grad views)
+    queue: Optional[ParamGradQueue] = None       # defer dW/db/LN-parameter work to the end of backward
 
 
 class MHASublayerFn(torch.autograd.Function):
@@ -201,13 +266,21 @@ class MHASublayerFn(torch.autograd.Function):
         args.mask, args.mask_sb, args.mask_sq = L.ptr(mask_u8), ctx.mask_strides[0], ctx.mask_strides[1]
         args.ln_a, args.ln_b = ln_a.data_ptr(), ln_b.data_ptr()
         args.w_qkv, args.b_qkv, args.w_o, args.b_o = w_qkv_lp.data_ptr(), b_qkv.data_ptr(), w_o_lp.data_ptr(), b_o.data_ptr()
+        args.w_qkv_t, args.w_o_t = L.ptr(cfg.w_qkv_lpT), L.ptr(cfg.w_o_lpT)
         args.xn, args.mean, args.rstd = xn.data_ptr(), mean.data_ptr(), rstd.data_ptr()
         args.qkv, args.kv, args.o, args.lse = qkv.data_ptr(), L.ptr(kv), o.data_ptr(), lse.data_ptr()
         args.dy, args.dx, args.dmem, args.dmem_accumulate = dy.data_ptr(), dx.data_ptr(), L.ptr(dmem), 0
         args.d_ln_a, args.d_ln_b = d_ln_a.data_ptr(), d_ln_b.data_ptr()
         args.d_w_qkv, args.d_b_qkv, args.d_w_o, args.d_b_o = d_w_qkv.data_ptr(), d_b_qkv.data_ptr(), d_w_o.data_ptr(), d_b_o.data_ptr()
         args.ws_lp, args.ws_f32 = ws_lp.data_ptr(), ws_f32.data_ptr()
+        defer = g is not None and cfg.queue is not None
+        args.defer_param_grads = int(defer)
         L.check(lib.mtn_mha_sublayer_bwd(code, C.byref(args), L.stream_ptr()))
+        if defer:
+            probs = (L.GemmProblem * 3)()
+            ln = L.LnFinalizeDesc()
+            n = lib.mtn_mha_param_grad_work(code, C.byref(args), probs, C.byref(ln))
+            cfg.queue.add(code, [probs[i] for i in range(n)], ln, [ws_lp, ws_f32, o, xn, mem_lp] if mem_lp is not None else [ws_lp, ws_f32, o, xn])
         if g is not None:
             return dx, dmem, None, None, None, None, None, None, None, None, None
         return dx, dmem, None, None, d_ln_a, d_ln_b, d_w_qkv, d_b_qkv, d_w_o, d_b_o, None
@@ -223,7 +296,10 @@ class FfnConfig:
     lp_dtype: torch.dtype = torch.bfloat16
     w1_lp: Optional[torch.Tensor] = None
     w2_lp: Optional[torch.Tensor] = None
+    w1_lpT: Optional[torch.Tensor] = None
+    w2_lpT: Optional[torch.Tensor] = None
     grads: Optional[dict] = None  # ln_a ln_b w1 b1 w2 b2
+    queue: Optional[ParamGradQueue] = None
 
 
 class FFNSublayerFn(torch.autograd.Function):
@@ -286,15 +362,163 @@ class FFNSublayerFn(torch.autograd.Function):
         args.drop_out = _drop(cfg.p_out, cfg.salt * 4 + 1, cfg.seed)
         args.x, args.ln_a, args.ln_b = x.data_ptr(), ln_a.data_ptr(), ln_b.data_ptr()
         args.w1, args.b1, args.w2, args.b2 = w1_lp.data_ptr(), b1.data_ptr(), w2_lp.data_ptr(), b2.data_ptr()
+        args.w1_t, args.w2_t = L.ptr(cfg.w1_lpT), L.ptr(cfg.w2_lpT)
         args.xn, args.mean, args.rstd, args.hid = xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), hid.data_ptr()
         args.dy, args.dx = dy.data_ptr(), dx.data_ptr()
         args.d_ln_a, args.d_ln_b = d_ln_a.data_ptr(), d_ln_b.data_ptr()
         args.d_w1, args.d_b1, args.d_w2, args.d_b2 = d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr()
         args.ws_lp, args.ws_f32 = ws_lp.data_ptr(), ws_f32.data_ptr()
+        defer = g is not None and cfg.queue is not None
+        args.defer_param_grads = int(defer)
         L.check(lib.mtn_ffn_sublayer_bwd(code, C.byref(args), L.stream_ptr()))
+        if defer:
+            probs = (L.GemmProblem * 2)()
+            ln = L.LnFinalizeDesc()
+            n = lib.mtn_ffn_param_grad_work(code, C.byref(args), probs, C.byref(ln))
+            cfg.queue.add(code, [probs[i] for i in range(n)], ln, [ws_lp, ws_f32, hid, xn])
         if g is not None:
             return dx, None, None, None, None, None, None, None
         return dx, d_ln_a, d_ln_b, d_w1, d_b1, d_w2, d_b2, None
+
+
+# ------------------------------------------------------------------------------------------ lockstep sublayer groups
+@dataclass
+class GroupMember:
+    """One sublayer of a lockstep group.  kind 'mha': params = (ln_a, ln_b, b_qkv, b_o), cfg = MhaConfig with the compute-dtype
+    weights and `grads` destinations set; kind 'ffn': params = (ln_a, ln_b, b1, b2), cfg = FfnConfig likewise."""
+    kind: str
+    cfg: object
+    params: tuple
+    mask: Optional[torch.Tensor] = None
+    mem_lp: Optional[torch.Tensor] = None
+
+
+class SublayerGroupFn(torch.autograd.Function):
+    """Independent sublayers of one DecoderLayer executed in lockstep (one grouped launch per stage, see csrc/sublayer.hip).
+    apply(members, x_0, mem_0, x_1, mem_1, ...) -> (y_0, y_1, ...); mem_i is None for self-attention / FFN members.
+    Parameter gradients go straight to cfg.grads (flat gradient buffer) through cfg.queue (always deferred)."""
+
+    @staticmethod
+    def forward(ctx, members, *tensors):
+        lib = L.load()
+        xs = [t.contiguous() for t in tensors[0::2]]
+        mems = list(tensors[1::2])
+        _require_cuda(*xs)
+        dev = xs[0].device
+        lp = members[0].cfg.lp_dtype
+        code = L.dtype_code(lp)
+        n_mha = sum(1 for m in members if m.kind == "mha")
+        n_ffn = len(members) - n_mha
+        mha_args = (L.MhaArgs * max(1, n_mha))()
+        ffn_args = (L.FfnArgs * max(1, n_ffn))()
+        saved, ys = [], []
+        im = jf = 0
+        for mem_t, x, mb in zip(mems, xs, members):
+            cfg = mb.cfg
+            ln_a, ln_b = mb.params[0], mb.params[1]
+            y = torch.empty_like(x)
+            d = x.size(-1)
+            if mb.kind == "mha":
+                B, a, _ = x.shape
+                self_attn = mem_t is None
+                m = a if self_attn else mem_t.size(1)
+                mem_lp = mb.mem_lp
+                if not self_attn and mem_lp is None:
+                    mem_lp = cast_to_lp(mem_t, lp)
+                mask_u8, sb, sq = _mask_u8(mb.mask, B, a, m)
+                xn = torch.empty(B * a, d, device=dev, dtype=lp)
+                mean = torch.empty(B * a, device=dev, dtype=torch.float32)
+                rstd = torch.empty_like(mean)
+                qkv = torch.empty(B * a, 3 * d if self_attn else d, device=dev, dtype=lp)
+                kv = None if self_attn else torch.empty(B * m, 2 * d, device=dev, dtype=lp)
+                o = torch.empty(B * a, d, device=dev, dtype=lp)
+                lse = torch.empty(2 * B * cfg.heads * a, device=dev, dtype=torch.float32)
+                A = mha_args[im]; im += 1
+                A.B, A.a, A.m, A.d, A.h = B, a, m, d, cfg.heads
+                A.self_attn, A.ln_eps = int(self_attn), cfg.eps
+                A.drop_attn = _drop(cfg.p_attn, cfg.salt * 4 + 0, cfg.seed)
+                A.drop_out = _drop(cfg.p_out, cfg.salt * 4 + 1, cfg.seed)
+                A.x, A.mem = x.data_ptr(), L.ptr(mem_lp)
+                A.mask, A.mask_sb, A.mask_sq = L.ptr(mask_u8), sb, sq
+                A.ln_a, A.ln_b = ln_a.data_ptr(), ln_b.data_ptr()
+                A.w_qkv, A.b_qkv, A.w_o, A.b_o = cfg.w_qkv_lp.data_ptr(), mb.params[2].data_ptr(), cfg.w_o_lp.data_ptr(), mb.params[3].data_ptr()
+                A.w_qkv_t, A.w_o_t = L.ptr(cfg.w_qkv_lpT), L.ptr(cfg.w_o_lpT)
+                A.y, A.xn, A.mean, A.rstd = y.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+                A.qkv, A.kv, A.o, A.lse = qkv.data_ptr(), L.ptr(kv), o.data_ptr(), lse.data_ptr()
+                saved.append(dict(x=x, mem_lp=mem_lp, mask=mask_u8, xn=xn, mean=mean, rstd=rstd, qkv=qkv, kv=kv, o=o, lse=lse,
+                                  need_dmem=(not self_attn) and mem_t.requires_grad, m=m))
+            else:
+                rows = x.numel() // d
+                ff = cfg.w1_lp.size(0)
+                xn = torch.empty(rows, d, device=dev, dtype=lp)
+                mean = torch.empty(rows, device=dev, dtype=torch.float32)
+                rstd = torch.empty_like(mean)
+                hid = torch.empty(rows, ff, device=dev, dtype=lp)
+                A = ffn_args[jf]; jf += 1
+                A.rows, A.d, A.d_ff, A.ln_eps = rows, d, ff, cfg.eps
+                A.drop_hidden = _drop(cfg.p_hidden, cfg.salt * 4 + 2, cfg.seed)
+                A.drop_out = _drop(cfg.p_out, cfg.salt * 4 + 1, cfg.seed)
+                A.x, A.ln_a, A.ln_b = x.data_ptr(), ln_a.data_ptr(), ln_b.data_ptr()
+                A.w1, A.b1, A.w2, A.b2 = cfg.w1_lp.data_ptr(), mb.params[2].data_ptr(), cfg.w2_lp.data_ptr(), mb.params[3].data_ptr()
+                A.w1_t, A.w2_t = L.ptr(cfg.w1_lpT), L.ptr(cfg.w2_lpT)
+                A.y, A.xn, A.mean, A.rstd, A.hid = y.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), hid.data_ptr()
+                saved.append(dict(x=x, xn=xn, mean=mean, rstd=rstd, hid=hid))
+            ys.append(y)
+        L.check(lib.mtn_sublayer_group_fwd(code, n_mha, mha_args, n_ffn, ffn_args, L.stream_ptr()))
+        ctx.members, ctx.saved_bufs, ctx.code = members, saved, code
+        ctx.mha_args, ctx.ffn_args, ctx.n_mha, ctx.n_ffn = mha_args, ffn_args, n_mha, n_ffn
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = L.load()
+        members, saved, code = ctx.members, ctx.saved_bufs, ctx.code
+        mha_args, ffn_args = ctx.mha_args, ctx.ffn_args      # forward pointers are still valid (buffers are kept alive in `saved`)
+        grads_out, keep_all = [], []
+        im = jf = 0
+        work = []
+        for dy, mb, sv in zip(dys, members, saved):
+            cfg, g = mb.cfg, mb.cfg.grads
+            x = sv["x"]
+            dev = x.device
+            dy = dy.contiguous() if dy is not None else torch.zeros_like(x)
+            dx = torch.empty_like(x)
+            if mb.kind == "mha":
+                A = mha_args[im]; im += 1
+                B, a, d, m = A.B, A.a, A.d, sv["m"]
+                dmem = torch.empty(B, m, d, device=dev, dtype=torch.float32) if sv["need_dmem"] else None
+                ws_lp = torch.empty(lib.mtn_mha_bwd_ws_lp_elems(B, a, m, d, A.self_attn), device=dev, dtype=cfg.lp_dtype)
+                ws_f32 = torch.empty(lib.mtn_mha_bwd_ws_f32_floats(B, a, m, d), device=dev, dtype=torch.float32)
+                A.dy, A.dx, A.dmem, A.dmem_accumulate = dy.data_ptr(), dx.data_ptr(), L.ptr(dmem), 0
+                A.d_ln_a, A.d_ln_b = g["ln_a"].data_ptr(), g["ln_b"].data_ptr()
+                A.d_w_qkv, A.d_b_qkv, A.d_w_o, A.d_b_o = g["w_qkv"].data_ptr(), g["b_qkv"].data_ptr(), g["w_o"].data_ptr(), g["b_o"].data_ptr()
+                A.ws_lp, A.ws_f32, A.defer_param_grads = ws_lp.data_ptr(), ws_f32.data_ptr(), 1
+                grads_out += [dx, dmem]
+                keep = [dy, ws_lp, ws_f32, sv["o"], sv["xn"]] + ([sv["mem_lp"]] if sv["mem_lp"] is not None else [])
+                work.append(("mha", A, keep))
+            else:
+                A = ffn_args[jf]; jf += 1
+                rows, d, ff = A.rows, A.d, A.d_ff
+                ws_lp = torch.empty(rows * d + rows * ff, device=dev, dtype=cfg.lp_dtype)
+                ws_f32 = torch.empty(lib.mtn_ffn_bwd_ws_f32_floats(rows, d, ff), device=dev, dtype=torch.float32)
+                A.dy, A.dx = dy.data_ptr(), dx.data_ptr()
+                A.d_ln_a, A.d_ln_b = g["ln_a"].data_ptr(), g["ln_b"].data_ptr()
+                A.d_w1, A.d_b1, A.d_w2, A.d_b2 = g["w1"].data_ptr(), g["b1"].data_ptr(), g["w2"].data_ptr(), g["b2"].data_ptr()
+                A.ws_lp, A.ws_f32, A.defer_param_grads = ws_lp.data_ptr(), ws_f32.data_ptr(), 1
+                grads_out += [dx, None]
+                keep = [dy, ws_lp, ws_f32, sv["hid"], sv["xn"]]
+                work.append(("ffn", A, keep))
+            keep_all.append(dy)
+        L.check(lib.mtn_sublayer_group_bwd(code, ctx.n_mha, mha_args, ctx.n_ffn, ffn_args, L.stream_ptr()))
+        for kind, A, keep in work:
+            probs = (L.GemmProblem * 3)()
+            ln = L.LnFinalizeDesc()
+            if kind == "mha":
+                n = lib.mtn_mha_param_grad_work(code, C.byref(A), probs, C.byref(ln))
+            else:
+                n = lib.mtn_ffn_param_grad_work(code, C.byref(A), probs, C.byref(ln))
+            members[0].cfg.queue.add(code, [probs[i] for i in range(n)], ln, keep)
+        return (None, *grads_out)
 
 
 # ------------------------------------------------------------------------------------------ attention core (tests / decode)

@@ -1,0 +1,22 @@
+import sqlite3, glob, sys
+from collections import defaultdict
+db = sorted(glob.glob(sys.argv[1] + '/**/*_results.db', recursive=True))[-1]
+c = sqlite3.connect(db)
+rows = c.execute("select name, start, end, grid_x, workgroup_x, queue_id from kernels order by start").fetchall()
+adam = [i for i,r in enumerate(rows) if 'adam_kernel' in r[0]]
+step = rows[adam[-2]+1:adam[-1]+1]
+t0, t1 = step[0][1], step[-1][2]
+iv = sorted((r[1], r[2]) for r in step)
+busy = 0; cs, ce = iv[0]
+for a,b in iv[1:]:
+    if a > ce: busy += ce-cs; cs, ce = a,b
+    else: ce = max(ce,b)
+busy += ce-cs
+print(f"step wall {(t1-t0)/1e3:.1f} us, kernels {len(step)}, busy {busy/1e3:.1f} us, sum {sum(r[2]-r[1] for r in step)/1e3:.1f} us")
+agg = defaultdict(list)
+for r in step:
+    n = r[0].split('(')[0][-44:]
+    agg[(n, r[3]//max(1,r[4]))].append((r[2]-r[1])/1e3)
+tot = sum(sum(v) for v in agg.values())
+for k,v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:int(sys.argv[2]) if len(sys.argv)>2 else 30]:
+    print(f"{k[0]:46s} wgs={k[1]:6d} n={len(v):4d} avg={sum(v)/len(v):8.2f} us  total={sum(v):8.1f} ({100*sum(v)/tot:4.1f}%)")
