@@ -1,0 +1,89 @@
+"""Data-parallel path on CPU (gloo, world_size 2): the bucketed flat-gradient all-reduce + global-token loss normalisation
+make N ranks x local batch equal ONE rank x concatenated batch.  The compute engine here is the CPU oracle
+(the HIP kernels need a GPU); the DP plumbing under test (mtn_amd.dp) is the code the GPU path uses."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat_grads(params):
+    return torch.cat([p.grad.reshape(-1) for p in params])
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from mtn_amd import dp
+    from oracle import fixtures as fx
+    r, w, _ = dp.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    c = dict(fx.GOLDEN_CONFIGS["small_diffall"], B=4)
+    raw = fx.det_batch(c["vocab"], c["B"], c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=5)
+    s, e = dp.shard_range(c["B"], rank, world)
+    shard = {k: (v[s:e] if k != "fts" else [f[s:e] for f in v]) for k, v in raw.items()}
+    model, _ = fx.oracle_from_config(c, requires_grad=True)
+    names = sorted(model.p)
+    params = [model.p[k] for k in names]
+    flat = torch.zeros(sum(p.numel() for p in params))
+    off = 0
+    for p in params:                                   # gradients live in ONE flat buffer, as in the GPU model
+        p.grad = flat[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+    sync = dp.GradSync(lambda: flat, n_buckets=3)
+    b = fx.oracle_batch(shard)
+    ae_y = b.cap
+    norms = torch.stack([b.ntokens, (ae_y != fx.PAD).sum()]).float()
+    sync.all_reduce_scalars(norms)                     # global token counts
+    out, ae_out = model.forward(b)
+    loss = model.loss(b, out, ae_out, norm=norms[0], ae_norm=norms[1])
+    loss.backward()
+    sync()
+    torch.save({"flat": flat.clone(), "norms": norms}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradients_equal_single_rank_on_concatenated_batch(tmp_path):
+    sys.path.insert(0, ROOT)
+    from oracle import fixtures as fx
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["flat"], r1["flat"])                       # replicas hold identical reduced gradients
+    c = dict(fx.GOLDEN_CONFIGS["small_diffall"], B=4)
+    raw = fx.det_batch(c["vocab"], c["B"], c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=5)
+    model, _ = fx.oracle_from_config(c, requires_grad=True)
+    b = fx.oracle_batch(raw)
+    out, ae_out = model.forward(b)
+    model.loss(b, out, ae_out).backward()
+    ref = torch.cat([model.p[k].grad.reshape(-1) for k in sorted(model.p)])
+    assert torch.allclose(r0["norms"], torch.stack([b.ntokens, (b.cap != fx.PAD).sum()]).float())
+    err = float((r0["flat"] - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+
+
+def test_shard_range_and_buckets():
+    from mtn_amd import dp
+    assert [dp.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert sum(e - s for s, e in (dp.shard_range(64 * 8, r, 8) for r in range(8))) == 512
+    gs = dp.GradSync(lambda: None, n_buckets=4)
+    bk = gs.buckets(106_650_000)
+    assert bk[0][0] == 0 and bk[-1][1] == 106_650_000 and all(a[1] == b[0] for a, b in zip(bk, bk[1:])) and len(bk) == 4

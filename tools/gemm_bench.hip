@@ -1,5 +1,5 @@
 // Standalone micro-benchmark of the GEMM kernels (hipEvent timing, warm and cold weights).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/gemm_bench scratch/gemm_bench.hip && /tmp/gemm_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/gemm_bench tools/gemm_bench.hip && /tmp/gemm_bench
 #include "../mtn_amd/csrc/gemm.hip"
 #include "../mtn_amd/csrc/elementwise.hip"
 #include <vector>
