@@ -5,6 +5,8 @@
 // (a fully masked row is uniform, not NaN), probabilities are dropped out with the counter-based mask.
 // Query lengths on this path are short (T,Q <= ~54 in DSTC7; 20 in the bench configs), so the contraction
 // runs on the VALU with 4x-register-tiled LDS reads; the d_model x d_model projections around it are MFMA.
+#include <stdlib.h>
+
 #include "common.h"
 
 static constexpr int AQ = 32;       // query rows per forward workgroup
@@ -323,6 +325,233 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnGroup G) {
     }
 }
 
+// ====================================================================================================================
+// MFMA forward.  One wave per (batch row, head, 32 query rows).  Scores are computed TRANSPOSED, S^T = K Q^T
+// (A = K rows, B = Q rows, both contraction-contiguous straight from global memory as 16-byte fragments), so that in the
+// MFMA C layout a lane holds, for ONE query column (lane & 15), the keys 4*(lane>>4)+r of every 16-key tile:
+//   * the softmax row max / row sum are in-register reductions + two wave shuffles (xor 16, 32);
+//   * P^T is already the B-operand fragment of O^T = V^T P^T (contraction slot (lane>>4, j) <-> key 16*(j>>2)+4*(lane>>4)+(j&3)),
+//     no cross-lane traffic to repack it;
+// V is staged through LDS transposed (4x4 in-register block transposes) so that the A-operand fragment (V^T rows = head
+// columns, 4 consecutive keys per slot group) is an 8/16-byte LDS read.  fp32 mode runs the same code on the exact-fp32 MFMA.
+// ====================================================================================================================
+static constexpr int MQ = 32;   // query rows per wave (2 MFMA column tiles)
+static constexpr int MK = 64;   // keys per tile      (4 MFMA row tiles)
+
+template <typename T> __device__ __forceinline__ uint4 load_frag(const T* base, bool valid) {
+    return valid ? *(const uint4*)base : make_uint4(0, 0, 0, 0);
+}
+
+// 4x4 block transpose staging: src rows [r0, r0+nrows) x ncols (row stride ld, rows clamped to rmax-1) -> dst[col][row]
+template <typename T>
+__device__ __forceinline__ void stage_transposed(unsigned char* dst, int dst_row_bytes, const T* src, int ld, int r0, int nrows,
+                                                 int rmax, int ncols, int lane) {
+    const int cb_n = ncols >> 2, nblk = (nrows >> 2) * cb_n;
+    for (int blk = lane; blk < nblk; blk += 64) {
+        const int kb = blk / cb_n, cb = blk - kb * cb_n;
+        if constexpr (sizeof(T) == 2) {
+            uint2 v[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                int r = r0 + kb * 4 + kk;
+                r = r < rmax ? r : rmax - 1;
+                v[kk] = *(const uint2*)(src + (size_t)r * ld + cb * 4);
+            }
+            unsigned char* p = dst + (size_t)(cb * 4) * dst_row_bytes + kb * 8;
+            *(uint2*)(p) = make_uint2((v[0].x & 0xffffu) | (v[1].x << 16), (v[2].x & 0xffffu) | (v[3].x << 16));
+            *(uint2*)(p + dst_row_bytes) = make_uint2((v[0].x >> 16) | (v[1].x & 0xffff0000u), (v[2].x >> 16) | (v[3].x & 0xffff0000u));
+            *(uint2*)(p + 2 * dst_row_bytes) = make_uint2((v[0].y & 0xffffu) | (v[1].y << 16), (v[2].y & 0xffffu) | (v[3].y << 16));
+            *(uint2*)(p + 3 * dst_row_bytes) = make_uint2((v[0].y >> 16) | (v[1].y & 0xffff0000u), (v[2].y >> 16) | (v[3].y & 0xffff0000u));
+        } else {
+            uint4 v[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                int r = r0 + kb * 4 + kk;
+                r = r < rmax ? r : rmax - 1;
+                v[kk] = *(const uint4*)(src + (size_t)r * ld + cb * 4);
+            }
+            unsigned char* p = dst + (size_t)(cb * 4) * dst_row_bytes + kb * 16;
+            *(uint4*)(p) = make_uint4(v[0].x, v[1].x, v[2].x, v[3].x);
+            *(uint4*)(p + dst_row_bytes) = make_uint4(v[0].y, v[1].y, v[2].y, v[3].y);
+            *(uint4*)(p + 2 * dst_row_bytes) = make_uint4(v[0].z, v[1].z, v[2].z, v[3].z);
+            *(uint4*)(p + 3 * dst_row_bytes) = make_uint4(v[0].w, v[1].w, v[2].w, v[3].w);
+        }
+    }
+}
+
+// C tiles (4 values per lane each) -> one B/A-operand fragment of a contraction step (bf16: two tiles, fp32: one)
+template <typename T> __device__ __forceinline__ uint4 frag_from_c(const f32x4_t& lo, const f32x4_t& hi);
+template <> __device__ __forceinline__ uint4 frag_from_c<bf16_t>(const f32x4_t& lo, const f32x4_t& hi) {
+    return make_uint4((uint32_t)f32_to_bf16(lo[0]) | ((uint32_t)f32_to_bf16(lo[1]) << 16), (uint32_t)f32_to_bf16(lo[2]) | ((uint32_t)f32_to_bf16(lo[3]) << 16),
+                      (uint32_t)f32_to_bf16(hi[0]) | ((uint32_t)f32_to_bf16(hi[1]) << 16), (uint32_t)f32_to_bf16(hi[2]) | ((uint32_t)f32_to_bf16(hi[3]) << 16));
+}
+template <> __device__ __forceinline__ uint4 frag_from_c<float>(const f32x4_t& lo, const f32x4_t&) {
+    return make_uint4(__float_as_uint(lo[0]), __float_as_uint(lo[1]), __float_as_uint(lo[2]), __float_as_uint(lo[3]));
+}
+// transposed-LDS fragment: row `row` of the [col][key] image, contraction step u (bf16: keys 32u+4lg.. and 32u+16+4lg..; fp32: 16u+4lg..)
+template <typename T> __device__ __forceinline__ uint4 frag_from_tlds(const unsigned char* img, int row_bytes, int row, int u, int lg) {
+    const unsigned char* p = img + (size_t)row * row_bytes;
+    if constexpr (sizeof(T) == 2) {
+        uint2 a = *(const uint2*)(p + (u * 32 + 4 * lg) * 2), b = *(const uint2*)(p + (u * 32 + 16 + 4 * lg) * 2);
+        return make_uint4(a.x, a.y, b.x, b.y);
+    } else {
+        return *(const uint4*)(p + (u * 16 + 4 * lg) * 4);
+    }
+}
+
+template <typename T, int DK>
+__global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnGroup G) {
+    constexpr int EPV = LP<T>::EPV, KSTEP = LP<T>::KSTEP;
+    constexpr int NKS = (DK + KSTEP - 1) / KSTEP;     // contraction steps over the head dimension
+    constexpr int NDT = DK / 16;                      // 16-column tiles of the head dimension
+    constexpr int TPK = KSTEP / 16;                   // 16-key C tiles per contraction step over keys (bf16 2, fp32 1)
+    constexpr int NU = MK / KSTEP;                    // contraction steps per key tile
+    constexpr int VT_ROW = MK * (int)sizeof(T) + 16;  // bytes per row of the transposed V image
+    extern __shared__ __attribute__((aligned(16))) unsigned char vt[];   // [DK][VT_ROW]
+    const mtn_attn_args& A = G.a[blockIdx.z];
+    if ((int)blockIdx.x >= A.B * A.h || (int)blockIdx.y * MQ >= A.a) return;
+    const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x / A.h, hh = blockIdx.x % A.h, q0 = blockIdx.y * MQ;
+    const int a = A.a, m = A.m;
+    const float scale = rsqrtf((float)DK);
+    const T* qg = (const T*)A.q + (size_t)b * a * A.ldq + hh * DK;
+    const T* kg = (const T*)A.k + (size_t)b * m * A.ldkv + hh * DK;
+    const T* vg = (const T*)A.v + (size_t)b * m * A.ldkv + hh * DK;
+    const DropState ds = drop_init(A.drop);
+
+    uint4 qf[2][NKS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = q0 + qt * 16 + l15;
+        q = q < a ? q : a - 1;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[qt][ks] = load_frag<T>(qg + (size_t)q * A.ldq + ks * KSTEP + lg * EPV, ks * KSTEP + lg * EPV < DK);
+    }
+    f32x4_t ot[NDT][2];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) ot[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+
+    for (int j0 = 0; j0 < m; j0 += MK) {
+        // ---- S^T tile = K Q^T
+        f32x4_t st[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            int key = j0 + kt * 16 + l15;
+            key = key < m ? key : m - 1;
+            uint4 kf[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) kf[ks] = load_frag<T>(kg + (size_t)key * A.ldkv + ks * KSTEP + lg * EPV, ks * KSTEP + lg * EPV < DK);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                st[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) mma16<T>(st[kt][qt], kf[ks], qf[qt][ks]);
+            }
+        }
+        // ---- stage V^T for this key tile while the scores settle (single wave: the barrier is a wave-local fence)
+        __syncthreads();
+        stage_transposed<T>(vt, VT_ROW, vg, A.ldkv, j0, MK, m, DK, lane);
+        // ---- mask, scale, online softmax (per query column = per lane&15)
+        float alpha[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            int q = q0 + qt * 16 + l15;
+            const int qc = q < a ? q : a - 1;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = j0 + kt * 16 + 4 * lg + r;
+                    float sv = st[kt][qt][r] * scale;
+                    if (key >= m) sv = -INFINITY;
+                    else if (A.mask && A.mask[(size_t)b * A.mask_sb + (size_t)qc * A.mask_sq + key] == 0) sv = -1e9f;
+                    st[kt][qt][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(mrun[qt], mx);
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = __expf(st[kt][qt][r] - mn);     // exp(-inf) = 0 for tile padding
+                    psum += pv;
+                    if (ds.on) {
+                        const int key = j0 + kt * 16 + 4 * lg + r;
+                        const uint64_t idx = ((uint64_t)(b * A.h + hh) * a + qc) * (uint64_t)m + key;
+                        pv = drop_keep(ds, idx) ? pv * ds.scale : 0.f;
+                    }
+                    st[kt][qt][r] = pv;
+                }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            alpha[qt] = (mrun[qt] == -INFINITY) ? 0.f : __expf(mrun[qt] - mn);
+            lrun[qt] = lrun[qt] * alpha[qt] + psum;
+            mrun[qt] = mn;
+        }
+        __syncthreads();
+        // ---- O^T = alpha * O^T + V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                ot[dt][qt][0] *= alpha[qt]; ot[dt][qt][1] *= alpha[qt]; ot[dt][qt][2] *= alpha[qt]; ot[dt][qt][3] *= alpha[qt];
+            }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            uint4 pf[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) pf[qt] = frag_from_c<T>(st[u * TPK][qt], st[u * TPK + TPK - 1][qt]);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const uint4 vf = frag_from_tlds<T>(vt, VT_ROW, dt * 16 + l15, u, lg);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) mma16<T>(ot[dt][qt], vf, pf[qt]);
+            }
+        }
+    }
+    // ---- epilogue: lane holds O^T[dcol = dt*16 + 4*lg + r][q = qt*16 + l15]
+    T* og = (T*)A.o + (size_t)b * a * A.ldo + hh * DK;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + l15;
+        if (q < a) {
+            const float inv = 1.0f / lrun[qt];
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const f32x4_t o = ot[dt][qt];
+                store4<T>(og + (size_t)q * A.ldo + dt * 16 + 4 * lg, make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv));
+            }
+            if (A.lse && lg == 0) {
+                float* stp = A.lse + 2 * ((size_t)(b * A.h + hh) * a + q);
+                stp[0] = mrun[qt];
+                stp[1] = inv;
+            }
+        }
+    }
+}
+
+template <typename T, int DK> static int launch_fwd_mfma(const AttnGroup& G, dim3 grid, hipStream_t s) {
+    const size_t lds = (size_t)DK * (MK * sizeof(T) + 16);
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, DK>), grid, dim3(64), lds, s, G);
+    return MTN_OK;
+}
+template <typename T> static int dispatch_fwd_mfma(int dk, const AttnGroup& G, dim3 grid, hipStream_t s) {
+    switch (dk) {
+        case 16: return launch_fwd_mfma<T, 16>(G, grid, s);
+        case 32: return launch_fwd_mfma<T, 32>(G, grid, s);
+        case 64: return launch_fwd_mfma<T, 64>(G, grid, s);
+        case 128: return launch_fwd_mfma<T, 128>(G, grid, s);
+    }
+    return -1;
+}
+
 // ------------------------------------------------------------------------------------------ host
 static size_t fwd_lds_bytes(int dk) { return sizeof(float) * ((size_t)(2 * AQ + 2 * MT_F) * (dk + 4) + (size_t)AQ * (MT_F + 4) + 3 * AQ); }
 static size_t bwd_lds_bytes(int a, int dk) {
@@ -367,8 +596,22 @@ extern "C" int mtn_attention_fwd_group(int dtype, int count, const mtn_attn_args
         if (args[i].B * args[i].h > gx) gx = args[i].B * args[i].h;
         if ((args[i].a + AQ - 1) / AQ > gy) gy = (args[i].a + AQ - 1) / AQ;
     }
-    dim3 grid(gx, gy, count), block(256);
     hipStream_t s = (hipStream_t)stream;
+    {   // MFMA path: every member has the same head size in {16,32,64,128} and 8-byte aligned rows
+        bool ok = getenv("MTN_ATTN_VALU") == nullptr;
+        const int dk = args[0].dk;
+        int gym = 0;
+        for (int i = 0; i < count; ++i) {
+            ok = ok && args[i].dk == dk && (dk == 16 || dk == 32 || dk == 64 || dk == 128) && args[i].ldq % 8 == 0 && args[i].ldkv % 8 == 0 && args[i].ldo % 4 == 0;
+            if ((args[i].a + MQ - 1) / MQ > gym) gym = (args[i].a + MQ - 1) / MQ;
+        }
+        if (ok) {
+            dim3 gridm(gx, gym, count);
+            int rc = (dtype == MTN_BF16) ? dispatch_fwd_mfma<bf16_t>(dk, G, gridm, s) : dispatch_fwd_mfma<float>(dk, G, gridm, s);
+            if (rc == MTN_OK) { MTN_CHECK_LAUNCH(); return MTN_OK; }
+        }
+    }
+    dim3 grid(gx, gy, count), block(256);
     if (dtype == MTN_BF16) {
         if (int rc = set_lds(attn_fwd_kernel<bf16_t>, lds)) return rc;
         hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, block, lds, s, G);
