@@ -379,6 +379,65 @@ __device__ __forceinline__ void stage_transposed(unsigned char* dst, int dst_row
     }
 }
 
+// Same staging split in two so the global loads can be issued ahead of the code that needs the LDS image:
+// NB = blocks per lane = ceil((nrows/4)*(ncols/4)/64), compile time.
+template <typename T, int NB> struct TStage {
+    uint4 v[NB][sizeof(T) == 2 ? 2 : 4];
+    __device__ __forceinline__ void load(const T* src, int ld, int r0, int nrows, int rmax, int ncols, int lane) {
+        const int cb_n = ncols >> 2, nblk = (nrows >> 2) * cb_n;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int blk = lane + 64 * i;
+            if (blk < nblk) {
+                const int kb = blk / cb_n, cb = blk - kb * cb_n;
+                if constexpr (sizeof(T) == 2) {
+                    uint2 t[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        int r = r0 + kb * 4 + kk;
+                        r = r < rmax ? r : rmax - 1;
+                        t[kk] = *(const uint2*)(src + (size_t)r * ld + cb * 4);
+                    }
+                    v[i][0] = make_uint4(t[0].x, t[0].y, t[1].x, t[1].y);
+                    v[i][1] = make_uint4(t[2].x, t[2].y, t[3].x, t[3].y);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        int r = r0 + kb * 4 + kk;
+                        r = r < rmax ? r : rmax - 1;
+                        v[i][kk] = *(const uint4*)(src + (size_t)r * ld + cb * 4);
+                    }
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* dst, int dst_row_bytes, int nrows, int ncols, int lane) const {
+        const int cb_n = ncols >> 2, nblk = (nrows >> 2) * cb_n;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int blk = lane + 64 * i;
+            if (blk < nblk) {
+                const int kb = blk / cb_n, cb = blk - kb * cb_n;
+                if constexpr (sizeof(T) == 2) {
+                    const uint32_t a0 = v[i][0].x, a1 = v[i][0].y, b0 = v[i][0].z, b1 = v[i][0].w;   // rows k0 (a), k1 (b)
+                    const uint32_t c0 = v[i][1].x, c1 = v[i][1].y, d0 = v[i][1].z, d1 = v[i][1].w;   // rows k2 (c), k3 (d)
+                    unsigned char* p = dst + (size_t)(cb * 4) * dst_row_bytes + kb * 8;
+                    *(uint2*)(p) = make_uint2((a0 & 0xffffu) | (b0 << 16), (c0 & 0xffffu) | (d0 << 16));
+                    *(uint2*)(p + dst_row_bytes) = make_uint2((a0 >> 16) | (b0 & 0xffff0000u), (c0 >> 16) | (d0 & 0xffff0000u));
+                    *(uint2*)(p + 2 * dst_row_bytes) = make_uint2((a1 & 0xffffu) | (b1 << 16), (c1 & 0xffffu) | (d1 << 16));
+                    *(uint2*)(p + 3 * dst_row_bytes) = make_uint2((a1 >> 16) | (b1 & 0xffff0000u), (c1 >> 16) | (d1 & 0xffff0000u));
+                } else {
+                    unsigned char* p = dst + (size_t)(cb * 4) * dst_row_bytes + kb * 16;
+                    *(uint4*)(p) = make_uint4(v[i][0].x, v[i][1].x, v[i][2].x, v[i][3].x);
+                    *(uint4*)(p + dst_row_bytes) = make_uint4(v[i][0].y, v[i][1].y, v[i][2].y, v[i][3].y);
+                    *(uint4*)(p + 2 * dst_row_bytes) = make_uint4(v[i][0].z, v[i][1].z, v[i][2].z, v[i][3].z);
+                    *(uint4*)(p + 3 * dst_row_bytes) = make_uint4(v[i][0].w, v[i][1].w, v[i][2].w, v[i][3].w);
+                }
+            }
+        }
+    }
+};
+
 // C tiles (4 values per lane each) -> one B/A-operand fragment of a contraction step (bf16: two tiles, fp32: one)
 template <typename T> __device__ __forceinline__ uint4 frag_from_c(const f32x4_t& lo, const f32x4_t& hi);
 template <> __device__ __forceinline__ uint4 frag_from_c<bf16_t>(const f32x4_t& lo, const f32x4_t& hi) {
@@ -434,26 +493,54 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnGroup G) {
         for (int qt = 0; qt < 2; ++qt) ot[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
 
+    constexpr int NBV = ((MK / 4) * (DK / 4) + 63) / 64;
     for (int j0 = 0; j0 < m; j0 += MK) {
-        // ---- S^T tile = K Q^T
-        f32x4_t st[4][2];
+        // ---- all global loads of the tile go out first: K fragments, V (for the transposed image), mask bytes
+        uint4 kf[4][NKS];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             int key = j0 + kt * 16 + l15;
             key = key < m ? key : m - 1;
-            uint4 kf[NKS];
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) kf[ks] = load_frag<T>(kg + (size_t)key * A.ldkv + ks * KSTEP + lg * EPV, ks * KSTEP + lg * EPV < DK);
+            for (int ks = 0; ks < NKS; ++ks) kf[kt][ks] = load_frag<T>(kg + (size_t)key * A.ldkv + ks * KSTEP + lg * EPV, ks * KSTEP + lg * EPV < DK);
+        }
+        TStage<T, NBV> vst;
+        vst.load(vg, A.ldkv, j0, MK, m, DK, lane);
+        uint32_t mk[2][4];           // 4 mask bytes (keys 4lg..4lg+3 of tile kt) per query column; 1 = keep
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            int q = q0 + qt * 16 + l15;
+            q = q < a ? q : a - 1;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                uint32_t w = 0x01010101u;
+                if (A.mask && (qt == 0 || A.mask_sq != 0)) {
+                    w = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int key = j0 + kt * 16 + 4 * lg + r;
+                        key = key < m ? key : m - 1;
+                        w |= (uint32_t)(A.mask[(size_t)b * A.mask_sb + (size_t)q * A.mask_sq + key] != 0) << (8 * r);
+                    }
+                } else if (A.mask) {
+                    w = mk[0][kt];   // key-padding mask: same for every query row
+                }
+                mk[qt][kt] = w;
+            }
+        }
+        // ---- S^T tile = K Q^T
+        f32x4_t st[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 st[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) mma16<T>(st[kt][qt], kf[ks], qf[qt][ks]);
+                for (int ks = 0; ks < NKS; ++ks) mma16<T>(st[kt][qt], kf[kt][ks], qf[qt][ks]);
             }
-        }
-        // ---- stage V^T for this key tile while the scores settle (single wave: the barrier is a wave-local fence)
+        // ---- V^T image for this key tile (single wave: the barrier is a wave-local fence)
         __syncthreads();
-        stage_transposed<T>(vt, VT_ROW, vg, A.ldkv, j0, MK, m, DK, lane);
+        vst.store(vt, VT_ROW, MK, DK, lane);
         // ---- mask, scale, online softmax (per query column = per lane&15)
         float alpha[2];
 #pragma unroll
@@ -468,7 +555,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnGroup G) {
                     const int key = j0 + kt * 16 + 4 * lg + r;
                     float sv = st[kt][qt][r] * scale;
                     if (key >= m) sv = -INFINITY;
-                    else if (A.mask && A.mask[(size_t)b * A.mask_sb + (size_t)qc * A.mask_sq + key] == 0) sv = -1e9f;
+                    else if (((mk[qt][kt] >> (8 * r)) & 0xffu) == 0) sv = -1e9f;
                     st[kt][qt][r] = sv;
                     mx = fmaxf(mx, sv);
                 }
@@ -548,6 +635,220 @@ template <typename T> static int dispatch_fwd_mfma(int dk, const AttnGroup& G, d
         case 32: return launch_fwd_mfma<T, 32>(G, grid, s);
         case 64: return launch_fwd_mfma<T, 64>(G, grid, s);
         case 128: return launch_fwd_mfma<T, 128>(G, grid, s);
+    }
+    return -1;
+}
+
+// ====================================================================================================================
+// MFMA backward (query blocks of <= 32 rows: T,Q <= 32 — longer queries take the VALU kernel above).  One wave per
+// (batch row, head), keys in tiles of 32.  Here scores are computed UN-transposed, S = Q K^T and dP = dO V^T (all four
+// operands contraction-contiguous from global memory), so that in the C layout a lane holds one KEY column (lane & 15)
+// and the query rows 4*(lane>>4)+r: P and dS are then directly the B-operand fragments of the two contractions over the
+// query index, dV^T = dO^T Pdrop and dK^T = Q^T dS (A operands dO^T, Q^T come from transposed LDS images built once).
+// dQ^T = K^T dS^T contracts over keys: dS makes one round trip through LDS ([q][key] image) to come back with the query
+// index on lane & 15, and K^T is staged transposed per key tile.
+// ====================================================================================================================
+static constexpr int BQ = 32;   // query rows per block
+static constexpr int BK = 32;   // keys per tile
+
+template <typename T, int DK>
+__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnGroup G) {
+    constexpr int EPV = LP<T>::EPV, KSTEP = LP<T>::KSTEP;
+    constexpr int NKS = (DK + KSTEP - 1) / KSTEP;
+    constexpr int NDT = DK / 16;
+    constexpr int TPK = KSTEP / 16;                    // C tiles per contraction step over a 32-long index (bf16 2, fp32 1)
+    constexpr int NU = 32 / KSTEP;                     // contraction steps over 32 queries / 32 keys (bf16 1, fp32 2)
+    constexpr int ROWB = 32 * (int)sizeof(T) + 16;     // bytes per row of the transposed images (32 entries + pad)
+    extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+    unsigned char* dOt = bsm;                 // [DK][ROWB]  dO^T  (row = head column, entries = query rows)
+    unsigned char* Qt = dOt + DK * ROWB;     // [DK][ROWB]  Q^T
+    unsigned char* Kt = Qt + DK * ROWB;      // [DK][ROWB]  K^T of the current key tile
+    unsigned char* dSs = Kt + DK * ROWB;     // [32][ROWB]  dS  (row = query, entries = keys of the tile)
+    float* Ds = (float*)(dSs + 32 * ROWB);   // [32]        D_q = sum_c dO[q][c] O[q][c]
+    const mtn_attn_args& A = G.a[blockIdx.z];
+    if ((int)blockIdx.x >= A.B * A.h) return;
+    const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x / A.h, hh = blockIdx.x % A.h;
+    const int a = A.a, m = A.m;
+    const float scale = rsqrtf((float)DK);
+    const T* qg = (const T*)A.q + (size_t)b * a * A.ldq + hh * DK;
+    const T* kg = (const T*)A.k + (size_t)b * m * A.ldkv + hh * DK;
+    const T* vg = (const T*)A.v + (size_t)b * m * A.ldkv + hh * DK;
+    const T* og = (const T*)A.o + (size_t)b * a * A.ldo + hh * DK;
+    const T* dog = (const T*)A.d_o + (size_t)b * a * A.ldo + hh * DK;
+    const DropState ds = drop_init(A.drop);
+
+    // ---- prologue: A-operand fragments of Q and dO (rows = queries), transposed images, D_q
+    uint4 qf[2][NKS], dof[2][NKS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = qt * 16 + l15;
+        q = q < a ? q : a - 1;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bool ok = ks * KSTEP + lg * EPV < DK;
+            qf[qt][ks] = load_frag<T>(qg + (size_t)q * A.ldq + ks * KSTEP + lg * EPV, ok);
+            dof[qt][ks] = load_frag<T>(dog + (size_t)q * A.ldo + ks * KSTEP + lg * EPV, ok);
+        }
+    }
+    stage_transposed<T>(dOt, ROWB, dog, A.ldo, 0, BQ, a, DK, lane);
+    stage_transposed<T>(Qt, ROWB, qg, A.ldq, 0, BQ, a, DK, lane);
+    {   // D_q: lanes 2q and 2q+1 each sum half of row q
+        int q = lane >> 1;
+        const int half = lane & 1;
+        float sacc = 0.f;
+        if (q < a) {
+            const T* dp = dog + (size_t)q * A.ldo + half * (DK / 2);
+            const T* op = og + (size_t)q * A.ldo + half * (DK / 2);
+#pragma unroll
+            for (int c = 0; c < DK / 2; c += 4) {
+                float4 x = load4<T>(dp + c), y = load4<T>(op + c);
+                sacc += dot4(x, y);
+            }
+        }
+        sacc += __shfl_xor(sacc, 1, 64);
+        if (half == 0) Ds[q] = sacc;
+    }
+    __syncthreads();
+    float mxq[2][4], invq[2][4], Dq[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + 4 * lg + r;
+            const int qc = q < a ? q : a - 1;
+            const float* stp = A.lse + 2 * ((size_t)(b * A.h + hh) * a + qc);
+            mxq[qt][r] = stp[0];
+            invq[qt][r] = stp[1];
+            Dq[qt][r] = Ds[q];
+        }
+    f32x4_t dqt[NDT][2];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) dqt[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    T* dqg = (T*)A.dq + (size_t)b * a * A.ldq + hh * DK;
+    T* dkg = (T*)A.dk_out + (size_t)b * m * A.ldkv + hh * DK;
+    T* dvg = (T*)A.dv_out + (size_t)b * m * A.ldkv + hh * DK;
+
+    for (int j0 = 0; j0 < m; j0 += BK) {
+        // ---- S = Q K^T, dP = dO V^T   (C layout: rows q = qt*16+4lg+r, column key = kt*16 + l15)
+        f32x4_t sc[2][2], dp[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            int key = j0 + kt * 16 + l15;
+            key = key < m ? key : m - 1;
+            uint4 kf[NKS], vf[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bool ok = ks * KSTEP + lg * EPV < DK;
+                kf[ks] = load_frag<T>(kg + (size_t)key * A.ldkv + ks * KSTEP + lg * EPV, ok);
+                vf[ks] = load_frag<T>(vg + (size_t)key * A.ldkv + ks * KSTEP + lg * EPV, ok);
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                sc[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                dp[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    mma16<T>(sc[qt][kt], qf[qt][ks], kf[ks]);
+                    mma16<T>(dp[qt][kt], dof[qt][ks], vf[ks]);
+                }
+            }
+        }
+        __syncthreads();                                   // previous tile's readers of Kt / dSs are done
+        stage_transposed<T>(Kt, ROWB, kg, A.ldkv, j0, BK, m, DK, lane);
+        // ---- P, dS in registers (sc <- dropped-out P, dp <- dS); dS also goes to LDS as [q][key]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int key = j0 + kt * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qt * 16 + 4 * lg + r;
+                    float pd = 0.f, dsv = 0.f;
+                    if (key < m && q < a) {
+                        const bool keep_score = !(A.mask && A.mask[(size_t)b * A.mask_sb + (size_t)q * A.mask_sq + key] == 0);
+                        const float sv = keep_score ? sc[qt][kt][r] * scale : -1e9f;
+                        const float p = __expf(sv - mxq[qt][r]) * invq[qt][r];
+                        float dpd = dp[qt][kt][r];
+                        pd = p;
+                        if (ds.on) {
+                            const uint64_t idx = ((uint64_t)(b * A.h + hh) * a + q) * (uint64_t)m + key;
+                            const bool kp = drop_keep(ds, idx);
+                            pd = kp ? p * ds.scale : 0.f;
+                            dpd = kp ? dpd * ds.scale : 0.f;
+                        }
+                        dsv = keep_score ? p * (dpd - Dq[qt][r]) : 0.f;
+                    }
+                    sc[qt][kt][r] = pd;
+                    dp[qt][kt][r] = dsv;
+                    *(T*)(dSs + (size_t)q * ROWB + (kt * 16 + l15) * sizeof(T)) = LP<T>::from_f32(dsv);
+                }
+            }
+        // ---- dV^T = dO^T Pdrop, dK^T = Q^T dS (contraction over the 32 query rows), written per key tile
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = j0 + kt * 16 + l15;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                f32x4_t av = f32x4_t{0.f, 0.f, 0.f, 0.f}, ak = av;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const uint4 pf = frag_from_c<T>(sc[u * TPK][kt], sc[u * TPK + TPK - 1][kt]);
+                    const uint4 sf = frag_from_c<T>(dp[u * TPK][kt], dp[u * TPK + TPK - 1][kt]);
+                    mma16<T>(av, frag_from_tlds<T>(dOt, ROWB, dt * 16 + l15, u, lg), pf);
+                    mma16<T>(ak, frag_from_tlds<T>(Qt, ROWB, dt * 16 + l15, u, lg), sf);
+                }
+                if (key < m) {   // lane holds rows (head columns) dt*16 + 4lg + r of key column `key`
+                    store4<T>(dvg + (size_t)key * A.ldkv + dt * 16 + 4 * lg, make_float4(av[0], av[1], av[2], av[3]));
+                    store4<T>(dkg + (size_t)key * A.ldkv + dt * 16 + 4 * lg, make_float4(ak[0] * scale, ak[1] * scale, ak[2] * scale, ak[3] * scale));
+                }
+            }
+        }
+        __syncthreads();                                   // Kt and dSs are complete
+        // ---- dQ^T += K^T dS^T (contraction over the 32 keys of the tile)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            uint4 sf[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) sf[qt] = frag_from_tlds<T>(dSs, ROWB, qt * 16 + l15, u, lg);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const uint4 kfT = frag_from_tlds<T>(Kt, ROWB, dt * 16 + l15, u, lg);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) mma16<T>(dqt[dt][qt], kfT, sf[qt]);
+            }
+        }
+    }
+    // ---- dQ: lane holds dQ^T[d = dt*16 + 4lg + r][q = qt*16 + l15]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = qt * 16 + l15;
+        if (q < a) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const f32x4_t v = dqt[dt][qt];
+                store4<T>(dqg + (size_t)q * A.ldq + dt * 16 + 4 * lg, make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale));
+            }
+        }
+    }
+}
+
+template <typename T, int DK> static int launch_bwd_mfma(const AttnGroup& G, dim3 grid, hipStream_t s) {
+    const size_t rowb = 32 * sizeof(T) + 16;
+    const size_t lds = (3 * (size_t)DK + 32) * rowb + 32 * sizeof(float);
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<T, DK>), grid, dim3(64), lds, s, G);
+    return MTN_OK;
+}
+template <typename T> static int dispatch_bwd_mfma(int dk, const AttnGroup& G, dim3 grid, hipStream_t s) {
+    switch (dk) {
+        case 16: return launch_bwd_mfma<T, 16>(G, grid, s);
+        case 32: return launch_bwd_mfma<T, 32>(G, grid, s);
+        case 64: return launch_bwd_mfma<T, 64>(G, grid, s);
+        case 128: return launch_bwd_mfma<T, 128>(G, grid, s);
     }
     return -1;
 }
@@ -641,6 +942,17 @@ extern "C" int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args
     MTN_CHECK_ARG(lds <= 160 * 1024, "attention backward tile does not fit LDS");
     dim3 grid(gx, 1, count), block(256);
     hipStream_t s = (hipStream_t)stream;
+    {   // MFMA path: same supported head size everywhere, query blocks of at most 32 rows
+        bool ok = getenv("MTN_ATTN_VALU") == nullptr;
+        const int dk = args[0].dk;
+        for (int i = 0; i < count; ++i)
+            ok = ok && args[i].dk == dk && (dk == 16 || dk == 32 || dk == 64 || dk == 128) && args[i].a <= BQ && args[i].ldq % 8 == 0 &&
+                 args[i].ldkv % 8 == 0 && args[i].ldo % 8 == 0;
+        if (ok) {
+            int rc = (dtype == MTN_BF16) ? dispatch_bwd_mfma<bf16_t>(dk, G, grid, s) : dispatch_bwd_mfma<float>(dk, G, grid, s);
+            if (rc == MTN_OK) { MTN_CHECK_LAUNCH(); return MTN_OK; }
+        }
+    }
     if (dtype == MTN_BF16) {
         if (int rc = set_lds(attn_bwd_kernel<bf16_t>, lds)) return rc;
         hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), grid, block, lds, s, G);

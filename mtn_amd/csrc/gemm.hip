@@ -89,6 +89,58 @@ template <typename T, bool TR> struct Stage {
     }
 };
 
+// Epilogue for 4 consecutive output columns of one row: v += bias; relu; dropout; gate; v += residual; store fp32 / lowp.
+template <typename T>
+__device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropState& ds, bool vec, int row, int col, int N, const f32x4_t& acc) {
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    const size_t o = (size_t)row * P.ldc + col;
+    const int nv = (col + 4 <= N) ? 4 : N - col;
+    if (P.bias) {
+        if (vec) { float4 b = *(const float4*)(P.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        else for (int r = 0; r < nv; ++r) v[r] += P.bias[col + r];
+    }
+    if (P.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if (ds.on) {
+        const uint64_t idx = (uint64_t)row * (uint64_t)N + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = drop_keep(ds, idx + r) ? v[r] * ds.scale : 0.f;
+    }
+    if (P.gate) {
+        const T* gp = (const T*)P.gate + o;
+        if (vec) {
+            if constexpr (sizeof(T) == 2) {
+                uint2 u = *(const uint2*)gp;
+                const float g0 = __uint_as_float(u.x << 16), g1 = __uint_as_float(u.x & 0xffff0000u), g2 = __uint_as_float(u.y << 16), g3 = __uint_as_float(u.y & 0xffff0000u);
+                v[0] = g0 > 0.f ? v[0] * P.gate_scale : 0.f; v[1] = g1 > 0.f ? v[1] * P.gate_scale : 0.f;
+                v[2] = g2 > 0.f ? v[2] * P.gate_scale : 0.f; v[3] = g3 > 0.f ? v[3] * P.gate_scale : 0.f;
+            } else {
+                float4 gq = *(const float4*)gp;
+                v[0] = gq.x > 0.f ? v[0] * P.gate_scale : 0.f; v[1] = gq.y > 0.f ? v[1] * P.gate_scale : 0.f;
+                v[2] = gq.z > 0.f ? v[2] * P.gate_scale : 0.f; v[3] = gq.w > 0.f ? v[3] * P.gate_scale : 0.f;
+            }
+        } else for (int r = 0; r < nv; ++r) v[r] = LP<T>::to_f32(gp[r]) > 0.f ? v[r] * P.gate_scale : 0.f;
+    }
+    if (P.residual) {
+        const float* rp = P.residual + (size_t)row * P.ldr + col;
+        if (vec) { float4 q = *(const float4*)rp; v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+        else for (int r = 0; r < nv; ++r) v[r] += rp[r];
+    }
+    if (P.out_f32) {
+        if (vec) *(float4*)(P.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int r = 0; r < nv; ++r) P.out_f32[o + r] = v[r];
+    }
+    if (P.out_lp) {
+        T* op = (T*)P.out_lp + o;
+        if (vec) {
+            if constexpr (sizeof(T) == 2) {
+                *(uint2*)op = make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16), (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
+            } else {
+                *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else for (int r = 0; r < nv; ++r) op[r] = LP<T>::from_f32(v[r]);
+    }
+}
+
 template <typename T, bool A_T, bool B_T>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
     constexpr int BK = 128 / (int)sizeof(T);
@@ -156,43 +208,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma16<T>(acc[i][j], a[i], b[j]);
+                for (int j = 0; j < 2; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator: see epilogue
         }
         __syncthreads();
     }
 
     if (do_rowsum && tid < TILE && row0 + tid < M) P.rowsum_out[row0 + tid] = rsum;
 
-    // ---- epilogue: lane holds C[row = 4*lg + r][col = l15] of each 16x16 tile
+    // ---- epilogue: operands were swapped in the MFMAs, so a lane holds one output row (l15) x four consecutive columns
     const DropState ds = drop_init(P.drop);
-    const float* __restrict__ bias = P.bias;
-    const float* __restrict__ res = P.residual;
-    const T* __restrict__ gate = (const T*)P.gate;
-    float* __restrict__ of = P.out_f32;
-    T* __restrict__ ol = (T*)P.out_lp;
+    const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + wr * 32 + i * 16 + l15;
+        if (row >= M) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int col = col0 + wc * 32 + j * 16 + l15;
+            const int col = col0 + wc * 32 + j * 16 + lg * 4;
             if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + wr * 32 + i * 16 + lg * 4 + r;
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bv;
-                if (P.relu) v = fmaxf(v, 0.f);
-                if (ds.on) v = drop_keep(ds, (uint64_t)row * (uint64_t)N + col) ? v * ds.scale : 0.f;
-                const size_t o = (size_t)row * P.ldc + col;
-                if (gate) v = (LP<T>::to_f32(gate[o]) > 0.f) ? v * P.gate_scale : 0.f;
-                if (res) v += res[(size_t)row * P.ldr + col];
-                if (of) of[o] = v;
-                if (ol) ol[o] = LP<T>::from_f32(v);
-            }
+            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
         }
+    }
 }
-
 
 // ====================================================================================================================
 // Fast path for row-major x row-major problems (forward Linears, and dX = dY (W^T)^T through the transposed weight
@@ -292,7 +329,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma16<T>(acc[i][j], a[i], b[j]);
+                for (int j = 0; j < 2; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator: see epilogue
         }
 #ifndef MTN_DBG_NO_LOAD
         if (s + 2 < nstages) {           // refill this buffer with stage s+2 once every wave is done reading it
@@ -305,34 +342,22 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
 #endif
     }
 
-    // ---- epilogue (same as gemm_kernel): lane holds C[row = 4*lg + r][col = l15] of each 16x16 tile
+    // ---- epilogue.  The MFMAs were issued with the operands swapped (acc = W-tile x X-tile^T), so a lane holds, for ONE
+    //      output row m = l15, FOUR CONSECUTIVE output columns n = 4*lg + r of each 16x16 tile: bias, residual, gate and
+    //      both outputs move as 8/16-byte vectors (4x fewer memory instructions than the row-per-register layout).
     const DropState ds = drop_init(P.drop);
-    const float* __restrict__ bias = P.bias;
-    const float* __restrict__ res = P.residual;
-    const T* __restrict__ gate = (const T*)P.gate;
-    float* __restrict__ of = P.out_f32;
-    T* __restrict__ ol = (T*)P.out_lp;
+    const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + wr * 32 + i * 16 + l15;
+        if (row >= M) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int col = col0 + wc * 32 + j * 16 + l15;
+            const int col = col0 + wc * 32 + j * 16 + lg * 4;
             if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + wr * 32 + i * 16 + lg * 4 + r;
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bv;
-                if (P.relu) v = fmaxf(v, 0.f);
-                if (ds.on) v = drop_keep(ds, (uint64_t)row * (uint64_t)N + col) ? v * ds.scale : 0.f;
-                const size_t o = (size_t)row * P.ldc + col;
-                if (gate) v = (LP<T>::to_f32(gate[o]) > 0.f) ? v * P.gate_scale : 0.f;
-                if (res) v += res[(size_t)row * P.ldr + col];
-                if (of) of[o] = v;
-                if (ol) ol[o] = LP<T>::from_f32(v);
-            }
+            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
         }
+    }
 }
 
 template <typename T>
