@@ -275,6 +275,33 @@ int mtn_cast_group(int dtype, int count, const mtn_cast_desc* descs /* host arra
 /* dst(lowp)[i] = src[i] * keep(i)/(1-p): gradient entering a dropped-out branch (mtn.py:127). */
 int mtn_dropout_bwd_to_lp(int dtype, long n, const float* src, mtn_dropout drop, void* dst, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Loss head: Generator log-softmax (mtn.py:62-69) + LabelSmoothing KLDivLoss(sum) (label_smoothing.py:20-32) +
+ * the weighted sum of SimpleLossCompute (data_utils.py:133-144), per row, without materialising log-probabilities or
+ * target distributions.  Rows of up to MTN_LOSSHEAD_MAX_SEG streams (main decoder output, auto-encoder outputs) are
+ * stacked: rows[s] rows of stream s with targets target[s] (int64), loss weight coef[s] / *norm[s] (norm = device scalar).
+ *   fwd: logits float [sum rows, ldz] -> lse[row], rowloss[row] (already weighted; the loss is their sum)
+ *   bwd: dlogits lowp [sum rows, ldd] = *gloss * weight * (softmax * sum(td) - td); columns V..ldd-1 are zero-filled
+ * ------------------------------------------------------------------------------------------ */
+#define MTN_LOSSHEAD_MAX_SEG 4
+typedef struct {
+    int n_seg;
+    int rows[MTN_LOSSHEAD_MAX_SEG];
+    const long* target[MTN_LOSSHEAD_MAX_SEG];
+    const float* norm[MTN_LOSSHEAD_MAX_SEG];
+    float coef[MTN_LOSSHEAD_MAX_SEG];
+    int V, ldz, pad;
+    float smoothing;
+    const float* logits;
+    float* lse;
+    float* rowloss;
+    const float* gloss; /* backward: device scalar dL/dloss */
+    void* dlogits;
+    int ldd;
+} mtn_losshead_args;
+int mtn_losshead_fwd(const mtn_losshead_args* args, void* stream);
+int mtn_losshead_bwd(int dtype, const mtn_losshead_args* args, void* stream);
+
 /* Transposed compute-dtype weight copies (operand of dX = dY W on the LDS-DMA GEMM path): for each descriptor the
  * [rows, cols] matrix at src+off is written as [cols, rows] at dst+off.  `descs_device` is a DEVICE array (built once),
  * tile_start = running sum of ceil(rows/64)*ceil(cols/64), total_tiles = the final sum. */

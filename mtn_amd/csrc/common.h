@@ -67,6 +67,15 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4_t& acc, const uin
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
+template <typename T> __device__ __forceinline__ void store_lp4(T* p, float4 v);      // 4 consecutive elements, 8/16-byte aligned
+template <> __device__ __forceinline__ void store_lp4<float>(float* p, float4 v) { *(float4*)p = v; }
+template <> __device__ __forceinline__ void store_lp4<bf16_t>(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *(uint2*)p = u;
+}
+
 // ---------------------------------------------------------------- dropout keep-mask
 // Counter-based: keep(idx) is a pure function of (seed, salt, idx).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {

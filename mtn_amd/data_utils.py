@@ -141,11 +141,42 @@ class SimpleLossCompute:
     step contains no host synchronisation; ``grad_sync`` (optional callable) runs between backward and the
     optimiser step — that is where data-parallel gradient all-reduce goes."""
 
-    def __init__(self, generator, ae_generator, criterion, opt=None, l=1.0, sync=True, grad_sync=None):
+    def __init__(self, generator, ae_generator, criterion, opt=None, l=1.0, sync=True, grad_sync=None, fused=True):
         self.generator, self.ae_generator, self.criterion = generator, ae_generator, criterion
-        self.opt, self.l, self.sync, self.grad_sync = opt, l, sync, grad_sync
+        self.opt, self.l, self.sync, self.grad_sync, self.fused = opt, l, sync, grad_sync, fused
+
+    def _fused_loss(self, x, y, norm, ae_x, ae_y, ae_norm):
+        """Generator + log-softmax + label-smoothed KL + weighted sum as the fused HIP loss head (ops.GeneratorLossFn).
+        Returns None when the fused path does not apply (CPU tensors, un-flattened model, vocab not a multiple of 8,
+        foreign criterion): the caller then composes the same value from PyTorch ops."""
+        from . import ops
+        gens = [self.generator]
+        xs, ys, norms, coefs = [x], [y], [norm], [1.0]
+        if ae_x is not None:
+            lst = ae_x if isinstance(ae_x, (list, tuple)) else [ae_x]
+            for i, a in enumerate(lst):
+                if self.ae_generator is not None:
+                    gens.append(self.ae_generator[i] if isinstance(ae_x, (list, tuple)) else self.ae_generator)
+                else:
+                    gens.append(self.generator)
+                xs.append(a); ys.append(ae_y); norms.append(ae_norm); coefs.append(self.l)
+        if not (isinstance(self.criterion, LabelSmoothing) and x.is_cuda and len(xs) <= 4):
+            return None
+        fused = [getattr(g, "_fused", None) for g in gens]
+        if any(f is None for f in fused) or self.criterion.size % 8 != 0:
+            return None
+        if not torch.is_grad_enabled():
+            pass
+        spec = dict(targets=ys, norms=[n if torch.is_tensor(n) else torch.tensor(float(n), device=x.device) for n in norms], coefs=coefs,
+                    gens=[(f["w_lp"], f["bias"], f["grad_w"], f["grad_b"]) for f in fused], vocab=self.criterion.size,
+                    pad=self.criterion.padding_idx, smoothing=self.criterion.smoothing, lp_dtype=fused[0]["lp_dtype"])
+        spec["norms"] = [n.detach().float().reshape(1) for n in spec["norms"]]
+        return ops.GeneratorLossFn.apply(spec, *xs)
 
     def loss(self, x, y, norm, ae_x=None, ae_y=None, ae_norm=None):
+        fused = self._fused_loss(x, y, norm, ae_x, ae_y, ae_norm) if self.fused else None
+        if fused is not None:
+            return fused
         out = self.generator(x)
         loss = self.criterion(out.reshape(-1, out.size(-1)), y.reshape(-1)) / norm.float()
         if ae_x is not None:

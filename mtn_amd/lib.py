@@ -64,6 +64,13 @@ class FfnArgs(C.Structure):
                 ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int)]
 
 
+class LossHeadArgs(C.Structure):
+    _fields_ = [("n_seg", C.c_int), ("rows", C.c_int * 4), ("target", C.c_void_p * 4), ("norm", C.c_void_p * 4), ("coef", C.c_float * 4),
+                ("V", C.c_int), ("ldz", C.c_int), ("pad", C.c_int), ("smoothing", C.c_float),
+                ("logits", C.c_void_p), ("lse", C.c_void_p), ("rowloss", C.c_void_p),
+                ("gloss", C.c_void_p), ("dlogits", C.c_void_p), ("ldd", C.c_int)]
+
+
 class TransposeDesc(C.Structure):
     _fields_ = [("off", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("tile_start", C.c_int), ("reserved", C.c_int)]
 
@@ -120,6 +127,8 @@ SYMBOLS = {
     "mtn_ffn_bwd_ws_f32_floats": (C.c_long, [C.c_int, C.c_int, C.c_int]),
     "mtn_cast_f32_to_lp": (C.c_int, [C.c_int, C.c_long, _P, _P, _P]),
     "mtn_dropout_bwd_to_lp": (C.c_int, [C.c_int, C.c_long, _P, Dropout, _P, _P]),
+    "mtn_losshead_fwd": (C.c_int, [C.POINTER(LossHeadArgs), _P]),
+    "mtn_losshead_bwd": (C.c_int, [C.c_int, C.POINTER(LossHeadArgs), _P]),
     "mtn_transpose_group": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, _P]),
     "mtn_noam_tick": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     "mtn_adam_step": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P]),

@@ -400,6 +400,7 @@ class Generator(nn.Module):
     def __init__(self, d_model: int, vocab: int):
         super().__init__()
         self.proj = nn.Linear(d_model, vocab)
+        self._fused = None          # compute-dtype weight / flat-gradient views (fused loss head), set at flatten
 
     def forward(self, x):                      # mtn.py:68-69
         return F.log_softmax(self.proj(x), dim=-1)
@@ -541,6 +542,11 @@ class EncoderDecoder(nn.Module):
                     m._fused["w1_lpT"] = self._flat_lpT[o1:o1 + ffd * dm].view(dm, ffd)
                     m._fused["w2_lpT"] = self._flat_lpT[o2:o2 + ffd * dm].view(ffd, dm)
                     tdescs += [(o1, ffd, dm), (o2, dm, ffd)]
+            elif isinstance(m, Generator):
+                o_w, o_b = path_off[id(m.proj.weight)], path_off[id(m.proj.bias)]
+                nw, nb = m.proj.weight.numel(), m.proj.bias.numel()
+                m._fused = dict(w_lp=self._flat_lp[o_w:o_w + nw].view(m.proj.weight.shape), bias=flat[o_b:o_b + nb],
+                                grad_w=grad[o_w:o_w + nw].view(m.proj.weight.shape), grad_b=grad[o_b:o_b + nb], lp_dtype=lp)
             elif isinstance(m, LayerNorm) and id(m.a_2) in path_off:
                 m._grads = (views(m.a_2)[2], views(m.b_2)[2])
                 m._lp_dtype = lp

@@ -445,8 +445,16 @@ class SublayerGroupFn(torch.autograd.Function):
                 A.w_qkv_t, A.w_o_t = L.ptr(cfg.w_qkv_lpT), L.ptr(cfg.w_o_lpT)
                 A.y, A.xn, A.mean, A.rstd = y.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr()
                 A.qkv, A.kv, A.o, A.lse = qkv.data_ptr(), L.ptr(kv), o.data_ptr(), lse.data_ptr()
+                need_dmem = (not self_attn) and mem_t.requires_grad
+                gacc = None
+                if need_dmem:          # a memory serves every layer: its gradient is accumulated in place by the dmem GEMMs
+                    gacc = getattr(mem_t, "_mtn_gacc", None)
+                    if gacc is None:
+                        gacc = {"buf": None, "remaining": 0}
+                        mem_t._mtn_gacc = gacc
+                    gacc["remaining"] += 1
                 saved.append(dict(x=x, mem_lp=mem_lp, mask=mask_u8, xn=xn, mean=mean, rstd=rstd, qkv=qkv, kv=kv, o=o, lse=lse,
-                                  need_dmem=(not self_attn) and mem_t.requires_grad, m=m))
+                                  need_dmem=need_dmem, gacc=gacc, m=m))
             else:
                 rows = x.numel() // d
                 ff = cfg.w1_lp.size(0)
@@ -486,14 +494,24 @@ class SublayerGroupFn(torch.autograd.Function):
             if mb.kind == "mha":
                 A = mha_args[im]; im += 1
                 B, a, d, m = A.B, A.a, A.d, sv["m"]
-                dmem = torch.empty(B, m, d, device=dev, dtype=torch.float32) if sv["need_dmem"] else None
+                dmem, dmem_ret, accumulate = None, None, 0
+                if sv["need_dmem"]:
+                    gacc = sv["gacc"]
+                    if gacc["buf"] is None:
+                        gacc["buf"] = torch.empty(B, m, d, device=dev, dtype=torch.float32)
+                    else:
+                        accumulate = 1
+                    dmem = gacc["buf"]
+                    gacc["remaining"] -= 1
+                    if gacc["remaining"] == 0:       # last user (first in forward order): hand the sum to autograd once
+                        dmem_ret, gacc["buf"] = dmem, None
                 ws_lp = torch.empty(lib.mtn_mha_bwd_ws_lp_elems(B, a, m, d, A.self_attn), device=dev, dtype=cfg.lp_dtype)
                 ws_f32 = torch.empty(lib.mtn_mha_bwd_ws_f32_floats(B, a, m, d), device=dev, dtype=torch.float32)
-                A.dy, A.dx, A.dmem, A.dmem_accumulate = dy.data_ptr(), dx.data_ptr(), L.ptr(dmem), 0
+                A.dy, A.dx, A.dmem, A.dmem_accumulate = dy.data_ptr(), dx.data_ptr(), L.ptr(dmem), accumulate
                 A.d_ln_a, A.d_ln_b = g["ln_a"].data_ptr(), g["ln_b"].data_ptr()
                 A.d_w_qkv, A.d_b_qkv, A.d_w_o, A.d_b_o = g["w_qkv"].data_ptr(), g["b_qkv"].data_ptr(), g["w_o"].data_ptr(), g["b_o"].data_ptr()
                 A.ws_lp, A.ws_f32, A.defer_param_grads = ws_lp.data_ptr(), ws_f32.data_ptr(), 1
-                grads_out += [dx, dmem]
+                grads_out += [dx, dmem_ret]
                 keep = [dy, ws_lp, ws_f32, sv["o"], sv["xn"]] + ([sv["mem_lp"]] if sv["mem_lp"] is not None else [])
                 work.append(("mha", A, keep))
             else:
@@ -519,6 +537,93 @@ class SublayerGroupFn(torch.autograd.Function):
                 n = lib.mtn_ffn_param_grad_work(code, C.byref(A), probs, C.byref(ln))
             members[0].cfg.queue.add(code, [probs[i] for i in range(n)], ln, keep)
         return (None, *grads_out)
+
+
+# ------------------------------------------------------------------------------------------ loss head
+class GeneratorLossFn(torch.autograd.Function):
+    """sum_i coef_i * KLDiv(log_softmax(x_i W_i^T + b_i), smooth(y_i)) / norm_i  — Generator (mtn.py:62-69) +
+    LabelSmoothing (label_smoothing.py) + SimpleLossCompute's weighted sum (data_utils.py:133-144) as: one grouped cast,
+    one grouped GEMM (logits), one row kernel (log-sum-exp + closed-form KL); backward: one row kernel (dlogits), two
+    grouped GEMMs (dX, dW+db).  `spec`: targets, norms (device float scalars), coefs, gens [(w_lp, bias, grad_w, grad_b)],
+    vocab, pad, smoothing, lp_dtype.  Generator gradients are written to the flat gradient buffer (not returned)."""
+
+    @staticmethod
+    def forward(ctx, spec, *xs):
+        lib = L.load()
+        lp = spec["lp_dtype"]
+        code = L.dtype_code(lp)
+        dev = xs[0].device
+        d, V = xs[0].size(-1), spec["vocab"]
+        rows = [x.numel() // d for x in xs]
+        R = sum(rows)
+        x_lp = torch.empty(R, d, device=dev, dtype=lp)
+        logits = torch.empty(R, V, device=dev, dtype=torch.float32)
+        casts = (L.CastDesc * len(xs))()
+        off = 0
+        offs = []
+        for i, x in enumerate(xs):
+            xc = x.contiguous()
+            casts[i].n, casts[i].src, casts[i].dst = xc.numel(), xc.data_ptr(), x_lp[off:off + rows[i]].data_ptr()
+            casts[i].drop = L.Dropout(0.0, 0, None)
+            offs.append(off)
+            off += rows[i]
+            ctx_keep = xc
+        if lp == torch.float32:
+            for i, x in enumerate(xs):
+                x_lp[offs[i]:offs[i] + rows[i]].copy_(x.reshape(rows[i], d))
+        else:
+            L.check(lib.mtn_cast_group(code, len(xs), casts, L.stream_ptr()))
+        gens = spec["gens"]
+        shared = all(g[0].data_ptr() == gens[0][0].data_ptr() for g in gens)
+        segs = [(0, R, gens[0])] if shared else [(offs[i], rows[i], gens[i]) for i in range(len(xs))]
+        probs = []
+        for o, r, (w_lp, bias, _gw, _gb) in segs:
+            p = L.GemmProblem()
+            p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K = x_lp[o:].data_ptr(), w_lp.data_ptr(), d, d, r, V, d
+            p.bias, p.gate_scale, p.out_f32, p.ldc = bias.data_ptr(), 1.0, logits[o:].data_ptr(), V
+            probs.append(p)
+        gemm(code, probs)
+        A = L.LossHeadArgs()
+        A.n_seg = len(xs)
+        norms = [n.float().reshape(1) if n.dtype != torch.float32 or n.dim() == 0 else n for n in spec["norms"]]
+        targets = [t.contiguous().view(-1) for t in spec["targets"]]
+        for i in range(len(xs)):
+            A.rows[i], A.target[i], A.norm[i], A.coef[i] = rows[i], targets[i].data_ptr(), norms[i].data_ptr(), float(spec["coefs"][i])
+        A.V, A.ldz, A.pad, A.smoothing = V, V, spec["pad"], float(spec["smoothing"])
+        lse = torch.empty(R, device=dev, dtype=torch.float32)
+        rowloss = torch.empty(R, device=dev, dtype=torch.float32)
+        A.logits, A.lse, A.rowloss = logits.data_ptr(), lse.data_ptr(), rowloss.data_ptr()
+        L.check(lib.mtn_losshead_fwd(C.byref(A), L.stream_ptr()))
+        ctx.args, ctx.keep = A, (x_lp, logits, lse, norms, targets)
+        ctx.meta = (spec, segs, rows, offs, d, V, R, code, [x.shape for x in xs])
+        return rowloss.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        spec, segs, rows, offs, d, V, R, code, shapes = ctx.meta
+        x_lp, logits, lse, norms, targets = ctx.keep
+        lp = spec["lp_dtype"]
+        dev = x_lp.device
+        A = ctx.args
+        gl = g.contiguous().float().reshape(1)
+        dlogits = torch.empty(R, V, device=dev, dtype=lp)
+        A.gloss, A.dlogits, A.ldd = gl.data_ptr(), dlogits.data_ptr(), V
+        L.check(lib.mtn_losshead_bwd(code, C.byref(A), L.stream_ptr()))
+        dx = torch.empty(R, d, device=dev, dtype=torch.float32)
+        p_dx, p_dw = [], []
+        for o, r, (w_lp, bias, gw, gb) in segs:
+            p = L.GemmProblem()      # dX = dlogits W
+            p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K, p.b_trans = dlogits[o:].data_ptr(), w_lp.data_ptr(), V, d, r, d, V, 1
+            p.gate_scale, p.out_f32, p.ldc = 1.0, dx[o:].data_ptr(), d
+            p_dx.append(p)
+            q = L.GemmProblem()      # dW = dlogits^T x, db = column sums of dlogits
+            q.A, q.B, q.lda, q.ldb, q.M, q.N, q.K, q.a_trans, q.b_trans = dlogits[o:].data_ptr(), x_lp[o:].data_ptr(), V, d, V, d, r, 1, 1
+            q.gate_scale, q.out_f32, q.ldc, q.rowsum_out = 1.0, gw.data_ptr(), d, gb.data_ptr()
+            p_dw.append(q)
+        gemm(code, p_dx)
+        gemm(code, p_dw)
+        return (None,) + tuple(dx[offs[i]:offs[i] + rows[i]].view(shapes[i]) for i in range(len(rows)))
 
 
 # ------------------------------------------------------------------------------------------ attention core (tests / decode)

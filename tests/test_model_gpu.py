@@ -323,3 +323,47 @@ def test_lockstep_schedule_equals_sequential_schedule(dev, name):
         assert torch.equal(g1, g2)
     else:   # one seed tensor feeds both auto-encoder chains: autograd sums its gradient contributions in schedule order
         assert relmax(g1, g2) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quirk", [False, True])
+def test_fused_loss_head_matches_composed_loss(dev, dtype, quirk):
+    """Generator + log-softmax + LabelSmoothing KL + weighted sum as ONE fused head (csrc/losshead.hip) vs the same value
+    composed from the oracle's functions: loss, d(loss)/d(hidden) and the generator's weight/bias gradients.  `quirk`:
+    the only <pad> target sits at flat row 0 (label_smoothing.py:29 then does NOT zero that row)."""
+    from mtn_amd import LabelSmoothing, SimpleLossCompute
+    c = dict(fx.GOLDEN_CONFIGS["small_diffall"], vocab=104, diff_gen=False, diff_embed=False)
+    model = build_model(c, dtype, dev).eval()
+    model.prepare()
+    g = torch.Generator().manual_seed(7)
+    B, T, Q, d, V = 3, 6, 5, c["d_model"], c["vocab"]
+    xs = [torch.randn(B, L, d, generator=g) for L in (T, Q)]
+    y = torch.randint(4, V, (B, T), generator=g)
+    ya = torch.randint(4, V, (B, Q), generator=g)
+    if quirk:
+        y[0, 0] = fx.PAD
+    else:
+        y[0, -2:] = fx.PAD; y[2, -1] = fx.PAD; ya[1, -3:] = fx.PAD
+    norm, ae_norm = (y != fx.PAD).sum(), (ya != fx.PAD).sum()
+    # oracle composition on CPU
+    W = model.generator.proj.weight.detach().float().cpu().clone().requires_grad_()
+    bb = model.generator.proj.bias.detach().float().cpu().clone().requires_grad_()
+    xr = [x.clone().requires_grad_() for x in xs]
+    lp = lambda x: torch.log_softmax(orc.linear(x, W, bb), -1)
+    ref = orc.label_smoothing_kl(lp(xr[0]).reshape(-1, V), y.reshape(-1), fx.PAD, 0.1) / norm.float() \
+        + 0.7 * orc.label_smoothing_kl(lp(xr[1]).reshape(-1, V), ya.reshape(-1), fx.PAD, 0.1) / ae_norm.float()
+    ref.backward()
+    # fused head on the GPU
+    xd = [x.to(dev).requires_grad_() for x in xs]
+    lc = SimpleLossCompute(model.generator, None, LabelSmoothing(V, fx.PAD, 0.1), opt=None, l=0.7)
+    model.zero_glue_grads()
+    loss = lc.loss(xd[0], y.to(dev), norm.to(dev), [xd[1]], ya.to(dev), ae_norm.to(dev))
+    assert loss.grad_fn is not None and "GeneratorLossFn" in type(loss.grad_fn).__name__
+    loss.backward()
+    torch.cuda.synchronize()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert abs(float(loss) - float(ref)) < tol * abs(float(ref))
+    for a, r in zip(xd, xr):
+        assert relmax(a.grad, r.grad) < tol
+    assert relmax(model.generator.proj.weight.grad, W.grad) < tol
+    assert relmax(model.generator.proj.bias.grad, bb.grad) < tol
