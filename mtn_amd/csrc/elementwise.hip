@@ -170,8 +170,13 @@ __global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p
     const float gs = grad_scale ? *grad_scale : 1.0f;
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        float4 pv = *(const float4*)(p + i * 4), gv = *(const float4*)(g + i * 4);
-        float4 mv = *(const float4*)(m + i * 4), vv = *(const float4*)(v + i * 4);
+        // the 16 B/param fp32 streams are touched once per step: non-temporal, so that they do not evict the bf16 weights
+        // (the forward/backward working set) from L2 / Infinity Cache
+        typedef __attribute__((ext_vector_type(4))) float nt4;
+        nt4 p_ = __builtin_nontemporal_load((const nt4*)(p + i * 4)), g_ = __builtin_nontemporal_load((const nt4*)(g + i * 4));
+        nt4 m_ = __builtin_nontemporal_load((const nt4*)(m + i * 4)), v_ = __builtin_nontemporal_load((const nt4*)(v + i * 4));
+        float4 pv = make_float4(p_[0], p_[1], p_[2], p_[3]), gv = make_float4(g_[0], g_[1], g_[2], g_[3]);
+        float4 mv = make_float4(m_[0], m_[1], m_[2], m_[3]), vv = make_float4(v_[0], v_[1], v_[2], v_[3]);
         float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -180,9 +185,9 @@ __global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p
             vp[k] = beta2 * vp[k] + (1.0f - beta2) * gk * gk;
             pp[k] -= step_size * mp[k] / (sqrtf(vp[k]) * inv_sqrt_bc2 + eps);
         }
-        *(float4*)(p + i * 4) = pv;
-        *(float4*)(m + i * 4) = mv;
-        *(float4*)(v + i * 4) = vv;
+        __builtin_nontemporal_store(nt4{pv.x, pv.y, pv.z, pv.w}, (nt4*)(p + i * 4));
+        __builtin_nontemporal_store(nt4{mv.x, mv.y, mv.z, mv.w}, (nt4*)(m + i * 4));
+        __builtin_nontemporal_store(nt4{vv.x, vv.y, vv.z, vv.w}, (nt4*)(v + i * 4));
         if (p_lp) {
             if constexpr (sizeof(T) == 2) {
                 uint2 u;

@@ -8,6 +8,8 @@
 // contraction-major, e.g. dY and X in dW = dY^T X) is transposed in registers in 4x4 blocks on the way to
 // LDS, so the MFMA fragment reads are always 16-byte, contraction-contiguous.
 // LDS rows are padded to 144 bytes: the 16 rows of a fragment read land on 16 distinct 16-byte slots.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct GemmGroup {
@@ -245,18 +247,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
 //   * counted vmcnt + raw s_barrier: the next stage stays in flight across the barrier.
 // ====================================================================================================================
 static constexpr int DMA_ROWB = 512;                         // bytes per tile row per stage
-static constexpr int DMA_TILE_BYTES = TILE * DMA_ROWB;       // 32 KiB per operand per stage
-static constexpr int DMA_STAGE_BYTES = 2 * DMA_TILE_BYTES;   // A + B
-static constexpr int DMA_LDS_BYTES = 2 * DMA_STAGE_BYTES;    // two stages = 128 KiB
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <typename T>
+// one operand tile of ROWS rows x 512 B: ROWS/8 LDS-DMA instructions per wave (2 rows = 1 KiB per wave-instruction)
+template <typename T, int ROWS>
 __device__ __forceinline__ void dma_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_tile, int ld_bytes, int R,
                                                int K, int row0, int k0, int wave, int lane) {
     constexpr int EPV = LP<T>::EPV;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < ROWS / 8; ++j) {
         const int row = j * 8 + wave * 2 + (lane >> 5);          // tile row written by this lane
         const int c = (lane & 31) ^ (row & 15);                  // source 16-byte chunk that lands in slot (lane & 31)
         const int gk = k0 + c * EPV;
@@ -267,18 +267,25 @@ __device__ __forceinline__ void dma_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsi
     }
 }
 
-template <typename T>
+// Tile BM x BN (64x64, 32x64 or 32x32), 4 waves as 2x2, each wave (BM/32) x (BN/32) MFMA 16x16 tiles.  The smaller tiles
+// exist because these launches are bound by how fast ONE CU can pull its operand panels (~27 GB/s per CU measured, LDS-DMA
+// and register staging alike): a [640 x 512] output is 80 workgroups of 128 KiB at 64x64 but 320 workgroups of 64 KiB at
+// 32x32 — the whole chip pulls instead of a third of it.
+template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     constexpr int BK = DMA_ROWB / (int)sizeof(T);            // 256 bf16 / 128 fp32
+    constexpr int TM = BM / 32, TN = BN / 32;                // MFMA tiles per wave
+    constexpr int A_BYTES = BM * DMA_ROWB, B_BYTES = BN * DMA_ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NDMA = (BM + BN) / 8;                      // LDS-DMA instructions per wave per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     int g = 0;
     while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
     const mtn_gemm_problem& P = grp.p[g];
     const int M = P.M, N = P.N, K = P.K;
-    const int tiles_n = (N + TILE - 1) / TILE;
+    const int tiles_n = (N + BN - 1) / BN;
     const int t = (int)blockIdx.x - grp.tile_start[g];
-    const int row0 = (t / tiles_n) * TILE, col0 = (t % tiles_n) * TILE;
+    const int row0 = (t / tiles_n) * BM, col0 = (t % tiles_n) * BN;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
@@ -286,11 +293,11 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (M - 1) * lda_b + K * (int)sizeof(T), 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (N - 1) * ldb_b + K * (int)sizeof(T), 0x00020000);
 
-    f32x4_t acc[2][2];
+    f32x4_t acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nstages = (K + BK - 1) / BK;
 #ifdef MTN_DBG_EMPTY
@@ -298,20 +305,24 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     return;
 #endif
 #ifndef MTN_DBG_NO_LOAD
-    // prologue: up to two stages in flight (16 DMA instructions per wave per stage, always)
-    dma_issue_tile<T>(rA, smem, lda_b, M, K, row0, 0, wave, lane);
-    dma_issue_tile<T>(rB, smem + DMA_TILE_BYTES, ldb_b, N, K, col0, 0, wave, lane);
+    // prologue: up to two stages in flight (NDMA LDS-DMA instructions per wave per stage, always)
+    dma_issue_tile<T, BM>(rA, smem, lda_b, M, K, row0, 0, wave, lane);
+    dma_issue_tile<T, BN>(rB, smem + A_BYTES, ldb_b, N, K, col0, 0, wave, lane);
     if (nstages > 1) {
-        dma_issue_tile<T>(rA, smem + DMA_STAGE_BYTES, lda_b, M, K, row0, BK, wave, lane);
-        dma_issue_tile<T>(rB, smem + DMA_STAGE_BYTES + DMA_TILE_BYTES, ldb_b, N, K, col0, BK, wave, lane);
+        dma_issue_tile<T, BM>(rA, smem + STAGE_BYTES, lda_b, M, K, row0, BK, wave, lane);
+        dma_issue_tile<T, BN>(rB, smem + STAGE_BYTES + A_BYTES, ldb_b, N, K, col0, BK, wave, lane);
     }
 #endif
     for (int s = 0; s < nstages; ++s) {
-        if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage s landed, stage s+1 still flying
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage s landed, stage s+1 (if any) still flying: vmcnt(NDMA) / vmcnt(0)
+        if (s + 1 < nstages) {
+            if constexpr (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const unsigned char* sA = smem + (s & 1) * DMA_STAGE_BYTES;
-        const unsigned char* sB = sA + DMA_TILE_BYTES;
+        const unsigned char* sA = smem + (s & 1) * STAGE_BYTES;
+        const unsigned char* sB = sA + A_BYTES;
         const int kleft = K - s * BK;
         int ksteps = kleft >= BK ? 8 : (kleft * (int)sizeof(T) + 63) / 64;   // 64-byte contraction steps holding data
 #ifdef MTN_DBG_NO_COMPUTE
@@ -319,25 +330,29 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
 #endif
 #pragma unroll 2
         for (int ks = 0; ks < ksteps; ++ks) {
-            uint4 a[2], b[2];
+            uint4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ra = wr * 32 + i * 16 + l15, rb = wc * 32 + i * 16 + l15;
+            for (int i = 0; i < TM; ++i) {
+                const int ra = wr * (BM / 2) + i * 16 + l15;
                 a[i] = *(const uint4*)(sA + ra * DMA_ROWB + (((ks * 4 + lg) ^ (ra & 15)) << 4));
-                b[i] = *(const uint4*)(sB + rb * DMA_ROWB + (((ks * 4 + lg) ^ (rb & 15)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TN; ++j) {
+                const int rb = wc * (BN / 2) + j * 16 + l15;
+                b[j] = *(const uint4*)(sB + rb * DMA_ROWB + (((ks * 4 + lg) ^ (rb & 15)) << 4));
+            }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator: see epilogue
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator: see epilogue
         }
 #ifndef MTN_DBG_NO_LOAD
         if (s + 2 < nstages) {           // refill this buffer with stage s+2 once every wave is done reading it
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            unsigned char* dst = smem + (s & 1) * DMA_STAGE_BYTES;
-            dma_issue_tile<T>(rA, dst, lda_b, M, K, row0, (s + 2) * BK, wave, lane);
-            dma_issue_tile<T>(rB, dst + DMA_TILE_BYTES, ldb_b, N, K, col0, (s + 2) * BK, wave, lane);
+            unsigned char* dst = smem + (s & 1) * STAGE_BYTES;
+            dma_issue_tile<T, BM>(rA, dst, lda_b, M, K, row0, (s + 2) * BK, wave, lane);
+            dma_issue_tile<T, BN>(rB, dst + A_BYTES, ldb_b, N, K, col0, (s + 2) * BK, wave, lane);
         }
 #endif
     }
@@ -348,29 +363,70 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     const DropState ds = drop_init(P.drop);
     const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = row0 + wr * 32 + i * 16 + l15;
+    for (int i = 0; i < TM; ++i) {
+        const int row = row0 + wr * (BM / 2) + i * 16 + l15;
         if (row >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = col0 + wc * 32 + j * 16 + lg * 4;
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wc * (BN / 2) + j * 16 + lg * 4;
             if (col >= N) continue;
             epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
         }
     }
 }
 
+template <typename T, int BM, int BN>
+static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
+    constexpr int LDS = 2 * (BM + BN) * DMA_ROWB;
+    static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set && LDS > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { mtn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN>), dim3(tiles), dim3(256), LDS, s, grp);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}
+
+// tile_start[] for a given tile shape; returns the total
+static int retile(GemmGroup& grp, int bm, int bn) {
+    int tiles = 0;
+    for (int i = 0; i < grp.count; ++i) {
+        grp.tile_start[i] = tiles;
+        tiles += ((grp.p[i].M + bm - 1) / bm) * ((grp.p[i].N + bn - 1) / bn);
+    }
+    for (int i = grp.count; i <= MTN_GEMM_MAX_GROUP; ++i) grp.tile_start[i] = tiles;
+    return tiles;
+}
+
 template <typename T>
 static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, bool dma_ok, hipStream_t s) {
     dim3 grid(total_tiles), block(256);
     if (!at && !bt && dma_ok) {
-        static bool attr_set = false;          // 128 KiB dynamic LDS needs the opt-in once per kernel
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
-            if (e != hipSuccess) { mtn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
-            attr_set = true;
+        // Tile choice by the bytes ONE CU has to pull (the bound of these launches, ~27 GB/s per CU): 64x64 tiles run one
+        // workgroup per CU in ceil(tiles/256) rounds of (64+64)*K bytes; 32x32 tiles spread 4x the workgroups of half the
+        // size, two per CU (their DMA latencies overlap: x0.75, fitted on tools/gemm_bench.hip).  MTN_GEMM_TILE forces one.
+        GemmGroup g2 = grp;
+        const char* force = getenv("MTN_GEMM_TILE");
+        const int f = force ? atoi(force) : 0;
+        double b64 = 0, b32 = 0, wg32max = 0;
+        int t64 = 0;
+        for (int i = 0; i < grp.count; ++i) {
+            const mtn_gemm_problem& q = grp.p[i];
+            const double kb = (double)q.K * sizeof(T);
+            const int n64 = ((q.M + 63) / 64) * ((q.N + 63) / 64), n32 = ((q.M + 31) / 32) * ((q.N + 31) / 32);
+            t64 += n64;
+            b64 += n64 * 128.0 * kb;
+            b32 += n32 * 64.0 * kb;
+            if (64.0 * kb > wg32max) wg32max = 64.0 * kb;
         }
-        hipLaunchKernelGGL((gemm_dma_kernel<T>), grid, block, DMA_LDS_BYTES, s, grp);
+        const double c64 = (double)((t64 + 255) / 256) * (b64 / t64);
+        double c32 = 0.75 * b32 / 256.0;
+        if (c32 < wg32max) c32 = wg32max;
+        if (f == 64 || (!f && c64 <= c32)) return launch_dma<T, 64, 64>(g2, retile(g2, 64, 64), s);
+        if (f == 3264) return launch_dma<T, 32, 64>(g2, retile(g2, 32, 64), s);
+        return launch_dma<T, 32, 32>(g2, retile(g2, 32, 32), s);
     } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp);
     else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp);
     else if (at && bt) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, s, grp);
