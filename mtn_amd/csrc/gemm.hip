@@ -234,6 +234,149 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
 }
 
 // ====================================================================================================================
+// dW = dY^T X (both operands contraction-major) with 128x128 tiles: the parameter-gradient launches carry ~2000 64x64
+// workgroups each re-reading its two operand panels; at 128x128 every panel byte feeds twice the outputs, which halves
+// the bytes each CU pulls (the bound, see gemm_dma_kernel).  4 waves x (4x4 MFMA tiles), 128 B of contraction per step,
+// 4x4 in-register block transposes on the way to LDS exactly as in gemm_kernel<T,true,true>.
+// ====================================================================================================================
+template <typename T> struct StageT128 {      // one 128-row x 128-byte contraction-major operand tile
+    uint4 r[sizeof(T) == 2 ? 4 : 4];
+    __device__ __forceinline__ void load(const T* __restrict__ base, int ld, int R, int K, int row0, int k0, int tid) {
+        if constexpr (sizeof(T) == 2) {       // 64 k x 128 rows: 16 x 32 blocks of 4x4, two per thread
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int blk = tid + 256 * j, kb = blk >> 5, rb = blk & 31;
+                const int gr = row0 + rb * 4;
+                uint2 v[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int gk = k0 + kb * 4 + kk;
+                    v[kk] = (gk < K && gr < R) ? *(const uint2*)(base + (size_t)gk * ld + gr) : make_uint2(0, 0);
+                }
+                r[2 * j].x = (v[0].x & 0xffffu) | (v[1].x << 16);        r[2 * j].y = (v[2].x & 0xffffu) | (v[3].x << 16);
+                r[2 * j].z = (v[0].x >> 16) | (v[1].x & 0xffff0000u);    r[2 * j].w = (v[2].x >> 16) | (v[3].x & 0xffff0000u);
+                r[2 * j + 1].x = (v[0].y & 0xffffu) | (v[1].y << 16);    r[2 * j + 1].y = (v[2].y & 0xffffu) | (v[3].y << 16);
+                r[2 * j + 1].z = (v[0].y >> 16) | (v[1].y & 0xffff0000u); r[2 * j + 1].w = (v[2].y >> 16) | (v[3].y & 0xffff0000u);
+            }
+        } else {                              // 32 k x 128 rows: 8 x 32 blocks, one per thread
+            const int kb = tid >> 5, rb = tid & 31;
+            const int gr = row0 + rb * 4;
+            uint4 v[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int gk = k0 + kb * 4 + kk;
+                v[kk] = (gk < K && gr < R) ? *(const uint4*)(base + (size_t)gk * ld + gr) : make_uint4(0, 0, 0, 0);
+            }
+            r[0] = make_uint4(v[0].x, v[1].x, v[2].x, v[3].x);
+            r[1] = make_uint4(v[0].y, v[1].y, v[2].y, v[3].y);
+            r[2] = make_uint4(v[0].z, v[1].z, v[2].z, v[3].z);
+            r[3] = make_uint4(v[0].w, v[1].w, v[2].w, v[3].w);
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* s, int tid) const {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int blk = tid + 256 * j, kb = blk >> 5, rb = blk & 31;
+                unsigned char* p = s + (rb * 4) * LDSROW + kb * 8;
+                *(uint2*)(p) = make_uint2(r[2 * j].x, r[2 * j].y);
+                *(uint2*)(p + LDSROW) = make_uint2(r[2 * j].z, r[2 * j].w);
+                *(uint2*)(p + 2 * LDSROW) = make_uint2(r[2 * j + 1].x, r[2 * j + 1].y);
+                *(uint2*)(p + 3 * LDSROW) = make_uint2(r[2 * j + 1].z, r[2 * j + 1].w);
+            }
+        } else {
+            const int kb = tid >> 5, rb = tid & 31;
+            unsigned char* p = s + (rb * 4) * LDSROW + kb * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(uint4*)(p + q * LDSROW) = r[q];
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tt128_kernel(const GemmGroup grp) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    constexpr int BT = 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * LDSROW];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + BT * LDSROW;
+    const int tid = threadIdx.x;
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
+    const mtn_gemm_problem& P = grp.p[g];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = (N + BT - 1) / BT;
+    const int t = (int)blockIdx.x - grp.tile_start[g];
+    const int row0 = (t / tiles_n) * BT, col0 = (t % tiles_n) * BT;
+    const T* __restrict__ A = (const T*)P.A;
+    const T* __restrict__ B = (const T*)P.B;
+    const bool do_rowsum = (P.rowsum_out != nullptr) && (col0 == 0);
+    const int lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1, lg = lane >> 4, l15 = lane & 15;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float rsum = 0.f;
+    StageT128<T> stA, stB;
+    stA.load(A, P.lda, M, K, row0, 0, tid);
+    stB.load(B, P.ldb, N, K, col0, 0, tid);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        stA.store(sA, tid);
+        stB.store(sB, tid);
+        __syncthreads();
+        if (k0 + BK < K) {
+            stA.load(A, P.lda, M, K, row0, k0 + BK, tid);
+            stB.load(B, P.ldb, N, K, col0, k0 + BK, tid);
+        }
+        if (do_rowsum && tid < BT) {
+            const uint4* rp = (const uint4*)(sA + tid * LDSROW);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                uint4 u = rp[q];
+                if constexpr (sizeof(T) == 2) {
+                    rsum += __uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u) + __uint_as_float(u.y << 16) +
+                            __uint_as_float(u.y & 0xffff0000u) + __uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u) +
+                            __uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u);
+                } else {
+                    rsum += __uint_as_float(u.x) + __uint_as_float(u.y) + __uint_as_float(u.z) + __uint_as_float(u.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *(const uint4*)(sA + (wr * 64 + i * 16 + l15) * LDSROW + ks * 64 + lg * 16);
+                b[i] = *(const uint4*)(sB + (wc * 64 + i * 16 + l15) * LDSROW + ks * 64 + lg * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator (vector epilogue)
+        }
+        __syncthreads();
+    }
+    if (do_rowsum && tid < BT && row0 + tid < M) P.rowsum_out[row0 + tid] = rsum;
+    const DropState ds = drop_init(P.drop);
+    const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + wr * 64 + i * 16 + l15;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col0 + wc * 64 + j * 16 + lg * 4;
+            if (col >= N) continue;
+            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+        }
+    }
+}
+
+// ====================================================================================================================
 // Fast path for row-major x row-major problems (forward Linears, and dX = dY (W^T)^T through the transposed weight
 // copy): the problems on this path are SMALL (M = B*L = 640..4096 rows, K = 512..2048) and latency-bound, so the
 // kernel is built around memory-level parallelism rather than MFMA issue rate:
@@ -429,7 +572,17 @@ static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, 
         return launch_dma<T, 32, 32>(g2, retile(g2, 32, 32), s);
     } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp);
     else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp);
-    else if (at && bt) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, s, grp);
+    else if (at && bt) {
+        // measured on the train step: 2 x 128x128 workgroups per CU hide latency worse than 8 x 64x64 ones (7.51 vs 7.25 ms per
+        // step) although they pull half the bytes — kept behind MTN_GEMM_TT128=1 for larger batches.
+        bool big = getenv("MTN_GEMM_TT128") != nullptr;
+        for (int i = 0; i < grp.count; ++i) big = big && grp.p[i].M >= 128 && grp.p[i].N >= 128;
+        if (big) {
+            GemmGroup g2 = grp;
+            const int tiles = retile(g2, 128, 128);
+            hipLaunchKernelGGL((gemm_tt128_kernel<T>), dim3(tiles), block, 0, s, g2);
+        } else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, s, grp);
+    }
     else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, s, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;

@@ -186,3 +186,32 @@ def test_attention_dropout_statistics_and_consistency(dev):
             p_row0 = o[b, 0, hh * dk:(hh + 1) * dk]            # = Pdrop[0, j]
             dv_col = dv[b, :dk, hh * dk]                       # dV[j, c] = Pdrop[0, j] * go[0, c]
             assert torch.allclose(dv_col, p_row0, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_tt_128_tile_group(dev, dtype):
+    """Parameter-gradient layout (both operands contraction-major) on the 128x128-tile kernel: grouped, ragged output
+    sizes (not multiples of 128), ragged contraction, row sums = bias gradients."""
+    import os
+    from mtn_amd import lib as L, ops
+    os.environ["MTN_GEMM_TT128"] = "1"
+    g = torch.Generator().manual_seed(9)
+    probs, checks = [], []
+    for (M, N, K) in [(512, 512, 640), (1536, 512, 100), (200, 136, 333), (3000, 512, 64)]:
+        a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        A, B = a.t().contiguous().to(dev, dtype), b.t().contiguous().to(dev, dtype)
+        out = torch.full((M, N), float("nan"), device=dev)
+        rs = torch.full((M,), float("nan"), device=dev)
+        p = _gemm_problem(L, A, B, M, N, K, 1, 1, M, N)
+        p.out_f32, p.ldc, p.rowsum_out = out.data_ptr(), N, rs.data_ptr()
+        probs.append(p)
+        ar, br = lp_round(a, dtype).double(), lp_round(b, dtype).double()
+        checks.append((out, rs, ar @ br.t(), ar.sum(1), (A, B)))
+    try:
+        ops.gemm(L.dtype_code(dtype), probs)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["MTN_GEMM_TT128"]
+    for out, rs, ref, rsum, _keep in checks:
+        assert relmax(out, ref) < 1e-4
+        assert relmax(rs, rsum) < 1e-4
