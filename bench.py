@@ -125,7 +125,7 @@ def main():
     model.to(dev).train()
     model.prepare()
     sync = None
-    if world > 1:
+    if world > 1 or os.environ.get("MTN_FORCE_DIST") == "1":
         sync = dp.GradSync(lambda: model.flat_buffers()[2], compress_bf16=args.bf16_grad_allreduce)
         sync.broadcast_(model._flat)
         model._flat_version = -1

@@ -24,7 +24,8 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("MTN_FORCE_DIST") == "1"        # exercise the RCCL path with a single rank (1-GPU boxes)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -71,7 +72,7 @@ class GradSync:
         return t
 
     def __call__(self):
-        if self.world == 1:
+        if self.world == 1 and os.environ.get("MTN_FORCE_DIST") != "1":
             return
         g = self.flat_grad_fn()
         for s, e in self.buckets(g.numel()):

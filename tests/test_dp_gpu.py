@@ -1,0 +1,94 @@
+"""Data parallelism with the real HIP path: two ranks sharing cuda:0 (gloo backend, the only one that allows two ranks on one
+device) run TrainStep (hipGraph fwd+bwd | eager all-reduce of the flat gradient | hipGraph Adam) on half batches and must
+end with the parameters of ONE rank stepping on the concatenated batch."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(c, dev, dtype):
+    from mtn_amd import make_model
+    from oracle import fixtures as fx
+    m = make_model(c["vocab"], c["vocab"], N=c["N"], d_model=c["d_model"], d_ff=c["d_ff"], h=c["h"], dropout=0.0, ft_sizes=c["ft_sizes"],
+                   diff_encoder=c["diff_encoder"], diff_embed=c["diff_embed"], diff_gen=c["diff_gen"], auto_encoder_ft=c["auto_encoder_ft"],
+                   compute_dtype=dtype, attn_dropout=0.0)
+    m.load_state_dict(fx.det_state_dict(fx.state_shapes(**c)), strict=False)
+    return m.to(dev).train()
+
+
+def _batch(c, raw, dev):
+    from mtn_amd import Batch
+    from oracle import fixtures as fx
+    t = torch.from_numpy
+    return Batch(t(raw["query"]), t(raw["his"]), None, [t(f) for f in raw["fts"]], t(raw["cap"]), t(raw["trg"]), t(raw["trg_y"]), pad=fx.PAD, device=dev)
+
+
+def _worker(rank, world, port, out_dir, use_graph):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from mtn_amd import dp
+    from mtn_amd.train_step import TrainStep
+    from oracle import fixtures as fx
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = dict(fx.GOLDEN_CONFIGS["cfg1_query"], B=4)
+    raw = fx.det_batch(c["vocab"], c["B"], c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=3)
+    s, e = dp.shard_range(c["B"], rank, world)
+    shard = {k: (v[s:e] if k != "fts" else [f[s:e] for f in v]) for k, v in raw.items()}
+    model = _make(c, dev, "fp32")
+    sync = dp.GradSync(lambda: model.flat_buffers()[2], n_buckets=3)
+    step = TrainStep(model, _batch(c, shard, dev), c["vocab"], pad=fx.PAD, warmup=10, grad_sync=sync, use_graph=use_graph)
+    losses = [float(step())]
+    torch.cuda.synchronize()
+    grad1 = model._flat_grad.cpu().clone()          # reduced gradient of step 1 (the optimiser does not touch it)
+    losses += [float(step()) for _ in range(2)]
+    torch.cuda.synchronize()
+    torch.save({"flat": model._flat.cpu(), "grad1": grad1, "losses": losses}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_two_rank_dp_equals_single_rank_on_concatenated_batch(tmp_path, use_graph):
+    import torch.multiprocessing as mp
+    from mtn_amd.train_step import TrainStep
+    from oracle import fixtures as fx
+    assert torch.cuda.is_available()
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, str(tmp_path), use_graph), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["flat"], r1["flat"])                       # replicas stay identical
+    dev = torch.device("cuda:0")
+    c = dict(fx.GOLDEN_CONFIGS["cfg1_query"], B=4)
+    raw = fx.det_batch(c["vocab"], c["B"], c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=3)
+    model = _make(c, dev, "fp32")
+    step = TrainStep(model, _batch(c, raw, dev), c["vocab"], pad=fx.PAD, warmup=10, use_graph=False)
+    losses = [float(step())]
+    torch.cuda.synchronize()
+    gref = model._flat_grad.cpu().clone()
+    losses += [float(step()) for _ in range(2)]
+    # gradients: exact up to fp32 summation order (2 half-batch GEMMs + all-reduce vs one GEMM)
+    err = float((r0["grad1"] - gref).abs().max() / gref.abs().max())
+    assert err < 1e-5, err
+    # losses: every rank normalises by the GLOBAL token counts, so the single-rank loss is the sum of the rank losses.
+    # (Parameters after Adam are not compared element-wise: Adam turns noise-level gradients — the mathematically zero
+    # key-bias gradients — into O(lr) updates of arbitrary sign.)
+    dp_losses = [a + b for a, b in zip(r0["losses"], r1["losses"])]
+    for a, b in zip(dp_losses, losses):
+        assert abs(a - b) < 2e-3 * abs(b), (dp_losses, losses)
