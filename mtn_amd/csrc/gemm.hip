@@ -518,6 +518,138 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     }
 }
 
+// ====================================================================================================================
+// dW = dY^T X on LDS-DMA (bf16).  Both operands are contraction-major in memory ([rows of the batch][features]), which is
+// exactly what LDS-DMA can copy (lane-linear 16-byte chunks, no transposition in flight): the [k][n] tiles land in LDS
+// as they are and the MFMA fragments are read with the transposing LDS read ds_read_b64_tr_b16.  Semantics measured on
+// gfx950 (tools/tr_probe.hip): inside each 16-lane group, result lane i element j = element (i%4) of the 8-byte chunk
+// supplied by lane 4j + i/4.  So lane t of a group supplies &T[k0 + t/4][n0 + 4*(t%4)] and lane i receives T[k0..k0+3][n0+i]:
+// a 4(k) x 16(n) block delivered column-per-lane; two reads (k0 and k0+4) make one 16x16x32 fragment with the standard
+// slot order (lane group g covers k = 8g..8g+7).
+// Stage = 128 contraction rows x (64+64) features = 32 KiB, two stages = 64 KiB -> two workgroups per CU.
+// Bias gradients (row sums of dY^T) ride on one extra MFMA per fragment against an all-ones operand.
+// ====================================================================================================================
+static constexpr int TTD_KS = 128;                        // contraction rows per stage
+static constexpr int TTD_TILE_BYTES = TTD_KS * 128;       // one operand tile per stage: 128 k x 64 features x 2 B
+static constexpr int TTD_LDS = 4 * TTD_TILE_BYTES;        // 2 operands x 2 stages
+
+__device__ __forceinline__ void ttd_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_tile, int ld_bytes, int R, int K,
+                                               int col0, int k0, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int krow = (j * 4 + wave) * 8 + (lane >> 3);           // row of the tile written by this lane
+        const int p = lane & 7;                                      // 16-byte slot inside the 128-byte row
+        const int c = p ^ ((krow >> 1) & 7);                         // source chunk (XOR swizzle: the 4 rows of a transposing read hit different banks)
+        const int gk = k0 + krow, gn = col0 + c * 8;
+        unsigned voff = (gk < K && gn < R) ? (unsigned)gk * (unsigned)ld_bytes + (unsigned)gn * 2u : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + (j * 4 + wave) * 1024), 16, voff, 0, 0, 0);
+    }
+}
+
+// fragment for feature tile n_off (multiple of 16) and contraction step ks (32 rows) of a [k][64 features] image
+__device__ __forceinline__ uint4 ttd_frag(const unsigned char* img, int n_off, int ks, int l15, int lg) {
+    uint4 f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int krow = ks * 32 + 8 * lg + 4 * r + (l15 >> 2);
+        const int col = n_off + 4 * (l15 & 3);                       // element column
+        const int slot = (col >> 3) ^ ((krow >> 1) & 7);             // swizzled 16-byte slot
+        const unsigned addr = (unsigned)(size_t)(img + krow * 128 + slot * 16 + (col & 7) * 2);
+        unsigned long long v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        if (r == 0) { f.x = (unsigned)v; f.y = (unsigned)(v >> 32); }
+        else { f.z = (unsigned)v; f.w = (unsigned)(v >> 32); }
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(256) void gemm_tt_dma_kernel(const GemmGroup grp) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
+    const mtn_gemm_problem& P = grp.p[g];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = (N + 63) / 64;
+    const int t = (int)blockIdx.x - grp.tile_start[g];
+    const int row0 = (t / tiles_n) * 64, col0 = (t % tiles_n) * 64;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
+    const int lda_b = P.lda * 2, ldb_b = P.ldb * 2;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (K - 1) * lda_b + M * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (K - 1) * ldb_b + N * 2, 0x00020000);
+    const bool do_rowsum = (P.rowsum_out != nullptr) && (col0 == 0);
+
+    f32x4_t acc[2][2], rs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // bf16 1.0 x 8
+
+    const int nstages = (K + TTD_KS - 1) / TTD_KS;
+    ttd_issue_tile(rA, smem, lda_b, M, K, row0, 0, wave, lane);
+    ttd_issue_tile(rB, smem + TTD_TILE_BYTES, ldb_b, N, K, col0, 0, wave, lane);
+    if (nstages > 1) {
+        ttd_issue_tile(rA, smem + 2 * TTD_TILE_BYTES, lda_b, M, K, row0, TTD_KS, wave, lane);
+        ttd_issue_tile(rB, smem + 3 * TTD_TILE_BYTES, ldb_b, N, K, col0, TTD_KS, wave, lane);
+    }
+    for (int s = 0; s < nstages; ++s) {
+        if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // 8 LDS-DMA instructions per wave per stage
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* sA = smem + (s & 1) * 2 * TTD_TILE_BYTES;
+        const unsigned char* sB = sA + TTD_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < TTD_KS / 32; ++ks) {
+            uint4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = ttd_frag(sA, wr * 32 + i * 16, ks, l15, lg);
+                b[i] = ttd_frag(sB, wc * 32 + i * 16, ks, l15, lg);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator (vector epilogue)
+                if (do_rowsum && wc == 0) mma16<T>(rs[i], ones, a[i]);
+            }
+        }
+        if (s + 2 < nstages) {
+            __builtin_amdgcn_s_barrier();
+            unsigned char* dst = smem + (s & 1) * 2 * TTD_TILE_BYTES;
+            ttd_issue_tile(rA, dst, lda_b, M, K, row0, (s + 2) * TTD_KS, wave, lane);
+            ttd_issue_tile(rB, dst + TTD_TILE_BYTES, ldb_b, N, K, col0, (s + 2) * TTD_KS, wave, lane);
+        }
+    }
+    if (do_rowsum && wc == 0 && lg == 0) {       // every accumulator row of rs[] holds the same sums; column l15 = output row
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + wr * 32 + i * 16 + l15;
+            if (row < M) P.rowsum_out[row] = rs[i][0];
+        }
+    }
+    const DropState ds = drop_init(P.drop);
+    const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + wr * 32 + i * 16 + l15;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wc * 32 + j * 16 + lg * 4;
+            if (col >= N) continue;
+            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+        }
+    }
+}
+
 template <typename T, int BM, int BN>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
     constexpr int LDS = 2 * (BM + BN) * DMA_ROWB;
@@ -577,7 +709,13 @@ static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, 
         // step) although they pull half the bytes — kept behind MTN_GEMM_TT128=1 for larger batches.
         bool big = getenv("MTN_GEMM_TT128") != nullptr;
         for (int i = 0; i < grp.count; ++i) big = big && grp.p[i].M >= 128 && grp.p[i].N >= 128;
-        if (big) {
+        bool ttd = (sizeof(T) == 2) && getenv("MTN_GEMM_TT_REG") == nullptr;      // LDS-DMA + transposing LDS reads (bf16)
+        for (int i = 0; i < grp.count; ++i)
+            ttd = ttd && grp.p[i].M % 8 == 0 && grp.p[i].N % 8 == 0 && (long)grp.p[i].K * grp.p[i].lda * 2 < (1L << 31) &&
+                  (long)grp.p[i].K * grp.p[i].ldb * 2 < (1L << 31);
+        if (ttd) {
+            if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(gemm_tt_dma_kernel, grid, block, TTD_LDS, s, grp);
+        } else if (big) {
             GemmGroup g2 = grp;
             const int tiles = retile(g2, 128, 128);
             hipLaunchKernelGGL((gemm_tt128_kernel<T>), dim3(tiles), block, 0, s, g2);
