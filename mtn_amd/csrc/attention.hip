@@ -458,18 +458,22 @@ template <typename T> __device__ __forceinline__ uint4 frag_from_tlds(const unsi
     }
 }
 
-template <typename T, int DK>
-__global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnGroup G) {
+// NW = waves per workgroup: 1, or 4 with the key tiles dealt round-robin to the waves (long memories: the per-tile chain of
+// dependent memory round trips runs 4-wide) and the partial (max, sum, O) combined through LDS at the end.
+template <typename T, int DK, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnGroup G) {
     constexpr int EPV = LP<T>::EPV, KSTEP = LP<T>::KSTEP;
     constexpr int NKS = (DK + KSTEP - 1) / KSTEP;     // contraction steps over the head dimension
     constexpr int NDT = DK / 16;                      // 16-column tiles of the head dimension
     constexpr int TPK = KSTEP / 16;                   // 16-key C tiles per contraction step over keys (bf16 2, fp32 1)
     constexpr int NU = MK / KSTEP;                    // contraction steps per key tile
     constexpr int VT_ROW = MK * (int)sizeof(T) + 16;  // bytes per row of the transposed V image
-    extern __shared__ __attribute__((aligned(16))) unsigned char vt[];   // [DK][VT_ROW]
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];   // per wave: V^T image [DK][VT_ROW]; then the combine area
     const mtn_attn_args& A = G.a[blockIdx.z];
     if ((int)blockIdx.x >= A.B * A.h || (int)blockIdx.y * MQ >= A.a) return;
-    const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* vt = fsm + (size_t)wave * DK * VT_ROW;
     const int b = blockIdx.x / A.h, hh = blockIdx.x % A.h, q0 = blockIdx.y * MQ;
     const int a = A.a, m = A.m;
     const float scale = rsqrtf((float)DK);
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnGroup G) {
     float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
 
     constexpr int NBV = ((MK / 4) * (DK / 4) + 63) / 64;
-    for (int j0 = 0; j0 < m; j0 += MK) {
+    for (int j0 = wave * MK; j0 < m; j0 += NW * MK) {
         // ---- all global loads of the tile go out first: K fragments, V (for the transposed image), mask bytes
         uint4 kf[4][NKS];
 #pragma unroll
@@ -538,8 +542,9 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnGroup G) {
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) mma16<T>(st[kt][qt], kf[kt][ks], qf[qt][ks]);
             }
-        // ---- V^T image for this key tile (single wave: the barrier is a wave-local fence)
-        __syncthreads();
+        // ---- V^T image for this key tile (wave-private LDS: LDS operations of one wave complete in order, only the
+        //      compiler needs a fence)
+        __builtin_amdgcn_wave_barrier();
         vst.store(vt, VT_ROW, MK, DK, lane);
         // ---- mask, scale, online softmax (per query column = per lane&15)
         float alpha[2];
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnGroup G) {
             lrun[qt] = lrun[qt] * alpha[qt] + psum;
             mrun[qt] = mn;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         // ---- O^T = alpha * O^T + V^T P^T
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
@@ -605,36 +610,81 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(const AttnGroup G) {
     }
     // ---- epilogue: lane holds O^T[dcol = dt*16 + 4*lg + r][q = qt*16 + l15]
     T* og = (T*)A.o + (size_t)b * a * A.ldo + hh * DK;
+    if constexpr (NW == 1) {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int q = q0 + qt * 16 + l15;
-        if (q < a) {
-            const float inv = 1.0f / lrun[qt];
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = q0 + qt * 16 + l15;
+            if (q < a) {
+                const float inv = 1.0f / lrun[qt];
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const f32x4_t o = ot[dt][qt];
-                store4<T>(og + (size_t)q * A.ldo + dt * 16 + 4 * lg, make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv));
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const f32x4_t o = ot[dt][qt];
+                    store4<T>(og + (size_t)q * A.ldo + dt * 16 + 4 * lg, make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv));
+                }
+                if (A.lse && lg == 0) {
+                    float* stp = A.lse + 2 * ((size_t)(b * A.h + hh) * a + q);
+                    stp[0] = mrun[qt];
+                    stp[1] = inv;
+                }
             }
-            if (A.lse && lg == 0) {
+        }
+    } else {
+        // partial results of the NW waves -> LDS, then every thread combines a few (q, 4 columns) entries
+        float* cO = (float*)(fsm + (size_t)NW * DK * VT_ROW);      // [NW][DK][33]
+        float* cm = cO + NW * DK * 33;                             // [NW][32]
+        float* cl = cm + NW * 32;                                  // [NW][32]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cO[(wave * DK + dt * 16 + 4 * lg + r) * 33 + qt * 16 + l15] = ot[dt][qt][r];
+            if (lg == 0) { cm[wave * 32 + qt * 16 + l15] = mrun[qt]; cl[wave * 32 + qt * 16 + l15] = lrun[qt]; }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 32 * (DK / 4); idx += 64 * NW) {
+            const int ql = idx & 31, d4 = (idx >> 5) * 4;
+            const int q = q0 + ql;
+            if (q >= a) continue;
+            float M = cm[ql];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, cm[w * 32 + ql]);
+            float den = 0.f, num[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float f = __expf(cm[w * 32 + ql] - M);          // waves without a tile hold max = -inf -> factor 0
+                den += f * cl[w * 32 + ql];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) num[r] += f * cO[(w * DK + d4 + r) * 33 + ql];
+            }
+            const float inv = 1.0f / den;
+            store4<T>(og + (size_t)q * A.ldo + d4, make_float4(num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv));
+            if (A.lse && d4 == 0) {
                 float* stp = A.lse + 2 * ((size_t)(b * A.h + hh) * a + q);
-                stp[0] = mrun[qt];
+                stp[0] = M;
                 stp[1] = inv;
             }
         }
     }
 }
 
-template <typename T, int DK> static int launch_fwd_mfma(const AttnGroup& G, dim3 grid, hipStream_t s) {
-    const size_t lds = (size_t)DK * (MK * sizeof(T) + 16);
-    hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, DK>), grid, dim3(64), lds, s, G);
+template <typename T, int DK> static int launch_fwd_mfma(const AttnGroup& G, dim3 grid, bool split, hipStream_t s) {
+    const size_t vt = (size_t)DK * (MK * sizeof(T) + 16);
+    if (!split) {
+        hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, DK, 1>), grid, dim3(64), vt, s, G);
+    } else {
+        const size_t lds = 4 * vt + sizeof(float) * (4 * DK * 33 + 2 * 4 * 32);
+        if (int rc = set_lds(attn_fwd_mfma_kernel<T, DK, 4>, lds)) return rc;
+        hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, DK, 4>), grid, dim3(256), lds, s, G);
+    }
     return MTN_OK;
 }
-template <typename T> static int dispatch_fwd_mfma(int dk, const AttnGroup& G, dim3 grid, hipStream_t s) {
+template <typename T> static int dispatch_fwd_mfma(int dk, const AttnGroup& G, dim3 grid, bool split, hipStream_t s) {
     switch (dk) {
-        case 16: return launch_fwd_mfma<T, 16>(G, grid, s);
-        case 32: return launch_fwd_mfma<T, 32>(G, grid, s);
-        case 64: return launch_fwd_mfma<T, 64>(G, grid, s);
-        case 128: return launch_fwd_mfma<T, 128>(G, grid, s);
+        case 16: return launch_fwd_mfma<T, 16>(G, grid, split, s);
+        case 32: return launch_fwd_mfma<T, 32>(G, grid, split, s);
+        case 64: return launch_fwd_mfma<T, 64>(G, grid, split, s);
+        case 128: return launch_fwd_mfma<T, 128>(G, grid, split, s);
     }
     return -1;
 }
@@ -651,8 +701,8 @@ template <typename T> static int dispatch_fwd_mfma(int dk, const AttnGroup& G, d
 static constexpr int BQ = 32;   // query rows per block
 static constexpr int BK = 32;   // keys per tile
 
-template <typename T, int DK>
-__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnGroup G) {
+template <typename T, int DK, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_mfma_kernel(const AttnGroup G) {
     constexpr int EPV = LP<T>::EPV, KSTEP = LP<T>::KSTEP;
     constexpr int NKS = (DK + KSTEP - 1) / KSTEP;
     constexpr int NDT = DK / 16;
@@ -660,14 +710,15 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnGroup G) {
     constexpr int NU = 32 / KSTEP;                     // contraction steps over 32 queries / 32 keys (bf16 1, fp32 2)
     constexpr int ROWB = 32 * (int)sizeof(T) + 16;     // bytes per row of the transposed images (32 entries + pad)
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
-    unsigned char* dOt = bsm;                 // [DK][ROWB]  dO^T  (row = head column, entries = query rows)
-    unsigned char* Qt = dOt + DK * ROWB;     // [DK][ROWB]  Q^T
-    unsigned char* Kt = Qt + DK * ROWB;      // [DK][ROWB]  K^T of the current key tile
-    unsigned char* dSs = Kt + DK * ROWB;     // [32][ROWB]  dS  (row = query, entries = keys of the tile)
-    float* Ds = (float*)(dSs + 32 * ROWB);   // [32]        D_q = sum_c dO[q][c] O[q][c]
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* dOt = bsm;                 // [DK][ROWB]  dO^T  (row = head column, entries = query rows)   shared by the waves
+    unsigned char* Qt = dOt + DK * ROWB;     // [DK][ROWB]  Q^T                                               shared
+    float* Ds = (float*)(Qt + DK * ROWB);    // [32]        D_q = sum_c dO[q][c] O[q][c]                      shared
+    unsigned char* Kt = (unsigned char*)(Ds + 32) + (size_t)wave * (DK + 32) * ROWB;   // [DK][ROWB] K^T of the wave's current key tile
+    unsigned char* dSs = Kt + DK * ROWB;     // [32][ROWB]  dS  (row = query, entries = keys of the tile)      per wave
     const mtn_attn_args& A = G.a[blockIdx.z];
     if ((int)blockIdx.x >= A.B * A.h) return;
-    const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x / A.h, hh = blockIdx.x % A.h;
     const int a = A.a, m = A.m;
     const float scale = rsqrtf((float)DK);
@@ -691,9 +742,15 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnGroup G) {
             dof[qt][ks] = load_frag<T>(dog + (size_t)q * A.ldo + ks * KSTEP + lg * EPV, ok);
         }
     }
-    stage_transposed<T>(dOt, ROWB, dog, A.ldo, 0, BQ, a, DK, lane);
-    stage_transposed<T>(Qt, ROWB, qg, A.ldq, 0, BQ, a, DK, lane);
-    {   // D_q: lanes 2q and 2q+1 each sum half of row q
+    constexpr int NBT = ((32 / 4) * (DK / 4) + 63) / 64;     // 4x4 blocks per lane for a 32-row transposed image
+    if (wave == 0) {                                          // the shared images are built by wave 0 (small: 2 x 32 x DK)
+        TStage<T, NBT> sdo, sq;
+        sdo.load(dog, A.ldo, 0, BQ, a, DK, lane);
+        sq.load(qg, A.ldq, 0, BQ, a, DK, lane);
+        sdo.store(dOt, ROWB, BQ, DK, lane);
+        sq.store(Qt, ROWB, BQ, DK, lane);
+    }
+    if (wave == 0) {   // D_q: lanes 2q and 2q+1 each sum half of row q
         int q = lane >> 1;
         const int half = lane & 1;
         float sacc = 0.f;
@@ -732,33 +789,63 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnGroup G) {
     T* dkg = (T*)A.dk_out + (size_t)b * m * A.ldkv + hh * DK;
     T* dvg = (T*)A.dv_out + (size_t)b * m * A.ldkv + hh * DK;
 
-    for (int j0 = 0; j0 < m; j0 += BK) {
-        // ---- S = Q K^T, dP = dO V^T   (C layout: rows q = qt*16+4lg+r, column key = kt*16 + l15)
-        f32x4_t sc[2][2], dp[2][2];
+    for (int j0 = wave * BK; j0 < m; j0 += NW * BK) {
+        // ---- all global loads of the tile first: K/V fragments, K for the transposed image, mask bytes
+        uint4 kf[2][NKS], vf[2][NKS];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             int key = j0 + kt * 16 + l15;
             key = key < m ? key : m - 1;
-            uint4 kf[NKS], vf[NKS];
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const bool ok = ks * KSTEP + lg * EPV < DK;
-                kf[ks] = load_frag<T>(kg + (size_t)key * A.ldkv + ks * KSTEP + lg * EPV, ok);
-                vf[ks] = load_frag<T>(vg + (size_t)key * A.ldkv + ks * KSTEP + lg * EPV, ok);
+                kf[kt][ks] = load_frag<T>(kg + (size_t)key * A.ldkv + ks * KSTEP + lg * EPV, ok);
+                vf[kt][ks] = load_frag<T>(vg + (size_t)key * A.ldkv + ks * KSTEP + lg * EPV, ok);
             }
+        }
+        TStage<T, NBT> skt;
+        skt.load(kg, A.ldkv, j0, BK, m, DK, lane);
+        uint32_t mk[2][2];           // mask bytes of query rows 4lg..4lg+3 (tile qt) for key column kt*16+l15; 1 = keep
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            int key = j0 + kt * 16 + l15;
+            key = key < m ? key : m - 1;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                uint32_t w = 0x01010101u;
+                if (A.mask) {
+                    if (A.mask_sq == 0) {
+                        const uint32_t bq = A.mask[(size_t)b * A.mask_sb + key] != 0;
+                        w = bq * 0x01010101u;
+                    } else {
+                        w = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int q = qt * 16 + 4 * lg + r;
+                            q = q < a ? q : a - 1;
+                            w |= (uint32_t)(A.mask[(size_t)b * A.mask_sb + (size_t)q * A.mask_sq + key] != 0) << (8 * r);
+                        }
+                    }
+                }
+                mk[qt][kt] = w;
+            }
+        }
+        // ---- S = Q K^T, dP = dO V^T   (C layout: rows q = qt*16+4lg+r, column key = kt*16 + l15)
+        f32x4_t sc[2][2], dp[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 sc[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 dp[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    mma16<T>(sc[qt][kt], qf[qt][ks], kf[ks]);
-                    mma16<T>(dp[qt][kt], dof[qt][ks], vf[ks]);
+                    mma16<T>(sc[qt][kt], qf[qt][ks], kf[kt][ks]);
+                    mma16<T>(dp[qt][kt], dof[qt][ks], vf[kt][ks]);
                 }
             }
-        }
-        __syncthreads();                                   // previous tile's readers of Kt / dSs are done
-        stage_transposed<T>(Kt, ROWB, kg, A.ldkv, j0, BK, m, DK, lane);
+        __builtin_amdgcn_wave_barrier();                   // wave-private Kt / dSs: in-order LDS, compiler fence only
+        skt.store(Kt, ROWB, BK, DK, lane);
         // ---- P, dS in registers (sc <- dropped-out P, dp <- dS); dS also goes to LDS as [q][key]
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
@@ -770,7 +857,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnGroup G) {
                     const int q = qt * 16 + 4 * lg + r;
                     float pd = 0.f, dsv = 0.f;
                     if (key < m && q < a) {
-                        const bool keep_score = !(A.mask && A.mask[(size_t)b * A.mask_sb + (size_t)q * A.mask_sq + key] == 0);
+                        const bool keep_score = ((mk[qt][kt] >> (8 * r)) & 0xffu) != 0;
                         const float sv = keep_score ? sc[qt][kt][r] * scale : -1e9f;
                         const float p = __expf(sv - mxq[qt][r]) * invq[qt][r];
                         float dpd = dp[qt][kt][r];
@@ -808,7 +895,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnGroup G) {
                 }
             }
         }
-        __syncthreads();                                   // Kt and dSs are complete
+        __builtin_amdgcn_wave_barrier();                   // Kt and dSs are complete (same wave)
         // ---- dQ^T += K^T dS^T (contraction over the 32 keys of the tile)
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -824,31 +911,58 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnGroup G) {
         }
     }
     // ---- dQ: lane holds dQ^T[d = dt*16 + 4lg + r][q = qt*16 + l15]
+    if constexpr (NW == 1) {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int q = qt * 16 + l15;
-        if (q < a) {
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = qt * 16 + l15;
+            if (q < a) {
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const f32x4_t v = dqt[dt][qt];
-                store4<T>(dqg + (size_t)q * A.ldq + dt * 16 + 4 * lg, make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale));
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const f32x4_t v = dqt[dt][qt];
+                    store4<T>(dqg + (size_t)q * A.ldq + dt * 16 + 4 * lg, make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale));
+                }
             }
+        }
+    } else {   // sum the waves' partial dQ^T through LDS
+        float* cq = (float*)((unsigned char*)(Ds + 32) + (size_t)NW * (DK + 32) * ROWB);     // [NW][DK][33]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cq[(wave * DK + dt * 16 + 4 * lg + r) * 33 + qt * 16 + l15] = dqt[dt][qt][r];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 32 * (DK / 4); idx += 64 * NW) {
+            const int q = idx & 31, d4 = (idx >> 5) * 4;
+            if (q >= a) continue;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += cq[(w * DK + d4 + r) * 33 + q];
+            store4<T>(dqg + (size_t)q * A.ldq + d4, make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale));
         }
     }
 }
 
-template <typename T, int DK> static int launch_bwd_mfma(const AttnGroup& G, dim3 grid, hipStream_t s) {
+template <typename T, int DK> static int launch_bwd_mfma(const AttnGroup& G, dim3 grid, bool split, hipStream_t s) {
     const size_t rowb = 32 * sizeof(T) + 16;
-    const size_t lds = (3 * (size_t)DK + 32) * rowb + 32 * sizeof(float);
-    hipLaunchKernelGGL((attn_bwd_mfma_kernel<T, DK>), grid, dim3(64), lds, s, G);
+    const size_t shared = 2 * (size_t)DK * rowb + 32 * sizeof(float), per_wave = ((size_t)DK + 32) * rowb;
+    if (!split) {
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<T, DK, 1>), grid, dim3(64), shared + per_wave, s, G);
+    } else {
+        const size_t lds = shared + 4 * per_wave + sizeof(float) * 4 * DK * 33;
+        if (int rc = set_lds(attn_bwd_mfma_kernel<T, DK, 4>, lds)) return rc;
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<T, DK, 4>), grid, dim3(256), lds, s, G);
+    }
     return MTN_OK;
 }
-template <typename T> static int dispatch_bwd_mfma(int dk, const AttnGroup& G, dim3 grid, hipStream_t s) {
+template <typename T> static int dispatch_bwd_mfma(int dk, const AttnGroup& G, dim3 grid, bool split, hipStream_t s) {
     switch (dk) {
-        case 16: return launch_bwd_mfma<T, 16>(G, grid, s);
-        case 32: return launch_bwd_mfma<T, 32>(G, grid, s);
-        case 64: return launch_bwd_mfma<T, 64>(G, grid, s);
-        case 128: return launch_bwd_mfma<T, 128>(G, grid, s);
+        case 16: return launch_bwd_mfma<T, 16>(G, grid, split, s);
+        case 32: return launch_bwd_mfma<T, 32>(G, grid, split, s);
+        case 64: return launch_bwd_mfma<T, 64>(G, grid, split, s);
+        case 128: return launch_bwd_mfma<T, 128>(G, grid, split, s);
     }
     return -1;
 }
@@ -908,7 +1022,9 @@ extern "C" int mtn_attention_fwd_group(int dtype, int count, const mtn_attn_args
         }
         if (ok) {
             dim3 gridm(gx, gym, count);
-            int rc = (dtype == MTN_BF16) ? dispatch_fwd_mfma<bf16_t>(dk, G, gridm, s) : dispatch_fwd_mfma<float>(dk, G, gridm, s);
+            bool split = false;                         // a memory longer than one key tile: 4 waves share the tiles
+            for (int i = 0; i < count; ++i) split = split || args[i].m > MK;
+            int rc = (dtype == MTN_BF16) ? dispatch_fwd_mfma<bf16_t>(dk, G, gridm, split, s) : dispatch_fwd_mfma<float>(dk, G, gridm, split, s);
             if (rc == MTN_OK) { MTN_CHECK_LAUNCH(); return MTN_OK; }
         }
     }
@@ -949,7 +1065,9 @@ extern "C" int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args
             ok = ok && args[i].dk == dk && (dk == 16 || dk == 32 || dk == 64 || dk == 128) && args[i].a <= BQ && args[i].ldq % 8 == 0 &&
                  args[i].ldkv % 8 == 0 && args[i].ldo % 8 == 0;
         if (ok) {
-            int rc = (dtype == MTN_BF16) ? dispatch_bwd_mfma<bf16_t>(dk, G, grid, s) : dispatch_bwd_mfma<float>(dk, G, grid, s);
+            bool split = false;
+            for (int i = 0; i < count; ++i) split = split || args[i].m > BK;
+            int rc = (dtype == MTN_BF16) ? dispatch_bwd_mfma<bf16_t>(dk, G, grid, split, s) : dispatch_bwd_mfma<float>(dk, G, grid, split, s);
             if (rc == MTN_OK) { MTN_CHECK_LAUNCH(); return MTN_OK; }
         }
     }
