@@ -100,7 +100,29 @@ typedef struct {
     float* y_f32;
     void* y_lp;
     float *mean, *rstd;
+    /* Optional fused source (Embeddings + PositionalEncoding, mtn.py:282-309): when `tokens` is set the row is built as
+     * x[row] = dropout(lut[tokens[row]] * emb_scale + pe[row % seq_len]) instead of being read from `x`; when only `pe` is
+     * set, x[row] = dropout(x[row] + pe[row % seq_len]) (feature streams, mtn.py:378).  `x_out` (optional) receives that
+     * row (saved for backward).  no_ln != 0: no normalisation, y = the row (target embedding, mtn.py:59). */
+    const long* tokens;
+    const float* lut;
+    float emb_scale;
+    const float* pe;
+    int seq_len;
+    mtn_dropout drop;
+    float* x_out;
+    int no_ln;
 } mtn_ln_fwd_desc;
+/* Embedding backward: dlut[tokens[row]] += dx[row] * emb_scale * keep(row*d+c)/(1-p)   (atomic adds; dlut pre-zeroed). */
+typedef struct {
+    int rows, d;
+    const long* tokens;
+    const float* dx;
+    float emb_scale;
+    mtn_dropout drop;
+    float* dlut;
+} mtn_embed_bwd_desc;
+int mtn_embed_bwd_group(int count, const mtn_embed_bwd_desc* descs /* host array, <= MTN_LN_MAX_GROUP */, void* stream);
 typedef struct {
     int rows, d;
     float eps;

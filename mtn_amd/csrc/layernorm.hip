@@ -11,6 +11,29 @@ struct LnFwdGroup {
     mtn_ln_fwd_desc d[MTN_LN_MAX_GROUP];
 };
 
+// value of 4 consecutive columns of a (possibly synthesised) input row
+__device__ __forceinline__ float4 ln_src(const mtn_ln_fwd_desc& D, const DropState& ds, int row, int c, long tok, int pos) {
+    float4 v;
+    if (D.tokens) {
+        v = *(const float4*)(D.lut + (size_t)tok * D.d + c);
+        v.x *= D.emb_scale; v.y *= D.emb_scale; v.z *= D.emb_scale; v.w *= D.emb_scale;
+    } else {
+        v = *(const float4*)(D.x + (size_t)row * D.d + c);
+    }
+    if (D.pe) {
+        const float4 p = *(const float4*)(D.pe + (size_t)pos * D.d + c);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        if (ds.on) {
+            const uint64_t idx = (uint64_t)row * D.d + c;
+            v.x = drop_keep(ds, idx) ? v.x * ds.scale : 0.f;
+            v.y = drop_keep(ds, idx + 1) ? v.y * ds.scale : 0.f;
+            v.z = drop_keep(ds, idx + 2) ? v.z * ds.scale : 0.f;
+            v.w = drop_keep(ds, idx + 3) ? v.w * ds.scale : 0.f;
+        }
+    }
+    return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp) {
     int g = 0;
@@ -20,47 +43,45 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp) {
     const int lane = threadIdx.x & 63;
     const int row = ((int)blockIdx.x - grp.block_start[g]) * 4 + (threadIdx.x >> 6);
     if (row >= D.rows) return;
-    const float* xr = D.x + (size_t)row * d;
-    float s = 0.f;
-    for (int c = lane * 4; c < d; c += 256) {
-        float4 v = *(const float4*)(xr + c);
-        s += (v.x + v.y) + (v.z + v.w);
-    }
-    const float mean = wave_sum(s) / (float)d;
-    float q = 0.f;
-    for (int c = lane * 4; c < d; c += 256) {
-        float4 v = *(const float4*)(xr + c);
-        float e0 = v.x - mean, e1 = v.y - mean, e2 = v.z - mean, e3 = v.w - mean;
-        q += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
-    }
-    const float std_u = sqrtf(wave_sum(q) / (float)(d - 1));
-    const float rstd = 1.0f / (std_u + D.eps);
-    if (lane == 0) {
-        if (D.mean) D.mean[row] = mean;
-        if (D.rstd) D.rstd[row] = rstd;
-    }
+    const DropState ds = drop_init(D.drop);
+    const long tok = D.tokens ? D.tokens[row] : 0;
+    const int pos = D.pe ? row % D.seq_len : 0;
     T* y_lp = (T*)D.y_lp;
-    for (int c = lane * 4; c < d; c += 256) {
-        float4 v = *(const float4*)(xr + c);
-        float4 ga = *(const float4*)(D.a2 + c);
-        float4 b = *(const float4*)(D.b2 + c);
-        float4 o;
-        o.x = ga.x * (v.x - mean) * rstd + b.x;
-        o.y = ga.y * (v.y - mean) * rstd + b.y;
-        o.z = ga.z * (v.z - mean) * rstd + b.z;
-        o.w = ga.w * (v.w - mean) * rstd + b.w;
-        if (D.y_f32) *(float4*)(D.y_f32 + (size_t)row * d + c) = o;
-        if (y_lp) {
-            T* yp = y_lp + (size_t)row * d + c;
-            if constexpr (sizeof(T) == 2) {
-                uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
-                pk.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
-                *(uint2*)yp = pk;
-            } else {
-                *(float4*)yp = o;
-            }
+    float mean = 0.f, rstd = 1.f;
+    if (!D.no_ln) {
+        float s = 0.f;
+        for (int c = lane * 4; c < d; c += 256) {
+            float4 v = ln_src(D, ds, row, c, tok, pos);
+            s += (v.x + v.y) + (v.z + v.w);
         }
+        mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+        for (int c = lane * 4; c < d; c += 256) {
+            float4 v = ln_src(D, ds, row, c, tok, pos);
+            float e0 = v.x - mean, e1 = v.y - mean, e2 = v.z - mean, e3 = v.w - mean;
+            q += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+        }
+        const float std_u = sqrtf(wave_sum(q) / (float)(d - 1));
+        rstd = 1.0f / (std_u + D.eps);
+        if (lane == 0) {
+            if (D.mean) D.mean[row] = mean;
+            if (D.rstd) D.rstd[row] = rstd;
+        }
+    }
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 v = ln_src(D, ds, row, c, tok, pos);
+        if (D.x_out) *(float4*)(D.x_out + (size_t)row * d + c) = v;
+        float4 o = v;
+        if (!D.no_ln) {
+            float4 ga = *(const float4*)(D.a2 + c);
+            float4 b = *(const float4*)(D.b2 + c);
+            o.x = ga.x * (v.x - mean) * rstd + b.x;
+            o.y = ga.y * (v.y - mean) * rstd + b.y;
+            o.z = ga.z * (v.z - mean) * rstd + b.z;
+            o.w = ga.w * (v.w - mean) * rstd + b.w;
+        }
+        if (D.y_f32) *(float4*)(D.y_f32 + (size_t)row * d + c) = o;
+        if (y_lp) store_lp4<T>(y_lp + (size_t)row * d + c, o);
     }
 }
 
@@ -74,7 +95,8 @@ extern "C" int mtn_layernorm_fwd_group(int dtype, int count, const mtn_ln_fwd_de
     for (int i = 0; i < count; ++i) {
         const mtn_ln_fwd_desc& D = descs[i];
         MTN_CHECK_ARG(D.rows > 0 && D.d >= 4 && D.d % 4 == 0, "rows>0 and d%4==0 required");
-        MTN_CHECK_ARG(D.x && D.a2 && D.b2, "null input");
+        MTN_CHECK_ARG((D.x || (D.tokens && D.lut)) && (D.no_ln || (D.a2 && D.b2)), "null input");
+        MTN_CHECK_ARG(!D.pe || D.seq_len > 0, "positional encoding needs seq_len");
         grp.block_start[i] = blocks;
         blocks += (D.rows + 3) / 4;
         grp.d[i] = D;
@@ -89,7 +111,9 @@ extern "C" int mtn_layernorm_fwd_group(int dtype, int count, const mtn_ln_fwd_de
 
 extern "C" int mtn_layernorm_fwd(int dtype, int rows, int d, float eps, const float* x, const float* a2, const float* b2,
                                  float* y_f32, void* y_lp, float* mean, float* rstd, void* stream) {
-    mtn_ln_fwd_desc D = {rows, d, eps, x, a2, b2, y_f32, y_lp, mean, rstd};
+    mtn_ln_fwd_desc D;
+    memset(&D, 0, sizeof(D));
+    D.rows = rows; D.d = d; D.eps = eps; D.x = x; D.a2 = a2; D.b2 = b2; D.y_f32 = y_f32; D.y_lp = y_lp; D.mean = mean; D.rstd = rstd;
     return mtn_layernorm_fwd_group(dtype, 1, &D, stream);
 }
 
@@ -277,5 +301,46 @@ extern "C" int mtn_layernorm_bwd(int rows, int d, float eps, const float* x, con
         mtn_ln_finalize_desc F = {partial, ln_bwd_blocks(rows), d, da2, db2};
         return mtn_layernorm_bwd_finalize(1, &F, stream);
     }
+    return MTN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ embedding backward
+struct EmbedBwdGroup {
+    int count;
+    int block_start[MTN_LN_MAX_GROUP + 1];
+    mtn_embed_bwd_desc d[MTN_LN_MAX_GROUP];
+};
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdGroup grp) {
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.block_start[g + 1]) ++g;
+    const mtn_embed_bwd_desc& D = grp.d[g];
+    const int lane = threadIdx.x & 63;
+    const int row = ((int)blockIdx.x - grp.block_start[g]) * 4 + (threadIdx.x >> 6);
+    if (row >= D.rows) return;
+    const DropState ds = drop_init(D.drop);
+    const long tok = D.tokens[row];
+    float* dst = D.dlut + (size_t)tok * D.d;
+    const float* src = D.dx + (size_t)row * D.d;
+    for (int c = lane; c < D.d; c += 64) {
+        float v = src[c] * D.emb_scale;
+        if (ds.on) v = drop_keep(ds, (uint64_t)row * D.d + c) ? v * ds.scale : 0.f;
+        atomicAdd(dst + c, v);
+    }
+}
+extern "C" int mtn_embed_bwd_group(int count, const mtn_embed_bwd_desc* descs, void* stream) {
+    MTN_CHECK_ARG(count >= 1 && count <= MTN_LN_MAX_GROUP && descs, "bad group");
+    EmbedBwdGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    grp.count = count;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        MTN_CHECK_ARG(descs[i].rows > 0 && descs[i].d > 0 && descs[i].tokens && descs[i].dx && descs[i].dlut, "bad descriptor");
+        grp.block_start[i] = blocks;
+        blocks += (descs[i].rows + 3) / 4;
+        grp.d[i] = descs[i];
+    }
+    for (int i = count; i <= MTN_LN_MAX_GROUP; ++i) grp.block_start[i] = blocks;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
+    MTN_CHECK_LAUNCH();
     return MTN_OK;
 }

@@ -98,11 +98,15 @@ extern "C" int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* 
         int n = 0;
         for (int i = 0; i < n_mha; ++i) {
             const mtn_mha_args* a = &mha[i];
-            L[n++] = mtn_ln_fwd_desc{a->B * a->a, a->d, a->ln_eps, a->x, a->ln_a, a->ln_b, nullptr, a->xn, a->mean, a->rstd};
+            memset(&L[n], 0, sizeof(L[n]));
+            L[n].rows = a->B * a->a; L[n].d = a->d; L[n].eps = a->ln_eps; L[n].x = a->x; L[n].a2 = a->ln_a; L[n].b2 = a->ln_b;
+            L[n].y_lp = a->xn; L[n].mean = a->mean; L[n].rstd = a->rstd; ++n;
         }
         for (int i = 0; i < n_ffn; ++i) {
             const mtn_ffn_args* a = &ffn[i];
-            L[n++] = mtn_ln_fwd_desc{a->rows, a->d, a->ln_eps, a->x, a->ln_a, a->ln_b, nullptr, a->xn, a->mean, a->rstd};
+            memset(&L[n], 0, sizeof(L[n]));
+            L[n].rows = a->rows; L[n].d = a->d; L[n].eps = a->ln_eps; L[n].x = a->x; L[n].a2 = a->ln_a; L[n].b2 = a->ln_b;
+            L[n].y_lp = a->xn; L[n].mean = a->mean; L[n].rstd = a->rstd; ++n;
         }
         RUN(mtn_layernorm_fwd_group(dtype, n, L, stream));
     }

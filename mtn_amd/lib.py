@@ -77,7 +77,14 @@ class TransposeDesc(C.Structure):
 
 class LnFwdDesc(C.Structure):
     _fields_ = [("rows", C.c_int), ("d", C.c_int), ("eps", C.c_float), ("x", C.c_void_p), ("a2", C.c_void_p), ("b2", C.c_void_p),
-                ("y_f32", C.c_void_p), ("y_lp", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p)]
+                ("y_f32", C.c_void_p), ("y_lp", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("tokens", C.c_void_p), ("lut", C.c_void_p), ("emb_scale", C.c_float), ("pe", C.c_void_p), ("seq_len", C.c_int),
+                ("drop", Dropout), ("x_out", C.c_void_p), ("no_ln", C.c_int)]
+
+
+class EmbedBwdDesc(C.Structure):
+    _fields_ = [("rows", C.c_int), ("d", C.c_int), ("tokens", C.c_void_p), ("dx", C.c_void_p), ("emb_scale", C.c_float),
+                ("drop", Dropout), ("dlut", C.c_void_p)]
 
 
 class LnBwdDesc(C.Structure):
@@ -104,6 +111,7 @@ SYMBOLS = {
     "mtn_gemm": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
     "mtn_layernorm_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mtn_layernorm_fwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(LnFwdDesc), _P]),
+    "mtn_embed_bwd_group": (C.c_int, [C.c_int, C.POINTER(EmbedBwdDesc), _P]),
     "mtn_layernorm_bwd_group": (C.c_int, [C.c_int, C.POINTER(LnBwdDesc), _P]),
     "mtn_attention_fwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(AttnArgs), _P]),
     "mtn_attention_bwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(AttnArgs), _P]),

@@ -436,6 +436,8 @@ class EncoderDecoder(nn.Module):
         self._streams = None                   # side streams for the two auto-encoder chains (sequential schedule only)
         self.multi_stream = False
         self.lockstep = True                   # independent sublayers of a layer share launches (ops.SublayerGroupFn)
+        self.fused_embed = True                # Embeddings + PositionalEncoding + Encoder LayerNorm in one grouped launch
+        self._embed_calls = 0
 
     # ---- flat parameter storage ------------------------------------------------------------------
     def _ordered_params(self):
@@ -630,12 +632,51 @@ class EncoderDecoder(nn.Module):
     def vid_encode(self, video_features, video_features_mask=None, encoded_query=None):   # mtn.py:32-36
         return [self.vid_encoder[i](ft) for i, ft in enumerate(video_features)]
 
+    def _embed_fused(self, items):
+        """items: [(tokens, Sequential(Embeddings, PositionalEncoding), LayerNorm | None)] -> list of fp32 tensors, each
+        carrying its compute-dtype copy (._mtn_lp) when normalised.  One grouped HIP launch (ops.EmbedNormFn)."""
+        luts, streams = [], []
+        for k, (tok, emb, ln) in enumerate(items):
+            lut = emb[0].lut.weight
+            idx = next((j for j, t in enumerate(luts) if t is lut), None)
+            if idx is None:
+                luts.append(lut); idx = len(luts) - 1
+            lninfo = None
+            if ln is not None:
+                ga, gb = ln._grads if ln._grads is not None else (None, None)
+                lninfo = (ln.a_2, ln.b_2, ln.eps, ga, gb)
+            streams.append(dict(tokens=tok, lut=idx, pe=emb[1].pe[0], scale=math.sqrt(emb[0].d_model),
+                                p=emb[1].dropout.p if self.training else 0.0, salt=900000 + self._embed_calls * 16 + k, ln=lninfo))
+        self._embed_calls += 1
+        spec = dict(streams=streams, lp_dtype=self.compute_dtype, seed=self._seed if self.training else None, queue=self._queue)
+        outs = ops.EmbedNormFn.apply(spec, *luts)
+        for y, y_lp, (_, _, ln) in zip(outs, spec["_lp_out"], items):
+            if ln is not None:
+                y._mtn_lp = y_lp if y_lp is not None else y.detach()
+        return list(outs)
+
+    def _fused_embed_ok(self, tokens):
+        return self.fused_embed and tokens.is_cuda and self._flat is not None and all(n._grads is not None for n in self.query_encoder.norm)
+
     def encode(self, query, query_mask, his=None, his_mask=None, cap=None, cap_mask=None, vid=None, vid_mask=None):
         """mtn.py:38-56 — every text stream goes through ``query_embed``; returns
         [q_mem, [vid_mem], cap_mem, his_mem, ae] with ae = list of auto-encoder seeds or None."""
         self.prepare()
         if self.training:
             self.advance_dropout_seed()
+        self._embed_calls = 0
+        if self._fused_embed_ok(query):
+            nF = len(vid)
+            norm = self.query_encoder.norm
+            items = [(query, self.query_embed, norm[0]), (cap, self.query_embed, norm[nF + 1]), (his, self.query_embed, norm[nF + 2])]
+            if self.diff_encoder:
+                ft = cap if self.auto_encoder_ft in ("caption", "summary") else query
+                for i in range(nF):
+                    emb = self.auto_encoder_embed[i] if self.auto_encoder_embed is not None else self.query_embed
+                    items.append((ft, emb, norm[nF + 3 + i]))
+            outs = self._embed_fused(items)
+            vids = [self.query_encoder._apply_norm(1 + i, v) for i, v in enumerate(self.vid_encode(vid, vid_mask))]
+            return [outs[0], vids, outs[1], outs[2], outs[3:] if self.diff_encoder else None]
         streams = [self.query_embed(query), self.vid_encode(vid, vid_mask), self.query_embed(cap), self.query_embed(his)]
         if not self.diff_encoder:
             out = self.query_encoder(*streams)
@@ -651,7 +692,11 @@ class EncoderDecoder(nn.Module):
     def decode(self, encoded_vid_features, his_memory, cap_memory, query_memory, vid_features_mask, his_mask, cap_mask,
                query_mask, tgt, tgt_mask, auto_encoded_ft):          # mtn.py:58-60
         self.prepare()
-        return self.decoder(encoded_vid_features, vid_features_mask, self.tgt_embed(tgt), his_memory, his_mask, cap_memory,
+        if self._fused_embed_ok(tgt):
+            x0 = self._embed_fused([(tgt, self.tgt_embed, None)])[0]
+        else:
+            x0 = self.tgt_embed(tgt)
+        return self.decoder(encoded_vid_features, vid_features_mask, x0, his_memory, his_mask, cap_memory,
                             cap_mask, query_memory, query_mask, tgt_mask, auto_encoded_ft, self.auto_encoder_ft)
 
 

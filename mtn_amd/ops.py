@@ -539,6 +539,100 @@ class SublayerGroupFn(torch.autograd.Function):
         return (None, *grads_out)
 
 
+# ------------------------------------------------------------------------------------------ fused embeddings
+class EmbedNormFn(torch.autograd.Function):
+    """Embeddings (lut[tok] * sqrt(d), mtn.py:288-289) + PositionalEncoding (+pe, dropout, mtn.py:307-309) + the Encoder's
+    LayerNorm for that stream (mtn.py:83-101), for several token streams in ONE grouped launch; backward = grouped LayerNorm
+    backward + one grouped scatter-add into the embedding-table gradients.
+    apply(spec, *luts) -> one fp32 tensor per stream.  spec["streams"]: dicts with tokens (B,L) int64, lut (index into luts),
+    pe (max_len,d), scale, p (dropout), salt, ln = None | (a2, b2, eps, grad_a, grad_b).  Table gradients are accumulated into
+    lut.grad when it exists (flat gradient buffer), else returned."""
+
+    @staticmethod
+    def forward(ctx, spec, *luts):
+        lib = L.load()
+        streams = spec["streams"]
+        lp = spec["lp_dtype"]
+        code = L.dtype_code(lp) if lp is not None else L.MTN_F32
+        dev = luts[0].device
+        descs = (L.LnFwdDesc * len(streams))()
+        outs, saved = [], []
+        for i, st in enumerate(streams):
+            tok = st["tokens"].contiguous()
+            B, Ls = tok.shape
+            d = luts[st["lut"]].size(1)
+            rows = B * Ls
+            y = torch.empty(B, Ls, d, device=dev, dtype=torch.float32)
+            D = descs[i]
+            D.rows, D.d, D.tokens, D.lut, D.emb_scale = rows, d, tok.data_ptr(), luts[st["lut"]].data_ptr(), float(st["scale"])
+            D.pe, D.seq_len = st["pe"].data_ptr(), Ls
+            D.drop = _drop(st["p"], st["salt"], spec["seed"])
+            sv = dict(tok=tok, rows=rows, d=d)
+            if st["ln"] is not None:
+                a2, b2, eps = st["ln"][0], st["ln"][1], st["ln"][2]
+                x_save = torch.empty(rows, d, device=dev, dtype=torch.float32)
+                mean = torch.empty(rows, device=dev, dtype=torch.float32)
+                rstd = torch.empty_like(mean)
+                y_lp = torch.empty(B, Ls, d, device=dev, dtype=lp) if (lp is not None and lp != torch.float32) else None
+                D.eps, D.a2, D.b2, D.x_out, D.mean, D.rstd = eps, a2.data_ptr(), b2.data_ptr(), x_save.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+                D.y_f32, D.y_lp, D.no_ln = y.data_ptr(), L.ptr(y_lp), 0
+                sv.update(x=x_save, mean=mean, rstd=rstd, a2=a2, y_lp=y_lp)
+            else:
+                D.y_f32, D.no_ln = y.data_ptr(), 1
+            outs.append(y)
+            saved.append(sv)
+        L.check(lib.mtn_layernorm_fwd_group(code, len(streams), descs, L.stream_ptr()))
+        ctx.spec, ctx.saved_streams, ctx.luts = spec, saved, luts
+        ctx.lp_copies = [sv.get("y_lp") for sv in saved]
+        spec["_lp_out"] = ctx.lp_copies
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = L.load()
+        spec, saved, luts = ctx.spec, ctx.saved_streams, ctx.luts
+        streams = spec["streams"]
+        dev = luts[0].device
+        queue = spec.get("queue")
+        ln_descs, ln_final, emb = [], [], (L.EmbedBwdDesc * len(streams))()
+        keep = []
+        ret = [None] * len(luts)
+        dluts = []
+        for j, lut in enumerate(luts):
+            if lut.grad is not None:
+                dluts.append(lut.grad)
+            else:
+                g = torch.zeros_like(lut)
+                dluts.append(g)
+                ret[j] = g
+        for i, (st, sv, dy) in enumerate(zip(streams, saved, dys)):
+            dy = dy.contiguous() if dy is not None else torch.zeros(sv["rows"], sv["d"], device=dev)
+            dx = dy
+            if st["ln"] is not None:
+                dx = torch.empty(sv["rows"], sv["d"], device=dev, dtype=torch.float32)
+                partial = torch.empty(lib.mtn_layernorm_bwd_partial_floats(sv["rows"], sv["d"]), device=dev, dtype=torch.float32)
+                ln_descs.append(L.LnBwdDesc(sv["rows"], sv["d"], st["ln"][2], sv["x"].data_ptr(), sv["a2"].data_ptr(), sv["mean"].data_ptr(),
+                                            sv["rstd"].data_ptr(), dy.data_ptr(), None, dx.data_ptr(), partial.data_ptr()))
+                ga, gb = st["ln"][3], st["ln"][4]
+                ln_final.append((L.LnFinalizeDesc(partial.data_ptr(), lib.mtn_layernorm_bwd_nparts(sv["rows"]), sv["d"], ga.data_ptr(), gb.data_ptr()), partial))
+            keep += [dy, dx]
+            E = emb[i]
+            E.rows, E.d, E.tokens, E.dx, E.emb_scale = sv["rows"], sv["d"], sv["tok"].data_ptr(), dx.data_ptr(), float(st["scale"])
+            E.drop = _drop(st["p"], st["salt"], spec["seed"])
+            E.dlut = dluts[st["lut"]].data_ptr()
+        if ln_descs:
+            arr = (L.LnBwdDesc * len(ln_descs))(*ln_descs)
+            L.check(lib.mtn_layernorm_bwd_group(len(ln_descs), arr, L.stream_ptr()))
+            if queue is not None:
+                for desc, partial in ln_final:
+                    queue.add(queue.dtype, [], desc, [partial])
+            else:
+                farr = (L.LnFinalizeDesc * len(ln_final))(*[f[0] for f in ln_final])
+                L.check(lib.mtn_layernorm_bwd_finalize(len(ln_final), farr, L.stream_ptr()))
+        L.check(lib.mtn_embed_bwd_group(len(streams), emb, L.stream_ptr()))
+        return (None, *ret)
+
+
 # ------------------------------------------------------------------------------------------ loss head
 class GeneratorLossFn(torch.autograd.Function):
     """sum_i coef_i * KLDiv(log_softmax(x_i W_i^T + b_i), smooth(y_i)) / norm_i  — Generator (mtn.py:62-69) +

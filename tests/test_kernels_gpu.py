@@ -111,6 +111,63 @@ def test_layernorm_fwd_bwd(dev, rows, d):
     assert relmax(bd.grad, br.grad) < 1e-4
 
 
+def test_fused_embedding_streams(dev):
+    """Embeddings * sqrt(d) + positional encoding (+ dropout) (+ Encoder LayerNorm) for several token streams in one grouped
+    launch (mtn.py:288-289, 307-309, 83-101): outputs, table / LayerNorm gradients, and dropout-mask consistency."""
+    import math
+    from mtn_amd import ops
+    from oracle.mtn_oracle import layer_norm as ref_ln, positional_encoding
+    V, d, B = 50, 64, 3
+    g = torch.Generator().manual_seed(5)
+    lut = torch.randn(V, d, generator=g)
+    lut2 = torch.randn(V, d, generator=g)
+    toks = [torch.randint(0, V, (B, Lq), generator=g) for Lq in (7, 12, 5)]
+    lns = [(1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)) for _ in range(2)]
+    gys = [torch.randn(B, t.size(1), d, generator=g) for t in toks]
+    pe = positional_encoding(64, d)
+    # oracle: streams 0,1 share `lut` and are normalised; stream 2 uses lut2 and is not
+    lr, l2r = lut.clone().requires_grad_(), lut2.clone().requires_grad_()
+    lnr = [(a.clone().requires_grad_(), b.clone().requires_grad_()) for a, b in lns]
+    ref = []
+    for i, t in enumerate(toks):
+        e = (lr if i < 2 else l2r)[t] * math.sqrt(d) + pe[: t.size(1)]
+        ref.append(ref_ln(e, lnr[i][0], lnr[i][1], 1e-6) if i < 2 else e)
+    torch.autograd.backward(ref, gys)
+    # HIP
+    ld, l2d = lut.to(dev).requires_grad_(), lut2.to(dev).requires_grad_()
+    lnd = [(a.to(dev), b.to(dev), torch.zeros(d, device=dev), torch.zeros(d, device=dev)) for a, b in lns]
+    ped = pe.to(dev).contiguous()
+    def spec(p, seed):
+        streams = [dict(tokens=t.to(dev), lut=0 if i < 2 else 1, pe=ped, scale=math.sqrt(d), p=p, salt=70 + i,
+                        ln=(lnd[i][0], lnd[i][1], 1e-6, lnd[i][2], lnd[i][3]) if i < 2 else None) for i, t in enumerate(toks)]
+        return dict(streams=streams, lp_dtype=torch.bfloat16, seed=seed, queue=None)
+    sp = spec(0.0, None)
+    ys = ops.EmbedNormFn.apply(sp, ld, l2d)
+    torch.autograd.backward(ys, [t.to(dev) for t in gys])
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert relmax(ys[i], ref[i]) < 1e-5
+    assert relmax(sp["_lp_out"][0].float(), ref[0]) < 1e-2 and sp["_lp_out"][2] is None
+    assert relmax(ld.grad, lr.grad) < 1e-4 and relmax(l2d.grad, l2r.grad) < 1e-5
+    for i in range(2):
+        assert relmax(lnd[i][2], lnr[i][0].grad) < 1e-4 and relmax(lnd[i][3], lnr[i][1].grad) < 1e-4
+    # dropout on the un-normalised stream: kept elements scaled by 1/(1-p); backward uses the same mask
+    seed = torch.full((1,), 1234, device=dev, dtype=torch.int64)
+    l2d.grad = None
+    ld.grad = None
+    ys = ops.EmbedNormFn.apply(spec(0.25, seed), ld, l2d)
+    y2 = ys[2]
+    keep = (y2 != 0)
+    frac = keep.float().mean().item()
+    assert 0.65 < frac < 0.85
+    assert absmax(y2, ref[2].detach().to(dev) * keep / 0.75) < 1e-4
+    torch.autograd.backward(ys, [t.to(dev) for t in gys])
+    torch.cuda.synchronize()
+    want = torch.zeros(V, d, device=dev).index_add_(0, toks[2].to(dev).reshape(-1),
+                                                    (gys[2].to(dev) * keep / 0.75).reshape(-1, d) * math.sqrt(d))
+    assert relmax(l2d.grad, want) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ attention core
 def _attn_ref(q, k, v, mask, h):
     from oracle.mtn_oracle import scaled_dot_attention

@@ -263,7 +263,9 @@ def test_dropout_training_step_runs_and_is_seed_deterministic(dev):
     l1, g1 = run(1000)
     l2, g2 = run(1000)
     l3, g3 = run(2000)
-    assert l1 == l2 and torch.equal(g1, g2)
+    n_glue = model._glue_numel                   # embedding-table gradients are float atomics: order-dependent rounding
+    assert l1 == l2 and torch.equal(g1[n_glue:], g2[n_glue:])
+    assert (g1[:n_glue] - g2[:n_glue]).abs().max() <= 1e-5 * g1[:n_glue].abs().max()
     assert l1 != l3
     assert torch.isfinite(g1).all() and torch.isfinite(g3).all()
     model.eval()
@@ -320,7 +322,8 @@ def test_lockstep_schedule_equals_sequential_schedule(dev, name):
         assert torch.equal(x, y)
     assert torch.isfinite(g1).all()
     if c["diff_encoder"]:
-        assert torch.equal(g1, g2)
+        n_glue = model._glue_numel           # embedding-table gradients: float atomics, order-dependent rounding
+        assert torch.equal(g1[n_glue:], g2[n_glue:]) and relmax(g1[:n_glue], g2[:n_glue]) < 1e-5
     else:   # one seed tensor feeds both auto-encoder chains: autograd sums its gradient contributions in schedule order
         assert relmax(g1, g2) < 1e-5
 
