@@ -32,7 +32,14 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            kw = {}
+            try:       # the overlapped gradient exchange shares the GPU with backward kernels: give RCCL's stream priority
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kw["pg_options"] = opts
+            except Exception:
+                pass
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
@@ -70,6 +77,27 @@ class GradSync:
         if self.world > 1:
             dist.broadcast(t, src=src, group=self.group)
         return t
+
+    def reduce_range(self, lo: int, hi: int):
+        """Asynchronous sum all-reduce of flat_grad[lo:hi] (issued behind everything already queued on the current stream;
+        later work on the current stream does NOT wait for it).  Returns a handle for wait()."""
+        if (self.world == 1 and os.environ.get("MTN_FORCE_DIST") != "1") or hi <= lo:
+            return None
+        chunk = self.flat_grad_fn()[lo:hi]
+        if self.compress:
+            c16 = chunk.to(torch.bfloat16)
+            return (dist.all_reduce(c16, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk, c16)
+        return (dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None)
+
+    def wait(self, handles):
+        """Make the current stream wait for the exchanges issued by reduce_range()."""
+        for h in handles:
+            if h is None:
+                continue
+            work, chunk, c16 = h
+            work.wait()
+            if c16 is not None:
+                chunk.copy_(c16)
 
     def __call__(self):
         if self.world == 1 and os.environ.get("MTN_FORCE_DIST") != "1":

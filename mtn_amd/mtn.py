@@ -689,13 +689,52 @@ class EncoderDecoder(nn.Module):
             ae = [self.query_embed(ft) for _ in range(len(vid))]
         return self.query_encoder(*streams, ae)
 
+    def embed_target(self, tgt):
+        """tgt_embed of mtn.py:59 (lookup * sqrt(d) + positional encoding + dropout)."""
+        if self._fused_embed_ok(tgt):
+            return self._embed_fused([(tgt, self.tgt_embed, None)])[0]
+        return self.tgt_embed(tgt)
+
+    def forward_segmented(self, b):
+        """forward(b) with the autograd graph CUT at every decoder-layer boundary, for a backward that runs one layer at a
+        time (train_step.TrainStep under data parallelism: layer k's gradient slice is all-reduced while layer k-1's
+        backward runs).  Same arithmetic and launches as forward().  Returns a dict:
+          enc_out / enc_leaf : encoder-side outputs (memories, auto-encoder seeds, embedded target) and their detached twins
+          layers             : per layer (inputs [x, *ae] as leaves, outputs [x, *ae])
+          top_in             : leaves feeding the final LayerNorms;  out, ae_out : as forward()."""
+        q, v, cp, hs, ae = self.encode(b.query, b.query_mask, b.his, b.his_mask, b.cap, b.cap_mask, b.fts, b.fts_mask)
+        x = self.embed_target(b.trg)
+        enc_out = [q, cp, hs, x] + list(v) + (list(ae) if ae is not None else [])
+
+        def cut(t):
+            u = t.detach().requires_grad_()
+            if hasattr(t, "_mtn_lp"):
+                u._mtn_lp = t._mtn_lp
+            return u
+
+        enc_leaf = [cut(t) for t in enc_out]
+        nF = len(v)
+        q_l, cp_l, hs_l, x_l = enc_leaf[:4]
+        v_l = enc_leaf[4:4 + nF]
+        ae_l = enc_leaf[4 + nF:] if ae is not None else None
+        ops.prepare_masks(b.trg_mask, b.his_mask, b.cap_mask, b.query_mask, b.fts_mask)
+        layers = []
+        x_in, ae_in = x_l, ae_l
+        for layer in self.decoder.layers:
+            x_out, ae_out = layer(x_in, cp_l, b.cap_mask, hs_l, b.his_mask, q_l, b.query_mask, b.trg_mask, v_l, b.fts_mask,
+                                  ae_in, self.auto_encoder_ft)
+            ins = [x_in] + (list(ae_in) if isinstance(ae_in, (list, tuple)) else [])
+            layers.append((ins, [x_out] + list(ae_out)))
+            x_in, ae_in = cut(x_out), [cut(a) for a in ae_out]
+        top_in = [x_in] + ae_in
+        out = self.decoder.norm(x_in)
+        ae_fin = [self.decoder.ae_norm[i](a) for i, a in enumerate(ae_in)]
+        return dict(enc_out=enc_out, enc_leaf=enc_leaf, layers=layers, top_in=top_in, out=out, ae_out=ae_fin)
+
     def decode(self, encoded_vid_features, his_memory, cap_memory, query_memory, vid_features_mask, his_mask, cap_mask,
                query_mask, tgt, tgt_mask, auto_encoded_ft):          # mtn.py:58-60
         self.prepare()
-        if self._fused_embed_ok(tgt):
-            x0 = self._embed_fused([(tgt, self.tgt_embed, None)])[0]
-        else:
-            x0 = self.tgt_embed(tgt)
+        x0 = self.embed_target(tgt)
         return self.decoder(encoded_vid_features, vid_features_mask, x0, his_memory, his_mask, cap_memory,
                             cap_mask, query_memory, query_mask, tgt_mask, auto_encoded_ft, self.auto_encoder_ft)
 

@@ -1,12 +1,17 @@
 """One training step of the reference's batch loop (train.py:29-40 + data_utils.py:123-156) as a replayable unit:
 zero glue grads -> forward -> generator + label-smoothed loss -> backward -> [gradient all-reduce] -> fused Noam/Adam.
 
-On one GPU the whole step is captured into a single hipGraph (≈1300 short kernels: launch-bound if driven from
-Python).  With data parallelism the step is two graphs with the RCCL all-reduce of the flat gradient buffer
-launched eagerly between them (collectives are kept out of graph capture on purpose: see DESIGN.md §multi-GPU).
+On one GPU the whole step is captured into a single hipGraph (≈460 short kernels: launch-bound if driven from
+Python).  With data parallelism the backward pass is cut at the decoder-layer boundaries (model.forward_segmented) and
+the step becomes N+3 hipGraphs — [forward + loss + top layer] [layer N-2] … [layer 0] [encoder side] [Adam] — with the RCCL
+all-reduce of each finished gradient slice (one layer = 17 M floats = 67 MB at cfg2) launched eagerly, asynchronously,
+right after the graph that produced it: the exchange of layer k runs on RCCL's stream while layer k-1's backward runs.
+Collectives stay out of graph capture on purpose.  ``overlap=False`` (or MTN_DP_OVERLAP=0) keeps
+the simpler schedule: one graph for forward+backward, the whole-buffer all-reduce, one graph for Adam.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional
 
 import torch
@@ -16,7 +21,7 @@ from .data_utils import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
 
 class TrainStep:
     def __init__(self, model, batch, vocab: int, pad: int = 1, warmup: int = 4000, factor: float = 1.0, lam: float = 1.0,
-                 smoothing: float = 0.1, grad_sync=None, use_graph: bool = True):
+                 smoothing: float = 0.1, grad_sync=None, use_graph: bool = True, overlap: Optional[bool] = None):
         self.model, self.batch = model, batch
         self.opt = NoamOpt(model.decoder.layers[0].size, factor, warmup, FusedAdam(model))
         self.crit = LabelSmoothing(vocab, pad, smoothing)
@@ -26,6 +31,11 @@ class TrainStep:
         self.use_graph = use_graph
         self._g_fb = self._g_opt = None
         self._loss = None
+        if overlap is None:
+            overlap = os.environ.get("MTN_DP_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap) and grad_sync is not None
+        self._g_seg = None
+        self._st = None
         ae_y = batch.cap if model.auto_encoder_ft in ("caption", "summary") else batch.query
         self._ae_y = ae_y
         # loss normalisers (train.py:35-39).  Under DP they are all-reduced ONCE here for a static batch so that
@@ -46,6 +56,56 @@ class TrainStep:
     def _optim(self):
         self.opt.step()
 
+    # ---- layer-segmented backward (data parallel, overlapped exchange)
+    def _segments(self):
+        """[(callable, (lo, hi) slice of the flat gradient buffer that is final once the callable has run)]"""
+        m = self.model
+        m.prepare()
+        sl = m._layer_slices
+        total = m._flat_grad.numel()
+        N = len(sl)
+        assert all(sl[k][1] == sl[k + 1][0] for k in range(N - 1)), "layer slices not contiguous"
+
+        def bwd(outs, leaves):
+            pairs = [(o, l.grad) for o, l in zip(outs, leaves) if l.grad is not None]
+            if pairs:
+                torch.autograd.backward([p[0] for p in pairs], [p[1] for p in pairs])
+
+        def top():
+            b = self.batch
+            m.zero_glue_grads()
+            st = m.forward_segmented(b)
+            self._st = st
+            loss = self.lc.loss(st["out"], b.trg_y, self._norms[0], st["ae_out"], self._ae_y, self._norms[1])
+            loss.backward()                                     # loss head + final LayerNorms
+            ins, outs = st["layers"][N - 1]
+            bwd(outs, st["top_in"])                             # top decoder layer
+            self._loss_t = loss.detach()
+
+        def layer(k):
+            def run():
+                st = self._st
+                ins, outs = st["layers"][k]
+                bwd(outs, st["layers"][k + 1][0])
+            return run
+
+        def enc():
+            st = self._st
+            bwd(st["enc_out"], st["enc_leaf"])                  # embeddings, feature Linears, Encoder LayerNorms
+            self._st = None
+
+        segs = [(top, (sl[N - 1][0], total))]
+        segs += [(layer(k), sl[k]) for k in range(N - 2, -1, -1)]
+        segs.append((enc, (0, sl[0][0])))                         # glue parameters + the Encoder LayerNorm bank
+        return segs
+
+    def _run_segmented(self, runners):
+        works = []
+        for run, (lo, hi) in runners:
+            run()
+            works.append(self.grad_sync.reduce_range(lo, hi))
+        self.grad_sync.wait(works)
+
     def _capture(self):
         m = self.model
         m.prepare()
@@ -56,6 +116,26 @@ class TrainStep:
                 self._fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.overlap:
+            segs = self._segments()
+            with torch.cuda.stream(side):
+                for fn, _ in segs:                      # warm-up of the segmented schedule (no exchange: gradients are discarded)
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._g_seg, pool = [], None
+            for fn, rng in segs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    fn()
+                pool = g.pool()
+                self._g_seg.append((g.replay, rng))
+            self._loss = self._loss_t
+            self._g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_opt, pool=pool):
+                self._optim()
+            self._g_fb = self._g_seg[0]
+            return
         self._g_fb = torch.cuda.CUDAGraph()
         if self.grad_sync is None:
             with torch.cuda.graph(self._g_fb):
@@ -72,13 +152,21 @@ class TrainStep:
     def __call__(self) -> torch.Tensor:
         """Runs one step; returns the (device) loss tensor of data_utils.py:156 without synchronising."""
         if not self.use_graph:
-            loss = self._fwd_bwd()
-            if self.grad_sync is not None:
-                self.grad_sync()
+            if self.overlap:
+                self._run_segmented(self._segments())
+                loss = self._loss_t
+            else:
+                loss = self._fwd_bwd()
+                if self.grad_sync is not None:
+                    self.grad_sync()
             self._optim()
             return loss
         if self._g_fb is None:
             self._capture()
+        if self.overlap:
+            self._run_segmented(self._g_seg)
+            self._g_opt.replay()
+            return self._loss
         self._g_fb.replay()
         if self.grad_sync is not None:
             self.grad_sync()

@@ -25,7 +25,7 @@ def _flat_grads(params):
     return torch.cat([p.grad.reshape(-1) for p in params])
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
@@ -53,18 +53,24 @@ def _worker(rank, world, port, out_dir):
     out, ae_out = model.forward(b)
     loss = model.loss(b, out, ae_out, norm=norms[0], ae_norm=norms[1])
     loss.backward()
-    sync()
+    if mode == "buckets":
+        sync()                                         # whole buffer, after backward
+    else:                                              # the overlapped schedule's calls: asynchronous slices, one wait
+        n = flat.numel()
+        cuts = [0, n // 5, n // 2, n]
+        sync.wait([sync.reduce_range(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])][::-1] + [sync.reduce_range(7, 7)])
     torch.save({"flat": flat.clone(), "norms": norms}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gradients_equal_single_rank_on_concatenated_batch(tmp_path):
+@pytest.mark.parametrize("mode", ["buckets", "ranges"])
+def test_two_rank_gradients_equal_single_rank_on_concatenated_batch(tmp_path, mode):
     sys.path.insert(0, ROOT)
     from oracle import fixtures as fx
     port = _free_port()
-    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True, start_method="spawn")
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0["flat"], r1["flat"])                       # replicas hold identical reduced gradients
