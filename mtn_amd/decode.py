@@ -1,0 +1,191 @@
+"""Decode path (BASELINE configs[4]): greedy / beam search over the MTN decoder for ONE dialogue, as generate.py drives it
+through data_utils.py:159-242, on the HIP kernels.
+
+What the reference does per generated token (data_utils.py:200-205): for EVERY live hypothesis, one full ``model.decode`` of
+its prefix — which re-runs all N decoder layers *including the auto-encoder chains*, although those chains depend only on
+the dialogue (query/caption, video), never on the target prefix.  Here:
+
+* the encoder side and the N x F auto-encoder chains run ONCE per dialogue (``DecoderLayer.forward_ae_chains``);
+* all live hypotheses are decoded together, as the batch dimension of one target-stream pass
+  (``DecoderLayer.forward_target``: 4 text attentions + F attend-to-auto-encoder + FFN per layer);
+* the pass has a FIXED shape — (width, max_len) tokens under the causal mask, log-probabilities read at position l — so the
+  whole pass is ONE hipGraph replayed per token (≈170 launches of a few µs: launch-latency-bound; a K/V cache would not
+  shorten it at the reference's max_len = 20, it would only shrink kernels that are already at the latency floor);
+* hypothesis bookkeeping stays on the host exactly as in the reference (same candidate order, same tie behaviour).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .data_utils import subsequent_mask
+
+
+class DecodeSession:
+    """Everything about one dialogue that does not depend on the target prefix, plus the replayable target-stream pass.
+    A session is reusable for further dialogues of the same shapes (``load``): buffers and the captured graph persist."""
+
+    def __init__(self, model, batch, max_len: int, width: int, pad: int = 1, use_graph: bool = True):
+        self.model, self.width, self.max_len, self.pad = model, width, max_len, pad
+        self.use_graph = use_graph and batch.query.is_cuda
+        dev = batch.query.device
+        self.q = self.cp = self.hs = self.aes = self.masks = None
+        self.tokens = torch.full((width, max_len), pad, dtype=torch.long, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.long, device=dev)
+        self.trg_mask = subsequent_mask(max_len, device=dev)       # (1, L, L): data_utils.py:204 uses the causal mask only
+        ops.prepare_masks(self.trg_mask)
+        self.logp = None
+        self._graph = None
+        self.load(batch)
+
+    @staticmethod
+    def signature(model, batch, max_len, width):
+        return (id(model), model._flat.data_ptr() if model._flat is not None else 0, model.compute_dtype, width, max_len, tuple(batch.query.shape), tuple(batch.his.shape),
+                tuple(batch.cap.shape), tuple(tuple(f.shape) for f in batch.fts), str(batch.query.device))
+
+    def load(self, batch):
+        """Encoder side + the N x F auto-encoder chains of a new dialogue (target-independent: once per dialogue)."""
+        if batch.query.size(0) != 1:
+            raise ValueError("decode works on one dialogue at a time (data_utils.py:188: batch of one)")
+        model, width, b = self.model, self.width, batch
+        model.eval()
+        model.prepare()
+        lp = model.compute_dtype
+        with torch.no_grad():
+            q, v, cp, hs, ae = model.encode(b.query, b.query_mask, b.his, b.his_mask, b.cap, b.cap_mask, b.fts, b.fts_mask)
+            ops.prepare_masks(b.his_mask, b.cap_mask, b.query_mask, b.fts_mask)
+            aes_per_layer = []
+            for layer in model.decoder.layers:
+                ae = layer.forward_ae_chains(cp, b.cap_mask, q, b.query_mask, v, b.fts_mask, ae, model.auto_encoder_ft)
+                aes_per_layer.append(ae)
+
+            def widen(t, into=None):                           # (1, m, d) -> (width, m, d), with its compute-dtype copy
+                if into is None:
+                    into = torch.empty(width, t.size(1), t.size(2), device=t.device, dtype=t.dtype)
+                    into._mtn_lp = torch.empty_like(into, dtype=lp) if lp != torch.float32 else into
+                into.copy_(t.expand(width, -1, -1))
+                if into._mtn_lp is not into:
+                    into._mtn_lp.copy_(into)
+                return into
+
+            first = self.q is None
+            self.q, self.cp, self.hs = widen(q, self.q), widen(cp, self.cp), widen(hs, self.hs)
+            self.aes = [[widen(a, None if first else self.aes[k][i]) for i, a in enumerate(aes)] for k, aes in enumerate(aes_per_layer)]
+            new_masks = (b.cap_mask, b.his_mask, b.query_mask)
+            if first:
+                self.masks = tuple(mk.clone() for mk in new_masks)
+                ops.prepare_masks(*self.masks)
+            else:
+                for mine, mk in zip(self.masks, new_masks):    # the captured pass reads the uint8 images
+                    mine.copy_(mk)
+                    mine._mtn_u8.copy_(mk)
+
+    def _pass(self):
+        m = self.model
+        cap_mask, his_mask, q_mask = self.masks
+        x = m.embed_target(self.tokens)
+        for k, layer in enumerate(m.decoder.layers):
+            x = layer.forward_target(x, self.cp, cap_mask, self.hs, his_mask, self.q, q_mask, self.trg_mask, self.aes[k],
+                                     m.auto_encoder_ft)
+        x = m.decoder.norm(x)
+        last = x.index_select(1, self.pos).squeeze(1)               # (width, d): the position being extended
+        self.logp = m.generator(last).float()                       # (width, V) log-probabilities (mtn.py:68-69)
+
+    def step(self, prefixes: Sequence[Sequence[int]]) -> torch.Tensor:
+        """Log-probabilities (n, V) of the next token after each prefix (all prefixes have the same length)."""
+        n, l = len(prefixes), len(prefixes[0])
+        if n > self.width or l > self.max_len:
+            raise ValueError("more hypotheses / longer prefix than the session was built for")
+        host = torch.full((self.width, self.max_len), self.pad, dtype=torch.long)
+        host[:n, :l] = torch.tensor(prefixes, dtype=torch.long)
+        self.tokens.copy_(host, non_blocking=False)
+        self.pos.fill_(l - 1)
+        with torch.no_grad():
+            if not self.use_graph:
+                self._pass()
+            else:
+                if self._graph is None:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        self._pass()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._pass()
+                self._graph.replay()
+        return self.logp[:n]
+
+
+_SESSIONS: dict = {}
+
+
+def _session(model, batch, max_len, width, pad, use_graph) -> DecodeSession:
+    """Sessions are kept per (model, shapes): a dialogue with the shapes of an earlier one reuses its buffers and graph.
+    The cache is dropped when the model's weights change (prepare() version) or it grows past a few shapes."""
+    key = DecodeSession.signature(model, batch, max_len, width) + (bool(use_graph),)
+    model.prepare()
+    ver = getattr(model, "_flat_version", None)
+    hit = _SESSIONS.get(key)
+    if hit is not None and hit[1] == ver and hit[0].model is model:
+        hit[0].load(batch)
+        return hit[0]
+    if len(_SESSIONS) >= 8:
+        _SESSIONS.clear()
+    sess = DecodeSession(model, batch, max_len, width, pad=pad, use_graph=use_graph)
+    _SESSIONS[key] = (sess, ver)
+    return sess
+
+
+def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam=5, penalty=1.0,
+                       nbest=5, min_len=1, use_graph=True):
+    """data_utils.py:188-242, same arguments and return value: (n-best list of (token list, score) sorted by score,
+    best score).  A hypothesis ending with <eos> at length k scores logp + penalty * k; <unk> and <eos> never extend
+    a hypothesis; candidates are visited in descending log-probability exactly as the reference does (data_utils.py:219)."""
+    import numpy as np
+    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph)
+    hyps = [([], 0.0, [start_symbol])]
+    best, done = None, []
+    for l in range(max_len):
+        logp = sess.step([h[2] for h in hyps]).double().cpu().numpy()
+        new, argmin = [], 0
+        for (out, lp, st), row in zip(hyps, logp):
+            lp_vec = (row + lp).astype("float32")
+            if l >= min_len:
+                s = float(lp_vec[end_symbol]) + penalty * (len(out) + 1)
+                done.append((out, s))
+                if best is None or best < s:
+                    best = s
+            for o in np.argsort(lp_vec)[::-1]:
+                o = int(o)
+                if o == unk_symbol or o == end_symbol:
+                    continue
+                s = float(lp_vec[o])
+                if len(new) == beam:
+                    if new[argmin][1] < s:
+                        new[argmin] = (out + [o], s, st + [o])
+                        argmin = min(range(len(new)), key=lambda i: new[i][1])
+                    else:
+                        break
+                else:
+                    new.append((out + [o], s, st + [o]))
+                    if len(new) == beam:
+                        argmin = min(range(len(new)), key=lambda i: new[i][1])
+        hyps = new
+    if done:
+        return sorted(done, key=lambda h: -h[1])[:nbest], best
+    return [([], 0)], None
+
+
+def greedy_decode(model, batch, max_len, start_symbol, pad_symbol=1, use_graph=True):
+    """data_utils.py:159-186 (the reference's own greedy_decode cannot run: it calls decode() with the wrong arity, SURVEY
+    §8c) — pinned to: argmax of the generator's log-probabilities at every step, (1, max_len) tokens incl. <sos>."""
+    sess = _session(model, batch, max_len, 1, pad_symbol, use_graph)
+    ys = [start_symbol]
+    for _ in range(max_len - 1):
+        nxt = int(sess.step([ys]).argmax(dim=-1)[0])
+        ys.append(nxt)
+    return torch.tensor([ys], dtype=batch.query.dtype, device=batch.query.device)

@@ -208,10 +208,25 @@ class DecoderLayer(nn.Module):
         self.auto_encoder_feed_forward = auto_encoder_feed_forward
         self.sublayer = nn.ModuleList([SublayerConnection(size, dropout) for _ in range(5 + 4 * len(auto_encoder_vid_attn))])
 
-    def _forward_lockstep(self, x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask,
-                          ae_fts, ae_features):
-        """Same arithmetic as forward(), scheduled as lockstep groups: the first three text attentions of x run in the same
-        launches as the three sublayers of each auto-encoder chain (they do not depend on each other, mtn.py:183-213)."""
+    @staticmethod
+    def _run_group(items):
+        """items: [(sublayer_connection, module, mem, mask, input)] that do not depend on each other -> their outputs,
+        computed by one lockstep group (ops.SublayerGroupFn: shared launches)."""
+        members, tensors = [], []
+        for sc, mod, mem, mask, inp in items:
+            members.append(sc.member(mod, mem, mask))
+            tensors += [inp, mem if isinstance(mod, MultiHeadedAttention) else None]
+        # attention members first, then FFN members (the C side takes two arrays)
+        order = sorted(range(len(members)), key=lambda k: members[k].kind != "mha")
+        outs = ops.SublayerGroupFn.apply([members[k] for k in order], *[t for k in order for t in tensors[2 * k:2 * k + 2]])
+        res = [None] * len(members)
+        for pos, k in enumerate(order):
+            res[k] = outs[pos]
+        return res
+
+    def _plan(self, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask, ae_features):
+        """Sublayer schedule of mtn.py:183-213: (the four text attentions of x, per-modality auto-encoder chains, the
+        auto-encoder seed when the caller passes none, the auto-encoder mask)."""
         sl = self.sublayer
         if ae_features in ("caption", "summary"):
             text = [(sl[0], self.self_attn, None, tgt_mask), (sl[1], self.his_attn, his_memory, his_mask),
@@ -223,27 +238,23 @@ class DecoderLayer(nn.Module):
             seed_ae, ae_mask = q_memory, q_mask
         else:
             raise ValueError("auto_encoder_ft must be 'query', 'caption' or 'summary' (reference: mtn.py:187-202)")
+        nF = len(vid_fts)
+        chains = [[(sl[4 + 4 * i], self.auto_encoder_self_attn[i], None, ae_mask),
+                   (sl[5 + 4 * i], self.auto_encoder_vid_attn[i], vid_fts[i], vid_mask[i]),
+                   (sl[6 + 4 * i], self.auto_encoder_feed_forward[i], None, None)] for i in range(nF)]
+        return text, chains, seed_ae, ae_mask
+
+    def _forward_lockstep(self, x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask,
+                          ae_fts, ae_features):
+        """Same arithmetic as forward(), scheduled as lockstep groups: the first three text attentions of x run in the same
+        launches as the three sublayers of each auto-encoder chain (they do not depend on each other, mtn.py:183-213)."""
+        sl, run = self.sublayer, self._run_group
+        text, chains, seed_ae, ae_mask = self._plan(cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask,
+                                                    vid_fts, vid_mask, ae_features)
         if ae_fts is None:
             ae_fts = seed_ae
         nF = len(vid_fts)
         aes = [ae_fts[i] if isinstance(ae_fts, (list, tuple)) else ae_fts for i in range(nF)]
-        chains = [[(sl[4 + 4 * i], self.auto_encoder_self_attn[i], None, ae_mask),
-                   (sl[5 + 4 * i], self.auto_encoder_vid_attn[i], vid_fts[i], vid_mask[i]),
-                   (sl[6 + 4 * i], self.auto_encoder_feed_forward[i], None, None)] for i in range(nF)]
-
-        def run(items):                      # items: [(sublayer_connection, module, mem, mask, input)]
-            members, tensors = [], []
-            for sc, mod, mem, mask, inp in items:
-                members.append(sc.member(mod, mem, mask))
-                tensors += [inp, mem if isinstance(mod, MultiHeadedAttention) else None]
-            # attention members first, then FFN members (the C side takes two arrays)
-            order = sorted(range(len(members)), key=lambda k: members[k].kind != "mha")
-            outs = ops.SublayerGroupFn.apply([members[k] for k in order], *[t for k in order for t in tensors[2 * k:2 * k + 2]])
-            res = [None] * len(members)
-            for pos, k in enumerate(order):
-                res[k] = outs[pos]
-            return res
-
         for j in range(3):
             items = [text[j] + (x,)] + [chains[i][j] + (aes[i],) for i in range(nF)]
             outs = run(items)
@@ -253,6 +264,30 @@ class DecoderLayer(nn.Module):
             x = run([(sl[7 + 4 * i], self.auto_encoder_attn[i], aes[i], ae_mask, x)])[0]
         x = run([(sl[4 + 4 * nF], self.feed_forward, None, None, x)])[0]
         return x, aes
+
+    def forward_ae_chains(self, cap_memory, cap_mask, q_memory, q_mask, vid_fts, vid_mask, ae_fts, ae_features):
+        """Only the query-aware auto-encoder chains of this layer (self-attn -> attend-to-video -> FFN per modality,
+        mtn.py:204-209).  They do not depend on the target stream, so the decode path runs them once per dialogue."""
+        _, chains, seed_ae, _ = self._plan(cap_memory, cap_mask, None, None, q_memory, q_mask, None, vid_fts, vid_mask, ae_features)
+        if ae_fts is None:
+            ae_fts = seed_ae
+        nF = len(vid_fts)
+        aes = [ae_fts[i] if isinstance(ae_fts, (list, tuple)) else ae_fts for i in range(nF)]
+        for j in range(3):
+            aes = self._run_group([chains[i][j] + (aes[i],) for i in range(nF)])
+        return aes
+
+    def forward_target(self, x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, aes, ae_features):
+        """Only the target stream of this layer, given the layer's auto-encoder outputs ``aes`` (forward_ae_chains)."""
+        sl = self.sublayer
+        nF = len(aes)
+        text, _, _, ae_mask = self._plan(cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, [None] * nF,
+                                         [None] * nF, ae_features)
+        for j in range(4):
+            x = self._run_group([text[j] + (x,)])[0]
+        for i in range(nF):
+            x = self._run_group([(sl[7 + 4 * i], self.auto_encoder_attn[i], aes[i], ae_mask, x)])[0]
+        return self._run_group([(sl[4 + 4 * nF], self.feed_forward, None, None, x)])[0]
 
     def forward(self, x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask,
                 ae_fts, ae_features):

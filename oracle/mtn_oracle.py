@@ -378,3 +378,15 @@ def beam_search(model: OracleMTN, b, max_len: int, sos: int, unk: int, eos: int,
     if done:
         return sorted(done, key=lambda h: -h[1])[:nbest], best
     return [([], 0)], None
+
+
+def greedy_search(model: OracleMTN, b, max_len: int, sos: int) -> List[int]:
+    """data_utils.py:163-186 with decode() called at its real arity (the reference's own call has one argument too many and
+    cannot run): argmax of generator(decode(prefix)[:, -1]) per step; returns the token list incl. <sos>."""
+    q, v, cp, hs, ae = model.encode(b.query, b.query_mask, b.his, b.his_mask, b.cap, b.cap_mask, b.fts, b.fts_mask)
+    ys = [sos]
+    for _ in range(max_len - 1):
+        st = torch.tensor([ys], dtype=b.query.dtype)
+        x, _ = model.decode(v, hs, cp, q, b.fts_mask, b.his_mask, b.cap_mask, b.query_mask, st, subsequent_mask(st.size(1)), ae)
+        ys.append(int(model.generator(x[:, -1]).argmax(dim=-1)[0]))
+    return ys

@@ -1,0 +1,97 @@
+"""Decode path (BASELINE configs[4]) on the GPU: beam search against the n-best lists the REFERENCE produced
+(tests/golden/*.npz, beam.* keys, made by oracle/make_golden.py) and against the CPU oracle; greedy against the oracle.
+fp32 mode must reproduce the reference's token sequences exactly and its scores to 1e-3; bf16 mode is held to the scores
+(1e-2 relative on the best hypothesis) — near-ties between candidates may legitimately reorder under bf16 rounding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import mtn_oracle as orc
+from tests.test_model_gpu import build_model, dev_batch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def one_dialogue(c, seed=2):
+    return fx.det_batch(c["vocab"], 1, c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=seed, ragged=False)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+@pytest.mark.parametrize("name", list(fx.GOLDEN_CONFIGS))
+def test_beam_search_matches_reference_nbest(dev, name, use_graph):
+    from mtn_amd.decode import beam_search_decode
+    c = fx.GOLDEN_CONFIGS[name]
+    g = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    model = build_model(c, torch.float32, dev).eval()
+    b = dev_batch(one_dialogue(c), dev)
+    nbest, best = beam_search_decode(model, b, 8, fx.SOS, fx.UNK, fx.EOS, fx.PAD, use_graph=use_graph)
+    assert len(nbest) == int(g["beam.n"])
+    for i, (toks, score) in enumerate(nbest):
+        assert list(toks) == list(g[f"beam.tokens.{i}"]), i
+        assert abs(score - float(g[f"beam.score.{i}"])) < 1e-3
+    assert abs(best - float(g["beam.best"])) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["cfg1_query", "small_diffall"])
+def test_beam_search_bf16_scores_and_other_widths(dev, name):
+    """bf16 compute: best score within 1e-2 of the oracle's; beam 4 / nbest 3 / min_len 2 / penalty 0.5 against the oracle."""
+    from mtn_amd.decode import beam_search_decode
+    c = fx.GOLDEN_CONFIGS[name]
+    raw = one_dialogue(c, seed=7)
+    m_or, _ = fx.oracle_from_config(c)
+    with torch.no_grad():
+        ref_n, ref_best = orc.beam_search(m_or, fx.oracle_batch(raw), 10, fx.SOS, fx.UNK, fx.EOS, beam=4, penalty=0.5, nbest=3, min_len=2)
+    b = dev_batch(raw, dev)
+    model = build_model(c, torch.float32, dev).eval()
+    got_n, got_best = beam_search_decode(model, b, 10, fx.SOS, fx.UNK, fx.EOS, fx.PAD, beam=4, penalty=0.5, nbest=3, min_len=2)
+    assert [list(t) for t, _ in got_n] == [list(t) for t, _ in ref_n]
+    assert max(abs(a[1] - r[1]) for a, r in zip(got_n, ref_n)) < 1e-3 and abs(got_best - ref_best) < 1e-3
+    model16 = build_model(c, torch.bfloat16, dev).eval()
+    n16, best16 = beam_search_decode(model16, b, 10, fx.SOS, fx.UNK, fx.EOS, fx.PAD, beam=4, penalty=0.5, nbest=3, min_len=2)
+    assert len(n16) == len(ref_n)
+    assert abs(best16 - ref_best) < 1e-2 * max(1.0, abs(ref_best))
+
+
+@pytest.mark.parametrize("name", ["cfg1_caption", "small_shared"])
+def test_greedy_decode_matches_oracle(dev, name):
+    from mtn_amd.decode import greedy_decode
+    c = fx.GOLDEN_CONFIGS[name]
+    raw = one_dialogue(c, seed=3)
+    m_or, _ = fx.oracle_from_config(c)
+    with torch.no_grad():
+        want = orc.greedy_search(m_or, fx.oracle_batch(raw), 12, fx.SOS)
+    model = build_model(c, torch.float32, dev).eval()
+    ys = greedy_decode(model, dev_batch(raw, dev), 12, fx.SOS, fx.PAD)
+    assert ys.shape == (1, 12) and ys[0].tolist() == want
+
+
+def test_decode_session_logprobs_match_full_decode(dev):
+    """The fixed-shape, auto-encoder-cached target pass gives the log-probabilities of model.decode + generator on the
+    same prefixes (several hypotheses at once, prefix shorter than the session's max_len)."""
+    from mtn_amd.decode import DecodeSession
+    from mtn_amd import subsequent_mask
+    c = fx.GOLDEN_CONFIGS["cfg1_query"]
+    model = build_model(c, torch.bfloat16, dev).eval()
+    b = dev_batch(one_dialogue(c, seed=9), dev)
+    sess = DecodeSession(model, b, max_len=9, width=3, pad=fx.PAD)
+    prefixes = [[fx.SOS, 5, 9, 11], [fx.SOS, 7, 7, 30], [fx.SOS, 40, 2, 6]]
+    got = sess.step(prefixes).clone()
+    got2 = sess.step(prefixes).clone()            # graph replay
+    assert torch.equal(got, got2)
+    with torch.no_grad():
+        q, v, cp, hs, ae = model.encode(b.query, b.query_mask, b.his, b.his_mask, b.cap, b.cap_mask, b.fts, b.fts_mask)
+        for i, p in enumerate(prefixes):
+            st = torch.tensor([p], device=dev)
+            x, _ = model.decode(v, hs, cp, q, b.fts_mask, b.his_mask, b.cap_mask, b.query_mask, st, subsequent_mask(len(p), device=dev), ae)
+            want = model.generator(x[:, -1]).float()[0]
+            assert (got[i] - want).abs().max() < 2e-2 * want.abs().max()
