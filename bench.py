@@ -75,30 +75,66 @@ def cpu_baseline(model, cfg, B, steps):
             "sample": f"{steps} train steps (after 1 warm-up) of the same workload, batch {B}, fp32, dropout off; median step {med:.3f} s; nproc={os.cpu_count()}"}
 
 
-def gemm_kernel_roofline(dev, dtype_code, lp_dtype):
-    """Live HIP-event timing of the dominant kernel (grouped MFMA GEMM, forward layout) at the largest shape of the
-    step: the history K/V projection [B*H=4096, 2d=1024] x K=512.  Algorithmic FLOPs = 2*M*N*K per launch."""
-    from mtn_amd import lib as L, ops
-    M, N, K = 4096, 1024, 512
-    A = torch.randn(M, K, device=dev).to(lp_dtype)
-    W = torch.randn(N, K, device=dev).to(lp_dtype)
-    bias = torch.zeros(N, device=dev)
-    out = torch.empty(M, N, device=dev, dtype=lp_dtype)
-    p = L.GemmProblem()
-    p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K, p.gate_scale = A.data_ptr(), W.data_ptr(), K, K, M, N, K, 1.0
-    p.bias, p.out_lp, p.ldc = bias.data_ptr(), out.data_ptr(), N
-    for _ in range(5):
-        ops.gemm(dtype_code, [p])
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 50
-    e0.record()
-    for _ in range(n):
-        ops.gemm(dtype_code, [p])
-    e1.record()
+def gemm_census_roofline(step, peak_tflops):
+    """Live roofline of the step's dominant kernel family, the grouped MFMA GEMMs.  One eager pass of the step's
+    forward+backward is recorded by the library's launch census (include/mtn_hip.h: mtn_census_*), then EVERY recorded GEMM
+    launch is re-issued 10x back-to-back between two HIP events on the launch stream: duration per launch, algorithmic
+    FLOPs (2*M*N*K) and algorithmic bytes (operands once + outputs once) per launch, aggregated per kernel.  The dominant
+    kernel is the one with the largest summed duration; its average duration is what rocprofv3 --stats reports for the
+    same kernel name (profiles/)."""
+    import ctypes as C
+    from mtn_amd import lib as L
+    lib = L.load()
+    lib.mtn_census_begin()
+    step._fwd_bwd()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / n
-    tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
-    return {"kernel": "gemm_kernel<bf16,N,N> 64x64 tile", "shape": [M, N, K], "us_per_launch": round(us, 2), "achieved": round(tf, 1)}
+    n = lib.mtn_census_end()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    per = {}
+    for i in range(n):
+        info = L.CensusLaunch()
+        L.check(lib.mtn_census_info(i, C.byref(info)))
+        L.check(lib.mtn_census_replay(i, 2, st.cuda_stream))
+        e0.record(st)
+        L.check(lib.mtn_census_replay(i, reps, st.cuda_stream))
+        e1.record(st)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        k = per.setdefault(info.variant, {"launches": 0, "flops": 0.0, "bytes": 0.0, "us": 0.0, "workgroups": 0})
+        k["launches"] += 1; k["flops"] += info.flops; k["bytes"] += info.bytes; k["us"] += us; k["workgroups"] += info.workgroups
+    table = {}
+    for v, k in per.items():
+        name = lib.mtn_census_variant_name(v).decode()
+        table[name] = {"launches_per_step": k["launches"], "avg_us": round(k["us"] / k["launches"], 2),
+                       "total_us_per_step": round(k["us"], 1), "avg_workgroups": round(k["workgroups"] / k["launches"]),
+                       "gflop_per_launch": round(k["flops"] / k["launches"] / 1e9, 3),
+                       "algorithmic_MB_per_launch": round(k["bytes"] / k["launches"] / 1e6, 3),
+                       "achieved_TFLOPs": round(k["flops"] / k["us"] / 1e6, 1),
+                       "achieved_GBps_algorithmic": round(k["bytes"] / k["us"] / 1e3, 1)}
+    dom = max(table, key=lambda nm: table[nm]["total_us_per_step"])
+    tot_us = sum(k["us"] for k in per.values())
+    tot_fl = sum(k["flops"] for k in per.values())
+    return dom, table, {"launches_per_step": n, "total_us_per_step": round(tot_us, 1), "gflop_per_step": round(tot_fl / 1e9, 1),
+                        "achieved_TFLOPs": round(tot_fl / tot_us / 1e6, 1), "frac": round(tot_fl / tot_us / 1e6 / peak_tflops, 4)}
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json, written by
+    tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs with the gfx950 corrections of MI355X_MICROARCH.md)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))
+        for k, v in data.get("kernels", {}).items():
+            if kernel_name.split("<")[0] in k and kernel_name.split("<")[-1].split(">")[0].replace(" ", "") in k.replace(" ", ""):
+                return v.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+    return None
 
 
 def main():
@@ -165,20 +201,29 @@ def main():
         step_tf = value * gflop / 1e3                                 # whole job
         peak = (PEAK_BF16_TFLOPS if lp == torch.bfloat16 else PEAK_FP32_TFLOPS) * world
         ev_ms = e0.elapsed_time(e1) / args.steps
-        roof = {"bound": "mfma", "achieved": round(step_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(step_tf / peak, 5),
-                "traffic": None,
-                "what": "whole captured train step (one hipGraph launch = one step): algorithmic GFLOP/sample x samples per "
-                        "launch / HIP-event time per launch on the launch stream",
-                "gflop_per_sample": gflop, "gflop_per_sample_closed_form": round(gflop_formula, 3),
-                "hip_event_ms_per_step": round(ev_ms, 4),
-                "hbm_floor": {"bytes_per_step": 38 * sum(p.numel() for p in model.parameters()),
-                              "achieved_GBps": round(38 * sum(p.numel() for p in model.parameters()) / (ms * 1e-3) / 1e9, 1),
-                              "peak_GBps": PEAK_HBM_GBS}}
+        step_info = {"what": "whole captured train step (one hipGraph launch = one step): algorithmic GFLOP/sample x samples "
+                             "per launch / HIP-event time per launch on the launch stream",
+                     "achieved_TFLOPs": round(step_tf, 2), "frac": round(step_tf / peak, 5),
+                     "gflop_per_sample": gflop, "gflop_per_sample_closed_form": round(gflop_formula, 3),
+                     "hip_event_ms_per_step": round(ev_ms, 4),
+                     "hbm_floor": {"bytes_per_step": 38 * sum(p.numel() for p in model.parameters()),
+                                   "achieved_GBps": round(38 * sum(p.numel() for p in model.parameters()) / (ms * 1e-3) / 1e9, 1),
+                                   "peak_GBps": PEAK_HBM_GBS}}
         try:
-            roof["dominant_kernel"] = gemm_kernel_roofline(dev, lib.dtype_code(lp), lp)
-            roof["dominant_kernel"]["frac"] = round(roof["dominant_kernel"]["achieved"] / (peak / world), 4)
+            dom, table, allg = gemm_census_roofline(step, peak / world)
+            d = table[dom]
+            roof = {"bound": "mfma", "kernel": dom, "achieved": d["achieved_TFLOPs"], "peak": peak / world, "unit": "TFLOP/s",
+                    "frac": round(d["achieved_TFLOPs"] / (peak / world), 4), "traffic": pmc_traffic(dom),
+                    "what": "dominant kernel of the step (largest summed duration): algorithmic FLOPs per launch / HIP-event "
+                            "duration per launch, averaged over all of its launches in one step (library launch census, each "
+                            "launch replayed 10x back-to-back on the launch stream); traffic = HBM bytes per launch from the "
+                            "committed rocprofv3 PMC passes",
+                    "launches_per_step": d["launches_per_step"], "avg_us_per_launch": d["avg_us"],
+                    "gflop_per_launch": d["gflop_per_launch"], "algorithmic_bytes_per_launch": int(d["algorithmic_MB_per_launch"] * 1e6),
+                    "all_gemm_kernels": allg, "kernels": table, "step": step_info}
         except Exception as e:  # pragma: no cover
-            roof["dominant_kernel"] = {"error": str(e)}
+            roof = {"bound": "mfma", "achieved": round(step_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(step_tf / peak, 5),
+                    "traffic": None, "error": str(e), "step": step_info}
         line = {"metric": "train-step samples/sec (d_model=512, 6L MTN)", "value": round(value, 2), "unit": "samples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -197,6 +242,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

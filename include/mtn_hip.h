@@ -347,6 +347,25 @@ int mtn_noam_tick(float* state, float factor, int model_size, int warmup, float 
 int mtn_adam_step(int dtype, long n, float* p, const float* g, float* m, float* v, void* p_lp, const float* state,
                   const float* grad_scale, float beta1, float beta2, float eps, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement support (bench.py `roofline`): a census of the GEMM launches of one step.  Between mtn_census_begin() and
+ * mtn_census_end() (returns the number of launches) every mtn_gemm call is recorded on the host (no device work, no
+ * change to the launch); mtn_census_info() describes launch i — which kernel the dispatch picked, its workgroup count,
+ * algorithmic FLOPs (2·M·N·K summed over the group) and algorithmic bytes (operands read once + outputs written once) —
+ * and mtn_census_replay() re-issues it `reps` times on `stream` so the caller can bracket it with HIP events.  The replay
+ * reuses the recorded device pointers: call it only while the model's buffers are alive (outputs are overwritten).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int dtype, count, variant, workgroups;
+    double flops, bytes;
+    int M[4], N[4], K[4];               /* shapes of the first four problems of the group */
+} mtn_census_launch;
+int mtn_census_begin(void);
+int mtn_census_end(void);
+int mtn_census_info(int i, mtn_census_launch* out);
+int mtn_census_replay(int i, int reps, void* stream);
+const char* mtn_census_variant_name(int variant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -650,8 +650,23 @@ __global__ __launch_bounds__(256) void gemm_tt_dma_kernel(const GemmGroup grp) {
     }
 }
 
+// ---------------------------------------------------------------- launch census (measurement support, bench.py)
+// While recording, every mtn_gemm call keeps a copy of its problem list; mtn_census_replay re-issues a recorded launch so
+// that the caller can time each of the step's GEMM launches with HIP events on the launch stream.
+#include <vector>
+struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GEMM_MAX_GROUP]; };
+static std::vector<CensusEntry> g_census;
+static bool g_census_on = false;
+static int g_variant = 0, g_variant_tiles = 0;     // set by launch_gemm: which kernel the dispatch picked
+enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_COUNT };
+static const char* const g_variant_name[V_COUNT] = {
+    "gemm_kernel<N,N> 64x64 reg-staged", "gemm_kernel<N,T>", "gemm_kernel<T,N>", "gemm_kernel<T,T> 64x64 reg-staged",
+    "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel"};
+
 template <typename T, int BM, int BN>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
+    g_variant = (BM == 64) ? V_DMA64 : (BN == 64 ? V_DMA3264 : V_DMA32);
+    g_variant_tiles = tiles;
     constexpr int LDS = 2 * (BM + BN) * DMA_ROWB;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set && LDS > 64 * 1024) {
@@ -678,6 +693,8 @@ static int retile(GemmGroup& grp, int bm, int bn) {
 template <typename T>
 static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, bool dma_ok, hipStream_t s) {
     dim3 grid(total_tiles), block(256);
+    g_variant_tiles = total_tiles;
+    g_variant = at ? (bt ? V_REG_TT : V_REG_TN) : (bt ? V_REG_NT : V_REG_NN);
     if (!at && !bt && dma_ok) {
         // Tile choice by the bytes ONE CU has to pull (the bound of these launches, ~27 GB/s per CU): 64x64 tiles run one
         // workgroup per CU in ceil(tiles/256) rounds of (64+64)*K bytes; 32x32 tiles spread 4x the workgroups of half the
@@ -714,10 +731,12 @@ static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, 
             ttd = ttd && grp.p[i].M % 8 == 0 && grp.p[i].N % 8 == 0 && (long)grp.p[i].K * grp.p[i].lda * 2 < (1L << 31) &&
                   (long)grp.p[i].K * grp.p[i].ldb * 2 < (1L << 31);
         if (ttd) {
+            g_variant = V_TT_DMA;
             if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(gemm_tt_dma_kernel, grid, block, TTD_LDS, s, grp);
         } else if (big) {
             GemmGroup g2 = grp;
             const int tiles = retile(g2, 128, 128);
+            g_variant = V_TT128; g_variant_tiles = tiles;
             hipLaunchKernelGGL((gemm_tt128_kernel<T>), dim3(tiles), block, 0, s, g2);
         } else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, s, grp);
     }
@@ -760,6 +779,45 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
         const mtn_gemm_problem& p = problems[i];
         if (p.rowsum_out || (long)p.M * p.lda * esz >= (1L << 31) || (long)p.N * p.ldb * esz >= (1L << 31)) dma_ok = false;
     }
-    if (dtype == MTN_BF16) return launch_gemm<bf16_t>(grp, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s);
-    return launch_gemm<float>(grp, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s);
+    const int rc = (dtype == MTN_BF16) ? launch_gemm<bf16_t>(grp, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s)
+                                       : launch_gemm<float>(grp, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s);
+    if (g_census_on && rc == MTN_OK) {
+        CensusEntry e;
+        memset(&e, 0, sizeof(e));
+        e.dtype = dtype; e.count = count; e.variant = g_variant; e.tiles = g_variant_tiles;
+        for (int i = 0; i < count; ++i) e.p[i] = problems[i];
+        g_census.push_back(e);
+    }
+    return rc;
+}
+
+extern "C" int mtn_census_begin(void) { g_census.clear(); g_census_on = true; return MTN_OK; }
+extern "C" int mtn_census_end(void) { g_census_on = false; return (int)g_census.size(); }
+extern "C" const char* mtn_census_variant_name(int variant) { return (variant >= 0 && variant < V_COUNT) ? g_variant_name[variant] : "?"; }
+
+extern "C" int mtn_census_info(int i, mtn_census_launch* out) {
+    MTN_CHECK_ARG(i >= 0 && i < (int)g_census.size() && out, "bad census index");
+    const CensusEntry& e = g_census[i];
+    const double esz = (e.dtype == MTN_BF16) ? 2.0 : 4.0;
+    memset(out, 0, sizeof(*out));
+    out->dtype = e.dtype; out->count = e.count; out->variant = e.variant; out->workgroups = e.tiles;
+    for (int k = 0; k < e.count; ++k) {
+        const mtn_gemm_problem& p = e.p[k];
+        out->flops += 2.0 * p.M * p.N * p.K;
+        out->bytes += ((double)p.M + p.N) * p.K * esz + (double)p.M * p.N * ((p.out_f32 ? 4.0 : 0.0) + (p.out_lp ? esz : 0.0)) +
+                      (p.residual ? (double)p.M * p.N * 4.0 : 0.0);
+        if (k < 4) { out->M[k] = p.M; out->N[k] = p.N; out->K[k] = p.K; }
+    }
+    return MTN_OK;
+}
+
+extern "C" int mtn_census_replay(int i, int reps, void* stream) {
+    MTN_CHECK_ARG(i >= 0 && i < (int)g_census.size() && reps >= 1, "bad census index");
+    const bool was = g_census_on;
+    g_census_on = false;
+    const CensusEntry e = g_census[i];
+    int rc = MTN_OK;
+    for (int r = 0; r < reps && rc == MTN_OK; ++r) rc = mtn_gemm(e.dtype, e.count, e.p, stream);
+    g_census_on = was;
+    return rc;
 }

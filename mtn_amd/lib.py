@@ -105,7 +105,17 @@ GEMM_MAX_GROUP = 16
 
 # every symbol include/mtn_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+class CensusLaunch(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("count", C.c_int), ("variant", C.c_int), ("workgroups", C.c_int),
+                ("flops", C.c_double), ("bytes", C.c_double), ("M", C.c_int * 4), ("N", C.c_int * 4), ("K", C.c_int * 4)]
+
+
 SYMBOLS = {
+    "mtn_census_begin": (C.c_int, []),
+    "mtn_census_end": (C.c_int, []),
+    "mtn_census_info": (C.c_int, [C.c_int, C.POINTER(CensusLaunch)]),
+    "mtn_census_replay": (C.c_int, [C.c_int, C.c_int, _P]),
+    "mtn_census_variant_name": (C.c_char_p, [C.c_int]),
     "mtn_last_error": (C.c_char_p, []),
     "mtn_version": (C.c_int, []),
     "mtn_gemm": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),

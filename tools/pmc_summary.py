@@ -1,0 +1,69 @@
+"""Summarise two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs: the TCC block has 4 slots,
+FETCH_SIZE takes 3 and WRITE_SIZE 2) into profiles/<name>_pmc_traffic.json: HBM-side bytes per launch for every kernel of
+one train step, with the gfx950 corrections of MI355X_MICROARCH.md §HBM:
+  * counters are in KiB per dispatch (request counts x 64 B);
+  * FETCH_SIZE reports exactly half of a wide (16 B/lane) coalesced read on gfx950 -> doubled;
+  * WRITE_SIZE is uncalibrated -> calibrated here on adam_kernel, whose traffic is known exactly
+    (reads p,g,m,v = 16 B/param; writes p,m,v + bf16 copy = 14 B/param), and the same check is reported for FETCH_SIZE.
+usage: pmc_summary.py <fetch_dir> <write_dir> <out.json> <n_params_padded>"""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+
+def load(d, counter):
+    f = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True))[-1]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    return rows
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name).replace("void ", "").replace("unsigned short", "bf16")
+    return name[-70:]
+
+
+def one_step(rows):
+    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    return rows[adam[-2] + 1: adam[-1] + 1]
+
+
+def per_kernel(rows):
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        k = (short(r["Kernel_Name"]), int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"]) * 1024.0
+    return agg
+
+
+fetch_dir, write_dir, out, n_params = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
+F, W = per_kernel(one_step(load(fetch_dir, "FETCH_SIZE"))), per_kernel(one_step(load(write_dir, "WRITE_SIZE")))
+adam_f = next(v for k, v in F.items() if "adam_kernel" in k[0])
+adam_w = next(v for k, v in W.items() if "adam_kernel" in k[0])
+fetch_corr = 2.0                                                 # guide: wide coalesced reads are tallied at half
+write_cal = (14.0 * n_params) / (adam_w[1] / adam_w[0])           # known bytes / raw counter
+fetch_check = (16.0 * n_params) / (fetch_corr * adam_f[1] / adam_f[0])
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 2 --warmup 1",
+       "corrections": {"unit": "counter x 1024 B", "fetch_x": fetch_corr, "write_x_calibrated_on_adam_kernel": round(write_cal, 3),
+                       "fetch_known_over_corrected_on_adam_kernel": round(fetch_check, 3)},
+       "kernels": {}, "step": {}}
+tot_f = tot_w = 0.0
+for k in sorted(set(F) | set(W), key=lambda k: -(F.get(k, [0, 0])[1] + W.get(k, [0, 0])[1])):
+    nf, bf = F.get(k, [0, 0.0]); nw, bw = W.get(k, [0, 0.0])
+    n = max(nf, nw)
+    fb, wb = fetch_corr * bf, write_cal * bw
+    tot_f += fb; tot_w += wb
+    res["kernels"][f"{k[0]} wgs={k[1]}"] = {"launches_per_step": n, "fetch_bytes_per_launch": round(fb / max(1, nf)),
+                                            "write_bytes_per_launch": round(wb / max(1, nw)),
+                                            "hbm_bytes_per_launch": round(fb / max(1, nf) + wb / max(1, nw))}
+res["step"] = {"fetch_GB": round(tot_f / 1e9, 3), "write_GB": round(tot_w / 1e9, 3), "total_GB": round((tot_f + tot_w) / 1e9, 3)}
+# per kernel family (all grid sizes): what bench.py's roofline.traffic reads
+fam = defaultdict(lambda: [0, 0.0])
+for name, v in res["kernels"].items():
+    f = name.split(" wgs=")[0]
+    fam[f][0] += v["launches_per_step"]; fam[f][1] += v["hbm_bytes_per_launch"] * v["launches_per_step"]
+res["families"] = {f: {"launches_per_step": n, "hbm_bytes_per_launch": round(b / n)} for f, (n, b) in sorted(fam.items(), key=lambda kv: -kv[1][1])}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res["corrections"]), json.dumps(res["step"]))
+for f, v in list(res["families"].items())[:16]:
+    print(f"{f:72s} n={v['launches_per_step']:4d} {v['hbm_bytes_per_launch']/1e6:9.3f} MB/launch")
