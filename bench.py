@@ -41,14 +41,14 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--bf16-grad-allreduce", action="store_true")
     return ap.parse_args()
 
 
 def cpu_baseline(model, cfg, B, steps):
     """The CPU oracle (PyTorch-CPU fp32 restatement of the reference, oracle/mtn_oracle.py) running the same step on
-    the host cores of this box: forward -> loss -> backward -> Adam/Noam.  Bounded sample: 1 warm-up + `steps` steps."""
+    the host cores of this box: forward -> loss -> backward -> Adam/Noam.  Bounded sample: 2 warm-ups + `steps` steps (median)."""
     from oracle import fixtures as fx
     from oracle.mtn_oracle import OracleConfig, OracleMTN, noam_rate
     ocfg = OracleConfig(vocab=cfg["vocab"], n_layers=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], heads=cfg["h"],
@@ -59,7 +59,7 @@ def cpu_baseline(model, cfg, B, steps):
     ob = fx.oracle_batch(raw)
     opt = torch.optim.Adam(list(sd.values()), lr=0.0, betas=(0.9, 0.98), eps=1e-9)
     times = []
-    for s in range(steps + 1):
+    for s in range(steps + 2):
         t0 = time.perf_counter()
         out, ae = om.forward(ob)
         loss = om.loss(ob, out, ae)
@@ -69,10 +69,10 @@ def cpu_baseline(model, cfg, B, steps):
             gparam["lr"] = noam_rate(s + 1, cfg["d_model"], 4000)
         opt.step()
         times.append(time.perf_counter() - t0)
-    times = sorted(times[1:])
+    times = sorted(times[2:])
     med = times[len(times) // 2]
     return {"value": B / med, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train steps (after 1 warm-up) of the same workload, batch {B}, fp32, dropout off; median step {med:.3f} s; nproc={os.cpu_count()}"}
+            "sample": f"{steps} train steps (after 2 warm-ups) of the same workload, batch {B}, fp32, dropout off; median step {med:.3f} s; nproc={os.cpu_count()}"}
 
 
 def gemm_census_roofline(step, peak_tflops):
@@ -129,7 +129,7 @@ def pmc_traffic(kernel_name):
         return None
     try:
         data = json.load(open(files[-1]))
-        for k, v in data.get("kernels", {}).items():
+        for k, v in data.get("families", {}).items():
             if kernel_name.split("<")[0] in k and kernel_name.split("<")[-1].split(">")[0].replace(" ", "") in k.replace(" ", ""):
                 return v.get("hbm_bytes_per_launch")
     except Exception:
@@ -210,6 +210,15 @@ def main():
                                    "achieved_GBps": round(38 * sum(p.numel() for p in model.parameters()) / (ms * 1e-3) / 1e9, 1),
                                    "peak_GBps": PEAK_HBM_GBS}}
         try:
+            import ctypes as C
+            scratch = torch.empty(2048 * 256, device=dev, dtype=torch.float32)
+            tf = C.c_double(0.0)
+            lib.check(lib.load().mtn_measure_mfma_peak(20000, scratch.data_ptr(), torch.cuda.current_stream().cuda_stream, C.byref(tf)))
+            step_info["mfma_peak_measured_TFLOPs"] = round(tf.value, 1)
+            step_info["frac_of_measured_peak"] = round(step_tf / world / tf.value, 5) if lp == torch.bfloat16 else None
+        except Exception as e:  # pragma: no cover
+            step_info["mfma_peak_measured_TFLOPs"] = None
+        try:
             dom, table, allg = gemm_census_roofline(step, peak / world)
             d = table[dom]
             roof = {"bound": "mfma", "kernel": dom, "achieved": d["achieved_TFLOPs"], "peak": peak / world, "unit": "TFLOP/s",
@@ -220,6 +229,9 @@ def main():
                             "committed rocprofv3 PMC passes",
                     "launches_per_step": d["launches_per_step"], "avg_us_per_launch": d["avg_us"],
                     "gflop_per_launch": d["gflop_per_launch"], "algorithmic_bytes_per_launch": int(d["algorithmic_MB_per_launch"] * 1e6),
+                    "peak_measured": step_info.get("mfma_peak_measured_TFLOPs"),
+                    "frac_of_measured_peak": (round(d["achieved_TFLOPs"] / step_info["mfma_peak_measured_TFLOPs"], 4)
+                                              if step_info.get("mfma_peak_measured_TFLOPs") and lp == torch.bfloat16 else None),
                     "all_gemm_kernels": allg, "kernels": table, "step": step_info}
         except Exception as e:  # pragma: no cover
             roof = {"bound": "mfma", "achieved": round(step_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(step_tf / peak, 5),

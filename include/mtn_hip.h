@@ -129,6 +129,11 @@ typedef struct {
     const float *x, *a2, *mean, *rstd, *g, *dres;
     float* dx;
     float* partial; /* NULL: dx only */
+    /* optional second output: dx as the NEXT backward stage wants it — through that sublayer's output-dropout mask and in
+       the compute dtype (saves its cast launch).  dx_lp NULL = off; dx_lp_dtype MTN_F32 | MTN_BF16. */
+    void* dx_lp;
+    int dx_lp_dtype;
+    mtn_dropout dx_lp_drop;
 } mtn_ln_bwd_desc;
 /* Grouped forms: up to MTN_LN_MAX_GROUP independent row streams per launch. */
 int mtn_layernorm_fwd_group(int dtype, int count, const mtn_ln_fwd_desc* descs /* host array */, void* stream);
@@ -227,6 +232,14 @@ typedef struct {
     float* ws_f32; /* float scratch: mtn_mha_bwd_ws_f32_floats() */
     int defer_param_grads; /* 1: backward skips the dW/db GEMMs and the LayerNorm finalize; the caller batches them
                               later from mtn_mha_param_grad_work() (ws_lp/ws_f32 and saved buffers must stay alive) */
+    /* ---- gradient hand-off between consecutive sublayers of a chain (all optional) ----
+       dyl_ready: dropout-masked compute-dtype image of dy already produced by the sublayer that ran before this one in
+                  backward (its next_dyl): the cast stage is skipped and the dW GEMMs read it instead of ws_lp's copy.
+       next_dyl / next_drop: ask this backward's LayerNorm stage to also write dx through `next_drop` (the output dropout of
+                  the sublayer that will consume dx as its dy) in the compute dtype, [rows, d]. */
+    const void* dyl_ready;
+    void* next_dyl;
+    mtn_dropout next_drop;
 } mtn_mha_args;
 int mtn_mha_sublayer_fwd(int dtype, const mtn_mha_args* args, void* stream);
 int mtn_mha_sublayer_bwd(int dtype, const mtn_mha_args* args, void* stream);
@@ -262,6 +275,14 @@ typedef struct {
     void* ws_lp;   /* lowp scratch: rows*d + rows*d_ff elements */
     float* ws_f32; /* float scratch: mtn_ffn_bwd_ws_f32_floats() */
     int defer_param_grads;
+    /* ---- gradient hand-off between consecutive sublayers of a chain (all optional) ----
+       dyl_ready: dropout-masked compute-dtype image of dy already produced by the sublayer that ran before this one in
+                  backward (its next_dyl): the cast stage is skipped and the dW GEMMs read it instead of ws_lp's copy.
+       next_dyl / next_drop: ask this backward's LayerNorm stage to also write dx through `next_drop` (the output dropout of
+                  the sublayer that will consume dx as its dy) in the compute dtype, [rows, d]. */
+    const void* dyl_ready;
+    void* next_dyl;
+    mtn_dropout next_drop;
 } mtn_ffn_args;
 int mtn_ffn_sublayer_fwd(int dtype, const mtn_ffn_args* args, void* stream);
 int mtn_ffn_sublayer_bwd(int dtype, const mtn_ffn_args* args, void* stream);
@@ -365,6 +386,9 @@ int mtn_census_end(void);
 int mtn_census_info(int i, mtn_census_launch* out);
 int mtn_census_replay(int i, int reps, void* stream);
 const char* mtn_census_variant_name(int variant);
+/* Achievable dense bf16 MFMA rate of this box (register-only v_mfma_f32_16x16x32_bf16 issue, synchronises on its own
+ * events): the measured denominator bench.py reports beside the 2.5 PFLOP/s spec figure.  scratch: >= 2048*256 floats. */
+int mtn_measure_mfma_peak(int iters, float* scratch, void* stream, double* tflops);
 
 #ifdef __cplusplus
 }

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp) {
     const float* __restrict__ dres = D.dres;
     float* __restrict__ dx = D.dx;
     float* __restrict__ partial = D.partial;
+    const DropState nds = drop_init(D.dx_lp_drop);          // optional: dx again, as the next backward stage consumes it
     const int blk = (int)blockIdx.x - grp.block_start[gi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blk * LN_BWD_ROWS_PER_BLOCK + wave * LN_BWD_ROWS_PER_WAVE;
@@ -167,6 +168,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp) {
         const float* gr = g + (size_t)row * d;
         float4 hv[LN_MAXV], ev[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
+        unsigned keep = 0xffffffffu;               // hand-off dropout mask of this lane's elements: integer work that does not
+        if (D.dx_lp && nds.on) {                   // depend on the data, placed ahead of the loads' first use
+            keep = 0u;
+#pragma unroll
+            for (int j = 0; j < LN_MAXV; ++j) {
+                const int c = lane * 4 + 256 * j;
+                if (c < d) {
+                    const size_t e = (size_t)row * d + c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) keep |= (drop_keep(nds, e + k) ? 1u : 0u) << (j * 4 + k);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < LN_MAXV; ++j) {
             const int c = lane * 4 + 256 * j;
@@ -199,6 +213,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp) {
                     o.x += dv.x; o.y += dv.y; o.z += dv.z; o.w += dv.w;
                 }
                 *(float4*)(dx + (size_t)row * d + c) = o;
+                if (D.dx_lp) {
+                    const size_t e = (size_t)row * d + c;
+                    if (nds.on) {
+                        const unsigned kb = keep >> (j * 4);
+                        o.x = (kb & 1u) ? o.x * nds.scale : 0.f;
+                        o.y = (kb & 2u) ? o.y * nds.scale : 0.f;
+                        o.z = (kb & 4u) ? o.z * nds.scale : 0.f;
+                        o.w = (kb & 8u) ? o.w * nds.scale : 0.f;
+                    }
+                    if (D.dx_lp_dtype == MTN_BF16) store_lp4<bf16_t>((bf16_t*)D.dx_lp + e, o);
+                    else store_lp4<float>((float*)D.dx_lp + e, o);
+                }
             }
         }
     }

@@ -183,7 +183,7 @@ struct MhaWs { void *dyl, *dO, *dqkv, *dkv; float *dxn, *ln_partial; };
 static MhaWs mha_ws(const mtn_mha_args* a, int dtype) {
     const long rows = (long)a->B * a->a, d = a->d;
     MhaWs w;
-    w.dyl = a->ws_lp;                                   // [rows,d]  dropout-backward of dy
+    w.dyl = a->dyl_ready ? (void*)a->dyl_ready : a->ws_lp;   // [rows,d]  dropout-backward of dy (or the hand-off copy)
     w.dO = lp_off(a->ws_lp, rows * d, dtype);           // [rows,d]
     w.dqkv = lp_off(a->ws_lp, 2 * rows * d, dtype);     // self: [rows,3d]; cross: dq [rows,d] then dkv [rows_m,2d]
     w.dkv = lp_off(w.dqkv, rows * d, dtype);
@@ -194,7 +194,7 @@ static MhaWs mha_ws(const mtn_mha_args* a, int dtype) {
 struct FfnWs { void *dyl, *dh; float *dxn, *ln_partial; };
 static FfnWs ffn_ws(const mtn_ffn_args* a, int dtype) {
     FfnWs w;
-    w.dyl = a->ws_lp;                                               // [rows,d]
+    w.dyl = a->dyl_ready ? (void*)a->dyl_ready : a->ws_lp;          // [rows,d]
     w.dh = lp_off(a->ws_lp, (long)a->rows * a->d, dtype);           // [rows,d_ff]
     w.dxn = a->ws_f32;
     w.ln_partial = a->ws_f32 + (long)a->rows * a->d;
@@ -211,9 +211,11 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
     {
         mtn_cast_desc c[2 * MTN_SUBLAYER_MAX_GROUP];
         int n = 0;
-        for (int i = 0; i < n_mha; ++i) c[n++] = mtn_cast_desc{(long)mha[i].B * mha[i].a * mha[i].d, mha[i].dy, mha_ws(&mha[i], dtype).dyl, mha[i].drop_out};
-        for (int i = 0; i < n_ffn; ++i) c[n++] = mtn_cast_desc{(long)ffn[i].rows * ffn[i].d, ffn[i].dy, ffn_ws(&ffn[i], dtype).dyl, ffn[i].drop_out};
-        RUN(mtn_cast_group(dtype, n, c, stream));
+        for (int i = 0; i < n_mha; ++i)
+            if (!mha[i].dyl_ready) c[n++] = mtn_cast_desc{(long)mha[i].B * mha[i].a * mha[i].d, mha[i].dy, mha_ws(&mha[i], dtype).dyl, mha[i].drop_out};
+        for (int i = 0; i < n_ffn; ++i)
+            if (!ffn[i].dyl_ready) c[n++] = mtn_cast_desc{(long)ffn[i].rows * ffn[i].d, ffn[i].dy, ffn_ws(&ffn[i], dtype).dyl, ffn[i].drop_out};
+        if (n) RUN(mtn_cast_group(dtype, n, c, stream));
     }
     // 2. dO = dyl Wo ;  dh = (dyl W2) * relu'(h) * hidden-dropout mask (both recovered from the saved hidden: hid > 0)
     {
@@ -289,12 +291,14 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
         for (int i = 0; i < n_mha; ++i) {
             const mtn_mha_args* a = &mha[i];
             const MhaWs w = mha_ws(a, dtype);
-            L[n++] = mtn_ln_bwd_desc{a->B * a->a, a->d, a->ln_eps, a->x, a->ln_a, a->mean, a->rstd, w.dxn, a->dy, a->dx, w.ln_partial};
+            L[n++] = mtn_ln_bwd_desc{a->B * a->a, a->d, a->ln_eps, a->x, a->ln_a, a->mean, a->rstd, w.dxn, a->dy, a->dx, w.ln_partial,
+                                     a->next_dyl, dtype, a->next_drop};
         }
         for (int i = 0; i < n_ffn; ++i) {
             const mtn_ffn_args* a = &ffn[i];
             const FfnWs w = ffn_ws(a, dtype);
-            L[n++] = mtn_ln_bwd_desc{a->rows, a->d, a->ln_eps, a->x, a->ln_a, a->mean, a->rstd, w.dxn, a->dy, a->dx, w.ln_partial};
+            L[n++] = mtn_ln_bwd_desc{a->rows, a->d, a->ln_eps, a->x, a->ln_a, a->mean, a->rstd, w.dxn, a->dy, a->dx, w.ln_partial,
+                                     a->next_dyl, dtype, a->next_drop};
         }
         RUN(mtn_layernorm_bwd_group(n, L, stream));
     }

@@ -48,7 +48,8 @@ class MhaArgs(C.Structure):
                 ("dy", C.c_void_p), ("dx", C.c_void_p), ("dmem", C.c_void_p), ("dmem_accumulate", C.c_int),
                 ("d_ln_a", C.c_void_p), ("d_ln_b", C.c_void_p),
                 ("d_w_qkv", C.c_void_p), ("d_b_qkv", C.c_void_p), ("d_w_o", C.c_void_p), ("d_b_o", C.c_void_p),
-                ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int)]
+                ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int),
+                ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout)]
 
 
 class FfnArgs(C.Structure):
@@ -61,7 +62,8 @@ class FfnArgs(C.Structure):
                 ("dy", C.c_void_p), ("dx", C.c_void_p),
                 ("d_ln_a", C.c_void_p), ("d_ln_b", C.c_void_p), ("d_w1", C.c_void_p), ("d_b1", C.c_void_p),
                 ("d_w2", C.c_void_p), ("d_b2", C.c_void_p),
-                ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int)]
+                ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int),
+                ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout)]
 
 
 class LossHeadArgs(C.Structure):
@@ -89,7 +91,8 @@ class EmbedBwdDesc(C.Structure):
 
 class LnBwdDesc(C.Structure):
     _fields_ = [("rows", C.c_int), ("d", C.c_int), ("eps", C.c_float), ("x", C.c_void_p), ("a2", C.c_void_p), ("mean", C.c_void_p),
-                ("rstd", C.c_void_p), ("g", C.c_void_p), ("dres", C.c_void_p), ("dx", C.c_void_p), ("partial", C.c_void_p)]
+                ("rstd", C.c_void_p), ("g", C.c_void_p), ("dres", C.c_void_p), ("dx", C.c_void_p), ("partial", C.c_void_p),
+                ("dx_lp", C.c_void_p), ("dx_lp_dtype", C.c_int), ("dx_lp_drop", Dropout)]
 
 
 class CastDesc(C.Structure):
@@ -116,6 +119,7 @@ SYMBOLS = {
     "mtn_census_info": (C.c_int, [C.c_int, C.POINTER(CensusLaunch)]),
     "mtn_census_replay": (C.c_int, [C.c_int, C.c_int, _P]),
     "mtn_census_variant_name": (C.c_char_p, [C.c_int]),
+    "mtn_measure_mfma_peak": (C.c_int, [C.c_int, _P, _P, C.POINTER(C.c_double)]),
     "mtn_last_error": (C.c_char_p, []),
     "mtn_version": (C.c_int, []),
     "mtn_gemm": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),

@@ -17,6 +17,7 @@ PyTorch-ROCm ops (glue, <5 % of FLOPs).
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -27,6 +28,9 @@ from . import lib as L
 from . import ops
 
 ATTN_DROPOUT_DEFAULT = 0.1   # mtn.py:339 builds MultiHeadedAttention(h, d_model) without forwarding `dropout`
+
+
+_HANDOFF = os.environ.get("MTN_NO_HANDOFF") != "1"
 
 
 # ------------------------------------------------------------------------------------------ leaf modules
@@ -214,7 +218,11 @@ class DecoderLayer(nn.Module):
         computed by one lockstep group (ops.SublayerGroupFn: shared launches)."""
         members, tensors = [], []
         for sc, mod, mem, mask, inp in items:
-            members.append(sc.member(mod, mem, mask))
+            mb = sc.member(mod, mem, mask)
+            if torch.is_grad_enabled() and _HANDOFF:   # gradient hand-off along the chain (ops.GroupMember.holder / .feeds)
+                mb.feeds = getattr(inp, "_mtn_next", None)
+                mb.holder = dict(p=mb.cfg.p_out, salt=mb.cfg.salt * 4 + 1, seed=mb.cfg.seed, lp=mb.cfg.lp_dtype, dyl=None, dx=None, ver=None)
+            members.append(mb)
             tensors += [inp, mem if isinstance(mod, MultiHeadedAttention) else None]
         # attention members first, then FFN members (the C side takes two arrays)
         order = sorted(range(len(members)), key=lambda k: members[k].kind != "mha")
@@ -222,6 +230,8 @@ class DecoderLayer(nn.Module):
         res = [None] * len(members)
         for pos, k in enumerate(order):
             res[k] = outs[pos]
+            if members[k].holder is not None:
+                outs[pos]._mtn_next = members[k].holder
         return res
 
     def _plan(self, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask, ae_features):

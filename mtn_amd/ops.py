@@ -391,6 +391,10 @@ class GroupMember:
     params: tuple
     mask: Optional[torch.Tensor] = None
     mem_lp: Optional[torch.Tensor] = None
+    # gradient hand-off along a chain of sublayers (see include/mtn_hip.h, dyl_ready / next_dyl): `holder` travels with this
+    # member's OUTPUT tensor to the sublayer that consumes it; `feeds` is the holder found on this member's INPUT tensor.
+    holder: Optional[dict] = None
+    feeds: Optional[dict] = None
 
 
 class SublayerGroupFn(torch.autograd.Function):
@@ -491,6 +495,21 @@ class SublayerGroupFn(torch.autograd.Function):
             dev = x.device
             dy = dy.contiguous() if dy is not None else torch.zeros_like(x)
             dx = torch.empty_like(x)
+            # hand-off, consumer side: the sublayer that ran before us in backward already wrote dy through OUR output dropout
+            ready = None
+            h = mb.holder
+            if h is not None and h.get("dyl") is not None:
+                src = h["dx"]             # valid only if dy IS that dx, untouched (autograd may sum gradients in place)
+                if src.data_ptr() == dy.data_ptr() and src._version == h["ver"] and dy._version == h["ver"] and src.shape == dy.shape:
+                    ready = h["dyl"]
+            if h is not None:
+                h["dyl"] = h["dx"] = None
+            # producer side: write our dx also as the next sublayer's masked compute-dtype dy
+            nxt = None
+            f = mb.feeds
+            if f is not None and f.get("lp") == cfg.lp_dtype:
+                nxt = torch.empty(x.shape, device=dev, dtype=cfg.lp_dtype)
+                f["dyl"], f["dx"], f["ver"] = nxt, dx, dx._version     # holding dx also keeps autograd from summing into it in place
             if mb.kind == "mha":
                 A = mha_args[im]; im += 1
                 B, a, d, m = A.B, A.a, A.d, sv["m"]
@@ -511,8 +530,11 @@ class SublayerGroupFn(torch.autograd.Function):
                 A.d_ln_a, A.d_ln_b = g["ln_a"].data_ptr(), g["ln_b"].data_ptr()
                 A.d_w_qkv, A.d_b_qkv, A.d_w_o, A.d_b_o = g["w_qkv"].data_ptr(), g["b_qkv"].data_ptr(), g["w_o"].data_ptr(), g["b_o"].data_ptr()
                 A.ws_lp, A.ws_f32, A.defer_param_grads = ws_lp.data_ptr(), ws_f32.data_ptr(), 1
+                A.dyl_ready, A.next_dyl = L.ptr(ready), L.ptr(nxt)
+                if nxt is not None:
+                    A.next_drop = _drop(f["p"], f["salt"], f["seed"])
                 grads_out += [dx, dmem_ret]
-                keep = [dy, ws_lp, ws_f32, sv["o"], sv["xn"]] + ([sv["mem_lp"]] if sv["mem_lp"] is not None else [])
+                keep = [dy, ws_lp, ws_f32, sv["o"], sv["xn"]] + ([sv["mem_lp"]] if sv["mem_lp"] is not None else []) + ([ready] if ready is not None else [])
                 work.append(("mha", A, keep))
             else:
                 A = ffn_args[jf]; jf += 1
@@ -523,8 +545,11 @@ class SublayerGroupFn(torch.autograd.Function):
                 A.d_ln_a, A.d_ln_b = g["ln_a"].data_ptr(), g["ln_b"].data_ptr()
                 A.d_w1, A.d_b1, A.d_w2, A.d_b2 = g["w1"].data_ptr(), g["b1"].data_ptr(), g["w2"].data_ptr(), g["b2"].data_ptr()
                 A.ws_lp, A.ws_f32, A.defer_param_grads = ws_lp.data_ptr(), ws_f32.data_ptr(), 1
+                A.dyl_ready, A.next_dyl = L.ptr(ready), L.ptr(nxt)
+                if nxt is not None:
+                    A.next_drop = _drop(f["p"], f["salt"], f["seed"])
                 grads_out += [dx, None]
-                keep = [dy, ws_lp, ws_f32, sv["hid"], sv["xn"]]
+                keep = [dy, ws_lp, ws_f32, sv["hid"], sv["xn"]] + ([ready] if ready is not None else [])
                 work.append(("ffn", A, keep))
             keep_all.append(dy)
         L.check(lib.mtn_sublayer_group_bwd(code, ctx.n_mha, mha_args, ctx.n_ffn, ffn_args, L.stream_ptr()))
