@@ -311,9 +311,10 @@ typedef struct {
     const float* src;
     void* dst;
     mtn_dropout drop;
+    const float* gate; /* optional: elements with gate[i] <= 0 are zeroed (ReLU backward from the saved activation) */
 } mtn_cast_desc;
 #define MTN_CAST_MAX_GROUP 8
-/* Grouped cast / dropout-backward: dst_g(lowp)[i] = src_g[i] * keep_g(i)/(1-p_g). */
+/* Grouped cast / dropout-backward: dst_g(lowp)[i] = src_g[i] * keep_g(i)/(1-p_g) [* (gate_g[i] > 0)]. */
 int mtn_cast_group(int dtype, int count, const mtn_cast_desc* descs /* host array */, void* stream);
 /* dst(lowp)[i] = src[i] * keep(i)/(1-p): gradient entering a dropped-out branch (mtn.py:127). */
 int mtn_dropout_bwd_to_lp(int dtype, long n, const float* src, mtn_dropout drop, void* dst, void* stream);

@@ -44,6 +44,10 @@ __global__ __launch_bounds__(256) void cast_kernel(const CastGroup grp) {
             v.z = drop_keep(ds, (uint64_t)(i * 4 + 2)) ? v.z * ds.scale : 0.f;
             v.w = drop_keep(ds, (uint64_t)(i * 4 + 3)) ? v.w * ds.scale : 0.f;
         }
+        if (D.gate) {
+            const float4 gt = *(const float4*)(D.gate + i * 4);
+            v.x = gt.x > 0.f ? v.x : 0.f; v.y = gt.y > 0.f ? v.y : 0.f; v.z = gt.z > 0.f ? v.z : 0.f; v.w = gt.w > 0.f ? v.w : 0.f;
+        }
         if constexpr (sizeof(T) == 2) {
             uint2 u;
             u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
@@ -57,6 +61,7 @@ __global__ __launch_bounds__(256) void cast_kernel(const CastGroup grp) {
         long i = (n4 << 2) + threadIdx.x;
         float v = src[i];
         if (ds.on) v = drop_keep(ds, (uint64_t)i) ? v * ds.scale : 0.f;
+        if (D.gate && !(D.gate[i] > 0.f)) v = 0.f;
         dst[i] = LP<T>::from_f32(v);
     }
 }
@@ -82,7 +87,7 @@ extern "C" int mtn_cast_group(int dtype, int count, const mtn_cast_desc* descs, 
 }
 
 static int launch_cast(int dtype, long n, const float* src, void* dst, mtn_dropout drop, void* stream) {
-    mtn_cast_desc D = {n, src, dst, drop};
+    mtn_cast_desc D = {n, src, dst, drop, nullptr};
     return mtn_cast_group(dtype, 1, &D, stream);
 }
 

@@ -96,7 +96,7 @@ class LnBwdDesc(C.Structure):
 
 
 class CastDesc(C.Structure):
-    _fields_ = [("n", C.c_long), ("src", C.c_void_p), ("dst", C.c_void_p), ("drop", Dropout)]
+    _fields_ = [("n", C.c_long), ("src", C.c_void_p), ("dst", C.c_void_p), ("drop", Dropout), ("gate", C.c_void_p)]
 
 
 class LnFinalizeDesc(C.Structure):

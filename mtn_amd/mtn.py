@@ -542,6 +542,7 @@ class EncoderDecoder(nn.Module):
             p.grad = grad[o:o + p.numel()].view(p.shape)
         self._flat, self._flat_grad = flat, grad
         self._flat_params = params
+        self._flat_offsets = offs
         self._glue_numel = offs[len(glue)] if path else total
         path_off = {id(p): o for p, o in zip(params, offs)}
         self._layer_slices = [(path_off[id(path[s])], path_off[id(path[e - 1])] + pad(path[e - 1].numel())) for s, e in layer_marks]
@@ -700,6 +701,26 @@ class EncoderDecoder(nn.Module):
                 y._mtn_lp = y_lp if y_lp is not None else y.detach()
         return list(outs)
 
+    def _features_fused(self, vid):
+        """vid_encoder (Linear -> ReLU -> PE -> dropout, mtn.py:378) + the Encoder LayerNorm of every feature stream on the
+        HIP path (ops.FeatureEncodeFn): grouped cast, grouped GEMM, grouped LayerNorm launch."""
+        streams, weights = [], []
+        off = {id(p): o for p, o in zip(self._flat_params, self._flat_offsets)}
+        for i, x in enumerate(vid):
+            lin, pos = self.vid_encoder[i][0], self.vid_encoder[i][2]
+            ln = self.query_encoder.norm[1 + i]
+            o = off[id(lin.weight)]
+            w_lp = self._flat_lp[o:o + lin.weight.numel()].view(lin.weight.shape)
+            streams.append(dict(x=x, w_lp=w_lp, bias=lin.bias, grad_w=lin.weight.grad, grad_b=lin.bias.grad, pe=pos.pe[0],
+                                p=pos.dropout.p if self.training else 0.0, salt=910000 + i,
+                                ln=(ln.a_2, ln.b_2, ln.eps, ln._grads[0], ln._grads[1])))
+            weights.append(lin.weight)
+        spec = dict(streams=streams, lp_dtype=self.compute_dtype, seed=self._seed if self.training else None, queue=self._queue)
+        outs = ops.FeatureEncodeFn.apply(spec, *weights)
+        for y, y_lp in zip(outs, spec["_lp_out"]):
+            y._mtn_lp = y_lp if y_lp is not None else y.detach()
+        return list(outs)
+
     def _fused_embed_ok(self, tokens):
         return self.fused_embed and tokens.is_cuda and self._flat is not None and all(n._grads is not None for n in self.query_encoder.norm)
 
@@ -720,7 +741,10 @@ class EncoderDecoder(nn.Module):
                     emb = self.auto_encoder_embed[i] if self.auto_encoder_embed is not None else self.query_embed
                     items.append((ft, emb, norm[nF + 3 + i]))
             outs = self._embed_fused(items)
-            vids = [self.query_encoder._apply_norm(1 + i, v) for i, v in enumerate(self.vid_encode(vid, vid_mask))]
+            if all(v.size(-1) % 8 == 0 for v in vid):
+                vids = self._features_fused(vid)
+            else:           # feature widths the GEMM's 16-byte row alignment cannot take: PyTorch Linear, HIP LayerNorm
+                vids = [self.query_encoder._apply_norm(1 + i, v) for i, v in enumerate(self.vid_encode(vid, vid_mask))]
             return [outs[0], vids, outs[1], outs[2], outs[3:] if self.diff_encoder else None]
         streams = [self.query_embed(query), self.vid_encode(vid, vid_mask), self.query_embed(cap), self.query_embed(his)]
         if not self.diff_encoder:

@@ -658,6 +658,100 @@ class EmbedNormFn(torch.autograd.Function):
         return (None, *ret)
 
 
+# ------------------------------------------------------------------------------------------ feature streams
+class FeatureEncodeFn(torch.autograd.Function):
+    """vid_encoder of mtn.py:378 for ALL feature streams at once: Linear(ft_i, d) -> ReLU -> + positional encoding -> dropout,
+    followed by that stream's Encoder LayerNorm (mtn.py:83-101).  Forward = one grouped cast of the features, one grouped
+    MFMA GEMM (bias + ReLU in the epilogue), one grouped LayerNorm launch (PE, dropout, LN, compute-dtype copy); backward =
+    grouped LayerNorm backward, one grouped mask+cast (dropout, ReLU), dW/db GEMMs on the deferred queue.
+    apply(spec, *weights) -> one fp32 (B, V_i, d) tensor per stream.  spec["streams"]: dicts with x (B,V,ft) fp32, w (index),
+    w_lp, bias, grad_w, grad_b, pe, p, salt, ln = (a2, b2, eps, grad_a, grad_b).  Features get no gradient (inputs)."""
+
+    @staticmethod
+    def forward(ctx, spec, *weights):
+        lib = L.load()
+        streams, lp = spec["streams"], spec["lp_dtype"]
+        code = L.dtype_code(lp)
+        dev = weights[0].device
+        n = len(streams)
+        casts = (L.CastDesc * n)()
+        probs, lns, saved, outs = [], (L.LnFwdDesc * n)(), [], []
+        for i, st in enumerate(streams):
+            x = st["x"].contiguous()
+            B, V, F = x.shape
+            d = st["w_lp"].size(0)
+            rows = B * V
+            x_lp = torch.empty(rows, F, device=dev, dtype=lp)
+            casts[i].n, casts[i].src, casts[i].dst = rows * F, x.data_ptr(), x_lp.data_ptr()
+            h = torch.empty(rows, d, device=dev, dtype=torch.float32)
+            p = L.GemmProblem()
+            p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K = x_lp.data_ptr(), st["w_lp"].data_ptr(), F, F, rows, d, F
+            p.bias, p.relu, p.gate_scale, p.out_f32, p.ldc = st["bias"].data_ptr(), 1, 1.0, h.data_ptr(), d
+            probs.append(p)
+            a2, b2, eps = st["ln"][0], st["ln"][1], st["ln"][2]
+            y = torch.empty(B, V, d, device=dev, dtype=torch.float32)
+            y_lp = torch.empty(B, V, d, device=dev, dtype=lp) if lp != torch.float32 else None
+            xs = torch.empty(rows, d, device=dev, dtype=torch.float32)
+            mean = torch.empty(rows, device=dev, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            D = lns[i]
+            D.rows, D.d, D.eps, D.x, D.a2, D.b2 = rows, d, eps, h.data_ptr(), a2.data_ptr(), b2.data_ptr()
+            D.pe, D.seq_len, D.drop = st["pe"].data_ptr(), V, _drop(st["p"], st["salt"], spec["seed"])
+            D.x_out, D.mean, D.rstd, D.y_f32, D.y_lp = xs.data_ptr(), mean.data_ptr(), rstd.data_ptr(), y.data_ptr(), L.ptr(y_lp)
+            outs.append(y)
+            saved.append(dict(x_lp=x_lp, h=h, xs=xs, mean=mean, rstd=rstd, rows=rows, d=d, F=F, y_lp=y_lp, a2=a2))
+        if lp != torch.float32:
+            L.check(lib.mtn_cast_group(code, n, casts, L.stream_ptr()))
+        else:
+            for sv, st in zip(saved, streams):
+                sv["x_lp"].copy_(st["x"].reshape(sv["rows"], sv["F"]))
+        gemm(code, probs)
+        L.check(lib.mtn_layernorm_fwd_group(code, n, lns, L.stream_ptr()))
+        ctx.spec, ctx.saved_streams, ctx.n_w = spec, saved, len(weights)
+        spec["_lp_out"] = [sv["y_lp"] for sv in saved]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = L.load()
+        spec, saved = ctx.spec, ctx.saved_streams
+        streams, lp = spec["streams"], spec["lp_dtype"]
+        code = L.dtype_code(lp)
+        queue = spec.get("queue")
+        n = len(streams)
+        dev = saved[0]["h"].device
+        lnb = (L.LnBwdDesc * n)()
+        casts = (L.CastDesc * n)()
+        probs, finals, keep = [], [], []
+        for i, (st, sv, dy) in enumerate(zip(streams, saved, dys)):
+            rows, d, F = sv["rows"], sv["d"], sv["F"]
+            dy = dy.contiguous() if dy is not None else torch.zeros(rows, d, device=dev)
+            dxs = torch.empty(rows, d, device=dev, dtype=torch.float32)
+            partial = torch.empty(lib.mtn_layernorm_bwd_partial_floats(rows, d), device=dev, dtype=torch.float32)
+            B_ = lnb[i]
+            B_.rows, B_.d, B_.eps, B_.x, B_.a2, B_.mean, B_.rstd = rows, d, st["ln"][2], sv["xs"].data_ptr(), sv["a2"].data_ptr(), sv["mean"].data_ptr(), sv["rstd"].data_ptr()
+            B_.g, B_.dx, B_.partial = dy.data_ptr(), dxs.data_ptr(), partial.data_ptr()
+            finals.append((L.LnFinalizeDesc(partial.data_ptr(), lib.mtn_layernorm_bwd_nparts(rows), d, st["ln"][3].data_ptr(), st["ln"][4].data_ptr()), partial))
+            dh = torch.empty(rows, d, device=dev, dtype=lp)
+            casts[i].n, casts[i].src, casts[i].dst = rows * d, dxs.data_ptr(), dh.data_ptr()
+            casts[i].drop, casts[i].gate = _drop(st["p"], st["salt"], spec["seed"]), sv["h"].data_ptr()
+            p = L.GemmProblem()      # dW = dh^T x, db = column sums of dh
+            p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K, p.a_trans, p.b_trans = dh.data_ptr(), sv["x_lp"].data_ptr(), d, F, d, F, rows, 1, 1
+            p.gate_scale, p.out_f32, p.ldc, p.rowsum_out = 1.0, st["grad_w"].data_ptr(), F, st["grad_b"].data_ptr()
+            probs.append(p)
+            keep += [dy, dxs, dh, sv["x_lp"], sv["h"]]
+        L.check(lib.mtn_layernorm_bwd_group(n, lnb, L.stream_ptr()))
+        L.check(lib.mtn_cast_group(code, n, casts, L.stream_ptr()))
+        if queue is not None:
+            for k, (desc, partial) in enumerate(finals):
+                queue.add(code, [probs[k]], desc, [partial] + (keep if k == 0 else []))
+        else:
+            gemm(code, probs)
+            farr = (L.LnFinalizeDesc * n)(*[f[0] for f in finals])
+            L.check(lib.mtn_layernorm_bwd_finalize(n, farr, L.stream_ptr()))
+        return (None,) + (None,) * ctx.n_w
+
+
 # ------------------------------------------------------------------------------------------ loss head
 class GeneratorLossFn(torch.autograd.Function):
     """sum_i coef_i * KLDiv(log_softmax(x_i W_i^T + b_i), smooth(y_i)) / norm_i  — Generator (mtn.py:62-69) +

@@ -168,6 +168,65 @@ def test_fused_embedding_streams(dev):
     assert relmax(l2d.grad, want) < 1e-5
 
 
+def _feature_spec(dev, x, w, b, lnp, grads, pe, p, seed, lp):
+    streams = [dict(x=x, w_lp=w if lp == torch.float32 else w.to(lp), bias=b, grad_w=grads[0], grad_b=grads[1], pe=pe, p=p, salt=33,
+                    ln=(lnp[0], lnp[1], 1e-6, grads[2], grads[3]))]
+    return dict(streams=streams, lp_dtype=lp, seed=seed, queue=None)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_feature_stream_encode(dev, dtype):
+    """vid_encoder (Linear -> ReLU -> +PE -> dropout, mtn.py:378) + Encoder LayerNorm on the HIP path: outputs and parameter
+    gradients against the oracle without dropout; with dropout on, the backward uses the forward's mask (directional
+    derivative of the loss along a bias perturbation, same seed, fp32 mode)."""
+    from mtn_amd import ops
+    from oracle.mtn_oracle import layer_norm as ref_ln, positional_encoding
+    B, V, F, d = 3, 9, 40, 64
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, V, F, generator=g)
+    w, b = torch.randn(d, F, generator=g) * F ** -0.5, 0.1 * torch.randn(d, generator=g)
+    a2, b2 = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    gy = torch.randn(B, V, d, generator=g)
+    pe = positional_encoding(32, d)
+    leaves = [t.clone().requires_grad_() for t in (w, b, a2, b2)]
+    yr = ref_ln(torch.relu(x @ leaves[0].t() + leaves[1]) + pe[:V], leaves[2], leaves[3], 1e-6)
+    yr.backward(gy)
+    D = lambda t: t.to(dev)
+    wd, bd, ad, b2d = D(w).requires_grad_(), D(b), D(a2), D(b2)
+    grads = [torch.zeros_like(t) for t in (wd, bd, ad, b2d)]
+    spec = _feature_spec(dev, D(x), wd.detach(), bd, (ad, b2d), grads, D(pe).contiguous(), 0.0, None, dtype)
+    y = ops.FeatureEncodeFn.apply(spec, wd)[0]
+    y.backward(D(gy))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert relmax(y, yr) < tol
+    for got, ref in zip(grads, leaves):
+        if dtype == torch.float32:
+            assert relmax(got, ref.grad) < tol * 3
+        else:      # bf16 operands: rounding of the pre-LayerNorm activation is amplified by the LayerNorm backward projection
+            cos = torch.nn.functional.cosine_similarity(got.flatten().cpu().double(), ref.grad.flatten().double(), dim=0)
+            assert relmax(got, ref.grad) < 0.25 and cos > 0.9995
+    if dtype != torch.float32:
+        assert relmax(spec["_lp_out"][0].float(), yr) < 2e-2
+        return
+    seed = torch.full((1,), 77, device=dev, dtype=torch.int64)
+    v = D(torch.randn(d, generator=g))
+
+    def loss_at(bias):
+        sp = _feature_spec(dev, D(x), wd.detach(), bias, (ad, b2d), [torch.zeros_like(t) for t in (wd, bd, ad, b2d)], D(pe).contiguous(), 0.3, seed, dtype)
+        out = ops.FeatureEncodeFn.apply(sp, wd)[0]
+        return (out * D(gy)).sum(), sp
+
+    l0, sp0 = loss_at(bd)
+    l0.backward()
+    torch.cuda.synchronize()
+    gb = sp0["streams"][0]["grad_b"]
+    eps = 1e-3
+    num = (float(loss_at(bd + eps * v)[0]) - float(loss_at(bd - eps * v)[0])) / (2 * eps)
+    ana = float((gb * v).sum())
+    assert abs(num - ana) < 2e-2 * max(1.0, abs(ana)), (num, ana)
+
+
 # ------------------------------------------------------------------------------------------ attention core
 def _attn_ref(q, k, v, mask, h):
     from oracle.mtn_oracle import scaled_dot_attention
