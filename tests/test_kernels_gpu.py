@@ -205,7 +205,7 @@ def test_feature_stream_encode(dev, dtype):
             assert relmax(got, ref.grad) < tol * 3
         else:      # bf16 operands: rounding of the pre-LayerNorm activation is amplified by the LayerNorm backward projection
             cos = torch.nn.functional.cosine_similarity(got.flatten().cpu().double(), ref.grad.flatten().double(), dim=0)
-            assert relmax(got, ref.grad) < 0.25 and cos > 0.9995
+            assert relmax(got, ref.grad) < 0.25 and cos > 0.999
     if dtype != torch.float32:
         assert relmax(spec["_lp_out"][0].float(), yr) < 2e-2
         return
