@@ -370,6 +370,41 @@ int mtn_adam_step(int dtype, long n, float* p, const float* g, float* m, float* 
                   const float* grad_scale, float beta1, float beta2, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Device-side batch assembly (replaces the host padding of data_handler.py:206-274 `make_batch` and the mask passes of
+ * data_utils.py:23-54 `Batch`).  The corpus stays resident in HBM: each token field as one flat int64 buffer with per-item
+ * start/len tables, each feature type as one flat [frames, F] float buffer with per-video start/len tables.  A batch is
+ * the list of item ids (`ids`, device int32[B]; NULL = items 0..B-1).
+ *   tokens  : out[b,l] = l < len ? flat[start+l] : pad; mask[b,l] = (out != pad); std_mask[b,i,j] = (out[b,j] != pad) &
+ *             (j <= i) (optional, data_utils.py:48-54); *n_nonpad += #non-pad (optional, data_utils.py:45; zero it first).
+ *   features: frames start, start+skip, ...; out[b,v,:] = frame if it exists and has any element != 1, else 0;
+ *             mask[b,v] = that validity (the reference pads with ones, detects all-ones frames, then zeroes them).
+ * ------------------------------------------------------------------------------------------ */
+#define MTN_ASSEMBLE_MAX_GROUP 8
+typedef struct {
+    const int64_t* flat;  /* all items of this field, concatenated */
+    const int64_t* start; /* [n_items] offset of each item in flat */
+    const int32_t* len;   /* [n_items] */
+    const int32_t* ids;   /* [B] items of this batch, or NULL */
+    int B, L;             /* L = padded length (>= longest item of the batch; longer items are cut) */
+    int64_t pad;
+    int64_t* out;         /* [B, L] */
+    uint8_t* mask;        /* [B, L] or NULL */
+    uint8_t* std_mask;    /* [B, L, L] or NULL */
+    int64_t* n_nonpad;    /* scalar accumulator or NULL */
+} mtn_assemble_tokens_desc;
+int mtn_assemble_tokens(int count, const mtn_assemble_tokens_desc* descs /* host array */, void* stream);
+typedef struct {
+    const float* flat;    /* [total_frames, F] */
+    const int64_t* start; /* [n_videos] first frame of each video */
+    const int32_t* len;   /* [n_videos] frames per video */
+    const int32_t* ids;   /* [B] videos of this batch, or NULL */
+    int B, V, F, skip;    /* V = padded frame count; skip >= 1 (every skip-th frame, data_handler.py:233) */
+    float* out;           /* [B, V, F] */
+    uint8_t* mask;        /* [B, V] or NULL */
+} mtn_assemble_features_desc;
+int mtn_assemble_features(int count, const mtn_assemble_features_desc* descs /* host array */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement support (bench.py `roofline`): a census of the GEMM launches of one step.  Between mtn_census_begin() and
  * mtn_census_end() (returns the number of launches) every mtn_gemm call is recorded on the host (no device work, no
  * change to the launch); mtn_census_info() describes launch i — which kernel the dispatch picked, its workgroup count,

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmtn_hip.so")
-SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "elementwise.hip", "sublayer.hip", "losshead.hip"]
+SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "elementwise.hip", "sublayer.hip", "losshead.hip", "assemble.hip"]
 
 
 def _stale() -> bool:

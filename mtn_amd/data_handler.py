@@ -1,0 +1,179 @@
+"""Batch planning and device-side batch assembly (reference: data_handler.py:150-274, data_utils.py:23-54).
+
+The reference keeps dialogs in Python lists and feature files on disk; every step it pads each field with numpy on the
+host, `np.load`s the feature files, uploads, and derives masks with several torch passes (train.py:30).  On a GPU with
+288 GB of HBM the whole corpus fits on the device, so here
+
+* ``make_batch_indices`` plans the batches exactly as the reference does (length-sorted, batch size shrunk for long
+  histories) — host logic, no device work;
+* ``DeviceCorpus`` uploads the corpus ONCE: each token field as one flat int64 buffer + per-item start/length tables, each
+  feature type as one flat [frames, F] float buffer + per-video tables;
+* ``make_batch`` describes a batch by the ids of its items (one small H2D copy) and builds all padded tensors AND their
+  masks with two grouped HIP launches (csrc/assemble.hip) — no host padding, no per-step file I/O, no mask passes.
+
+Dataset parsing itself (json / .npy reading, vocabulary) is out of scope (no GPU work there): ``data`` is the
+dict the reference's ``load`` returns, with in-memory arrays as feature values (the reference accepts those too,
+data_handler.py:158).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .data_utils import Batch
+
+_FIELDS = (("his", 2), ("query", 3), ("trg", 4), ("trg_y", 5), ("cap", 6))     # dialog item columns (data_handler.py:130-133)
+
+
+def make_batch_indices(data: dict, batchsize: int = 100, max_length: int = 20, separate_caption: bool = False):
+    """data_handler.py:150-205: [(vids, qa_ids, x_len, h_len, q_len, a_len[, c_len], n)] and the sample count.
+    Samples are sorted by (history, [caption,] frames, question, answer) length, longest first; a batch takes
+    batchsize // (h_len // max_length + 1) samples (at least one) and is padded to the longest of each field."""
+    idxlist = []
+    for dialog in data["dialogs"]:
+        vid = dialog[0]
+        if data["features"] is not None:
+            x_len = []
+            for feat in data["features"]:
+                value = feat[vid]
+                x_len.append(value[1] if isinstance(value, tuple) else len(value))
+        else:
+            x_len = [0]
+        item = (vid, dialog[1], x_len, len(dialog[2]), len(dialog[3]), len(dialog[4]))
+        if separate_caption:
+            item = item + (len(dialog[6]),)
+        idxlist.append(item)
+    if batchsize > 1:
+        if separate_caption:
+            idxlist = sorted(idxlist, key=lambda s: (-s[3], -s[6], -s[2][0], -s[4], -s[5]))
+        else:
+            idxlist = sorted(idxlist, key=lambda s: (-s[3], -s[2][0], -s[4], -s[5]))
+    n_samples = len(idxlist)
+    batch_indices = []
+    bs = 0
+    while bs < n_samples:
+        in_len = idxlist[bs][3]
+        bsize = int(batchsize / int(in_len / max_length + 1))
+        be = min(bs + bsize, n_samples) if bsize > 0 else bs + 1
+        chunk = idxlist[bs:be]
+        x_len = [max(s[2][j] for s in chunk) for j in range(len(chunk[0][2]))]
+        entry = ([s[0] for s in chunk], [s[1] for s in chunk], x_len, max(s[3] for s in chunk), max(s[4] for s in chunk),
+                 max(s[5] for s in chunk))
+        if separate_caption:
+            entry = entry + (max(s[6] for s in chunk),)
+        batch_indices.append(entry + (be - bs,))
+        bs = be
+    return batch_indices, n_samples
+
+
+class DeviceCorpus:
+    """The corpus resident in HBM.  Token fields: flat int64 + start/len per dialog (indexed by qa_id).  Features: flat
+    [frames, F] float32 + start/len per video, in the order of ``data['features']``."""
+
+    def __init__(self, data: dict, device="cuda"):
+        self.device = torch.device(device)
+        dialogs = data["dialogs"]
+        self.n_dialogs = len(dialogs)
+        self.has_caption = len(dialogs[0]) > 6
+        by_id = sorted(dialogs, key=lambda d: d[1])
+        assert [d[1] for d in by_id] == list(range(self.n_dialogs)), "qa ids must be 0..n-1 (data_handler.py:134)"
+        self.tok: Dict[str, tuple] = {}
+        for name, col in _FIELDS:
+            if col == 6 and not self.has_caption:
+                continue
+            seqs = [np.asarray(d[col], dtype=np.int64).reshape(-1) for d in by_id]
+            lens = np.array([len(s) for s in seqs], dtype=np.int32)
+            start = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+            flat = np.concatenate(seqs) if len(seqs) else np.zeros(0, np.int64)
+            self.tok[name] = tuple(torch.from_numpy(a).to(self.device) for a in (flat, start, lens))
+        self.vid_index: Dict[object, int] = {}
+        self.feat: List[tuple] = []
+        if data.get("features"):
+            vids = sorted(data["features"][0].keys(), key=str)
+            self.vid_index = {v: i for i, v in enumerate(vids)}
+            for feat in data["features"]:
+                arrs = []
+                for v in vids:
+                    value = feat[v]
+                    arrs.append(np.asarray(np.load(value[0]) if isinstance(value, tuple) else value, dtype=np.float32))
+                lens = np.array([a.shape[0] for a in arrs], dtype=np.int32)
+                start = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+                flat = np.concatenate(arrs, axis=0)
+                self.feat.append(tuple(torch.from_numpy(a).to(self.device) for a in (flat, start, lens)) + (flat.shape[1],))
+
+    def nbytes(self) -> int:
+        n = sum(t.numel() * t.element_size() for f in self.tok.values() for t in f)
+        return n + sum(t.numel() * t.element_size() for f in self.feat for t in f[:3])
+
+
+def make_batch(corpus: DeviceCorpus, index, vocab, separate_caption: bool = False, skip: Sequence[int] = (1, 1, 1)) -> Batch:
+    """data_handler.py:219-274 on the device: ``index`` is one entry of make_batch_indices; ``vocab`` the vocabulary dict
+    (its '<blank>' is the pad id) or the pad id itself.  Returns the same Batch the reference builds (fields, shapes,
+    dtypes, mask semantics), with the masks' kernel images already attached."""
+    pad = int(vocab["<blank>"]) if isinstance(vocab, dict) else int(vocab)
+    if separate_caption:
+        x_len, h_len, q_len, a_len, c_len, n = index[2:]
+    else:
+        x_len, h_len, q_len, a_len, n = index[2:]
+        c_len = None
+    dev = corpus.device
+    lib = L.load()
+    ids = torch.tensor(list(index[1]), dtype=torch.int32).to(dev, non_blocking=True)
+    plan = [("query", q_len), ("his", h_len), ("trg", a_len), ("trg_y", a_len)] + ([("cap", c_len)] if separate_caption else [])
+    descs = (L.AssembleTokensDesc * len(plan))()
+    out: Dict[str, torch.Tensor] = {}
+    masks: Dict[str, torch.Tensor] = {}
+    ntok = torch.zeros(1, dtype=torch.int64, device=dev)
+    std = torch.empty(n, a_len, a_len, dtype=torch.uint8, device=dev)
+    for k, (name, Lf) in enumerate(plan):
+        flat, start, lens = corpus.tok[name]
+        out[name] = torch.empty(n, Lf, dtype=torch.int64, device=dev)
+        masks[name] = torch.empty(n, Lf, dtype=torch.uint8, device=dev)
+        D = descs[k]
+        D.flat, D.start, D.len, D.ids, D.B, D.L, D.pad = flat.data_ptr(), start.data_ptr(), lens.data_ptr(), ids.data_ptr(), n, Lf, pad
+        D.out, D.mask = out[name].data_ptr(), masks[name].data_ptr()
+        if name == "trg":
+            D.std_mask = std.data_ptr()
+        if name == "trg_y":
+            D.n_nonpad = ntok.data_ptr()
+    L.check(lib.mtn_assemble_tokens(len(plan), descs, L.stream_ptr()))
+    fts = fts_mask = None
+    if corpus.feat:
+        vids = torch.tensor([corpus.vid_index[v] for v in index[0]], dtype=torch.int32).to(dev, non_blocking=True)
+        fd = (L.AssembleFeaturesDesc * len(corpus.feat))()
+        fts, fmask = [], []
+        for i, (flat, start, lens, F) in enumerate(corpus.feat):
+            sk = int(skip[i]) if i < len(skip) else 1
+            V = int(x_len[i])            # the reference pads to the UNskipped longest video (data_handler.py:236)
+            o = torch.empty(n, V, F, dtype=torch.float32, device=dev)
+            mk = torch.empty(n, V, dtype=torch.uint8, device=dev)
+            D = fd[i]
+            D.flat, D.start, D.len, D.ids, D.B, D.V, D.F, D.skip = flat.data_ptr(), start.data_ptr(), lens.data_ptr(), vids.data_ptr(), n, V, F, sk
+            D.out, D.mask = o.data_ptr(), mk.data_ptr()
+            fts.append(o); fmask.append(mk)
+        L.check(lib.mtn_assemble_features(len(corpus.feat), fd, L.stream_ptr()))
+        fts_mask = [_as_bool(mk.unsqueeze(-2)) for mk in fmask]
+
+    b = Batch.__new__(Batch)
+    b.query, b.his, b.his_st = out["query"], out["his"], None
+    b.fts, b.fts_mask = fts, fts_mask
+    b.query_mask, b.his_mask = _as_bool(masks["query"].unsqueeze(-2)), _as_bool(masks["his"].unsqueeze(-2))
+    if separate_caption:
+        b.cap, b.cap_mask = out["cap"], _as_bool(masks["cap"].unsqueeze(-2))
+    else:
+        b.cap = b.cap_mask = None
+    b.trg, b.trg_y = out["trg"], out["trg_y"]
+    b.trg_mask = _as_bool(std)
+    b.ntokens = ntok[0]
+    return b
+
+
+def _as_bool(u8: torch.Tensor) -> torch.Tensor:
+    """Reinterpret a 0/1 uint8 mask as bool (no copy) and keep the uint8 image the kernels read attached to it."""
+    m = u8.view(torch.bool)
+    m._mtn_u8 = u8
+    return m

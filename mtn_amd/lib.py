@@ -108,12 +108,24 @@ GEMM_MAX_GROUP = 16
 
 # every symbol include/mtn_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+class AssembleTokensDesc(C.Structure):
+    _fields_ = [("flat", C.c_void_p), ("start", C.c_void_p), ("len", C.c_void_p), ("ids", C.c_void_p), ("B", C.c_int), ("L", C.c_int),
+                ("pad", C.c_int64), ("out", C.c_void_p), ("mask", C.c_void_p), ("std_mask", C.c_void_p), ("n_nonpad", C.c_void_p)]
+
+
+class AssembleFeaturesDesc(C.Structure):
+    _fields_ = [("flat", C.c_void_p), ("start", C.c_void_p), ("len", C.c_void_p), ("ids", C.c_void_p), ("B", C.c_int), ("V", C.c_int),
+                ("F", C.c_int), ("skip", C.c_int), ("out", C.c_void_p), ("mask", C.c_void_p)]
+
+
 class CensusLaunch(C.Structure):
     _fields_ = [("dtype", C.c_int), ("count", C.c_int), ("variant", C.c_int), ("workgroups", C.c_int),
                 ("flops", C.c_double), ("bytes", C.c_double), ("M", C.c_int * 4), ("N", C.c_int * 4), ("K", C.c_int * 4)]
 
 
 SYMBOLS = {
+    "mtn_assemble_tokens": (C.c_int, [C.c_int, C.POINTER(AssembleTokensDesc), _P]),
+    "mtn_assemble_features": (C.c_int, [C.c_int, C.POINTER(AssembleFeaturesDesc), _P]),
     "mtn_census_begin": (C.c_int, []),
     "mtn_census_end": (C.c_int, []),
     "mtn_census_info": (C.c_int, [C.c_int, C.POINTER(CensusLaunch)]),

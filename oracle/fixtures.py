@@ -162,3 +162,37 @@ def oracle_batch(raw: Dict[str, object]):
     t = torch.from_numpy
     return OracleBatch(query=t(raw["query"]), his=t(raw["his"]), cap=t(raw["cap"]), trg=t(raw["trg"]),
                        trg_y=t(raw["trg_y"]), fts=[t(f) for f in raw["fts"]], pad=PAD)
+
+
+def det_corpus(n_videos: int = 5, turns: int = 3, vocab: int = 60, ft_sizes: Sequence[int] = (16, 8), seed: int = 11,
+               caption: bool = True) -> Dict[str, object]:
+    """A deterministic miniature of what the reference's data_handler.load returns (data_handler.py:134-148): ``dialogs`` =
+    [vid, qa_id, history, question, answer_in, answer_out(, caption)] with ragged int64 arrays, ``features`` = one dict per
+    feature type mapping vid -> float32 [frames, ft] array (one frame of the first video is all ones: the reference treats
+    such a frame as padding, data_utils.py:29)."""
+    rs = np.random.RandomState(seed)
+    tok = lambda lo, hi: rs.randint(4, vocab, size=rs.randint(lo, hi + 1)).astype(np.int64)
+    dialogs, qa = [], 0
+    vids = [f"vid{v:02d}" for v in range(n_videos)]
+    for v in vids:
+        cap = tok(3, 12)
+        hist = np.zeros(0, np.int64)
+        for t in range(turns):
+            q, a = tok(2, 9), tok(2, 8)
+            ans = np.concatenate([[SOS], a, [EOS]]).astype(np.int64)
+            item = [v, qa, hist.copy() if len(hist) else np.array([PAD], np.int64), q, ans[:-1], ans[1:]]
+            if caption:
+                item.append(cap)
+            dialogs.append(item)
+            hist = np.concatenate([hist, q, a])
+            qa += 1
+    feats = []
+    for fi, F in enumerate(ft_sizes):
+        d = {}
+        for k, v in enumerate(vids):
+            arr = rs.randn(rs.randint(3, 10), F).astype(np.float32)
+            if k == 0 and fi == 0:
+                arr[1] = 1.0
+            d[v] = arr
+        feats.append(d)
+    return {"dialogs": dialogs, "features": feats, "vocab": {"<blank>": PAD, "<unk>": UNK, "<sos>": SOS, "<eos>": EOS}}

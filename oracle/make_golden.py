@@ -174,9 +174,63 @@ def run_config(name, c, ref_mtn, ref_du, ref_ls):
     print(f"{name}: {len(npz)} arrays, loss={float(out['loss']):.6f}, {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def run_batch_assembly():
+    """Batch planning + assembly of the reference (data_handler.py:150-274, data_utils.py:23-54) on the deterministic
+    mini-corpus of fixtures.det_corpus -> tests/golden/batch_assembly.npz.  The reference hard-codes .cuda() in
+    prepare_data / Batch (SURVEY §8c shim 2): for this run Tensor.cuda is an identity, the feature arrays are written to
+    temporary .npy files because make_batch np.loads them."""
+    import tempfile
+    from oracle.fixtures import det_corpus
+    import data_handler as ref_dh        # noqa
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {}
+    try:
+        for cap in (True, False):
+            data = det_corpus(caption=cap)
+            tmp = tempfile.mkdtemp(prefix="mtn_golden_")
+            feats = []
+            for fi, d in enumerate(data["features"]):
+                fd = {}
+                for vid, arr in d.items():
+                    path = os.path.join(tmp, f"f{fi}_{vid}.npy")
+                    np.save(path, arr)
+                    fd[vid] = (path, arr.shape[0])
+                feats.append(fd)
+            ref_data = {"dialogs": data["dialogs"], "features": feats, "vocab": data["vocab"]}
+            for bsz, mlen in ((4, 8), (1, 20), (6, 20)):
+                tag = f"cap{int(cap)}.b{bsz}"
+                idx, n = ref_dh.make_batch_indices(ref_data, batchsize=bsz, max_length=mlen, separate_caption=cap)
+                out[f"{tag}.n_samples"] = np.array(n)
+                out[f"{tag}.n_batches"] = np.array(len(idx))
+                for k, ix in enumerate(idx):
+                    out[f"{tag}.{k}.qa_ids"] = np.array(ix[1], dtype=np.int64)
+                    out[f"{tag}.{k}.vids"] = np.array([int(v[3:]) for v in ix[0]], dtype=np.int64)
+                    out[f"{tag}.{k}.lens"] = np.array(list(ix[2]) + list(ix[3:]), dtype=np.int64)
+                    if bsz == 1 and k >= 4:
+                        continue
+                    b = ref_dh.make_batch(ref_data, ix, data["vocab"], separate_caption=cap, skip=[1, 2] if bsz == 6 else [1, 1])
+                    for name in ("query", "his", "trg", "trg_y", "query_mask", "his_mask", "trg_mask"):
+                        out[f"{tag}.{k}.{name}"] = getattr(b, name).numpy()
+                    if cap:
+                        out[f"{tag}.{k}.cap"], out[f"{tag}.{k}.cap_mask"] = b.cap.numpy(), b.cap_mask.numpy()
+                    out[f"{tag}.{k}.ntokens"] = np.array(int(b.ntokens))
+                    for i, (f, m) in enumerate(zip(b.fts, b.fts_mask)):
+                        out[f"{tag}.{k}.fts.{i}"], out[f"{tag}.{k}.fts_mask.{i}"] = f.numpy(), m.numpy()
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    path = os.path.join(ROOT, "tests", "golden", "batch_assembly.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")
+
+
 def main():
     ref_mtn, ref_du, ref_ls = import_reference()
     torch.set_num_threads(8)
+    if "--batch-assembly-only" in sys.argv:
+        run_batch_assembly()
+        return
+    run_batch_assembly()
     for name, c in GOLDEN_CONFIGS.items():
         run_config(name, c, ref_mtn, ref_du, ref_ls)
 
