@@ -60,7 +60,52 @@ def parse(argv=None):
     p.add_argument("--vocab-size", default=3000, type=int, help="synthetic mode")
     p.add_argument("--ft-sizes", default=[2048, 128], nargs="+", type=int, help="synthetic mode: feature dims")
     p.add_argument("--lens", default=[20, 128, 40, 20, 32], nargs=5, type=int, help="synthetic mode: Q H C T frames")
+    p.add_argument("--corpus-videos", default=0, type=int,
+                   help="> 0: train on a synthetic ragged CORPUS of that many videos (10 turns each) through the reference's "
+                        "epoch loop — batch planning, device-side batch assembly, one eager step per batch — instead of "
+                        "replaying one fixed-shape batch")
     return p.parse_args(argv)
+
+
+def synthetic_corpus(n_videos, vocab, ft_sizes, seed, turns=10):
+    """A ragged corpus in the layout data_handler.load returns (dialogs + per-video feature arrays), lengths in the ranges
+    of the AVSD data: questions/answers 3-20 tokens, captions 10-40, 20-40 frames per video."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    tok = lambda lo, hi: rs.randint(4, vocab, size=rs.randint(lo, hi + 1)).astype(np.int64)
+    dialogs, qa = [], 0
+    vids = [f"v{v:05d}" for v in range(n_videos)]
+    for v in vids:
+        cap, hist = tok(10, 40), np.zeros(0, np.int64)
+        for _ in range(turns):
+            q, a = tok(3, 20), tok(3, 18)
+            ans = np.concatenate([[2], a, [3]]).astype(np.int64)                     # <sos> ... <eos>
+            dialogs.append([v, qa, hist.copy() if len(hist) else np.array([1], np.int64), q, ans[:-1], ans[1:], cap])
+            hist = np.concatenate([hist, q, a])
+            qa += 1
+    feats = [{v: rs.randn(rs.randint(20, 41), F).astype(np.float32) for v in vids} for F in ft_sizes]
+    return {"dialogs": dialogs, "features": feats, "vocab": {"<blank>": 1}}
+
+
+def run_epoch(corpus, indices, model, loss_compute, ae_ft, epoch, report_interval, rank, rng):
+    """train.py:23-50: shuffle the planned batches, assemble each on the device, forward, loss + backward + optimiser."""
+    from .data_handler import make_batch
+    order = list(range(len(indices)))
+    rng.shuffle(order)
+    t0, tokens, total_loss, total_tokens = time.time(), 0, 0.0, 0
+    for j, k in enumerate(order):
+        b = make_batch(corpus, indices[k], 1, separate_caption=True)
+        out, ae_out = model.forward(b)
+        ae_y = b.cap if ae_ft in ("caption", "summary") else b.query
+        loss = loss_compute(out, b.trg_y, b.ntokens, ae_out, ae_y, (ae_y != 1).sum())
+        total_loss += loss
+        total_tokens += int(b.ntokens)
+        tokens += int(b.ntokens)
+        if (j + 1) % report_interval == 0 and rank == 0:
+            dt = time.time() - t0
+            print("Epoch: %d Step: %d Loss: %f Tokens per Sec: %f" % (epoch + 1, j + 1, loss / float(b.ntokens), tokens / dt))
+            t0, tokens = time.time(), 0
+    return total_loss / max(1, total_tokens)
 
 
 def main(argv=None):
@@ -84,6 +129,30 @@ def main(argv=None):
         sync.broadcast_(model._flat)
         model._flat_version = -1
         model.prepare()
+    if args.corpus_videos > 0:
+        import random
+        from .data_handler import DeviceCorpus, make_batch_indices
+        from .data_utils import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
+        data = synthetic_corpus(args.corpus_videos, args.vocab_size, args.ft_sizes, args.rand_seed)
+        indices, n_samples = make_batch_indices(data, batchsize=args.batch_size, max_length=256, separate_caption=True)  # train.py:126
+        indices = indices[rank::world]                     # data parallel: every rank takes its share of the planned batches
+        corpus = DeviceCorpus(data, dev)
+        logging.info("corpus: %d dialogs in %d batches, %.1f MB resident on the device", n_samples, len(indices), corpus.nbytes() / 1e6)
+        opt = NoamOpt(args.d_model, 1, args.warmup_steps, FusedAdam(model))
+        lc = SimpleLossCompute(model.generator, model.auto_encoder_generator, LabelSmoothing(args.vocab_size, 1, 0.1), opt=opt,
+                               l=args.loss_l, grad_sync=sync)
+        rng = random.Random(args.rand_seed)
+        means = []
+        for epoch in range(args.num_epochs):
+            mean = run_epoch(corpus, indices, model, lc, args.auto_encoder_ft, epoch, args.report_interval, rank, rng)
+            means.append(mean)
+            if rank == 0:
+                print("epoch %d mean train loss per token: %f" % (epoch + 1, mean))
+            if args.model and rank == 0:
+                torch.save(model.state_dict(), f"{args.model}_{epoch + 1}.pth.tar")
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return means
     Q, H, C, T, V = args.lens
     batch = synthetic_batch(args.vocab_size, args.batch_size, Q, H, C, T, [V] * len(args.ft_sizes), args.ft_sizes, device=dev, seed=1 + rank)
     step = TrainStep(model, batch, args.vocab_size, pad=1, warmup=args.warmup_steps, lam=args.loss_l, grad_sync=sync)
