@@ -461,7 +461,7 @@ template <typename T> __device__ __forceinline__ uint4 frag_from_tlds(const unsi
 // NW = waves per workgroup: 1, or 4 with the key tiles dealt round-robin to the waves (long memories: the per-tile chain of
 // dependent memory round trips runs 4-wide) and the partial (max, sum, O) combined through LDS at the end.
 template <typename T, int DK, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnGroup G) {
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const AttnGroup G) {
     constexpr int EPV = LP<T>::EPV, KSTEP = LP<T>::KSTEP;
     constexpr int NKS = (DK + KSTEP - 1) / KSTEP;     // contraction steps over the head dimension
     constexpr int NDT = DK / 16;                      // 16-column tiles of the head dimension
@@ -476,6 +476,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnGroup 
     unsigned char* vt = fsm + (size_t)wave * DK * VT_ROW;
     const int b = blockIdx.x / A.h, hh = blockIdx.x % A.h, q0 = blockIdx.y * MQ;
     const int a = A.a, m = A.m;
+    // a member whose keys fit one tile needs one wave: in a 4-wave launch its other waves leave at once (their registers go
+    // back to the CU; exited waves do not count at barriers) and wave 0 finishes without the combine
+    const bool solo = (NW == 1) || (m <= MK);
+    if (NW > 1 && solo && wave > 0) return;
     const float scale = rsqrtf((float)DK);
     const T* qg = (const T*)A.q + (size_t)b * a * A.ldq + hh * DK;
     const T* kg = (const T*)A.k + (size_t)b * m * A.ldkv + hh * DK;
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnGroup 
     }
     // ---- epilogue: lane holds O^T[dcol = dt*16 + 4*lg + r][q = qt*16 + l15]
     T* og = (T*)A.o + (size_t)b * a * A.ldo + hh * DK;
-    if constexpr (NW == 1) {
+    if (solo) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int q = q0 + qt * 16 + l15;
@@ -630,7 +634,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnGroup 
         }
     } else {
         // partial results of the NW waves -> LDS, then every thread combines a few (q, 4 columns) entries
-        float* cO = (float*)(fsm + (size_t)NW * DK * VT_ROW);      // [NW][DK][33]
+        // (the combine area re-uses the waves' V^T images: every wave must be done with its image first)
+        __syncthreads();
+        float* cO = (float*)fsm;                                   // [NW][DK][33]
         float* cm = cO + NW * DK * 33;                             // [NW][32]
         float* cl = cm + NW * 32;                                  // [NW][32]
 #pragma unroll
@@ -668,23 +674,30 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_mfma_kernel(const AttnGroup 
     }
 }
 
-template <typename T, int DK> static int launch_fwd_mfma(const AttnGroup& G, dim3 grid, bool split, hipStream_t s) {
+template <typename T, int DK, int NW> static int launch_fwd_mfma_nw(const AttnGroup& G, dim3 grid, hipStream_t s) {
     const size_t vt = (size_t)DK * (MK * sizeof(T) + 16);
-    if (!split) {
+    if constexpr (NW == 1) {
         hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, DK, 1>), grid, dim3(64), vt, s, G);
     } else {
-        const size_t lds = 4 * vt + sizeof(float) * (4 * DK * 33 + 2 * 4 * 32);
-        if (int rc = set_lds(attn_fwd_mfma_kernel<T, DK, 4>, lds)) return rc;
-        hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, DK, 4>), grid, dim3(256), lds, s, G);
+        const size_t comb = sizeof(float) * (NW * DK * 33 + 2 * NW * 32);
+        const size_t lds = NW * vt > comb ? NW * vt : comb;        // the combine area aliases the V^T images
+        if (int rc = set_lds(attn_fwd_mfma_kernel<T, DK, NW>, lds)) return rc;
+        hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, DK, NW>), grid, dim3(64 * NW), lds, s, G);
     }
     return MTN_OK;
 }
-template <typename T> static int dispatch_fwd_mfma(int dk, const AttnGroup& G, dim3 grid, bool split, hipStream_t s) {
+// nw = waves per workgroup = key tiles of the longest memory, capped at 4 (1, 2 or 4)
+template <typename T, int DK> static int launch_fwd_mfma(const AttnGroup& G, dim3 grid, int nw, hipStream_t s) {
+    if (nw <= 1) return launch_fwd_mfma_nw<T, DK, 1>(G, grid, s);
+    if (nw == 2) return launch_fwd_mfma_nw<T, DK, 2>(G, grid, s);
+    return launch_fwd_mfma_nw<T, DK, 4>(G, grid, s);
+}
+template <typename T> static int dispatch_fwd_mfma(int dk, const AttnGroup& G, dim3 grid, int nw, hipStream_t s) {
     switch (dk) {
-        case 16: return launch_fwd_mfma<T, 16>(G, grid, split, s);
-        case 32: return launch_fwd_mfma<T, 32>(G, grid, split, s);
-        case 64: return launch_fwd_mfma<T, 64>(G, grid, split, s);
-        case 128: return launch_fwd_mfma<T, 128>(G, grid, split, s);
+        case 16: return launch_fwd_mfma<T, 16>(G, grid, nw, s);
+        case 32: return launch_fwd_mfma<T, 32>(G, grid, nw, s);
+        case 64: return launch_fwd_mfma<T, 64>(G, grid, nw, s);
+        case 128: return launch_fwd_mfma<T, 128>(G, grid, nw, s);
     }
     return -1;
 }
@@ -702,7 +715,7 @@ static constexpr int BQ = 32;   // query rows per block
 static constexpr int BK = 32;   // keys per tile
 
 template <typename T, int DK, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_mfma_kernel(const AttnGroup G) {
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGroup G) {
     constexpr int EPV = LP<T>::EPV, KSTEP = LP<T>::KSTEP;
     constexpr int NKS = (DK + KSTEP - 1) / KSTEP;
     constexpr int NDT = DK / 16;
@@ -721,6 +734,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_mfma_kernel(const AttnGroup 
     if ((int)blockIdx.x >= A.B * A.h) return;
     const int b = blockIdx.x / A.h, hh = blockIdx.x % A.h;
     const int a = A.a, m = A.m;
+    const bool solo = (NW == 1) || (m <= BK);          // one key tile: one wave (see the forward kernel)
+    if (NW > 1 && solo && wave > 0) return;
     const float scale = rsqrtf((float)DK);
     const T* qg = (const T*)A.q + (size_t)b * a * A.ldq + hh * DK;
     const T* kg = (const T*)A.k + (size_t)b * m * A.ldkv + hh * DK;
@@ -911,7 +926,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_mfma_kernel(const AttnGroup 
         }
     }
     // ---- dQ: lane holds dQ^T[d = dt*16 + 4lg + r][q = qt*16 + l15]
-    if constexpr (NW == 1) {
+    if (solo) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int q = qt * 16 + l15;
@@ -924,7 +939,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_mfma_kernel(const AttnGroup 
             }
         }
     } else {   // sum the waves' partial dQ^T through LDS
-        float* cq = (float*)((unsigned char*)(Ds + 32) + (size_t)NW * (DK + 32) * ROWB);     // [NW][DK][33]
+        __syncthreads();                                    // the partial sums re-use the waves' K^T / dS images
+        float* cq = (float*)(Ds + 32);                                                        // [NW][DK][33]
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -945,24 +961,30 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_mfma_kernel(const AttnGroup 
     }
 }
 
-template <typename T, int DK> static int launch_bwd_mfma(const AttnGroup& G, dim3 grid, bool split, hipStream_t s) {
+template <typename T, int DK, int NW> static int launch_bwd_mfma_nw(const AttnGroup& G, dim3 grid, hipStream_t s) {
     const size_t rowb = 32 * sizeof(T) + 16;
     const size_t shared = 2 * (size_t)DK * rowb + 32 * sizeof(float), per_wave = ((size_t)DK + 32) * rowb;
-    if (!split) {
+    if constexpr (NW == 1) {
         hipLaunchKernelGGL((attn_bwd_mfma_kernel<T, DK, 1>), grid, dim3(64), shared + per_wave, s, G);
     } else {
-        const size_t lds = shared + 4 * per_wave + sizeof(float) * 4 * DK * 33;
-        if (int rc = set_lds(attn_bwd_mfma_kernel<T, DK, 4>, lds)) return rc;
-        hipLaunchKernelGGL((attn_bwd_mfma_kernel<T, DK, 4>), grid, dim3(256), lds, s, G);
+        const size_t comb = sizeof(float) * NW * DK * 33;
+        const size_t lds = shared + (NW * per_wave > comb ? NW * per_wave : comb);   // the dQ combine area aliases the per-wave images
+        if (int rc = set_lds(attn_bwd_mfma_kernel<T, DK, NW>, lds)) return rc;
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<T, DK, NW>), grid, dim3(64 * NW), lds, s, G);
     }
     return MTN_OK;
 }
-template <typename T> static int dispatch_bwd_mfma(int dk, const AttnGroup& G, dim3 grid, bool split, hipStream_t s) {
+template <typename T, int DK> static int launch_bwd_mfma(const AttnGroup& G, dim3 grid, int nw, hipStream_t s) {
+    if (nw <= 1) return launch_bwd_mfma_nw<T, DK, 1>(G, grid, s);
+    if (nw == 2) return launch_bwd_mfma_nw<T, DK, 2>(G, grid, s);
+    return launch_bwd_mfma_nw<T, DK, 4>(G, grid, s);
+}
+template <typename T> static int dispatch_bwd_mfma(int dk, const AttnGroup& G, dim3 grid, int nw, hipStream_t s) {
     switch (dk) {
-        case 16: return launch_bwd_mfma<T, 16>(G, grid, split, s);
-        case 32: return launch_bwd_mfma<T, 32>(G, grid, split, s);
-        case 64: return launch_bwd_mfma<T, 64>(G, grid, split, s);
-        case 128: return launch_bwd_mfma<T, 128>(G, grid, split, s);
+        case 16: return launch_bwd_mfma<T, 16>(G, grid, nw, s);
+        case 32: return launch_bwd_mfma<T, 32>(G, grid, nw, s);
+        case 64: return launch_bwd_mfma<T, 64>(G, grid, nw, s);
+        case 128: return launch_bwd_mfma<T, 128>(G, grid, nw, s);
     }
     return -1;
 }
@@ -1022,9 +1044,10 @@ extern "C" int mtn_attention_fwd_group(int dtype, int count, const mtn_attn_args
         }
         if (ok) {
             dim3 gridm(gx, gym, count);
-            bool split = false;                         // a memory longer than one key tile: 4 waves share the tiles
-            for (int i = 0; i < count; ++i) split = split || args[i].m > MK;
-            int rc = (dtype == MTN_BF16) ? dispatch_fwd_mfma<bf16_t>(dk, G, gridm, split, s) : dispatch_fwd_mfma<float>(dk, G, gridm, split, s);
+            int nw = 1;                                 // a memory longer than one key tile: 2 or 4 waves share the tiles
+            for (int i = 0; i < count; ++i) { const int t = (args[i].m + MK - 1) / MK; nw = t > nw ? t : nw; }
+            nw = nw > 2 ? 4 : nw;
+            int rc = (dtype == MTN_BF16) ? dispatch_fwd_mfma<bf16_t>(dk, G, gridm, nw, s) : dispatch_fwd_mfma<float>(dk, G, gridm, nw, s);
             if (rc == MTN_OK) { MTN_CHECK_LAUNCH(); return MTN_OK; }
         }
     }
@@ -1065,9 +1088,13 @@ extern "C" int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args
             ok = ok && args[i].dk == dk && (dk == 16 || dk == 32 || dk == 64 || dk == 128) && args[i].a <= BQ && args[i].ldq % 8 == 0 &&
                  args[i].ldkv % 8 == 0 && args[i].ldo % 8 == 0;
         if (ok) {
-            bool split = false;
-            for (int i = 0; i < count; ++i) split = split || args[i].m > BK;
-            int rc = (dtype == MTN_BF16) ? dispatch_bwd_mfma<bf16_t>(dk, G, grid, split, s) : dispatch_bwd_mfma<float>(dk, G, grid, split, s);
+            int nw = 1;
+            for (int i = 0; i < count; ++i) { const int t = (args[i].m + BK - 1) / BK; nw = t > nw ? t : nw; }
+            // 2 waves up to 8 key tiles: a 226-register wave leaves room for 2 per SIMD, and a group's one-tile members
+            // (one live wave each) then share the CU with the long member instead of waiting for a second round
+            nw = nw <= 1 ? 1 : (nw <= 8 ? 2 : 4);
+            if (const char* f = getenv("MTN_ATTN_BWD_NW")) nw = atoi(f);
+            int rc = (dtype == MTN_BF16) ? dispatch_bwd_mfma<bf16_t>(dk, G, grid, nw, s) : dispatch_bwd_mfma<float>(dk, G, grid, nw, s);
             if (rc == MTN_OK) { MTN_CHECK_LAUNCH(); return MTN_OK; }
         }
     }

@@ -11,7 +11,7 @@ int main() {
     const int B = 32, h = 8, a = 20, dk = 64, d = h * dk;
     int ms[] = {20, 32, 40, 128};
     hipStream_t st; (void)hipStreamCreate(&st);
-    const int NR = 24;
+    const int NR = getenv("NR") ? atoi(getenv("NR")) : 24;
     for (int m : ms) {
         std::vector<void*> q(NR), kv(NR), o(NR), dO(NR), dq(NR), dkv(NR); std::vector<float*> lse(NR);
         for (int i = 0; i < NR; ++i) {
@@ -45,6 +45,43 @@ int main() {
                 printf("m=%3d %s %s: %6.2f us/launch\n", m, valu ? "valu" : "mfma", bwd ? "bwd" : "fwd", t * 1e3 / iters);
             }
         }
+    }
+    // ---- the step's his-attention group: x attends history (m = 128) + two auto-encoder video attentions (m = 32), dropout on
+    {
+        unsetenv("MTN_ATTN_VALU");
+        const int msz[3] = {128, 32, 32};
+        void *q[3], *kv[3], *o[3], *dO[3], *dq[3], *dkv[3]; float* lse[3]; unsigned char* mk[3];
+        for (int i = 0; i < 3; ++i) {
+            const int m = msz[i];
+            (void)hipMalloc(&q[i], (size_t)B * a * d * 2); fillr(q[i], (size_t)B * a * d * 2);
+            (void)hipMalloc(&kv[i], (size_t)B * m * 2 * d * 2); fillr(kv[i], (size_t)B * m * 2 * d * 2);
+            (void)hipMalloc(&o[i], (size_t)B * a * d * 2); (void)hipMalloc(&dO[i], (size_t)B * a * d * 2); fillr(dO[i], (size_t)B * a * d * 2);
+            (void)hipMalloc(&dq[i], (size_t)B * a * d * 2); (void)hipMalloc(&dkv[i], (size_t)B * m * 2 * d * 2);
+            (void)hipMalloc(&lse[i], (size_t)2 * B * h * a * 4);
+            (void)hipMalloc(&mk[i], (size_t)B * m); (void)hipMemset(mk[i], 1, (size_t)B * m);
+        }
+        uint64_t* seed; (void)hipMalloc(&seed, 8); (void)hipMemset(seed, 7, 8);
+        for (int drop = 0; drop < 2; ++drop)
+            for (int cnt = 1; cnt <= 3; cnt += 2)
+                for (int bwd = 0; bwd < 2; ++bwd) {
+                    mtn_attn_args A[3];
+                    for (int i = 0; i < 3; ++i) {
+                        memset(&A[i], 0, sizeof(A[i]));
+                        const int m = msz[i];
+                        A[i].B = B; A[i].h = h; A[i].a = a; A[i].m = m; A[i].dk = dk; A[i].q = q[i]; A[i].k = kv[i]; A[i].v = (char*)kv[i] + d * 2;
+                        A[i].ldq = d; A[i].ldkv = 2 * d; A[i].mask = mk[i]; A[i].mask_sb = m; A[i].mask_sq = 0; A[i].o = o[i]; A[i].ldo = d; A[i].lse = lse[i];
+                        A[i].d_o = dO[i]; A[i].dq = dq[i]; A[i].dk_out = dkv[i]; A[i].dv_out = (char*)dkv[i] + d * 2;
+                        if (drop) { A[i].drop.p = 0.1f; A[i].drop.salt = 5 + i; A[i].drop.seed = seed; }
+                    }
+                    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+                    const int iters = 200;
+                    for (int i = 0; i < 10; ++i) (void)(bwd ? mtn_attention_bwd_group(MTN_BF16, cnt, A, st) : mtn_attention_fwd_group(MTN_BF16, cnt, A, st));
+                    (void)hipEventRecord(e0, st);
+                    for (int i = 0; i < iters; ++i) if (bwd ? mtn_attention_bwd_group(MTN_BF16, cnt, A, st) : mtn_attention_fwd_group(MTN_BF16, cnt, A, st)) { printf("ERR %s\n", mtn_last_error()); return 1; }
+                    (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
+                    float t; (void)hipEventElapsedTime(&t, e0, e1);
+                    printf("group of %d (m=128,32,32) dropout %d %s: %6.2f us/launch\n", cnt, drop, bwd ? "bwd" : "fwd", t * 1e3 / iters);
+                }
     }
     return 0;
 }
