@@ -85,6 +85,69 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp) {
     }
 }
 
+// d <= 256*MAXV: the (possibly synthesised) row is read ONCE into registers; mean, variance and output come from there
+// (the generic kernel above re-reads the row for each of its three passes: three dependent memory round trips).
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void ln_fwd_small_kernel(const LnFwdGroup grp) {
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.block_start[g + 1]) ++g;
+    const mtn_ln_fwd_desc& D = grp.d[g];
+    const int d = D.d;
+    const int lane = threadIdx.x & 63;
+    const int row = ((int)blockIdx.x - grp.block_start[g]) * 4 + (threadIdx.x >> 6);
+    if (row >= D.rows) return;
+    const DropState ds = drop_init(D.drop);
+    const long tok = D.tokens ? D.tokens[row] : 0;
+    const int pos = D.pe ? row % D.seq_len : 0;
+    float4 v[MAXV], ga[MAXV], gb[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < d) {
+            v[j] = ln_src(D, ds, row, c, tok, pos);
+            if (!D.no_ln) { ga[j] = *(const float4*)(D.a2 + c); gb[j] = *(const float4*)(D.b2 + c); }
+        }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (!D.no_ln) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j)
+            if (lane * 4 + 256 * j < d) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j)
+            if (lane * 4 + 256 * j < d) {
+                const float e0 = v[j].x - mean, e1 = v[j].y - mean, e2 = v[j].z - mean, e3 = v[j].w - mean;
+                q += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+            }
+        const float std_u = sqrtf(wave_sum(q) / (float)(d - 1));
+        rstd = 1.0f / (std_u + D.eps);
+        if (lane == 0) {
+            if (D.mean) D.mean[row] = mean;
+            if (D.rstd) D.rstd[row] = rstd;
+        }
+    }
+    T* y_lp = (T*)D.y_lp;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < d) {
+            if (D.x_out) *(float4*)(D.x_out + (size_t)row * d + c) = v[j];
+            float4 o = v[j];
+            if (!D.no_ln) {
+                o.x = ga[j].x * (v[j].x - mean) * rstd + gb[j].x;
+                o.y = ga[j].y * (v[j].y - mean) * rstd + gb[j].y;
+                o.z = ga[j].z * (v[j].z - mean) * rstd + gb[j].z;
+                o.w = ga[j].w * (v[j].w - mean) * rstd + gb[j].w;
+            }
+            if (D.y_f32) *(float4*)(D.y_f32 + (size_t)row * d + c) = o;
+            if (y_lp) store_lp4<T>(y_lp + (size_t)row * d + c, o);
+        }
+    }
+}
+
 extern "C" int mtn_layernorm_fwd_group(int dtype, int count, const mtn_ln_fwd_desc* descs, void* stream) {
     MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
     MTN_CHECK_ARG(count >= 1 && count <= MTN_LN_MAX_GROUP && descs, "bad group");
@@ -103,7 +166,12 @@ extern "C" int mtn_layernorm_fwd_group(int dtype, int count, const mtn_ln_fwd_de
     }
     for (int i = count; i <= MTN_LN_MAX_GROUP; ++i) grp.block_start[i] = blocks;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MTN_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, grp);
+    int dmax = 0;
+    for (int i = 0; i < count; ++i) dmax = descs[i].d > dmax ? descs[i].d : dmax;
+    if (dmax <= 512 && getenv("MTN_LN_FWD_GENERIC") == nullptr) {
+        if (dtype == MTN_BF16) hipLaunchKernelGGL((ln_fwd_small_kernel<bf16_t, 2>), dim3(blocks), dim3(256), 0, s, grp);
+        else hipLaunchKernelGGL((ln_fwd_small_kernel<float, 2>), dim3(blocks), dim3(256), 0, s, grp);
+    } else if (dtype == MTN_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, grp);
     else hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
@@ -247,6 +315,136 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp) {
     }
 }
 
+// The same kernel for d <= 256*MAXV with ALL global loads of the wave's two rows issued before any arithmetic (the generic
+// kernel above walks the rows one after the other: two dependent memory round trips on the critical path of backward).
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_bwd_small_kernel(const LnBwdGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4 waves][2][d]
+    int gi = 0;
+    while (gi + 1 < grp.count && (int)blockIdx.x >= grp.block_start[gi + 1]) ++gi;
+    const mtn_ln_bwd_desc& D = grp.d[gi];
+    const int rows = D.rows, d = D.d;
+    const float eps = D.eps;
+    const int blk = (int)blockIdx.x - grp.block_start[gi];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blk * LN_BWD_ROWS_PER_BLOCK + wave * LN_BWD_ROWS_PER_WAVE;
+    constexpr int R = LN_BWD_ROWS_PER_WAVE;
+    float4 xv[R][MAXV], gv[R][MAXV], dv[R][MAXV], av[MAXV];
+    float mu[R], rs[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int row = r0 + rr < rows ? r0 + rr : rows - 1;           // clamped: rows past the end are computed, not stored
+        mu[rr] = D.mean[row]; rs[rr] = D.rstd[row];
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < d) {
+                xv[rr][j] = *(const float4*)(D.x + (size_t)row * d + c);
+                gv[rr][j] = *(const float4*)(D.g + (size_t)row * d + c);
+                dv[rr][j] = D.dres ? *(const float4*)(D.dres + (size_t)row * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < d) av[j] = *(const float4*)(D.a2 + c);
+    }
+    const DropState nds = drop_init(D.dx_lp_drop);
+    unsigned keep[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        keep[rr] = 0xffffffffu;
+        if (D.dx_lp && nds.on) {
+            keep[rr] = 0u;
+#pragma unroll
+            for (int j = 0; j < MAXV; ++j) {
+                const int c = lane * 4 + 256 * j;
+                if (c < d) {
+                    const size_t e = (size_t)(r0 + rr) * d + c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) keep[rr] |= (drop_keep(nds, e + k) ? 1u : 0u) << (j * 4 + k);
+                }
+            }
+        }
+    }
+    float4 ga[MAXV], gb[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) ga[j] = gb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float inv_d = 1.0f / (float)d;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int row = r0 + rr;
+        const bool live = row < rows;
+        const float r = rs[rr];
+        const float std_u = fmaxf(1.0f / r - eps, 1e-30f);
+        float4 hv[MAXV], ev[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < d) {
+                const float4 x4 = xv[rr][j], g4 = gv[rr][j], a4 = av[j];
+                float4 h = make_float4(g4.x * a4.x, g4.y * a4.y, g4.z * a4.z, g4.w * a4.w);
+                float4 e = make_float4(x4.x - mu[rr], x4.y - mu[rr], x4.z - mu[rr], x4.w - mu[rr]);
+                s1 += (h.x + h.y) + (h.z + h.w);
+                s2 += (h.x * e.x + h.y * e.y) + (h.z * e.z + h.w * e.w);
+                if (live) {
+                    ga[j].x += g4.x * e.x * r; ga[j].y += g4.y * e.y * r; ga[j].z += g4.z * e.z * r; ga[j].w += g4.w * e.w * r;
+                    gb[j].x += g4.x; gb[j].y += g4.y; gb[j].z += g4.z; gb[j].w += g4.w;
+                }
+                hv[j] = h; ev[j] = e;
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const float c1 = r * s1 * inv_d;
+        const float c2 = s2 * r * r / (std_u * (float)(d - 1));
+        if (!live) continue;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < d) {
+                float4 o;
+                o.x = r * hv[j].x - c1 - c2 * ev[j].x + dv[rr][j].x;
+                o.y = r * hv[j].y - c1 - c2 * ev[j].y + dv[rr][j].y;
+                o.z = r * hv[j].z - c1 - c2 * ev[j].z + dv[rr][j].z;
+                o.w = r * hv[j].w - c1 - c2 * ev[j].w + dv[rr][j].w;
+                *(float4*)(D.dx + (size_t)row * d + c) = o;
+                if (D.dx_lp) {
+                    const size_t e = (size_t)row * d + c;
+                    if (nds.on) {
+                        const unsigned kb = keep[rr] >> (j * 4);
+                        o.x = (kb & 1u) ? o.x * nds.scale : 0.f;
+                        o.y = (kb & 2u) ? o.y * nds.scale : 0.f;
+                        o.z = (kb & 4u) ? o.z * nds.scale : 0.f;
+                        o.w = (kb & 8u) ? o.w * nds.scale : 0.f;
+                    }
+                    if (D.dx_lp_dtype == MTN_BF16) store_lp4<bf16_t>((bf16_t*)D.dx_lp + e, o);
+                    else store_lp4<float>((float*)D.dx_lp + e, o);
+                }
+            }
+        }
+    }
+    if (D.partial == nullptr) return;
+    float* sa = sm + (size_t)wave * 2 * d;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < d) {
+            *(float4*)(sa + c) = ga[j];
+            *(float4*)(sa + d + c) = gb[j];
+        }
+    }
+    __syncthreads();
+    float* pp = D.partial + (size_t)blk * 2 * d;
+    for (int c = threadIdx.x * 4; c < 2 * d; c += 1024) {
+        float4 a = *(const float4*)(sm + c), b = *(const float4*)(sm + 2 * d + c);
+        float4 e = *(const float4*)(sm + 4 * d + c), f = *(const float4*)(sm + 6 * d + c);
+        *(float4*)(pp + c) = make_float4((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y), (a.z + b.z) + (e.z + f.z), (a.w + b.w) + (e.w + f.w));
+    }
+}
+
 // Grouped finalize: blockIdx.y = LayerNorm index, blockIdx.x covers the 2d columns (first d -> da2, next d -> db2).
 struct LnFinalizeGroup {
     int count;
@@ -312,7 +510,8 @@ extern "C" int mtn_layernorm_bwd_group(int count, const mtn_ln_bwd_desc* descs, 
     }
     for (int i = count; i <= MTN_LN_MAX_GROUP; ++i) grp.block_start[i] = blocks;
     const size_t lds = any_partial ? sizeof(float) * 8 * (size_t)dmax : 0;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, grp);
+    if (dmax <= 512 && getenv("MTN_LN_BWD_GENERIC") == nullptr) hipLaunchKernelGGL(ln_bwd_small_kernel<2>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, grp);
+    else hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
