@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
     Stage<T, B_T> stB;
     stA.load(A, P.lda, M, K, row0, 0, tid);
     stB.load(B, P.ldb, N, K, col0, 0, tid);
+    const DropState ds = drop_init(P.drop);        // the dropout key (scalar seed load + hashing) rides under the first tile loads
 
     for (int k0 = 0; k0 < K; k0 += BK) {
         stA.store(sA, tid);
@@ -218,7 +219,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
     if (do_rowsum && tid < TILE && row0 + tid < M) P.rowsum_out[row0 + tid] = rsum;
 
     // ---- epilogue: operands were swapped in the MFMAs, so a lane holds one output row (l15) x four consecutive columns
-    const DropState ds = drop_init(P.drop);
     const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -456,6 +456,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
         dma_issue_tile<T, BN>(rB, smem + STAGE_BYTES + A_BYTES, ldb_b, N, K, col0, BK, wave, lane);
     }
 #endif
+    const DropState ds = drop_init(P.drop);        // scalar seed load + key hashing ride under the operand DMA
     for (int s = 0; s < nstages; ++s) {
         // stage s landed, stage s+1 (if any) still flying: vmcnt(NDMA) / vmcnt(0)
         if (s + 1 < nstages) {
@@ -503,7 +504,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     // ---- epilogue.  The MFMAs were issued with the operands swapped (acc = W-tile x X-tile^T), so a lane holds, for ONE
     //      output row m = l15, FOUR CONSECUTIVE output columns n = 4*lg + r of each 16x16 tile: bias, residual, gate and
     //      both outputs move as 8/16-byte vectors (4x fewer memory instructions than the row-per-register layout).
-    const DropState ds = drop_init(P.drop);
     const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {

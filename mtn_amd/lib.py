@@ -180,10 +180,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise MtnHipError(f"{LIB_PATH} is missing: build it with `python -m mtn_amd.build` "
+    path = os.environ.get("MTN_HIP_LIB", LIB_PATH)      # A/B builds of the kernels (same ABI) — development only
+    if not os.path.exists(path):
+        raise MtnHipError(f"{path} is missing: build it with `python -m mtn_amd.build` "
                           "(hipcc --offload-arch=gfx950).  mtn_amd has no CPU/PyTorch fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)             # AttributeError here = ABI drift: fail loudly
         fn.restype, fn.argtypes = res, args
