@@ -168,7 +168,7 @@ class SimpleLossCompute:
         if not torch.is_grad_enabled():
             pass
         spec = dict(targets=ys, norms=[n if torch.is_tensor(n) else torch.tensor(float(n), device=x.device) for n in norms], coefs=coefs,
-                    gens=[(f["w_lp"], f["bias"], f["grad_w"], f["grad_b"]) for f in fused], vocab=self.criterion.size,
+                    gens=[(f["w_lp"], f["bias"], f["grad_w"], f["grad_b"], f.get("w_lpT")) for f in fused], vocab=self.criterion.size,
                     pad=self.criterion.padding_idx, smoothing=self.criterion.smoothing, lp_dtype=fused[0]["lp_dtype"])
         spec["norms"] = [n.detach().float().reshape(1) for n in spec["norms"]]
         return ops.GeneratorLossFn.apply(spec, *xs)

@@ -594,7 +594,11 @@ class EncoderDecoder(nn.Module):
                 o_w, o_b = path_off[id(m.proj.weight)], path_off[id(m.proj.bias)]
                 nw, nb = m.proj.weight.numel(), m.proj.bias.numel()
                 m._fused = dict(w_lp=self._flat_lp[o_w:o_w + nw].view(m.proj.weight.shape), bias=flat[o_b:o_b + nb],
-                                grad_w=grad[o_w:o_w + nw].view(m.proj.weight.shape), grad_b=grad[o_b:o_b + nb], lp_dtype=lp)
+                                grad_w=grad[o_w:o_w + nw].view(m.proj.weight.shape), grad_b=grad[o_b:o_b + nb], lp_dtype=lp, w_lpT=None)
+                vocab, dm = m.proj.weight.shape
+                if self._flat_lpT is not None and vocab % 8 == 0 and not any(t[0] == o_w for t in tdescs):
+                    m._fused["w_lpT"] = self._flat_lpT[o_w:o_w + nw].view(dm, vocab)     # dX of the loss head on the LDS-DMA path
+                    tdescs.append((o_w, vocab, dm))
             elif isinstance(m, LayerNorm) and id(m.a_2) in path_off:
                 m._grads = (views(m.a_2)[2], views(m.b_2)[2])
                 m._lp_dtype = lp

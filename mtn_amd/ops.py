@@ -790,7 +790,7 @@ class GeneratorLossFn(torch.autograd.Function):
         shared = all(g[0].data_ptr() == gens[0][0].data_ptr() for g in gens)
         segs = [(0, R, gens[0])] if shared else [(offs[i], rows[i], gens[i]) for i in range(len(xs))]
         probs = []
-        for o, r, (w_lp, bias, _gw, _gb) in segs:
+        for o, r, (w_lp, bias, _gw, _gb, *_rest) in segs:
             p = L.GemmProblem()
             p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K = x_lp[o:].data_ptr(), w_lp.data_ptr(), d, d, r, V, d
             p.bias, p.gate_scale, p.out_f32, p.ldc = bias.data_ptr(), 1.0, logits[o:].data_ptr(), V
@@ -825,9 +825,13 @@ class GeneratorLossFn(torch.autograd.Function):
         L.check(lib.mtn_losshead_bwd(code, C.byref(A), L.stream_ptr()))
         dx = torch.empty(R, d, device=dev, dtype=torch.float32)
         p_dx, p_dw = [], []
-        for o, r, (w_lp, bias, gw, gb) in segs:
-            p = L.GemmProblem()      # dX = dlogits W
-            p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K, p.b_trans = dlogits[o:].data_ptr(), w_lp.data_ptr(), V, d, r, d, V, 1
+        for o, r, (w_lp, bias, gw, gb, *rest) in segs:
+            p = L.GemmProblem()      # dX = dlogits W  (through the transposed weight copy when the model keeps one)
+            w_lpT = rest[0] if rest else None
+            if w_lpT is not None:
+                p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K, p.b_trans = dlogits[o:].data_ptr(), w_lpT.data_ptr(), V, V, r, d, V, 0
+            else:
+                p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K, p.b_trans = dlogits[o:].data_ptr(), w_lp.data_ptr(), V, d, r, d, V, 1
             p.gate_scale, p.out_f32, p.ldc = 1.0, dx[o:].data_ptr(), d
             p_dx.append(p)
             q = L.GemmProblem()      # dW = dlogits^T x, db = column sums of dlogits
