@@ -690,7 +690,8 @@ template <typename T, int DK, int NW> static int launch_fwd_mfma_nw(const AttnGr
 template <typename T, int DK> static int launch_fwd_mfma(const AttnGroup& G, dim3 grid, int nw, hipStream_t s) {
     if (nw <= 1) return launch_fwd_mfma_nw<T, DK, 1>(G, grid, s);
     if (nw == 2) return launch_fwd_mfma_nw<T, DK, 2>(G, grid, s);
-    return launch_fwd_mfma_nw<T, DK, 4>(G, grid, s);
+    if (nw <= 4) return launch_fwd_mfma_nw<T, DK, 4>(G, grid, s);
+    return launch_fwd_mfma_nw<T, DK, 8>(G, grid, s);
 }
 template <typename T> static int dispatch_fwd_mfma(int dk, const AttnGroup& G, dim3 grid, int nw, hipStream_t s) {
     switch (dk) {
@@ -977,7 +978,8 @@ template <typename T, int DK, int NW> static int launch_bwd_mfma_nw(const AttnGr
 template <typename T, int DK> static int launch_bwd_mfma(const AttnGroup& G, dim3 grid, int nw, hipStream_t s) {
     if (nw <= 1) return launch_bwd_mfma_nw<T, DK, 1>(G, grid, s);
     if (nw == 2) return launch_bwd_mfma_nw<T, DK, 2>(G, grid, s);
-    return launch_bwd_mfma_nw<T, DK, 4>(G, grid, s);
+    if (nw <= 4) return launch_bwd_mfma_nw<T, DK, 4>(G, grid, s);
+    return launch_bwd_mfma_nw<T, DK, 8>(G, grid, s);
 }
 template <typename T> static int dispatch_bwd_mfma(int dk, const AttnGroup& G, dim3 grid, int nw, hipStream_t s) {
     switch (dk) {
@@ -1044,9 +1046,12 @@ extern "C" int mtn_attention_fwd_group(int dtype, int count, const mtn_attn_args
         }
         if (ok) {
             dim3 gridm(gx, gym, count);
-            int nw = 1;                                 // a memory longer than one key tile: 2 or 4 waves share the tiles
-            for (int i = 0; i < count; ++i) { const int t = (args[i].m + MK - 1) / MK; nw = t > nw ? t : nw; }
-            nw = nw > 2 ? 4 : nw;
+            int nw = 1;                                 // a memory longer than one key tile: 2, 4 or 8 waves share the tiles
+            int wgs = 0;
+            for (int i = 0; i < count; ++i) { const int t = (args[i].m + MK - 1) / MK; nw = t > nw ? t : nw; wgs += args[i].B * args[i].h * gym; }
+            // 8 waves (one or two tiles each) when the launch leaves most of the chip idle anyway (small batch x long memory)
+            nw = nw <= 2 ? nw : ((nw > 4 && wgs <= 256) ? 8 : 4);
+            if (const char* f = getenv("MTN_ATTN_FWD_NW")) nw = atoi(f);
             int rc = (dtype == MTN_BF16) ? dispatch_fwd_mfma<bf16_t>(dk, G, gridm, nw, s) : dispatch_fwd_mfma<float>(dk, G, gridm, nw, s);
             if (rc == MTN_OK) { MTN_CHECK_LAUNCH(); return MTN_OK; }
         }
@@ -1092,7 +1097,9 @@ extern "C" int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args
             for (int i = 0; i < count; ++i) { const int t = (args[i].m + BK - 1) / BK; nw = t > nw ? t : nw; }
             // 2 waves up to 8 key tiles: a 226-register wave leaves room for 2 per SIMD, and a group's one-tile members
             // (one live wave each) then share the CU with the long member instead of waiting for a second round
-            nw = nw <= 1 ? 1 : (nw <= 8 ? 2 : 4);
+            int wgs = 0;
+            for (int i = 0; i < count; ++i) wgs += args[i].B * args[i].h;
+            nw = nw <= 1 ? 1 : (nw <= 8 ? 2 : ((wgs <= 256) ? 8 : 4));
             if (const char* f = getenv("MTN_ATTN_BWD_NW")) nw = atoi(f);
             int rc = (dtype == MTN_BF16) ? dispatch_bwd_mfma<bf16_t>(dk, G, grid, nw, s) : dispatch_bwd_mfma<float>(dk, G, grid, nw, s);
             if (rc == MTN_OK) { MTN_CHECK_LAUNCH(); return MTN_OK; }
