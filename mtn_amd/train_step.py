@@ -117,25 +117,37 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.overlap:
-            segs = self._segments()
-            with torch.cuda.stream(side):
-                for fn, _ in segs:                      # warm-up of the segmented schedule (no exchange: gradients are discarded)
-                    fn()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            self._g_seg, pool = [], None
-            for fn, rng in segs:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    fn()
-                pool = g.pool()
-                self._g_seg.append((g.replay, rng))
-            self._loss = self._loss_t
-            self._g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_opt, pool=pool):
-                self._optim()
-            self._g_fb = self._g_seg[0]
-            return
+            try:
+                self._capture_segmented(side)
+                return
+            except Exception as e:      # never lose the run to the more elaborate schedule: fall back to the simple one
+                import logging
+                logging.getLogger("mtn_amd").warning("layer-segmented capture failed (%s); using the two-graph schedule", e)
+                self.overlap, self._g_seg, self._st = False, None, None
+                torch.cuda.synchronize()
+        self._capture_simple()
+
+    def _capture_segmented(self, side):
+        segs = self._segments()
+        with torch.cuda.stream(side):
+            for fn, _ in segs:                      # warm-up of the segmented schedule (no exchange: gradients are discarded)
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._g_seg, pool = [], None
+        for fn, rng in segs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            pool = g.pool()
+            self._g_seg.append((g.replay, rng))
+        self._loss = self._loss_t
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt, pool=pool):
+            self._optim()
+        self._g_fb = self._g_seg[0]
+
+    def _capture_simple(self):
         self._g_fb = torch.cuda.CUDAGraph()
         if self.grad_sync is None:
             with torch.cuda.graph(self._g_fb):
