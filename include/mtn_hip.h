@@ -240,6 +240,9 @@ typedef struct {
     const void* dyl_ready;
     void* next_dyl;
     mtn_dropout next_drop;
+    /* forward, cross attention: 1 = `kv` already holds K|V of the memory (projected ahead of the layer loop for every layer
+       that attends the same constant memory, one grouped GEMM): the sublayer skips that projection.  Backward is unchanged. */
+    int kv_ready;
 } mtn_mha_args;
 int mtn_mha_sublayer_fwd(int dtype, const mtn_mha_args* args, void* stream);
 int mtn_mha_sublayer_bwd(int dtype, const mtn_mha_args* args, void* stream);

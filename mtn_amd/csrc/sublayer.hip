@@ -123,8 +123,10 @@ extern "C" int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* 
             } else {
                 p[n] = gemm_init(a->xn, d, a->w_qkv, d, rows, d, d, 0, 0);
                 p[n].bias = a->b_qkv; p[n].out_lp = a->qkv; p[n].ldc = d; ++n;
-                p[n] = gemm_init(a->mem, d, lp_off(a->w_qkv, (long)d * d, dtype), d, a->B * a->m, 2 * d, d, 0, 0);
-                p[n].bias = a->b_qkv + d; p[n].out_lp = a->kv; p[n].ldc = 2 * d; ++n;
+                if (!a->kv_ready) {
+                    p[n] = gemm_init(a->mem, d, lp_off(a->w_qkv, (long)d * d, dtype), d, a->B * a->m, 2 * d, d, 0, 0);
+                    p[n].bias = a->b_qkv + d; p[n].out_lp = a->kv; p[n].ldc = 2 * d; ++n;
+                }
             }
         }
         for (int i = 0; i < n_ffn; ++i) {

@@ -32,6 +32,7 @@ class DecodeSession:
         self.use_graph = use_graph and batch.query.is_cuda
         dev = batch.query.device
         self.q = self.cp = self.hs = self.aes = self.masks = None
+        self._kvs, self._kv_pairs = None, []
         self.tokens = torch.full((width, max_len), pad, dtype=torch.long, device=dev)
         self.pos = torch.zeros(1, dtype=torch.long, device=dev)
         self.trg_mask = subsequent_mask(max_len, device=dev)       # (1, L, L): data_utils.py:204 uses the causal mask only
@@ -73,6 +74,12 @@ class DecodeSession:
             first = self.q is None
             self.q, self.cp, self.hs = widen(q, self.q), widen(cp, self.cp), widen(hs, self.hs)
             self.aes = [[widen(a, None if first else self.aes[k][i]) for i, a in enumerate(aes)] for k, aes in enumerate(aes_per_layer)]
+            # K|V of the (widened) text memories for all layers: once per dialogue, not once per token; refreshed in place so
+            # that a captured pass keeps reading the same buffers
+            kvs = model.hoist_memory_kv(self.cp, self.hs, self.q, [], outs=None if first else self._kvs)
+            if kvs is not None:
+                self._kvs, self._kv_pairs = kvs, list(model._kv_targets)
+            model.clear_memory_kv()
             new_masks = (b.cap_mask, b.his_mask, b.query_mask)
             if first:
                 self.masks = tuple(mk.clone() for mk in new_masks)
@@ -86,9 +93,13 @@ class DecodeSession:
         m = self.model
         cap_mask, his_mask, q_mask = self.masks
         x = m.embed_target(self.tokens)
-        for k, layer in enumerate(m.decoder.layers):
-            x = layer.forward_target(x, self.cp, cap_mask, self.hs, his_mask, self.q, q_mask, self.trg_mask, self.aes[k],
-                                     m.auto_encoder_ft)
+        m.attach_memory_kv(self._kv_pairs)
+        try:
+            for k, layer in enumerate(m.decoder.layers):
+                x = layer.forward_target(x, self.cp, cap_mask, self.hs, his_mask, self.q, q_mask, self.trg_mask, self.aes[k],
+                                         m.auto_encoder_ft)
+        finally:
+            m.clear_memory_kv()
         x = m.decoder.norm(x)
         last = x.index_select(1, self.pos).squeeze(1)               # (width, d): the position being extended
         self.logp = m.generator(last).float()                       # (width, V) log-probabilities (mtn.py:68-69)

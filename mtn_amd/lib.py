@@ -49,7 +49,7 @@ class MhaArgs(C.Structure):
                 ("d_ln_a", C.c_void_p), ("d_ln_b", C.c_void_p),
                 ("d_w_qkv", C.c_void_p), ("d_b_qkv", C.c_void_p), ("d_w_o", C.c_void_p), ("d_b_o", C.c_void_p),
                 ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int),
-                ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout)]
+                ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout), ("kv_ready", C.c_int)]
 
 
 class FfnArgs(C.Structure):

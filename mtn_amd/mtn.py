@@ -219,6 +219,9 @@ class DecoderLayer(nn.Module):
         members, tensors = [], []
         for sc, mod, mem, mask, inp in items:
             mb = sc.member(mod, mem, mask)
+            kv = getattr(sc, "_kv_ready", None)        # K|V of a constant memory projected ahead of the layer loop
+            if kv is not None and mb.kind == "mha" and mem is not None and kv.size(0) == mem.size(0) * mem.size(1):
+                mb.kv_ready = kv
             if torch.is_grad_enabled() and _HANDOFF:   # gradient hand-off along the chain (ops.GroupMember.holder / .feeds)
                 mb.feeds = getattr(inp, "_mtn_next", None)
                 mb.holder = dict(p=mb.cfg.p_out, salt=mb.cfg.salt * 4 + 1, seed=mb.cfg.seed, lp=mb.cfg.lp_dtype, dyl=None, dx=None, ver=None)
@@ -482,6 +485,7 @@ class EncoderDecoder(nn.Module):
         self.multi_stream = False
         self.lockstep = True                   # independent sublayers of a layer share launches (ops.SublayerGroupFn)
         self.fused_embed = True                # Embeddings + PositionalEncoding + Encoder LayerNorm in one grouped launch
+        self.hoist_kv = os.environ.get("MTN_NO_KV_HOIST") != "1"   # K|V of the constant memories projected ahead of the layer loop
         self._embed_calls = 0
 
     # ---- flat parameter storage ------------------------------------------------------------------
@@ -762,6 +766,43 @@ class EncoderDecoder(nn.Module):
             ae = [self.query_embed(ft) for _ in range(len(vid))]
         return self.query_encoder(*streams, ae)
 
+    def hoist_memory_kv(self, cap_memory, his_memory, q_memory, vid_fts, outs=None):
+        """Project K|V of the encoder-side memories for every decoder layer that attends them (3 text cross-attentions + F
+        video attentions per layer) in a few grouped GEMMs ahead of the layer loop (ops.project_memories).  The projections
+        are left on the sublayer connections (``_kv_ready``) for the lockstep groups to pick up; clear_memory_kv() removes
+        them.  Returns the list of K|V buffers (pass it back as ``outs`` to refresh them in place)."""
+        if not (self.hoist_kv and self.lockstep and self._flat is not None and q_memory.is_cuda):
+            return None
+        nF = len(vid_fts)
+        items, targets = [], []
+        for layer in self.decoder.layers:
+            if layer._forward_hooks_on_sublayers() or nF + 1 > 4:
+                continue
+            text, chains, _, _ = layer._plan(cap_memory, None, his_memory, None, q_memory, None, None, vid_fts, [None] * nF,
+                                             self.auto_encoder_ft)
+            for sc, mod, mem, _ in list(text[1:]) + [chains[i][1] for i in range(nF)]:
+                mem_lp = getattr(mem, "_mtn_lp", None)
+                f = mod.fused()
+                if mem_lp is None or mem_lp.dtype != self.compute_dtype or f.get("w_qkv_lp") is None:
+                    continue
+                items.append((mem_lp, f["w_qkv_lp"], f["b_qkv"]))
+                targets.append(sc)
+        kvs = ops.project_memories(items, self.compute_dtype, outs)
+        self._kv_targets = list(zip(targets, kvs))
+        self.attach_memory_kv(self._kv_targets)
+        return kvs
+
+    @staticmethod
+    def attach_memory_kv(pairs):
+        for sc, kv in pairs:
+            object.__setattr__(sc, "_kv_ready", kv)
+
+    def clear_memory_kv(self):
+        for layer in self.decoder.layers:
+            for sc in layer.sublayer:
+                if getattr(sc, "_kv_ready", None) is not None:
+                    object.__setattr__(sc, "_kv_ready", None)
+
     def embed_target(self, tgt):
         """tgt_embed of mtn.py:59 (lookup * sqrt(d) + positional encoding + dropout)."""
         if self._fused_embed_ok(tgt):
@@ -791,6 +832,7 @@ class EncoderDecoder(nn.Module):
         v_l = enc_leaf[4:4 + nF]
         ae_l = enc_leaf[4 + nF:] if ae is not None else None
         ops.prepare_masks(b.trg_mask, b.his_mask, b.cap_mask, b.query_mask, b.fts_mask)
+        self.hoist_memory_kv(cp_l, hs_l, q_l, v_l)
         layers = []
         x_in, ae_in = x_l, ae_l
         for layer in self.decoder.layers:
@@ -799,6 +841,7 @@ class EncoderDecoder(nn.Module):
             ins = [x_in] + (list(ae_in) if isinstance(ae_in, (list, tuple)) else [])
             layers.append((ins, [x_out] + list(ae_out)))
             x_in, ae_in = cut(x_out), [cut(a) for a in ae_out]
+        self.clear_memory_kv()
         top_in = [x_in] + ae_in
         out = self.decoder.norm(x_in)
         ae_fin = [self.decoder.ae_norm[i](a) for i, a in enumerate(ae_in)]
@@ -808,6 +851,15 @@ class EncoderDecoder(nn.Module):
                query_mask, tgt, tgt_mask, auto_encoded_ft):          # mtn.py:58-60
         self.prepare()
         x0 = self.embed_target(tgt)
+        self.hoist_memory_kv(cap_memory, his_memory, query_memory, encoded_vid_features)
+        try:
+            return self._decode_layers(encoded_vid_features, vid_features_mask, x0, his_memory, his_mask, cap_memory, cap_mask,
+                                       query_memory, query_mask, tgt_mask, auto_encoded_ft)
+        finally:
+            self.clear_memory_kv()
+
+    def _decode_layers(self, encoded_vid_features, vid_features_mask, x0, his_memory, his_mask, cap_memory, cap_mask, query_memory,
+                       query_mask, tgt_mask, auto_encoded_ft):
         return self.decoder(encoded_vid_features, vid_features_mask, x0, his_memory, his_mask, cap_memory,
                             cap_mask, query_memory, query_mask, tgt_mask, auto_encoded_ft, self.auto_encoder_ft)
 

@@ -395,6 +395,7 @@ class GroupMember:
     # member's OUTPUT tensor to the sublayer that consumes it; `feeds` is the holder found on this member's INPUT tensor.
     holder: Optional[dict] = None
     feeds: Optional[dict] = None
+    kv_ready: Optional[torch.Tensor] = None     # K|V of a constant memory, projected ahead of the layer loop (project_memories)
 
 
 class SublayerGroupFn(torch.autograd.Function):
@@ -434,10 +435,11 @@ class SublayerGroupFn(torch.autograd.Function):
                 mean = torch.empty(B * a, device=dev, dtype=torch.float32)
                 rstd = torch.empty_like(mean)
                 qkv = torch.empty(B * a, 3 * d if self_attn else d, device=dev, dtype=lp)
-                kv = None if self_attn else torch.empty(B * m, 2 * d, device=dev, dtype=lp)
+                kv = None if self_attn else (mb.kv_ready if mb.kv_ready is not None else torch.empty(B * m, 2 * d, device=dev, dtype=lp))
                 o = torch.empty(B * a, d, device=dev, dtype=lp)
                 lse = torch.empty(2 * B * cfg.heads * a, device=dev, dtype=torch.float32)
                 A = mha_args[im]; im += 1
+                A.kv_ready = int((not self_attn) and mb.kv_ready is not None)
                 A.B, A.a, A.m, A.d, A.h = B, a, m, d, cfg.heads
                 A.self_attn, A.ln_eps = int(self_attn), cfg.eps
                 A.drop_attn = _drop(cfg.p_attn, cfg.salt * 4 + 0, cfg.seed)
@@ -562,6 +564,31 @@ class SublayerGroupFn(torch.autograd.Function):
                 n = lib.mtn_ffn_param_grad_work(code, C.byref(A), probs, C.byref(ln))
             members[0].cfg.queue.add(code, [probs[i] for i in range(n)], ln, keep)
         return (None, *grads_out)
+
+
+# ------------------------------------------------------------------------------------------ memory K/V, ahead of the layers
+def project_memories(items, lp_dtype, outs=None):
+    """K|V projections (mtn.py:257-258) of CONSTANT memories for many sublayers at once: items = [(mem_lp (B,m,d) compute dtype,
+    w_qkv_lp (3d,d), b_qkv (3d,) fp32)] -> list of (B*m, 2d) compute-dtype tensors.  The encoder-side memories (history,
+    caption, query, video) are the same tensors in every decoder layer, so their N x (3+F) projections do not depend on
+    anything computed inside the layer loop: they run here as a few large grouped GEMMs instead of riding in N x (3+F)
+    small per-sublayer launches (and, in the decode path, once per dialogue instead of once per token)."""
+    if not items:
+        return []
+    code = L.dtype_code(lp_dtype)
+    reuse, outs, probs = outs, [], []          # `outs`: write into these buffers (a captured graph keeps reading them)
+    for k, (mem_lp, w, b) in enumerate(items):
+        Bm = mem_lp.size(0) * mem_lp.size(1)
+        d = mem_lp.size(-1)
+        kv = reuse[k] if reuse is not None else torch.empty(Bm, 2 * d, device=mem_lp.device, dtype=lp_dtype)
+        p = L.GemmProblem()
+        p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K = mem_lp.data_ptr(), w.data_ptr() + d * d * w.element_size(), d, d, Bm, 2 * d, d
+        p.bias, p.gate_scale, p.out_lp, p.ldc = b.data_ptr() + d * b.element_size(), 1.0, kv.data_ptr(), 2 * d
+        outs.append(kv)
+        probs.append(p)
+    for i in range(0, len(probs), L.GEMM_MAX_GROUP):
+        gemm(code, probs[i:i + L.GEMM_MAX_GROUP])
+    return outs
 
 
 # ------------------------------------------------------------------------------------------ fused embeddings
