@@ -650,6 +650,138 @@ __global__ __launch_bounds__(256) void gemm_tt_dma_kernel(const GemmGroup grp) {
     }
 }
 
+// ====================================================================================================================
+// The same contraction with 128 x 128 output tiles for the large parameter-gradient launches: every operand byte pulled
+// into LDS feeds twice the outputs of the 64 x 64 kernel, which is what bounds these launches (L2 -> LDS fill).  Stage = 64
+// contraction rows x (128 + 128) features = 32 KiB, two stages = 64 KiB -> two workgroups per CU; 4 waves x (4 x 4) MFMA
+// tiles.  Rows of the [k][128 features] image are 256 B = one full sweep of the LDS banks, so the 16-byte slots are
+// XOR-swizzled with s(k) = 2*(k & 3) + 8*((k >> 3) & 1): the 8 rows one transposing read touches per LDS cycle
+// (k0..k0+3 of lane groups 0 and 1, 8 rows apart) then sit in 8 different 32-byte bank groups.
+// ====================================================================================================================
+static constexpr int TTB_KS = 64;                         // contraction rows per stage
+static constexpr int TTB_TILE_BYTES = TTB_KS * 256;       // one operand tile per stage: 64 k x 128 features x 2 B
+static constexpr int TTB_LDS = 4 * TTB_TILE_BYTES;        // 2 operands x 2 stages = 64 KiB
+
+__device__ __forceinline__ int ttb_swz(int krow) { return ((krow & 3) << 1) | (((krow >> 3) & 1) << 3); }
+
+__device__ __forceinline__ void ttb_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_tile, int ld_bytes, int R, int K,
+                                               int col0, int k0, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                    // 16 instructions per tile, 4 per wave: 4 rows of 256 B each
+        const int inst = j * 4 + wave;
+        const int krow = inst * 4 + (lane >> 4);
+        const int p = lane & 15;                                     // 16-byte slot inside the 256-byte row
+        const int c = p ^ ttb_swz(krow);                             // source chunk that lands in slot p
+        const int gk = k0 + krow, gn = col0 + c * 8;
+        unsigned voff = (gk < K && gn < R) ? (unsigned)gk * (unsigned)ld_bytes + (unsigned)gn * 2u : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + inst * 1024), 16, voff, 0, 0, 0);
+    }
+}
+
+// fragment for feature tile n_off (multiple of 16) and contraction step ks (32 rows) of a [k][128 features] image
+__device__ __forceinline__ uint4 ttb_frag(const unsigned char* img, int n_off, int ks, int l15, int lg) {
+    uint4 f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int krow = ks * 32 + 8 * lg + 4 * r + (l15 >> 2);
+        const int col = n_off + 4 * (l15 & 3);
+        const int slot = (col >> 3) ^ ttb_swz(krow);
+        const unsigned addr = (unsigned)(size_t)(img + krow * 256 + slot * 16 + (col & 7) * 2);
+        unsigned long long v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        if (r == 0) { f.x = (unsigned)v; f.y = (unsigned)(v >> 32); }
+        else { f.z = (unsigned)v; f.w = (unsigned)(v >> 32); }
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tt_dma128_kernel(const GemmGroup grp) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
+    const mtn_gemm_problem& P = grp.p[g];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = (N + 127) / 128;
+    const int t = (int)blockIdx.x - grp.tile_start[g];
+    const int row0 = (t / tiles_n) * 128, col0 = (t % tiles_n) * 128;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
+    const int lda_b = P.lda * 2, ldb_b = P.ldb * 2;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (K - 1) * lda_b + M * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (K - 1) * ldb_b + N * 2, 0x00020000);
+    const bool do_rowsum = (P.rowsum_out != nullptr) && (col0 == 0);
+
+    f32x4_t acc[4][4], rs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rs[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+
+    const int nstages = (K + TTB_KS - 1) / TTB_KS;
+    ttb_issue_tile(rA, smem, lda_b, M, K, row0, 0, wave, lane);
+    ttb_issue_tile(rB, smem + TTB_TILE_BYTES, ldb_b, N, K, col0, 0, wave, lane);
+    if (nstages > 1) {
+        ttb_issue_tile(rA, smem + 2 * TTB_TILE_BYTES, lda_b, M, K, row0, TTB_KS, wave, lane);
+        ttb_issue_tile(rB, smem + 3 * TTB_TILE_BYTES, ldb_b, N, K, col0, TTB_KS, wave, lane);
+    }
+    for (int s = 0; s < nstages; ++s) {
+        if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // 8 LDS-DMA instructions per wave per stage
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* sA = smem + (s & 1) * 2 * TTB_TILE_BYTES;
+        const unsigned char* sB = sA + TTB_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < TTB_KS / 32; ++ks) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = ttb_frag(sA, wr * 64 + i * 16, ks, l15, lg);
+                b[i] = ttb_frag(sB, wc * 64 + i * 16, ks, l15, lg);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator (vector epilogue)
+                if (do_rowsum && wc == 0) mma16<T>(rs[i], ones, a[i]);
+            }
+        }
+        if (s + 2 < nstages) {
+            __builtin_amdgcn_s_barrier();
+            unsigned char* dst = smem + (s & 1) * 2 * TTB_TILE_BYTES;
+            ttb_issue_tile(rA, dst, lda_b, M, K, row0, (s + 2) * TTB_KS, wave, lane);
+            ttb_issue_tile(rB, dst + TTB_TILE_BYTES, ldb_b, N, K, col0, (s + 2) * TTB_KS, wave, lane);
+        }
+    }
+    if (do_rowsum && wc == 0 && lg == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + wr * 64 + i * 16 + l15;
+            if (row < M) P.rowsum_out[row] = rs[i][0];
+        }
+    }
+    const DropState ds = drop_init(P.drop);
+    const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + wr * 64 + i * 16 + l15;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col0 + wc * 64 + j * 16 + lg * 4;
+            if (col >= N) continue;
+            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- launch census (measurement support, bench.py)
 // While recording, every mtn_gemm call keeps a copy of its problem list; mtn_census_replay re-issues a recorded launch so
 // that the caller can time each of the step's GEMM launches with HIP events on the launch stream.
@@ -658,10 +790,11 @@ struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GE
 static std::vector<CensusEntry> g_census;
 static bool g_census_on = false;
 static int g_variant = 0, g_variant_tiles = 0;     // set by launch_gemm: which kernel the dispatch picked
-enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_COUNT };
+enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_COUNT };
 static const char* const g_variant_name[V_COUNT] = {
     "gemm_kernel<N,N> 64x64 reg-staged", "gemm_kernel<N,T>", "gemm_kernel<T,N>", "gemm_kernel<T,T> 64x64 reg-staged",
-    "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel"};
+    "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
+    "gemm_tt_dma128_kernel"};
 
 template <typename T, int BM, int BN>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
@@ -730,7 +863,27 @@ static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, 
         for (int i = 0; i < grp.count; ++i)
             ttd = ttd && grp.p[i].M % 8 == 0 && grp.p[i].N % 8 == 0 && (long)grp.p[i].K * grp.p[i].lda * 2 < (1L << 31) &&
                   (long)grp.p[i].K * grp.p[i].ldb * 2 < (1L << 31);
-        if (ttd) {
+        bool ttb = ttd && getenv("MTN_GEMM_TT64") == nullptr;                    // 128x128 tiles when every problem fills them
+        int t128 = 0;
+        for (int i = 0; i < grp.count; ++i) {
+            ttb = ttb && grp.p[i].M >= 128 && grp.p[i].N >= 128;
+            t128 += ((grp.p[i].M + 127) / 128) * ((grp.p[i].N + 127) / 128);
+        }
+        const char* tmin = getenv("MTN_GEMM_TTB_MIN_TILES");
+        ttb = ttb && t128 >= (tmin ? atoi(tmin) : 192);
+        if (ttb) {
+            if constexpr (sizeof(T) == 2) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute((const void*)gemm_tt_dma128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TTB_LDS);
+                    attr_set = true;
+                }
+                GemmGroup g2 = grp;
+                const int tiles = retile(g2, 128, 128);
+                g_variant = V_TT_DMA128; g_variant_tiles = tiles;
+                hipLaunchKernelGGL(gemm_tt_dma128_kernel, dim3(tiles), block, TTB_LDS, s, g2);
+            }
+        } else if (ttd) {
             g_variant = V_TT_DMA;
             if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(gemm_tt_dma_kernel, grid, block, TTD_LDS, s, grp);
         } else if (big) {

@@ -108,6 +108,8 @@ class ParamGradQueue:
             cur.wait_stream(s)
         for t in self.keep:
             t.record_stream(cur)
+        # a grouped launch lasts as long as its longest contraction: keep the long ones (memories: K = B*m rows) together
+        self.gemm.sort(key=lambda p: -p.K)
         for i in range(0, len(self.gemm), L.GEMM_MAX_GROUP):
             chunk = self.gemm[i:i + L.GEMM_MAX_GROUP]
             arr = (L.GemmProblem * len(chunk))(*chunk)

@@ -331,3 +331,38 @@ def test_gemm_tt_128_tile_group(dev, dtype):
     for out, rs, ref, rsum, _keep in checks:
         assert relmax(out, ref) < 1e-4
         assert relmax(rs, rsum) < 1e-4
+
+
+def test_gemm_tt_dma_128_tile_group(dev):
+    """bf16 parameter-gradient GEMMs on the 128x128-tile LDS-DMA kernel (transposing LDS reads): grouped, ragged output sizes,
+    ragged contraction (not a multiple of the 64-row stage), row sums = bias gradients."""
+    import os
+    from mtn_amd import lib as L, ops
+    dtype = torch.bfloat16
+    os.environ["MTN_GEMM_TTB_MIN_TILES"] = "1"
+    g = torch.Generator().manual_seed(10)
+    probs, checks = [], []
+    for (M, N, K) in [(512, 512, 640), (1536, 512, 100), (200, 136, 333), (3000, 512, 64), (128, 2048, 4096)]:
+        a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        A, B = a.t().contiguous().to(dev, dtype), b.t().contiguous().to(dev, dtype)
+        out = torch.full((M, N), float("nan"), device=dev)
+        rs = torch.full((M,), float("nan"), device=dev)
+        p = _gemm_problem(L, A, B, M, N, K, 1, 1, M, N)
+        p.out_f32, p.ldc, p.rowsum_out = out.data_ptr(), N, rs.data_ptr()
+        probs.append(p)
+        ar, br = lp_round(a, dtype).double(), lp_round(b, dtype).double()
+        checks.append((out, rs, ar @ br.t(), ar.sum(1), (A, B)))
+    try:
+        L.load().mtn_census_begin()
+        ops.gemm(L.dtype_code(dtype), probs)
+        torch.cuda.synchronize()
+        assert L.load().mtn_census_end() == 1
+        info = L.CensusLaunch()
+        import ctypes as C
+        L.check(L.load().mtn_census_info(0, C.byref(info)))
+        assert L.load().mtn_census_variant_name(info.variant).decode() == "gemm_tt_dma128_kernel"
+    finally:
+        del os.environ["MTN_GEMM_TTB_MIN_TILES"]
+    for out, rs, ref, rsum, _keep in checks:
+        assert relmax(out, ref) < 1e-4
+        assert relmax(rs, rsum) < 1e-4
