@@ -110,10 +110,17 @@ class ParamGradQueue:
             t.record_stream(cur)
         # a grouped launch lasts as long as its longest contraction: keep the long ones (memories: K = B*m rows) together
         self.gemm.sort(key=lambda p: -p.K)
-        for i in range(0, len(self.gemm), L.GEMM_MAX_GROUP):
-            chunk = self.gemm[i:i + L.GEMM_MAX_GROUP]
-            arr = (L.GemmProblem * len(chunk))(*chunk)
-            L.check(lib.mtn_gemm(self.dtype, len(chunk), arr, cur.cuda_stream))
+        # ... and at most 512 of the 128x128 tiles (two resident workgroups per CU x 256 CUs) per launch: a launch that
+        # spills into a second round pays for a whole extra round
+        chunk, tiles = [], 0
+        for p in self.gemm + [None]:
+            t = 0 if p is None else ((p.M + 127) // 128) * ((p.N + 127) // 128)
+            if chunk and (p is None or len(chunk) == L.GEMM_MAX_GROUP or tiles + t > 512):
+                arr = (L.GemmProblem * len(chunk))(*chunk)
+                L.check(lib.mtn_gemm(self.dtype, len(chunk), arr, cur.cuda_stream))
+                chunk, tiles = [], 0
+            if p is not None:
+                chunk.append(p); tiles += t
         if self.ln:
             arr = (L.LnFinalizeDesc * len(self.ln))(*self.ln)
             L.check(lib.mtn_layernorm_bwd_finalize(len(self.ln), arr, cur.cuda_stream))
