@@ -14,9 +14,27 @@
 
 struct GemmGroup {
     int count;
+    int plain_tile_order;      // ablation (MTN_GEMM_PLAIN_TILES=1): row-major tile order, no XCD-aware mapping
     int tile_start[MTN_GEMM_MAX_GROUP + 1];
     mtn_gemm_problem p[MTN_GEMM_MAX_GROUP];
 };
+
+// XCD-aware tile mapping.  Workgroups are dealt to the 8 XCDs round-robin (id % 8) and every XCD has its own L2, so the
+// operand panels a problem's workgroups share are fetched once PER XCD that touches them.  Local workgroup t of a problem
+// (global id first_id + t) is mapped so that the workgroups of one XCD cover a contiguous band of tiles — bands of output
+// rows when the row operand is the larger one (its panels are then read by one XCD each), bands of columns otherwise.
+// A bijection on [0, T) for any T and any first_id; placement is only a performance assumption, never a correctness one.
+__device__ __forceinline__ void xcd_tile(const GemmGroup& grp, int g, int t, int T, int tiles_m, int tiles_n, bool row_band, int& tm, int& tn) {
+    int idx = t;
+    if (!grp.plain_tile_order && T >= 16) {
+        const int c = t & 7, r = t >> 3;                     // class (same XCD) in order of first appearance, rank inside it
+        const int per = T >> 3, rem = T & 7;
+        idx = c * per + (c < rem ? c : rem) + r;
+    }
+    (void)g;
+    if (row_band) { tm = idx / tiles_n; tn = idx - tm * tiles_n; }
+    else { tn = idx / tiles_m; tm = idx - tn * tiles_m; }
+}
 
 static constexpr int TILE = 64;
 static constexpr int LDSROW = 144;  // bytes per LDS tile row (128 data + 16 pad)
@@ -157,7 +175,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
     const int M = P.M, N = P.N, K = P.K;
     const int tiles_n = (N + TILE - 1) / TILE;
     const int t = (int)blockIdx.x - grp.tile_start[g];
-    const int row0 = (t / tiles_n) * TILE, col0 = (t % tiles_n) * TILE;
+    const int tiles_m = (M + TILE - 1) / TILE;
+    int tm_, tn_;
+    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
+    const int row0 = tm_ * TILE, col0 = tn_ * TILE;
     const T* __restrict__ A = (const T*)P.A;
     const T* __restrict__ B = (const T*)P.B;
     const bool do_rowsum = (P.rowsum_out != nullptr) && (col0 == 0);
@@ -307,7 +328,10 @@ __global__ __launch_bounds__(256) void gemm_tt128_kernel(const GemmGroup grp) {
     const int M = P.M, N = P.N, K = P.K;
     const int tiles_n = (N + BT - 1) / BT;
     const int t = (int)blockIdx.x - grp.tile_start[g];
-    const int row0 = (t / tiles_n) * BT, col0 = (t % tiles_n) * BT;
+    const int tiles_m = (M + BT - 1) / BT;
+    int tm_, tn_;
+    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
+    const int row0 = tm_ * BT, col0 = tn_ * BT;
     const T* __restrict__ A = (const T*)P.A;
     const T* __restrict__ B = (const T*)P.B;
     const bool do_rowsum = (P.rowsum_out != nullptr) && (col0 == 0);
@@ -428,7 +452,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     const int M = P.M, N = P.N, K = P.K;
     const int tiles_n = (N + BN - 1) / BN;
     const int t = (int)blockIdx.x - grp.tile_start[g];
-    const int row0 = (t / tiles_n) * BM, col0 = (t % tiles_n) * BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    int tm_, tn_;
+    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
+    const int row0 = tm_ * BM, col0 = tn_ * BN;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
@@ -573,7 +600,10 @@ __global__ __launch_bounds__(256) void gemm_tt_dma_kernel(const GemmGroup grp) {
     const int M = P.M, N = P.N, K = P.K;
     const int tiles_n = (N + 63) / 64;
     const int t = (int)blockIdx.x - grp.tile_start[g];
-    const int row0 = (t / tiles_n) * 64, col0 = (t % tiles_n) * 64;
+    const int tiles_m = (M + 64 - 1) / 64;
+    int tm_, tn_;
+    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
+    const int row0 = tm_ * 64, col0 = tn_ * 64;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
@@ -705,7 +735,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_dma128_kernel(const GemmGroup 
     const int M = P.M, N = P.N, K = P.K;
     const int tiles_n = (N + 127) / 128;
     const int t = (int)blockIdx.x - grp.tile_start[g];
-    const int row0 = (t / tiles_n) * 128, col0 = (t % tiles_n) * 128;
+    const int tiles_m = (M + 128 - 1) / 128;
+    int tm_, tn_;
+    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
+    const int row0 = tm_ * 128, col0 = tn_ * 128;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
@@ -782,6 +815,109 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_dma128_kernel(const GemmGroup 
     }
 }
 
+// ====================================================================================================================
+// Row-major x row-major (both operands contraction-contiguous) with 128 x 128 output tiles, for launches with enough tiles
+// to fill the chip (memory K/V projections of all layers, the loss head, the memory-gradient groups): half the operand bytes
+// per output of the 64 x 64 kernels.  Stage = (128 + 128) rows x 64 contraction elements (128 B per row) = 32 KiB, two stages,
+// two workgroups per CU, 4 waves x (4 x 4) MFMA tiles.  128-byte rows: two rows per sweep of the LDS banks, 16-byte slots
+// XOR-swizzled with (row & 7) -> the 16 lanes one ds_read_b128 cycle serves hit 16 different slots.
+// ====================================================================================================================
+static constexpr int NTB_BK = 64;                          // contraction elements per stage (bf16)
+static constexpr int NTB_TILE_BYTES = 128 * 128;           // one operand tile per stage: 128 rows x 128 B
+static constexpr int NTB_LDS = 4 * NTB_TILE_BYTES;         // 64 KiB
+
+__device__ __forceinline__ void ntb_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_tile, int ld_bytes, int R, int K,
+                                               int row0, int k0, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                    // 16 instructions per tile, 4 per wave: 8 rows of 128 B each
+        const int inst = j * 4 + wave;
+        const int row = inst * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);                        // source chunk that lands in slot (lane & 7)
+        const int gk = k0 + c * 8;
+        int grow = row0 + row;
+        grow = grow < R ? grow : R - 1;                              // rows past the end only feed outputs that are never stored
+        unsigned voff = (gk < K) ? (unsigned)grow * (unsigned)ld_bytes + (unsigned)gk * 2u : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + inst * 1024), 16, voff, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmGroup grp) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
+    const mtn_gemm_problem& P = grp.p[g];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = (N + 127) / 128;
+    const int t = (int)blockIdx.x - grp.tile_start[g];
+    const int tiles_m = (M + 128 - 1) / 128;
+    int tm_, tn_;
+    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
+    const int row0 = tm_ * 128, col0 = tn_ * 128;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
+    const int lda_b = P.lda * 2, ldb_b = P.ldb * 2;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (M - 1) * lda_b + K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (N - 1) * ldb_b + K * 2, 0x00020000);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nstages = (K + NTB_BK - 1) / NTB_BK;
+    ntb_issue_tile(rA, smem, lda_b, M, K, row0, 0, wave, lane);
+    ntb_issue_tile(rB, smem + NTB_TILE_BYTES, ldb_b, N, K, col0, 0, wave, lane);
+    if (nstages > 1) {
+        ntb_issue_tile(rA, smem + 2 * NTB_TILE_BYTES, lda_b, M, K, row0, NTB_BK, wave, lane);
+        ntb_issue_tile(rB, smem + 3 * NTB_TILE_BYTES, ldb_b, N, K, col0, NTB_BK, wave, lane);
+    }
+    const DropState ds = drop_init(P.drop);
+    for (int s = 0; s < nstages; ++s) {
+        if (s + 1 < nstages) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // 8 LDS-DMA instructions per wave per stage
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* sA = smem + (s & 1) * 2 * NTB_TILE_BYTES;
+        const unsigned char* sB = sA + NTB_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                               // 32 contraction elements = one 16-byte chunk per lane group
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wr * 64 + i * 16 + l15, rb = wc * 64 + i * 16 + l15;
+                a[i] = *(const uint4*)(sA + ra * 128 + (((ks * 4 + lg) ^ (ra & 7)) << 4));
+                b[i] = *(const uint4*)(sB + rb * 128 + (((ks * 4 + lg) ^ (rb & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator (vector epilogue)
+        }
+        if (s + 2 < nstages) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            unsigned char* dst = smem + (s & 1) * 2 * NTB_TILE_BYTES;
+            ntb_issue_tile(rA, dst, lda_b, M, K, row0, (s + 2) * NTB_BK, wave, lane);
+            ntb_issue_tile(rB, dst + NTB_TILE_BYTES, ldb_b, N, K, col0, (s + 2) * NTB_BK, wave, lane);
+        }
+    }
+    const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + wr * 64 + i * 16 + l15;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = col0 + wc * 64 + j * 16 + lg * 4;
+            if (col >= N) continue;
+            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- launch census (measurement support, bench.py)
 // While recording, every mtn_gemm call keeps a copy of its problem list; mtn_census_replay re-issues a recorded launch so
 // that the caller can time each of the step's GEMM launches with HIP events on the launch stream.
@@ -790,11 +926,11 @@ struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GE
 static std::vector<CensusEntry> g_census;
 static bool g_census_on = false;
 static int g_variant = 0, g_variant_tiles = 0;     // set by launch_gemm: which kernel the dispatch picked
-enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_COUNT };
+enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_DMA128, V_COUNT };
 static const char* const g_variant_name[V_COUNT] = {
     "gemm_kernel<N,N> 64x64 reg-staged", "gemm_kernel<N,T>", "gemm_kernel<T,N>", "gemm_kernel<T,T> 64x64 reg-staged",
     "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
-    "gemm_tt_dma128_kernel"};
+    "gemm_tt_dma128_kernel", "gemm_dma128_kernel"};
 
 template <typename T, int BM, int BN>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
@@ -828,6 +964,34 @@ static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, 
     dim3 grid(total_tiles), block(256);
     g_variant_tiles = total_tiles;
     g_variant = at ? (bt ? V_REG_TT : V_REG_TN) : (bt ? V_REG_NT : V_REG_NN);
+    if constexpr (sizeof(T) == 2) {
+        // 128x128 row-major tiles: measured 330-350 TFLOP/s on the memory K/V launches against 370-400 for the 64x64
+        // register-staged kernel at 5 workgroups per CU (K = 512 is too short to amortise a 16-fragment epilogue at two
+        // workgroups per CU) -> opt-in (MTN_GEMM_NTB_MIN_TILES=<tiles>), kept for larger contractions
+        if (!at && !bt && getenv("MTN_GEMM_NTB_MIN_TILES") != nullptr) {
+            bool ok = true;
+            int t128 = 0;
+            for (int i = 0; i < grp.count; ++i) {
+                const mtn_gemm_problem& q = grp.p[i];
+                ok = ok && !q.rowsum_out && q.K % 8 == 0 && (long)q.M * q.lda * 2 < (1L << 31) && (long)q.N * q.ldb * 2 < (1L << 31);
+                t128 += ((q.M + 127) / 128) * ((q.N + 127) / 128);
+            }
+            const char* tmin = getenv("MTN_GEMM_NTB_MIN_TILES");
+            if (ok && t128 >= atoi(tmin)) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute((const void*)gemm_dma128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NTB_LDS);
+                    attr_set = true;
+                }
+                GemmGroup g2 = grp;
+                const int tiles = retile(g2, 128, 128);
+                g_variant = V_DMA128; g_variant_tiles = tiles;
+                hipLaunchKernelGGL(gemm_dma128_kernel, dim3(tiles), block, NTB_LDS, s, g2);
+                MTN_CHECK_LAUNCH();
+                return MTN_OK;
+            }
+        }
+    }
     if (!at && !bt && dma_ok) {
         // Tile choice by the bytes ONE CU has to pull (the bound of these launches, ~27 GB/s per CU): 64x64 tiles run one
         // workgroup per CU in ceil(tiles/256) rounds of (64+64)*K bytes; 32x32 tiles spread 4x the workgroups of half the
@@ -904,6 +1068,7 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     GemmGroup grp;
     memset(&grp, 0, sizeof(grp));
     grp.count = count;
+    grp.plain_tile_order = getenv("MTN_GEMM_PLAIN_TILES") != nullptr;
     int tiles = 0;
     const int align = (dtype == MTN_BF16) ? 8 : 4;
     for (int i = 0; i < count; ++i) {

@@ -366,3 +366,29 @@ def test_gemm_tt_dma_128_tile_group(dev):
     for out, rs, ref, rsum, _keep in checks:
         assert relmax(out, ref) < 1e-4
         assert relmax(rs, rsum) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 72), (128, 1024, 512), (1000, 136, 1000)])
+def test_gemm_dma_128_tile_row_major(dev, M, N, K):
+    """The opt-in 128x128-tile LDS-DMA kernel for row-major x row-major problems (ragged M/N, K not a multiple of the
+    64-element stage, bias + ReLU + residual epilogue, fp32 and bf16 outputs)."""
+    import os
+    from mtn_amd import lib as L, ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    A, B = a.to(dev, dtype), b.to(dev, dtype)
+    out = torch.full((M, N), float("nan"), device=dev)
+    out_lp = torch.empty(M, N, device=dev, dtype=dtype)
+    bd, rd = bias.to(dev), res.to(dev)
+    p = _gemm_problem(L, A, B, M, N, K, 0, 0, K, K)
+    p.bias, p.relu, p.residual, p.ldr, p.out_f32, p.out_lp, p.ldc = bd.data_ptr(), 1, rd.data_ptr(), N, out.data_ptr(), out_lp.data_ptr(), N
+    os.environ["MTN_GEMM_NTB_MIN_TILES"] = "1"
+    try:
+        ops.gemm(L.dtype_code(dtype), [p])
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["MTN_GEMM_NTB_MIN_TILES"]
+    ref = torch.relu(lp_round(a, dtype).double() @ lp_round(b, dtype).double().t() + bias.double()) + res.double()
+    assert relmax(out, ref) < 1e-4 and relmax(out_lp.float(), ref) < 1e-2
