@@ -110,10 +110,12 @@ class DeviceCorpus:
         return n + sum(t.numel() * t.element_size() for f in self.feat for t in f[:3])
 
 
-def make_batch(corpus: DeviceCorpus, index, vocab, separate_caption: bool = False, skip: Sequence[int] = (1, 1, 1)) -> Batch:
+def make_batch(corpus: DeviceCorpus, index, vocab, separate_caption: bool = False, skip: Sequence[int] = (1, 1, 1),
+               out: Batch = None) -> Batch:
     """data_handler.py:219-274 on the device: ``index`` is one entry of make_batch_indices; ``vocab`` the vocabulary dict
     (its '<blank>' is the pad id) or the pad id itself.  Returns the same Batch the reference builds (fields, shapes,
-    dtypes, mask semantics), with the masks' kernel images already attached."""
+    dtypes, mask semantics), with the masks' kernel images already attached.  ``out``: a Batch made by an earlier call with
+    the same padded lengths and size — its tensors are refilled in place (what a captured hipGraph keeps reading)."""
     pad = int(vocab["<blank>"]) if isinstance(vocab, dict) else int(vocab)
     if separate_caption:
         x_len, h_len, q_len, a_len, c_len, n = index[2:]
@@ -125,14 +127,26 @@ def make_batch(corpus: DeviceCorpus, index, vocab, separate_caption: bool = Fals
     ids = torch.tensor(list(index[1]), dtype=torch.int32).to(dev, non_blocking=True)
     plan = [("query", q_len), ("his", h_len), ("trg", a_len), ("trg_y", a_len)] + ([("cap", c_len)] if separate_caption else [])
     descs = (L.AssembleTokensDesc * len(plan))()
+    reuse = out
     out: Dict[str, torch.Tensor] = {}
     masks: Dict[str, torch.Tensor] = {}
-    ntok = torch.zeros(1, dtype=torch.int64, device=dev)
-    std = torch.empty(n, a_len, a_len, dtype=torch.uint8, device=dev)
+    if reuse is None:
+        ntok = torch.zeros(1, dtype=torch.int64, device=dev)
+        std = torch.empty(n, a_len, a_len, dtype=torch.uint8, device=dev)
+    else:
+        ntok, std = reuse._ntok, reuse.trg_mask._mtn_u8
+        ntok.zero_()
+        assert tuple(std.shape) == (n, a_len, a_len), "out= batch has other padded lengths"
     for k, (name, Lf) in enumerate(plan):
         flat, start, lens = corpus.tok[name]
-        out[name] = torch.empty(n, Lf, dtype=torch.int64, device=dev)
-        masks[name] = torch.empty(n, Lf, dtype=torch.uint8, device=dev)
+        if reuse is None:
+            out[name] = torch.empty(n, Lf, dtype=torch.int64, device=dev)
+            masks[name] = torch.empty(n, Lf, dtype=torch.uint8, device=dev)
+        else:
+            out[name] = getattr(reuse, name)
+            masks[name] = (reuse.trg_pad_u8 if name == "trg" else reuse.trg_y_pad_u8 if name == "trg_y"
+                           else getattr(reuse, name + "_mask")._mtn_u8.view(n, Lf))
+            assert tuple(out[name].shape) == (n, Lf), "out= batch has other padded lengths"
         D = descs[k]
         D.flat, D.start, D.len, D.ids, D.B, D.L, D.pad = flat.data_ptr(), start.data_ptr(), lens.data_ptr(), ids.data_ptr(), n, Lf, pad
         D.out, D.mask = out[name].data_ptr(), masks[name].data_ptr()
@@ -149,16 +163,23 @@ def make_batch(corpus: DeviceCorpus, index, vocab, separate_caption: bool = Fals
         for i, (flat, start, lens, F) in enumerate(corpus.feat):
             sk = int(skip[i]) if i < len(skip) else 1
             V = int(x_len[i])            # the reference pads to the UNskipped longest video (data_handler.py:236)
-            o = torch.empty(n, V, F, dtype=torch.float32, device=dev)
-            mk = torch.empty(n, V, dtype=torch.uint8, device=dev)
+            if reuse is None:
+                o = torch.empty(n, V, F, dtype=torch.float32, device=dev)
+                mk = torch.empty(n, V, dtype=torch.uint8, device=dev)
+            else:
+                o, mk = reuse.fts[i], reuse.fts_mask[i]._mtn_u8.view(n, V)
+                assert tuple(o.shape) == (n, V, F), "out= batch has other padded lengths"
             D = fd[i]
             D.flat, D.start, D.len, D.ids, D.B, D.V, D.F, D.skip = flat.data_ptr(), start.data_ptr(), lens.data_ptr(), vids.data_ptr(), n, V, F, sk
             D.out, D.mask = o.data_ptr(), mk.data_ptr()
             fts.append(o); fmask.append(mk)
         L.check(lib.mtn_assemble_features(len(corpus.feat), fd, L.stream_ptr()))
         fts_mask = [_as_bool(mk.unsqueeze(-2)) for mk in fmask]
+    if reuse is not None:
+        return reuse
 
     b = Batch.__new__(Batch)
+    b._ntok, b.trg_pad_u8, b.trg_y_pad_u8 = ntok, masks["trg"], masks["trg_y"]
     b.query, b.his, b.his_st = out["query"], out["his"], None
     b.fts, b.fts_mask = fts, fts_mask
     b.query_mask, b.his_mask = _as_bool(masks["query"].unsqueeze(-2)), _as_bool(masks["his"].unsqueeze(-2))

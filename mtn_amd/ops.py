@@ -9,6 +9,7 @@ for device memory, streams and autograd bookkeeping only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -18,6 +19,9 @@ from . import lib as L
 
 
 # ------------------------------------------------------------------------------------------ helpers
+_XACC = os.environ.get("MTN_NO_XACC") != "1"
+
+
 def _drop(p: float, salt: int, seed: Optional[torch.Tensor]) -> L.Dropout:
     if p > 0.0 and seed is not None:
         return L.Dropout(float(p), int(salt) & 0xFFFFFFFF, seed.data_ptr())
@@ -427,6 +431,14 @@ class SublayerGroupFn(torch.autograd.Function):
         ffn_args = (L.FfnArgs * max(1, n_ffn))()
         saved, ys = [], []
         im = jf = 0
+        xaccs = []
+        for x_orig in tensors[0::2]:
+            # an input that an EARLIER sublayer already attends as memory (an auto-encoder output feeds the next layer's chain
+            # and is the memory of x's attention): both gradients meet in one buffer instead of an autograd add
+            xg = getattr(x_orig, "_mtn_gacc", None) if (_XACC and torch.is_grad_enabled() and x_orig.requires_grad) else None
+            if xg is not None:
+                xg["remaining"] += 1
+            xaccs.append(xg)
         for mem_t, x, mb in zip(mems, xs, members):
             cfg = mb.cfg
             ln_a, ln_b = mb.params[0], mb.params[1]
@@ -489,6 +501,7 @@ class SublayerGroupFn(torch.autograd.Function):
             ys.append(y)
         L.check(lib.mtn_sublayer_group_fwd(code, n_mha, mha_args, n_ffn, ffn_args, L.stream_ptr()))
         ctx.members, ctx.saved_bufs, ctx.code = members, saved, code
+        ctx.xaccs = xaccs
         ctx.mha_args, ctx.ffn_args, ctx.n_mha, ctx.n_ffn = mha_args, ffn_args, n_mha, n_ffn
         return tuple(ys)
 
@@ -500,12 +513,24 @@ class SublayerGroupFn(torch.autograd.Function):
         grads_out, keep_all = [], []
         im = jf = 0
         work = []
-        for dy, mb, sv in zip(dys, members, saved):
+        post = []                    # (buffer, dx) pairs to sum after the launch: input-role accumulators that were not first
+        for dy, mb, sv, xg in zip(dys, members, saved, ctx.xaccs):
             cfg, g = mb.cfg, mb.cfg.grads
             x = sv["x"]
             dev = x.device
             dy = dy.contiguous() if dy is not None else torch.zeros_like(x)
             dx = torch.empty_like(x)
+            dx_ret = dx
+            if xg is not None:           # see forward: the gradient of this input is collected in a shared buffer
+                xg["remaining"] -= 1
+                if xg["buf"] is None and xg["remaining"] > 0:
+                    xg["buf"], dx_ret = dx, None                      # first writer: the memory-role users accumulate into our dx
+                elif xg["buf"] is not None:
+                    buf = xg["buf"]
+                    post.append((buf, dx))
+                    dx_ret = None
+                    if xg["remaining"] == 0:
+                        dx_ret, xg["buf"] = buf, None
             # hand-off, consumer side: the sublayer that ran before us in backward already wrote dy through OUR output dropout
             ready = None
             h = mb.holder
@@ -518,7 +543,7 @@ class SublayerGroupFn(torch.autograd.Function):
             # producer side: write our dx also as the next sublayer's masked compute-dtype dy
             nxt = None
             f = mb.feeds
-            if f is not None and f.get("lp") == cfg.lp_dtype:
+            if f is not None and f.get("lp") == cfg.lp_dtype and xg is None:
                 nxt = torch.empty(x.shape, device=dev, dtype=cfg.lp_dtype)
                 f["dyl"], f["dx"], f["ver"] = nxt, dx, dx._version     # holding dx also keeps autograd from summing into it in place
             if mb.kind == "mha":
@@ -544,7 +569,7 @@ class SublayerGroupFn(torch.autograd.Function):
                 A.dyl_ready, A.next_dyl = L.ptr(ready), L.ptr(nxt)
                 if nxt is not None:
                     A.next_drop = _drop(f["p"], f["salt"], f["seed"])
-                grads_out += [dx, dmem_ret]
+                grads_out += [dx_ret, dmem_ret]
                 keep = [dy, ws_lp, ws_f32, sv["o"], sv["xn"]] + ([sv["mem_lp"]] if sv["mem_lp"] is not None else []) + ([ready] if ready is not None else [])
                 work.append(("mha", A, keep))
             else:
@@ -559,11 +584,13 @@ class SublayerGroupFn(torch.autograd.Function):
                 A.dyl_ready, A.next_dyl = L.ptr(ready), L.ptr(nxt)
                 if nxt is not None:
                     A.next_drop = _drop(f["p"], f["salt"], f["seed"])
-                grads_out += [dx, None]
+                grads_out += [dx_ret, None]
                 keep = [dy, ws_lp, ws_f32, sv["hid"], sv["xn"]] + ([ready] if ready is not None else [])
                 work.append(("ffn", A, keep))
             keep_all.append(dy)
         L.check(lib.mtn_sublayer_group_bwd(code, ctx.n_mha, mha_args, ctx.n_ffn, ffn_args, L.stream_ptr()))
+        for buf, dxp in post:
+            buf.add_(dxp)
         for kind, A, keep in work:
             probs = (L.GemmProblem * 3)()
             ln = L.LnFinalizeDesc()

@@ -60,6 +60,8 @@ def parse(argv=None):
     p.add_argument("--vocab-size", default=3000, type=int, help="synthetic mode")
     p.add_argument("--ft-sizes", default=[2048, 128], nargs="+", type=int, help="synthetic mode: feature dims")
     p.add_argument("--lens", default=[20, 128, 40, 20, 32], nargs=5, type=int, help="synthetic mode: Q H C T frames")
+    p.add_argument("--eager", action="store_true", help="corpus mode: one eager step per batch instead of captured graphs per padded shape")
+    p.add_argument("--bucket", default=8, type=int, help="corpus mode: batch lengths are rounded up to multiples of this")
     p.add_argument("--corpus-videos", default=0, type=int,
                    help="> 0: train on a synthetic ragged CORPUS of that many videos (10 turns each) through the reference's "
                         "epoch loop — batch planning, device-side batch assembly, one eager step per batch — instead of "
@@ -85,6 +87,27 @@ def synthetic_corpus(n_videos, vocab, ft_sizes, seed, turns=10):
             qa += 1
     feats = [{v: rs.randn(rs.randint(20, 41), F).astype(np.float32) for v in vids} for F in ft_sizes]
     return {"dialogs": dialogs, "features": feats, "vocab": {"<blank>": 1}}
+
+
+def run_epoch_graphed(trainer, indices, epoch, report_interval, rank, rng):
+    """The same epoch on captured graphs (train_step.BucketedTrainer): lengths rounded up to the bucket, one graph per padded
+    shape, batches assembled in place on the device; the host only syncs at the report interval."""
+    order = list(range(len(indices)))
+    rng.shuffle(order)
+    dev = trainer.corpus.device
+    loss_sum = torch.zeros((), device=dev)
+    tok_sum = torch.zeros((), device=dev, dtype=torch.int64)
+    t0, tok0 = time.time(), 0
+    for j, k in enumerate(order):
+        loss, b = trainer.step(indices[k])
+        loss_sum += loss * b._ntok[0]            # the step's loss is already divided by its token counts (train.py:36)
+        tok_sum += b._ntok[0]
+        if (j + 1) % report_interval == 0 and rank == 0:
+            ntok = int(tok_sum)
+            dt = time.time() - t0
+            print("Epoch: %d Step: %d Loss: %f Tokens per Sec: %f" % (epoch + 1, j + 1, float(loss), (ntok - tok0) / dt))
+            t0, tok0 = time.time(), ntok
+    return float(loss_sum) / max(1, int(tok_sum))
 
 
 def run_epoch(corpus, indices, model, loss_compute, ae_ft, epoch, report_interval, rank, rng):
@@ -138,13 +161,21 @@ def main(argv=None):
         indices = indices[rank::world]                     # data parallel: every rank takes its share of the planned batches
         corpus = DeviceCorpus(data, dev)
         logging.info("corpus: %d dialogs in %d batches, %.1f MB resident on the device", n_samples, len(indices), corpus.nbytes() / 1e6)
-        opt = NoamOpt(args.d_model, 1, args.warmup_steps, FusedAdam(model))
-        lc = SimpleLossCompute(model.generator, model.auto_encoder_generator, LabelSmoothing(args.vocab_size, 1, 0.1), opt=opt,
-                               l=args.loss_l, grad_sync=sync)
         rng = random.Random(args.rand_seed)
         means = []
+        if args.eager:
+            opt = NoamOpt(args.d_model, 1, args.warmup_steps, FusedAdam(model))
+            lc = SimpleLossCompute(model.generator, model.auto_encoder_generator, LabelSmoothing(args.vocab_size, 1, 0.1), opt=opt,
+                                   l=args.loss_l, grad_sync=sync)
+        else:
+            from .train_step import BucketedTrainer
+            trainer = BucketedTrainer(model, corpus, args.vocab_size, pad=1, warmup=args.warmup_steps, lam=args.loss_l,
+                                      bucket=args.bucket, grad_sync=sync)
         for epoch in range(args.num_epochs):
-            mean = run_epoch(corpus, indices, model, lc, args.auto_encoder_ft, epoch, args.report_interval, rank, rng)
+            if args.eager:
+                mean = run_epoch(corpus, indices, model, lc, args.auto_encoder_ft, epoch, args.report_interval, rank, rng)
+            else:
+                mean = run_epoch_graphed(trainer, indices, epoch, args.report_interval, rank, rng)
             means.append(mean)
             if rank == 0:
                 print("epoch %d mean train loss per token: %f" % (epoch + 1, mean))

@@ -21,9 +21,14 @@ from .data_utils import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
 
 class TrainStep:
     def __init__(self, model, batch, vocab: int, pad: int = 1, warmup: int = 4000, factor: float = 1.0, lam: float = 1.0,
-                 smoothing: float = 0.1, grad_sync=None, use_graph: bool = True, overlap: Optional[bool] = None):
+                 smoothing: float = 0.1, grad_sync=None, use_graph: bool = True, overlap: Optional[bool] = None, opt=None,
+                 dynamic_norms: bool = False):
+        """``opt``: share an existing NoamOpt (several TrainSteps over one model, e.g. one per batch shape).
+        ``dynamic_norms``: the batch tensors are refilled in place between steps, so the loss normalisers (token counts,
+        train.py:35-39) are recomputed from them inside the step instead of once at construction."""
         self.model, self.batch = model, batch
-        self.opt = NoamOpt(model.decoder.layers[0].size, factor, warmup, FusedAdam(model))
+        self.opt = opt if opt is not None else NoamOpt(model.decoder.layers[0].size, factor, warmup, FusedAdam(model))
+        self.dynamic_norms = dynamic_norms
         self.crit = LabelSmoothing(vocab, pad, smoothing)
         self.lc = SimpleLossCompute(model.generator, model.auto_encoder_generator, self.crit, opt=None, l=lam, sync=False)
         self.grad_sync = grad_sync
@@ -45,8 +50,16 @@ class TrainStep:
             grad_sync.all_reduce_scalars(self._norms)
 
     # ---- pieces
+    def _refresh_norms(self):
+        if self.dynamic_norms:
+            b = self.batch
+            self._norms.copy_(torch.stack([(b.trg_y != self.pad).sum(), (self._ae_y != self.pad).sum()]).float())
+            if self.grad_sync is not None:
+                self.grad_sync.all_reduce_scalars(self._norms)
+
     def _fwd_bwd(self):
         m, b = self.model, self.batch
+        self._refresh_norms()
         m.zero_glue_grads()
         out, ae_out = m.forward(b)
         loss = self.lc.loss(out, b.trg_y, self._norms[0], ae_out, self._ae_y, self._norms[1])
@@ -73,6 +86,7 @@ class TrainStep:
 
         def top():
             b = self.batch
+            self._refresh_norms()
             m.zero_glue_grads()
             st = m.forward_segmented(b)
             self._st = st
@@ -184,3 +198,40 @@ class TrainStep:
             self.grad_sync()
             self._g_opt.replay()
         return self._loss
+
+
+class BucketedTrainer:
+    """The reference's per-batch loop body (train.py:29-40) for batches of VARYING shape, on captured graphs: batch lengths
+    are rounded up to multiples of ``bucket`` (padding is masked everywhere on the path, so the real tokens see the same
+    arithmetic), one static Batch + one captured TrainStep is kept per padded shape, and every step refills that Batch in
+    place on the device (data_handler.make_batch(out=...)) and replays its graph.  One optimiser state for all shapes."""
+
+    def __init__(self, model, corpus, vocab_size: int, pad: int = 1, warmup: int = 4000, lam: float = 1.0, bucket: int = 8,
+                 grad_sync=None, max_shapes: int = 64):
+        self.model, self.corpus, self.vocab, self.pad, self.lam = model, corpus, vocab_size, pad, lam
+        self.bucket, self.grad_sync, self.max_shapes = bucket, grad_sync, max_shapes
+        self.opt = NoamOpt(model.decoder.layers[0].size, 1.0, warmup, FusedAdam(model))
+        self.steps = {}
+
+    def _padded(self, index):
+        up = lambda v: -(-int(v) // self.bucket) * self.bucket
+        x_len, h_len, q_len, a_len, c_len, n = index[2:]
+        return (index[0], index[1], [up(v) for v in x_len], up(h_len), up(q_len), up(a_len), up(c_len), n)
+
+    def step(self, index):
+        """One optimiser step on the batch described by ``index`` (an entry of data_handler.make_batch_indices with
+        separate_caption=True).  Returns (device loss tensor, the static Batch that now holds this batch)."""
+        from .data_handler import make_batch
+        pidx = self._padded(index)
+        key = (tuple(pidx[2]),) + tuple(pidx[3:])
+        hit = self.steps.get(key)
+        if hit is None:
+            if len(self.steps) >= self.max_shapes:
+                self.steps.pop(next(iter(self.steps)))
+            batch = make_batch(self.corpus, pidx, self.pad, separate_caption=True)
+            ts = TrainStep(self.model, batch, self.vocab, pad=self.pad, lam=self.lam, grad_sync=self.grad_sync, opt=self.opt,
+                           dynamic_norms=True)
+            self.steps[key] = hit = (batch, ts)
+        else:
+            make_batch(self.corpus, pidx, self.pad, separate_caption=True, out=hit[0])
+        return hit[1](), hit[0]
