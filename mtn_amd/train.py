@@ -60,6 +60,9 @@ def parse(argv=None):
     p.add_argument("--vocab-size", default=3000, type=int, help="synthetic mode")
     p.add_argument("--ft-sizes", default=[2048, 128], nargs="+", type=int, help="synthetic mode: feature dims")
     p.add_argument("--lens", default=[20, 128, 40, 20, 32], nargs=5, type=int, help="synthetic mode: Q H C T frames")
+    p.add_argument("--valid-videos", default=0, type=int,
+                   help="corpus mode: a held-out synthetic corpus of that many videos; its mean loss per token is evaluated in eval() mode "
+                        "after every epoch and the best model is kept as <model>_best (train.py:201-224)")
     p.add_argument("--eager", action="store_true", help="corpus mode: one eager step per batch instead of captured graphs per padded shape")
     p.add_argument("--bucket", default=8, type=int, help="corpus mode: batch lengths are rounded up to multiples of this")
     p.add_argument("--corpus-videos", default=0, type=int,
@@ -108,6 +111,26 @@ def run_epoch_graphed(trainer, indices, epoch, report_interval, rank, rng):
             print("Epoch: %d Step: %d Loss: %f Tokens per Sec: %f" % (epoch + 1, j + 1, float(loss), (ntok - tok0) / dt))
             t0, tok0 = time.time(), ntok
     return float(loss_sum) / max(1, int(tok_sum))
+
+
+def validate(corpus, indices, model, criterion, ae_ft, lam):
+    """train.py:201-210: the epoch loop with the model in eval() mode and no optimiser — mean loss per target token."""
+    from .data_handler import make_batch
+    from .data_utils import SimpleLossCompute
+    lc = SimpleLossCompute(model.generator, model.auto_encoder_generator, criterion, opt=None, l=lam, sync=False)
+    was_training = model.training
+    model.eval()
+    total = torch.zeros((), device=corpus.device)
+    tokens = torch.zeros((), device=corpus.device, dtype=torch.int64)
+    with torch.no_grad():
+        for ix in indices:
+            b = make_batch(corpus, ix, 1, separate_caption=True)
+            out, ae_out = model.forward(b)
+            ae_y = b.cap if ae_ft in ("caption", "summary") else b.query
+            total += lc(out, b.trg_y, b.ntokens, ae_out, ae_y, (ae_y != 1).sum())
+            tokens += b.ntokens
+    model.train(was_training)
+    return float(total) / max(1, int(tokens))
 
 
 def run_epoch(corpus, indices, model, loss_compute, ae_ft, epoch, report_interval, rank, rng):
@@ -171,6 +194,13 @@ def main(argv=None):
             from .train_step import BucketedTrainer
             trainer = BucketedTrainer(model, corpus, args.vocab_size, pad=1, warmup=args.warmup_steps, lam=args.loss_l,
                                       bucket=args.bucket, grad_sync=sync)
+        valid = None
+        if args.valid_videos > 0:
+            vdata = synthetic_corpus(args.valid_videos, args.vocab_size, args.ft_sizes, args.rand_seed + 1000)
+            vidx, vn = make_batch_indices(vdata, batchsize=args.batch_size, max_length=256, separate_caption=True)
+            valid = (DeviceCorpus(vdata, dev), vidx)
+            logging.info("#validation sample = %d  #validation batch = %d", vn, len(vidx))
+        min_valid = 1.0e10
         for epoch in range(args.num_epochs):
             if args.eager:
                 mean = run_epoch(corpus, indices, model, lc, args.auto_encoder_ft, epoch, args.report_interval, rank, rng)
@@ -181,6 +211,16 @@ def main(argv=None):
                 print("epoch %d mean train loss per token: %f" % (epoch + 1, mean))
             if args.model and rank == 0:
                 torch.save(model.state_dict(), f"{args.model}_{epoch + 1}.pth.tar")
+            if valid is not None:
+                from .data_utils import LabelSmoothing as _LS
+                vloss = validate(valid[0], valid[1], model, _LS(args.vocab_size, 1, 0.1), args.auto_encoder_ft, args.loss_l)
+                if rank == 0:
+                    print("epoch: %d validation loss: %f" % (epoch + 1, vloss))          # train.py:210
+                    if vloss < min_valid:
+                        print("validation loss reduced %.4f -> %.4f" % (min_valid, vloss))
+                        min_valid = vloss
+                        if args.model:
+                            torch.save(model.state_dict(), f"{args.model}_best.pth.tar")
         if world > 1:
             torch.distributed.destroy_process_group()
         return means
