@@ -435,7 +435,7 @@ class SublayerGroupFn(torch.autograd.Function):
         for x_orig in tensors[0::2]:
             # an input that an EARLIER sublayer already attends as memory (an auto-encoder output feeds the next layer's chain
             # and is the memory of x's attention): both gradients meet in one buffer instead of an autograd add
-            xg = getattr(x_orig, "_mtn_gacc", None) if (_XACC and torch.is_grad_enabled() and x_orig.requires_grad) else None
+            xg = getattr(x_orig, "_mtn_gacc", None) if (_XACC and x_orig.requires_grad) else None     # (grad mode is off inside forward)
             if xg is not None:
                 xg["remaining"] += 1
             xaccs.append(xg)
