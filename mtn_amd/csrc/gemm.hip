@@ -1091,7 +1091,8 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     // LDS-DMA path: row-major operands below 2 GiB, no row-sum side output, and a grid that fits the chip in about two
     // rounds (128 KiB of LDS = one workgroup per CU): large grids are throughput-bound and do better on the
     // register-staged kernel at 5 workgroups per CU.
-    bool dma_ok = !problems[0].rowsum_out && tiles <= 640;
+    const char* dmax = getenv("MTN_GEMM_DMA_MAX_TILES");
+    bool dma_ok = !problems[0].rowsum_out && tiles <= (dmax ? atoi(dmax) : 640);
     const long esz = (dtype == MTN_BF16) ? 2 : 4;
     for (int i = 0; i < count; ++i) {
         const mtn_gemm_problem& p = problems[i];
