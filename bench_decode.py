@@ -28,11 +28,12 @@ def main():
     ap.add_argument("--max-len", type=int, default=20)
     ap.add_argument("--dialogues", type=int, default=8)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch-dialogues", type=int, default=8, help="also time D dialogues decoded side by side (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     from mtn_amd import lib, make_model
-    from mtn_amd.decode import beam_search_decode, greedy_decode
+    from mtn_amd.decode import beam_search_decode, beam_search_decode_many, greedy_decode
     from mtn_amd.synthetic import CONFIGS, synthetic_batch
     assert torch.cuda.is_available(), "bench_decode.py needs a GPU (the HIP path has no CPU fallback)"
     dev = torch.device("cuda", 0)
@@ -78,6 +79,19 @@ def main():
                      "ms_per_step": round(1e3 * t_beam / args.dialogues / args.max_len, 3)},
             "greedy": {"tokens_per_s": round(args.dialogues * (args.max_len - 1) / t_greedy, 1),
                        "ms_per_step": round(1e3 * t_greedy / args.dialogues / (args.max_len - 1), 3)}}
+    if args.batch_dialogues > 0:
+        D = args.batch_dialogues
+        big = synthetic_batch(cfg["vocab"], D, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=300, ragged=True)
+        many = lambda: beam_search_decode_many(model, big, args.max_len, SOS, UNK, EOS, PAD, beam=args.beam, nbest=args.beam, use_graph=not args.no_graph)
+        many()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            many()
+        torch.cuda.synchronize()
+        t_many = (time.perf_counter() - t0) / 3
+        line["beam_batched"] = {"dialogues_side_by_side": D, "hypothesis_tokens_per_s": round(D * live / t_many, 1),
+                                "dialogues_per_s": round(D / t_many, 2), "ms_per_step": round(1e3 * t_many / args.max_len, 3)}
     if not args.no_cpu_baseline:
         from oracle import fixtures as fx
         from oracle.mtn_oracle import OracleConfig, OracleMTN, beam_search

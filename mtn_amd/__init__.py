@@ -4,4 +4,4 @@ from .mtn import make_model, EncoderDecoder  # noqa: F401
 from .data_utils import Batch, LabelSmoothing, NoamOpt, FusedAdam, SimpleLossCompute, subsequent_mask  # noqa: F401
 
 __version__ = "0.1.0"
-from .decode import beam_search_decode, greedy_decode, DecodeSession  # noqa: F401
+from .decode import beam_search_decode, beam_search_decode_many, greedy_decode, DecodeSession  # noqa: F401

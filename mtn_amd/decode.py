@@ -33,7 +33,8 @@ class DecodeSession:
         dev = batch.query.device
         self.q = self.cp = self.hs = self.aes = self.masks = None
         self._kvs, self._kv_pairs = None, []
-        self.tokens = torch.full((width, max_len), pad, dtype=torch.long, device=dev)
+        self.D = batch.query.size(0)
+        self.tokens = torch.full((self.D * width, max_len), pad, dtype=torch.long, device=dev)
         self.pos = torch.zeros(1, dtype=torch.long, device=dev)
         self.trg_mask = subsequent_mask(max_len, device=dev)       # (1, L, L): data_utils.py:204 uses the causal mask only
         ops.prepare_masks(self.trg_mask)
@@ -47,10 +48,11 @@ class DecodeSession:
                 tuple(batch.cap.shape), tuple(tuple(f.shape) for f in batch.fts), str(batch.query.device))
 
     def load(self, batch):
-        """Encoder side + the N x F auto-encoder chains of a new dialogue (target-independent: once per dialogue)."""
-        if batch.query.size(0) != 1:
-            raise ValueError("decode works on one dialogue at a time (data_utils.py:188: batch of one)")
+        """Encoder side + the N x F auto-encoder chains of a new dialogue (target-independent: once per dialogue).  A batch of
+        D dialogues is decoded side by side: every per-dialogue tensor is repeated `width` times along the batch dimension
+        (rows d*width .. d*width+width-1 belong to dialogue d)."""
         model, width, b = self.model, self.width, batch
+        self.D = D = b.query.size(0)
         model.eval()
         model.prepare()
         lp = model.compute_dtype
@@ -62,11 +64,11 @@ class DecodeSession:
                 ae = layer.forward_ae_chains(cp, b.cap_mask, q, b.query_mask, v, b.fts_mask, ae, model.auto_encoder_ft)
                 aes_per_layer.append(ae)
 
-            def widen(t, into=None):                           # (1, m, d) -> (width, m, d), with its compute-dtype copy
+            def widen(t, into=None):                           # (D, m, d) -> (D*width, m, d), with its compute-dtype copy
                 if into is None:
-                    into = torch.empty(width, t.size(1), t.size(2), device=t.device, dtype=t.dtype)
+                    into = torch.empty(D * width, t.size(1), t.size(2), device=t.device, dtype=t.dtype)
                     into._mtn_lp = torch.empty_like(into, dtype=lp) if lp != torch.float32 else into
-                into.copy_(t.expand(width, -1, -1))
+                into.view(D, width, t.size(1), t.size(2)).copy_(t.unsqueeze(1).expand(-1, width, -1, -1))
                 if into._mtn_lp is not into:
                     into._mtn_lp.copy_(into)
                 return into
@@ -81,13 +83,14 @@ class DecodeSession:
                 self._kvs, self._kv_pairs = kvs, list(model._kv_targets)
             model.clear_memory_kv()
             new_masks = (b.cap_mask, b.his_mask, b.query_mask)
+            rep = lambda mk: mk.repeat_interleave(width, dim=0)
             if first:
-                self.masks = tuple(mk.clone() for mk in new_masks)
+                self.masks = tuple(rep(mk) for mk in new_masks)
                 ops.prepare_masks(*self.masks)
             else:
                 for mine, mk in zip(self.masks, new_masks):    # the captured pass reads the uint8 images
-                    mine.copy_(mk)
-                    mine._mtn_u8.copy_(mk)
+                    mine.copy_(rep(mk))
+                    mine._mtn_u8.copy_(mine)
 
     def _pass(self):
         m = self.model
@@ -105,12 +108,20 @@ class DecodeSession:
         self.logp = m.generator(last).float()                       # (width, V) log-probabilities (mtn.py:68-69)
 
     def step(self, prefixes: Sequence[Sequence[int]]) -> torch.Tensor:
-        """Log-probabilities (n, V) of the next token after each prefix (all prefixes have the same length)."""
-        n, l = len(prefixes), len(prefixes[0])
-        if n > self.width or l > self.max_len:
+        """Log-probabilities (n, V) of the next token after each prefix of ONE dialogue (all prefixes have the same length)."""
+        return self.step_many([prefixes])[0]
+
+    def step_many(self, prefix_lists: Sequence[Sequence[Sequence[int]]]):
+        """One decode step for all dialogues of the session: prefix_lists[d] = live prefixes of dialogue d (same length
+        everywhere, at most `width` per dialogue) -> list of (n_d, V) log-probability tensors."""
+        if len(prefix_lists) != self.D:
+            raise ValueError("one prefix list per dialogue of the session")
+        l = len(prefix_lists[0][0])
+        if max(len(p) for p in prefix_lists) > self.width or l > self.max_len:
             raise ValueError("more hypotheses / longer prefix than the session was built for")
-        host = torch.full((self.width, self.max_len), self.pad, dtype=torch.long)
-        host[:n, :l] = torch.tensor(prefixes, dtype=torch.long)
+        host = torch.full((self.D * self.width, self.max_len), self.pad, dtype=torch.long)
+        for d, prefixes in enumerate(prefix_lists):
+            host[d * self.width:d * self.width + len(prefixes), :l] = torch.tensor(prefixes, dtype=torch.long)
         self.tokens.copy_(host, non_blocking=False)
         self.pos.fill_(l - 1)
         with torch.no_grad():
@@ -128,7 +139,7 @@ class DecodeSession:
                     with torch.cuda.graph(self._graph):
                         self._pass()
                 self._graph.replay()
-        return self.logp[:n]
+        return [self.logp[d * self.width:d * self.width + len(p)] for d, p in enumerate(prefix_lists)]
 
 
 _SESSIONS: dict = {}
@@ -151,31 +162,33 @@ def _session(model, batch, max_len, width, pad, use_graph) -> DecodeSession:
     return sess
 
 
-def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam=5, penalty=1.0,
-                       nbest=5, min_len=1, use_graph=True):
-    """data_utils.py:188-242, same arguments and return value: (n-best list of (token list, score) sorted by score,
-    best score).  A hypothesis ending with <eos> at length k scores logp + penalty * k; <unk> and <eos> never extend
-    a hypothesis; candidates are visited in descending log-probability exactly as the reference does (data_utils.py:219)."""
-    import numpy as np
-    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph)
-    hyps = [([], 0.0, [start_symbol])]
-    best, done = None, []
-    for l in range(max_len):
-        logp = sess.step([h[2] for h in hyps]).double().cpu().numpy()
+class _Beam:
+    """Hypothesis bookkeeping of data_utils.py:196-240 for one dialogue (same candidate order and tie behaviour)."""
+
+    def __init__(self, start_symbol, unk_symbol, end_symbol, beam, penalty, min_len):
+        self.unk, self.eos, self.beam, self.penalty, self.min_len = unk_symbol, end_symbol, beam, penalty, min_len
+        self.hyps = [([], 0.0, [start_symbol])]
+        self.best, self.done = None, []
+
+    def prefixes(self):
+        return [h[2] for h in self.hyps]
+
+    def advance(self, logp, l):
+        import numpy as np
         new, argmin = [], 0
-        for (out, lp, st), row in zip(hyps, logp):
+        for (out, lp, st), row in zip(self.hyps, logp):
             lp_vec = (row + lp).astype("float32")
-            if l >= min_len:
-                s = float(lp_vec[end_symbol]) + penalty * (len(out) + 1)
-                done.append((out, s))
-                if best is None or best < s:
-                    best = s
+            if l >= self.min_len:
+                s = float(lp_vec[self.eos]) + self.penalty * (len(out) + 1)
+                self.done.append((out, s))
+                if self.best is None or self.best < s:
+                    self.best = s
             for o in np.argsort(lp_vec)[::-1]:
                 o = int(o)
-                if o == unk_symbol or o == end_symbol:
+                if o == self.unk or o == self.eos:
                     continue
                 s = float(lp_vec[o])
-                if len(new) == beam:
+                if len(new) == self.beam:
                     if new[argmin][1] < s:
                         new[argmin] = (out + [o], s, st + [o])
                         argmin = min(range(len(new)), key=lambda i: new[i][1])
@@ -183,12 +196,42 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
                         break
                 else:
                     new.append((out + [o], s, st + [o]))
-                    if len(new) == beam:
+                    if len(new) == self.beam:
                         argmin = min(range(len(new)), key=lambda i: new[i][1])
-        hyps = new
-    if done:
-        return sorted(done, key=lambda h: -h[1])[:nbest], best
-    return [([], 0)], None
+        self.hyps = new
+
+    def result(self, nbest):
+        if self.done:
+            return sorted(self.done, key=lambda h: -h[1])[:nbest], self.best
+        return [([], 0)], None
+
+
+def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam=5, penalty=1.0,
+                            nbest=5, min_len=1, use_graph=True):
+    """beam_search_decode for a Batch of D dialogues at once: the D x beam live hypotheses are the batch dimension of ONE
+    target-stream pass per generated token (the pass is launch-latency-bound, so D dialogues cost little more than one).
+    Returns a list of D (n-best list, best score) pairs, each equal to what the single-dialogue search returns."""
+    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph)
+    beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
+    for l in range(max_len):
+        logps = sess.step_many([bm.prefixes() for bm in beams])
+        host = torch.cat(logps, 0).double().cpu().numpy()
+        o = 0
+        for bm, lp in zip(beams, logps):
+            bm.advance(host[o:o + lp.size(0)], l)
+            o += lp.size(0)
+    return [bm.result(nbest) for bm in beams]
+
+
+def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam=5, penalty=1.0,
+                       nbest=5, min_len=1, use_graph=True):
+    """data_utils.py:188-242, same arguments and return value: (n-best list of (token list, score) sorted by score,
+    best score).  A hypothesis ending with <eos> at length k scores logp + penalty * k; <unk> and <eos> never extend
+    a hypothesis; candidates are visited in descending log-probability exactly as the reference does (data_utils.py:219)."""
+    if batch.query.size(0) != 1:
+        raise ValueError("beam_search_decode works on one dialogue (data_utils.py:188); use beam_search_decode_many for a batch")
+    return beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam, penalty, nbest,
+                                   min_len, use_graph)[0]
 
 
 def greedy_decode(model, batch, max_len, start_symbol, pad_symbol=1, use_graph=True):

@@ -95,3 +95,27 @@ def test_decode_session_logprobs_match_full_decode(dev):
             x, _ = model.decode(v, hs, cp, q, b.fts_mask, b.his_mask, b.cap_mask, b.query_mask, st, subsequent_mask(len(p), device=dev), ae)
             want = model.generator(x[:, -1]).float()[0]
             assert (got[i] - want).abs().max() < 2e-2 * want.abs().max()
+
+
+def test_beam_search_many_dialogues_equals_one_by_one(dev):
+    """D ragged dialogues decoded side by side (D x beam hypotheses per pass) give, for every dialogue, the n-best list of the
+    single-dialogue search (and, for the first one, the reference's golden list)."""
+    from mtn_amd.decode import beam_search_decode, beam_search_decode_many
+    name = "cfg1_query"
+    c = fx.GOLDEN_CONFIGS[name]
+    model = build_model(c, torch.float32, dev).eval()
+    raws = [one_dialogue(c, seed=2), one_dialogue(c, seed=5), one_dialogue(c, seed=8)]
+    singles = [beam_search_decode(model, dev_batch(r, dev), 8, fx.SOS, fx.UNK, fx.EOS, fx.PAD) for r in raws]
+    g = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    assert [list(t) for t, _ in singles[0][0]] == [list(g[f"beam.tokens.{i}"]) for i in range(int(g["beam.n"]))]
+    # make the batch ragged: cut the 2nd dialogue's history/caption and pad
+    raws[1]["his"][:, 11:] = fx.PAD
+    raws[1]["cap"][:, 7:] = fx.PAD
+    singles[1] = beam_search_decode(model, dev_batch(raws[1], dev), 8, fx.SOS, fx.UNK, fx.EOS, fx.PAD)
+    cat = {k: (np.concatenate([r[k] for r in raws], 0) if k != "fts" else [np.concatenate([r["fts"][i] for r in raws], 0) for i in range(len(raws[0]["fts"]))])
+           for k in raws[0]}
+    many = beam_search_decode_many(model, dev_batch(cat, dev), 8, fx.SOS, fx.UNK, fx.EOS, fx.PAD)
+    assert len(many) == 3
+    for (nb1, best1), (nbm, bestm) in zip(singles, many):
+        assert [list(t) for t, _ in nbm] == [list(t) for t, _ in nb1]
+        assert max(abs(a[1] - b[1]) for a, b in zip(nbm, nb1)) < 1e-3 and abs(best1 - bestm) < 1e-3
