@@ -413,19 +413,21 @@ __global__ __launch_bounds__(256) void gemm_tt128_kernel(const GemmGroup grp) {
 //     and again on the fragment read (same involution);
 //   * counted vmcnt + raw s_barrier: the next stage stays in flight across the barrier.
 // ====================================================================================================================
-static constexpr int DMA_ROWB = 512;                         // bytes per tile row per stage
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-// one operand tile of ROWS rows x 512 B: ROWS/8 LDS-DMA instructions per wave (2 rows = 1 KiB per wave-instruction)
-template <typename T, int ROWS>
+// one operand tile of ROWS rows x ROWB bytes (512 or 256): ROWS*ROWB/4096 LDS-DMA instructions per wave, each 1 KiB
+// (2 rows of 512 B or 4 rows of 256 B); 16-byte slots XOR-swizzled with (row & 15) inside the row
+template <typename T, int ROWS, int ROWB>
 __device__ __forceinline__ void dma_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_tile, int ld_bytes, int R,
                                                int K, int row0, int k0, int wave, int lane) {
     constexpr int EPV = LP<T>::EPV;
+    constexpr int CPR = ROWB / 16;                               // 16-byte chunks per row (32 or 16)
+    constexpr int RPI = 1024 / ROWB;                             // rows per wave-instruction (2 or 4)
 #pragma unroll
-    for (int j = 0; j < ROWS / 8; ++j) {
-        const int row = j * 8 + wave * 2 + (lane >> 5);          // tile row written by this lane
-        const int c = (lane & 31) ^ (row & 15);                  // source 16-byte chunk that lands in slot (lane & 31)
+    for (int j = 0; j < ROWS * ROWB / 4096; ++j) {
+        const int row = (j * 4 + wave) * RPI + lane / CPR;       // tile row written by this lane
+        const int c = (lane % CPR) ^ (row & 15);                 // source chunk that lands in slot (lane % CPR)
         const int gk = k0 + c * EPV;
         int grow = row0 + row;
         grow = grow < R ? grow : R - 1;                          // rows past the end only feed outputs that are never stored
@@ -438,12 +440,15 @@ __device__ __forceinline__ void dma_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsi
 // exist because these launches are bound by how fast ONE CU can pull its operand panels (~27 GB/s per CU measured, LDS-DMA
 // and register staging alike): a [640 x 512] output is 80 workgroups of 128 KiB at 64x64 but 320 workgroups of 64 KiB at
 // 32x32 — the whole chip pulls instead of a third of it.
-template <typename T, int BM, int BN>
+// ROWB = bytes of contraction per row per stage: 512 (whole K <= 512-byte contractions in flight at once: best latency for
+// launches of one round) or 256 (half the LDS: twice the resident workgroups, for launches that would otherwise need a
+// second round).
+template <typename T, int BM, int BN, int DMA_ROWB>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
-    constexpr int BK = DMA_ROWB / (int)sizeof(T);            // 256 bf16 / 128 fp32
+    constexpr int BK = DMA_ROWB / (int)sizeof(T);            // 256 / 128 bf16, 128 / 64 fp32
     constexpr int TM = BM / 32, TN = BN / 32;                // MFMA tiles per wave
     constexpr int A_BYTES = BM * DMA_ROWB, B_BYTES = BN * DMA_ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int NDMA = (BM + BN) / 8;                      // LDS-DMA instructions per wave per stage
+    constexpr int NDMA = (BM + BN) * DMA_ROWB / 4096;        // LDS-DMA instructions per wave per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     int g = 0;
@@ -476,11 +481,11 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
 #endif
 #ifndef MTN_DBG_NO_LOAD
     // prologue: up to two stages in flight (NDMA LDS-DMA instructions per wave per stage, always)
-    dma_issue_tile<T, BM>(rA, smem, lda_b, M, K, row0, 0, wave, lane);
-    dma_issue_tile<T, BN>(rB, smem + A_BYTES, ldb_b, N, K, col0, 0, wave, lane);
+    dma_issue_tile<T, BM, DMA_ROWB>(rA, smem, lda_b, M, K, row0, 0, wave, lane);
+    dma_issue_tile<T, BN, DMA_ROWB>(rB, smem + A_BYTES, ldb_b, N, K, col0, 0, wave, lane);
     if (nstages > 1) {
-        dma_issue_tile<T, BM>(rA, smem + STAGE_BYTES, lda_b, M, K, row0, BK, wave, lane);
-        dma_issue_tile<T, BN>(rB, smem + STAGE_BYTES + A_BYTES, ldb_b, N, K, col0, BK, wave, lane);
+        dma_issue_tile<T, BM, DMA_ROWB>(rA, smem + STAGE_BYTES, lda_b, M, K, row0, BK, wave, lane);
+        dma_issue_tile<T, BN, DMA_ROWB>(rB, smem + STAGE_BYTES + A_BYTES, ldb_b, N, K, col0, BK, wave, lane);
     }
 #endif
     const DropState ds = drop_init(P.drop);        // scalar seed load + key hashing ride under the operand DMA
@@ -489,13 +494,16 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
         if (s + 1 < nstages) {
             if constexpr (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if constexpr (NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            static_assert(NDMA == 16 || NDMA == 12 || NDMA == 8 || NDMA == 6 || NDMA == 4, "unexpected stage size");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const unsigned char* sA = smem + (s & 1) * STAGE_BYTES;
         const unsigned char* sB = sA + A_BYTES;
         const int kleft = K - s * BK;
-        int ksteps = kleft >= BK ? 8 : (kleft * (int)sizeof(T) + 63) / 64;   // 64-byte contraction steps holding data
+        int ksteps = kleft >= BK ? DMA_ROWB / 64 : (kleft * (int)sizeof(T) + 63) / 64;   // 64-byte contraction steps holding data
 #ifdef MTN_DBG_NO_COMPUTE
         ksteps = 0;
 #endif
@@ -522,8 +530,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             unsigned char* dst = smem + (s & 1) * STAGE_BYTES;
-            dma_issue_tile<T, BM>(rA, dst, lda_b, M, K, row0, (s + 2) * BK, wave, lane);
-            dma_issue_tile<T, BN>(rB, dst + A_BYTES, ldb_b, N, K, col0, (s + 2) * BK, wave, lane);
+            dma_issue_tile<T, BM, DMA_ROWB>(rA, dst, lda_b, M, K, row0, (s + 2) * BK, wave, lane);
+            dma_issue_tile<T, BN, DMA_ROWB>(rB, dst + A_BYTES, ldb_b, N, K, col0, (s + 2) * BK, wave, lane);
         }
 #endif
     }
@@ -926,24 +934,24 @@ struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GE
 static std::vector<CensusEntry> g_census;
 static bool g_census_on = false;
 static int g_variant = 0, g_variant_tiles = 0;     // set by launch_gemm: which kernel the dispatch picked
-enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_DMA128, V_COUNT };
+enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_DMA128, V_DMA64H, V_DMA32H, V_COUNT };
 static const char* const g_variant_name[V_COUNT] = {
     "gemm_kernel<N,N> 64x64 reg-staged", "gemm_kernel<N,T>", "gemm_kernel<T,N>", "gemm_kernel<T,T> 64x64 reg-staged",
     "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
-    "gemm_tt_dma128_kernel", "gemm_dma128_kernel"};
+    "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages"};
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int ROWB>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
-    g_variant = (BM == 64) ? V_DMA64 : (BN == 64 ? V_DMA3264 : V_DMA32);
+    g_variant = (BM == 64) ? (ROWB == 512 ? V_DMA64 : V_DMA64H) : (BN == 64 ? V_DMA3264 : (ROWB == 512 ? V_DMA32 : V_DMA32H));
     g_variant_tiles = tiles;
-    constexpr int LDS = 2 * (BM + BN) * DMA_ROWB;
+    constexpr int LDS = 2 * (BM + BN) * ROWB;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set && LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN, ROWB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { mtn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN>), dim3(tiles), dim3(256), LDS, s, grp);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB>), dim3(tiles), dim3(256), LDS, s, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
@@ -1013,9 +1021,19 @@ static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, 
         const double c64 = (double)((t64 + 255) / 256) * (b64 / t64);
         double c32 = 0.75 * b32 / 256.0;
         if (c32 < wg32max) c32 = wg32max;
-        if (f == 64 || (!f && c64 <= c32)) return launch_dma<T, 64, 64>(g2, retile(g2, 64, 64), s);
-        if (f == 3264) return launch_dma<T, 32, 64>(g2, retile(g2, 32, 64), s);
-        return launch_dma<T, 32, 32>(g2, retile(g2, 32, 32), s);
+        // half-size stages (256 B of contraction per row) double the resident workgroups: taken when the launch would
+        // otherwise need a second round (64x64: one workgroup per CU at 128 KiB; 32x32: two at 64 KiB)
+        const bool half_ok = getenv("MTN_GEMM_NO_HALF") == nullptr;
+        const bool half_force = getenv("MTN_GEMM_FORCE_HALF") != nullptr;      // tests
+        if (f == 64 || (!f && c64 <= c32)) {
+            const int t = retile(g2, 64, 64);
+            if (half_force || (half_ok && t > 256)) return launch_dma<T, 64, 64, 256>(g2, t, s);
+            return launch_dma<T, 64, 64, 512>(g2, t, s);
+        }
+        if (f == 3264) return launch_dma<T, 32, 64, 512>(g2, retile(g2, 32, 64), s);
+        const int t = retile(g2, 32, 32);
+        if (half_force || (half_ok && t > 1024)) return launch_dma<T, 32, 32, 256>(g2, t, s);   // (measured in the step: 640 tiles 10.7 vs 10.1 us, 1280 tiles 12.7 vs 13.8 us)
+        return launch_dma<T, 32, 32, 512>(g2, t, s);
     } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp);
     else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp);
     else if (at && bt) {
