@@ -146,6 +146,7 @@ def main():
     rank, world, local = dp.init_distributed()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    local = local % torch.cuda.device_count()      # (several ranks may share a GPU in a gloo dry run of the multi-rank control flow)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib.load()
