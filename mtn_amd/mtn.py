@@ -224,7 +224,7 @@ class DecoderLayer(nn.Module):
                 mb.kv_ready = kv
             if torch.is_grad_enabled() and _HANDOFF:   # gradient hand-off along the chain (ops.GroupMember.holder / .feeds)
                 mb.feeds = getattr(inp, "_mtn_next", None)
-                mb.holder = dict(p=mb.cfg.p_out, salt=mb.cfg.salt * 4 + 1, seed=mb.cfg.seed, lp=mb.cfg.lp_dtype, dyl=None, dx=None, ver=None)
+                mb.holder = dict(p=mb.cfg.p_out, salt=mb.cfg.salt * 4 + 1, seed=mb.cfg.seed, lp=mb.cfg.lp_dtype, dyl=None, dx_ptr=None, ver=None, shape=None)
             members.append(mb)
             tensors += [inp, mem if isinstance(mod, MultiHeadedAttention) else None]
         # attention members first, then FFN members (the C side takes two arrays)
@@ -822,8 +822,9 @@ class EncoderDecoder(nn.Module):
 
         def cut(t):
             u = t.detach().requires_grad_()
-            if hasattr(t, "_mtn_lp"):
-                u._mtn_lp = t._mtn_lp
+            for attr in ("_mtn_lp", "_mtn_next"):      # compute-dtype copy; gradient hand-off to the producer across the cut
+                if hasattr(t, attr):
+                    setattr(u, attr, getattr(t, attr))
             return u
 
         enc_leaf = [cut(t) for t in enc_out]

@@ -535,17 +535,20 @@ class SublayerGroupFn(torch.autograd.Function):
             ready = None
             h = mb.holder
             if h is not None and h.get("dyl") is not None:
-                src = h["dx"]             # valid only if dy IS that dx, untouched (autograd may sum gradients in place)
-                if src.data_ptr() == dy.data_ptr() and src._version == h["ver"] and dy._version == h["ver"] and src.shape == dy.shape:
+                # valid only if dy IS the dx that was handed off, untouched: same storage address, same shape, and the version
+                # counter it had (autograd sums gradients in place with add_, which bumps it; any tensor derived from dx — a sum,
+                # a clone — is allocated while dx is still alive, so it cannot sit at dx's address).  The dx tensor itself is not
+                # held: a leaf's .grad may then take it over without a copy (layer-segmented backward).
+                if h["dx_ptr"] == dy.data_ptr() and dy._version == h["ver"] and tuple(h["shape"]) == tuple(dy.shape):
                     ready = h["dyl"]
             if h is not None:
-                h["dyl"] = h["dx"] = None
+                h["dyl"] = h["dx_ptr"] = None
             # producer side: write our dx also as the next sublayer's masked compute-dtype dy
             nxt = None
             f = mb.feeds
             if f is not None and f.get("lp") == cfg.lp_dtype and xg is None:
                 nxt = torch.empty(x.shape, device=dev, dtype=cfg.lp_dtype)
-                f["dyl"], f["dx"], f["ver"] = nxt, dx, dx._version     # holding dx also keeps autograd from summing into it in place
+                f["dyl"], f["dx_ptr"], f["ver"], f["shape"] = nxt, dx.data_ptr(), dx._version, dx.shape
             if mb.kind == "mha":
                 A = mha_args[im]; im += 1
                 B, a, d, m = A.B, A.a, A.d, sv["m"]
