@@ -98,13 +98,17 @@ def test_cfg2_train_step_graph_is_reproducible_and_learns():
         ts = TrainStep(m, b, cfg["vocab"], pad=1, warmup=100)
         runs.append([float(ts()) for _ in range(25)])
     assert runs[0][0] == runs[1][0]
-    assert max(abs(a - c) / abs(a) for a, c in zip(*runs)) < 2e-2       # float atomics in the table gradients, amplified by training
+    # float atomics in the embedding-table gradients make later steps differ from run to run, and training amplifies that:
+    # hold the early steps tightly, the whole curve loosely
+    assert max(abs(a - c) / abs(a) for a, c in zip(runs[0][:6], runs[1][:6])) < 1e-2
+    assert max(abs(a - c) for a, c in zip(*runs)) < 0.1 * runs[0][0]
     assert runs[0][-1] < 0.9 * runs[0][0]
 
 
 def test_cfg2_bf16_training_tracks_fp32_training():
-    """60 captured train steps of the full-size model on a fixed batch, dropout off: the bf16-compute run (fp32 master weights,
-    statistics and residual stream) follows the fp32-compute run's loss curve."""
+    """40 captured train steps of the full-size model on a fixed batch (dropout off, slow Noam warm-up so that the curve is
+    smooth): the bf16-compute run (fp32 master weights, statistics and residual stream) follows the fp32-compute run's loss
+    curve within 2 % at every step."""
     from mtn_amd import make_model
     from mtn_amd.synthetic import CONFIGS
     from mtn_amd.train_step import TrainStep
@@ -116,12 +120,8 @@ def test_cfg2_bf16_training_tracks_fp32_training():
         m = make_model(cfg["vocab"], cfg["vocab"], N=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"], dropout=0.0,
                        ft_sizes=cfg["ft_sizes"], diff_encoder=True, auto_encoder_ft="query", compute_dtype=dtype, attn_dropout=0.0).to(dev).train()
         b = _batch(cfg, dev, 16, ragged=True)
-        ts = TrainStep(m, b, cfg["vocab"], pad=1, warmup=100)
-        curves.append([float(ts()) for _ in range(60)])
+        ts = TrainStep(m, b, cfg["vocab"], pad=1, warmup=1000)
+        curves.append([float(ts()) for _ in range(40)])
     f32, b16 = curves
-    assert f32[-1] < 0.7 * f32[0]                                    # it trains
-    # the fixed batch is memorised within ~30 steps (loss 21 -> 0.05), after which the two runs wander apart in a chaotic regime:
-    # compare relatively while the loss is still above 5 % of its start, and absolutely (vs the starting loss) throughout
-    early = [(a, c) for a, c in zip(f32, b16) if a > 0.05 * f32[0]]
-    assert len(early) >= 10 and max(abs(a - c) / abs(a) for a, c in early) < 0.1, (f32[::5], b16[::5])
-    assert max(abs(a - c) for a, c in zip(f32, b16)) < 0.06 * f32[0], (f32[::10], b16[::10])
+    assert f32[-1] < 0.97 * f32[0]                                   # it trains
+    assert max(abs(a - c) / abs(a) for a, c in zip(f32, b16)) < 2e-2, (f32[::8], b16[::8])
