@@ -113,6 +113,27 @@ class FusedAdam:
     def zero_grad(self, set_to_none: bool = False):
         self.model.zero_glue_grads()
 
+    def state_dict(self):
+        """Optimiser state for checkpoints (the reference saves none: train.py:215-217 pickles the model only).  Moments are
+        stored per parameter NAME, so a checkpoint survives a different flat layout; ``schedule`` is the device-side Noam /
+        bias-correction state [step, lr, 1-b1^t, 1-b2^t]."""
+        off = 0
+        out = {"schedule": self.state.detach().cpu().clone(), "exp_avg": {}, "exp_avg_sq": {}}
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        for p, o in zip(self.model._flat_params, self.model._flat_offsets):
+            n = names[id(p)]
+            out["exp_avg"][n] = self.m[o:o + p.numel()].view(p.shape).detach().cpu().clone()
+            out["exp_avg_sq"][n] = self.v[o:o + p.numel()].view(p.shape).detach().cpu().clone()
+        return out
+
+    def load_state_dict(self, sd):
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        self.state.copy_(sd["schedule"].to(self.state.device))
+        for p, o in zip(self.model._flat_params, self.model._flat_offsets):
+            n = names[id(p)]
+            self.m[o:o + p.numel()].copy_(sd["exp_avg"][n].reshape(-1).to(self.m.device))
+            self.v[o:o + p.numel()].copy_(sd["exp_avg_sq"][n].reshape(-1).to(self.v.device))
+
 
 class NoamOpt:
     """Optimiser wrapper with the reference's interface (data_utils.py:92-117): ``step()``, ``rate()``,
@@ -128,6 +149,13 @@ class NoamOpt:
         self._step += 1
         self.optimizer.tick(self.factor, self.model_size, self.warmup)
         self.optimizer.step()
+
+    def state_dict(self):
+        return {"step": self._step, "optimizer": self.optimizer.state_dict()}
+
+    def load_state_dict(self, sd):
+        self._step = int(sd["step"])
+        self.optimizer.load_state_dict(sd["optimizer"])
 
     def rate(self, step=None):
         if step is None:

@@ -63,6 +63,9 @@ def parse(argv=None):
     p.add_argument("--valid-videos", default=0, type=int,
                    help="corpus mode: a held-out synthetic corpus of that many videos; its mean loss per token is evaluated in eval() mode "
                         "after every epoch and the best model is kept as <model>_best (train.py:201-224)")
+    p.add_argument("--resume", default="", type=str,
+                   help="corpus mode: checkpoint prefix to continue from (<prefix>.pth.tar = model state_dict in the reference's key "
+                        "schema, <prefix>_opt.pth.tar = optimiser moments + schedule state)")
     p.add_argument("--eager", action="store_true", help="corpus mode: one eager step per batch instead of captured graphs per padded shape")
     p.add_argument("--bucket", default=8, type=int, help="corpus mode: batch lengths are rounded up to multiples of this")
     p.add_argument("--corpus-videos", default=0, type=int,
@@ -201,6 +204,12 @@ def main(argv=None):
             valid = (DeviceCorpus(vdata, dev), vidx)
             logging.info("#validation sample = %d  #validation batch = %d", vn, len(vidx))
         min_valid = 1.0e10
+        the_opt = opt if args.eager else trainer.opt
+        if args.resume:
+            model.load_state_dict(torch.load(args.resume + ".pth.tar", map_location=dev), strict=False)
+            model.prepare()
+            the_opt.load_state_dict(torch.load(args.resume + "_opt.pth.tar"))
+            logging.info("resumed from %s at optimiser step %d", args.resume, the_opt._step)
         for epoch in range(args.num_epochs):
             if args.eager:
                 mean = run_epoch(corpus, indices, model, lc, args.auto_encoder_ft, epoch, args.report_interval, rank, rng)
@@ -211,6 +220,7 @@ def main(argv=None):
                 print("epoch %d mean train loss per token: %f" % (epoch + 1, mean))
             if args.model and rank == 0:
                 torch.save(model.state_dict(), f"{args.model}_{epoch + 1}.pth.tar")
+                torch.save(the_opt.state_dict(), f"{args.model}_{epoch + 1}_opt.pth.tar")
             if valid is not None:
                 from .data_utils import LabelSmoothing as _LS
                 vloss = validate(valid[0], valid[1], model, _LS(args.vocab_size, 1, 0.1), args.auto_encoder_ft, args.loss_l)

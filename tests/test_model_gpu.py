@@ -442,3 +442,30 @@ def test_segmented_graph_step_tracks_monolithic_graph_step(dev):
     assert losses[0][0] == losses[1][0]
     assert max(abs(a - b) / abs(a) for a, b in zip(*losses)) < 1e-3
     assert losses[0][3] < losses[0][0]
+
+
+def test_checkpoint_resume_continues_the_same_trajectory(dev, tmp_path):
+    """model.state_dict() (reference key schema) + NoamOpt.state_dict() (moments by parameter name + the device-side schedule
+    state) saved after 3 steps and loaded into a fresh model/optimiser: the next steps equal the uninterrupted run's."""
+    from mtn_amd.train_step import TrainStep
+    c = fx.GOLDEN_CONFIGS["cfg1_query"]
+    b = dev_batch(raw_batch(c), dev)
+
+    def fresh():
+        m = build_model(c, torch.bfloat16, dev, dropout=0.0, attn_dropout=0.0).train()
+        return m, TrainStep(m, b, c["vocab"], pad=fx.PAD, warmup=20, use_graph=False)
+
+    m1, t1 = fresh()
+    for _ in range(3):
+        t1()
+    path = tmp_path / "ck.pt"
+    torch.save({"model": m1.state_dict(), "opt": t1.opt.state_dict()}, path)
+    cont = [float(t1()) for _ in range(3)]
+    m2, t2 = fresh()
+    ck = torch.load(path)
+    m2.load_state_dict(ck["model"], strict=False)
+    m2.prepare()
+    t2.opt.load_state_dict(ck["opt"])
+    resumed = [float(t2()) for _ in range(3)]
+    assert max(abs(a - r) / abs(a) for a, r in zip(cont, resumed)) < 1e-4, (cont, resumed)
+    assert t2.opt._step == 6 and abs(t2.opt.rate() - t1.opt.rate()) < 1e-12
