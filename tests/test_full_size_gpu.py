@@ -125,3 +125,44 @@ def test_cfg2_bf16_training_tracks_fp32_training():
     f32, b16 = curves
     assert f32[-1] < 0.97 * f32[0]                                   # it trains
     assert max(abs(a - c) / abs(a) for a, c in zip(f32, b16)) < 2e-2, (f32[::8], b16[::8])
+
+
+@pytest.mark.parametrize("d_model,h,d_ff", [(1024, 8, 4096), (256, 16, 512), (768, 12, 3072)])
+def test_other_widths_match_oracle(d_model, h, d_ff):
+    """Widths outside the benchmark configurations exercise the generic kernel paths (LayerNorm rows wider than 512, head sizes
+    128 / 16, 64): forward, loss and a few gradients of a 2-layer model against the CPU oracle in fp32 mode, forward in bf16."""
+    from mtn_amd import make_model, LabelSmoothing, SimpleLossCompute
+    from oracle.mtn_oracle import OracleConfig, OracleMTN
+    from tests.test_model_gpu import dev_batch
+    from tests.util import relmax
+    dev = torch.device("cuda:0")
+    vocab, ft = 120, [64, 32]
+    raw = fx.det_batch(vocab, 3, 9, 21, 13, 8, [10, 6], ft, seed=6, ragged=True)
+    b = dev_batch(raw, dev)
+    torch.manual_seed(1)
+    m32 = make_model(vocab, vocab, N=2, d_model=d_model, d_ff=d_ff, h=h, dropout=0.0, ft_sizes=ft, diff_encoder=True,
+                     auto_encoder_ft="query", compute_dtype=torch.float32, attn_dropout=0.0).to(dev).train()
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in m32.state_dict().items() if not k.endswith(".pe")}
+    ocfg = OracleConfig(vocab=vocab, n_layers=2, d_model=d_model, d_ff=d_ff, heads=h, ft_sizes=tuple(ft), diff_encoder=True, auto_encoder_ft="query")
+    om = OracleMTN(ocfg, sd)
+    ob = fx.oracle_batch(raw)
+    want, want_ae = om.forward(ob)
+    wl = om.loss(ob, want, want_ae)
+    wl.backward()
+    out, ae = m32.forward(b)
+    lc = SimpleLossCompute(m32.generator, m32.auto_encoder_generator, LabelSmoothing(vocab, fx.PAD, 0.1), opt=None, sync=False)
+    loss = lc.loss(out, b.trg_y, b.ntokens, ae, b.query, (b.query != fx.PAD).sum())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert relmax(out, want) < 1e-3 and all(relmax(x, y) < 1e-3 for x, y in zip(ae, want_ae))
+    assert abs(float(loss) - float(wl)) < 1e-3 * abs(float(wl))
+    for key in ("decoder.layers.0.self_attn.linears.0.weight", "decoder.layers.1.feed_forward.w_2.weight", "decoder.layers.0.sublayer.5.norm.a_2",
+                "query_embed.0.lut.weight", "vid_encoder.0.0.weight", "decoder.layers.1.auto_encoder_vid_attn.1.linears.2.bias"):
+        got = dict(m32.named_parameters())[key].grad
+        assert relmax(got, sd[key].grad) < 3e-3, key
+    m16 = make_model(vocab, vocab, N=2, d_model=d_model, d_ff=d_ff, h=h, dropout=0.0, ft_sizes=ft, diff_encoder=True,
+                     auto_encoder_ft="query", compute_dtype=torch.bfloat16, attn_dropout=0.0).to(dev).eval()
+    m16.load_state_dict(m32.state_dict(), strict=False)
+    with torch.no_grad():
+        o16, _ = m16.forward(b)
+    assert relmax(o16, want) < 1e-2
