@@ -173,21 +173,29 @@ class _Beam:
     def prefixes(self):
         return [h[2] for h in self.hyps]
 
-    def advance(self, logp, l):
+    def advance(self, logp, l, top=None):
+        """logp: (n_hyp, V) log-probabilities on the host — or None when ``top`` = (values (n,k), indices (n,k), eos column (n,))
+        carries each row's k = beam+2 best entries in descending order: at most `beam` candidates per hypothesis can enter the
+        new beam and at most two (<unk>, <eos>) are skipped, so the rest of the vocabulary is never looked at."""
         import numpy as np
         new, argmin = [], 0
-        for (out, lp, st), row in zip(self.hyps, logp):
-            lp_vec = (row + lp).astype("float32")
+        for h, (out, lp, st) in enumerate(self.hyps):
+            if top is None:
+                lp_vec = (logp[h] + lp).astype("float32")
+                eos_val = float(lp_vec[self.eos])
+                order = ((int(o), float(lp_vec[o])) for o in np.argsort(lp_vec)[::-1])
+            else:
+                vals = (top[0][h] + lp).astype("float32")
+                eos_val = float(np.float32(top[2][h] + lp))
+                order = ((int(o), float(v)) for o, v in zip(top[1][h], vals))
             if l >= self.min_len:
-                s = float(lp_vec[self.eos]) + self.penalty * (len(out) + 1)
+                s = eos_val + self.penalty * (len(out) + 1)
                 self.done.append((out, s))
                 if self.best is None or self.best < s:
                     self.best = s
-            for o in np.argsort(lp_vec)[::-1]:
-                o = int(o)
+            for o, s in order:
                 if o == self.unk or o == self.eos:
                     continue
-                s = float(lp_vec[o])
                 if len(new) == self.beam:
                     if new[argmin][1] < s:
                         new[argmin] = (out + [o], s, st + [o])
@@ -213,13 +221,26 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
     Returns a list of D (n-best list, best score) pairs, each equal to what the single-dialogue search returns."""
     sess = _session(model, batch, max_len, beam, pad_symbol, use_graph)
     beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
+    k = beam + 2
     for l in range(max_len):
         logps = sess.step_many([bm.prefixes() for bm in beams])
-        host = torch.cat(logps, 0).double().cpu().numpy()
+        allp = torch.cat(logps, 0)
+        tv, ti = torch.topk(allp, min(k + 1, allp.size(1)), dim=-1)          # device-side selection: only the heads of the rows travel
+        packed = torch.cat([tv.double(), ti.double(), allp[:, end_symbol:end_symbol + 1].double()], 1).cpu().numpy()
+        kk = tv.size(1)
+        vals, idx, eos = packed[:, :kk], packed[:, kk:2 * kk].astype("int64"), packed[:, 2 * kk]
+        # exact ties inside a row's head would make the visiting order depend on the selection algorithm: the reference's
+        # order (argsort, data_utils.py:219) is then taken from the full row
+        tie = bool((vals[:, 1:] == vals[:, :-1]).any())
+        host = allp.double().cpu().numpy() if tie else None
         o = 0
         for bm, lp in zip(beams, logps):
-            bm.advance(host[o:o + lp.size(0)], l)
-            o += lp.size(0)
+            n = lp.size(0)
+            if tie:
+                bm.advance(host[o:o + n], l)
+            else:
+                bm.advance(None, l, top=(vals[o:o + n, :k], idx[o:o + n, :k], eos[o:o + n]))
+            o += n
     return [bm.result(nbest) for bm in beams]
 
 
