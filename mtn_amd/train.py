@@ -161,6 +161,7 @@ def main(argv=None):
     args = parse(argv)
     logging.basicConfig(level=logging.DEBUG if args.verbose else logging.INFO, format="%(asctime)s %(levelname)s: %(message)s")
     rank, world, local = dp.init_distributed()
+    local = local % torch.cuda.device_count()      # (several ranks may share a GPU in a gloo dry run)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if args.train_set:
@@ -184,7 +185,8 @@ def main(argv=None):
         from .data_utils import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
         data = synthetic_corpus(args.corpus_videos, args.vocab_size, args.ft_sizes, args.rand_seed)
         indices, n_samples = make_batch_indices(data, batchsize=args.batch_size, max_length=256, separate_caption=True)  # train.py:126
-        indices = indices[rank::world]                     # data parallel: every rank takes its share of the planned batches
+        indices = indices[:len(indices) // world * world][rank::world]   # data parallel: equal shares of the planned batches (every
+                                                                         # rank must issue the same number of gradient exchanges)
         corpus = DeviceCorpus(data, dev)
         logging.info("corpus: %d dialogs in %d batches, %.1f MB resident on the device", n_samples, len(indices), corpus.nbytes() / 1e6)
         rng = random.Random(args.rand_seed)

@@ -50,12 +50,21 @@ class TrainStep:
             grad_sync.all_reduce_scalars(self._norms)
 
     # ---- pieces
+    def local_norms(self):
+        b = self.batch
+        return torch.stack([(b.trg_y != self.pad).sum(), (self._ae_y != self.pad).sum()]).float()
+
     def _refresh_norms(self):
-        if self.dynamic_norms:
-            b = self.batch
-            self._norms.copy_(torch.stack([(b.trg_y != self.pad).sum(), (self._ae_y != self.pad).sum()]).float())
-            if self.grad_sync is not None:
-                self.grad_sync.all_reduce_scalars(self._norms)
+        """dynamic_norms on ONE rank: recomputed inside the (captured) step.  Under data parallelism the global counts need a
+        collective, which stays out of graph capture: the caller refreshes them eagerly (refresh_norms_eager) before the step."""
+        if self.dynamic_norms and self.grad_sync is None:
+            self._norms.copy_(self.local_norms())
+
+    def refresh_norms_eager(self):
+        if self.dynamic_norms and self.grad_sync is not None:
+            n = self.local_norms()
+            self.grad_sync.all_reduce_scalars(n)
+            self._norms.copy_(n)
 
     def _fwd_bwd(self):
         m, b = self.model, self.batch
@@ -234,4 +243,5 @@ class BucketedTrainer:
             self.steps[key] = hit = (batch, ts)
         else:
             make_batch(self.corpus, pidx, self.pad, separate_caption=True, out=hit[0])
+        hit[1].refresh_norms_eager()
         return hit[1](), hit[0]
