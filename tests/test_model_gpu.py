@@ -467,5 +467,7 @@ def test_checkpoint_resume_continues_the_same_trajectory(dev, tmp_path):
     m2.prepare()
     t2.opt.load_state_dict(ck["opt"])
     resumed = [float(t2()) for _ in range(3)]
-    assert max(abs(a - r) / abs(a) for a, r in zip(cont, resumed)) < 1e-4, (cont, resumed)
+    # (float atomics in the embedding-table gradients + Adam normalisation make two runs differ by ~1e-4; a lost optimiser state
+    #  would show as ~1e-1)
+    assert max(abs(a - r) / abs(a) for a, r in zip(cont, resumed)) < 3e-3, (cont, resumed)
     assert t2.opt._step == 6 and abs(t2.opt.rate() - t1.opt.rate()) < 1e-12
