@@ -113,7 +113,12 @@ typedef struct {
     float* x_out;
     int no_ln;
 } mtn_ln_fwd_desc;
-/* Embedding backward: dlut[tokens[row]] += dx[row] * emb_scale * keep(row*d+c)/(1-p)   (atomic adds; dlut pre-zeroed). */
+/* Embedding backward: dlut[tokens[row]] += dx[row] * emb_scale * keep(row*d+c)/(1-p).
+ * Default: float atomic adds (rounding depends on arrival order — the only run-to-run noise on the whole path).  With
+ * MTN_EMBED_DETERMINISTIC=1 in the environment and lut_rows > 0 on every descriptor (the vocabulary size of the table
+ * behind dlut) the sum is bitwise reproducible: each vocabulary entry is owned by one wave (frequent entries by one
+ * workgroup) that scans the token lists of all streams sharing the table and adds the matching rows in list order —
+ * no atomics; measured 41 vs 13 us (uniform tokens) and 182 vs 69 us (ragged, 25 % pads) at cfg2 batch 32. */
 typedef struct {
     int rows, d;
     const long* tokens;
@@ -121,6 +126,7 @@ typedef struct {
     float emb_scale;
     mtn_dropout drop;
     float* dlut;
+    int lut_rows;
 } mtn_embed_bwd_desc;
 int mtn_embed_bwd_group(int count, const mtn_embed_bwd_desc* descs /* host array, <= MTN_LN_MAX_GROUP */, void* stream);
 typedef struct {

@@ -563,8 +563,206 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdGroup grp)
         atomicAdd(dst + c, v);
     }
 }
+// Deterministic variant (no atomics, the same bits on every run).  A workgroup of 16 waves owns 16 vocabulary entries of one
+// table, one per wave.  The token lists of all streams that use the table — one virtual list, stream order then row order —
+// are staged through LDS in chunks (coalesced, once per workgroup and pass) and scanned with 64-token ballots:
+//   pass 1  each wave counts the occurrences of its entry;
+//   pass 2  a wave whose entry occurs at most EMB_HEAVY times adds those rows of dx itself, in list order, through the
+//           stream's scale and dropout mask (up to eight rows' loads in flight), and writes dlut[v] += sum, once;
+//   pass 3  a frequent entry (the pad id of a ragged batch, '.', '?', ...) would serialise thousands of rows in one wave, so
+//           all 16 waves take it together: wave w scans ballots w, w+16, ... of every chunk, the 16 partial sums meet in LDS
+//           and are added in wave order.
+// Which wave adds which row depends only on the token values and shapes, so the rounding is the same on every run.
+#define EMB_CH 16384                       // tokens per staged chunk (int32 in LDS)
+#define EMB_HEAVY 24
+#define EMB_MLP 8
+struct EmbedDetGroup {
+    int n_lut;
+    float* dlut[MTN_LN_MAX_GROUP];
+    int V[MTN_LN_MAX_GROUP], d[MTN_LN_MAX_GROUP], n[MTN_LN_MAX_GROUP], total[MTN_LN_MAX_GROUP];
+    int idx[MTN_LN_MAX_GROUP][MTN_LN_MAX_GROUP];
+    int first[MTN_LN_MAX_GROUP][MTN_LN_MAX_GROUP + 1];      // first virtual token of each stream of the table
+    mtn_embed_bwd_desc s[MTN_LN_MAX_GROUP];
+};
+struct EmbStream {                          // one stream of the table, as the workgroup keeps it in LDS
+    const long* tokens;
+    const float* dx;
+    float emb_scale;
+    int first;
+    DropState ds;
+};
+// add the rows of dx whose virtual token indices are the set bits of m (offset base) to acc, lowest index first
+__device__ __forceinline__ void emb_add_rows(unsigned long long m, int base, const EmbStream* st, int ns, int d, int c0, int lane,
+                                             float (&acc)[8]) {
+    while (m) {
+        int g[EMB_MLP], n = 0;
+#pragma unroll
+        for (int k = 0; k < EMB_MLP; ++k)
+            if (m) { g[k] = base + __builtin_ctzll(m); m &= m - 1; n = k + 1; }
+        float x[EMB_MLP][8];
+        int row[EMB_MLP], str[EMB_MLP];
+#pragma unroll
+        for (int k = 0; k < EMB_MLP; ++k) {
+            if (k < n) {
+                int si = 0;
+                while (si + 1 < ns && g[k] >= st[si + 1].first) ++si;
+                str[k] = si;
+                row[k] = g[k] - st[si].first;
+                const float* src = st[si].dx + (size_t)row[k] * d + c0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = lane * 4 + 256 * j;
+                    if (c0 + c + 3 < d) {
+                        const float4 q = *reinterpret_cast<const float4*>(src + c);
+                        x[k][4 * j] = q.x; x[k][4 * j + 1] = q.y; x[k][4 * j + 2] = q.z; x[k][4 * j + 3] = q.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[k][4 * j + e] = 0.f;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < EMB_MLP; ++k) {
+            if (k < n) {
+                const EmbStream& S = st[str[k]];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c0 + lane * 4 + 256 * (j >> 2) + (j & 3);
+                    float y = x[k][j] * S.emb_scale;
+                    if (S.ds.on) y = (c < d && drop_keep(S.ds, (uint64_t)row[k] * d + c)) ? y * S.ds.scale : 0.f;
+                    acc[j] += y;
+                }
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const EmbedDetGroup grp) {
+    __shared__ int tok[EMB_CH];
+    __shared__ float part_sum[16][512];
+    __shared__ EmbStream st[MTN_LN_MAX_GROUP];
+    __shared__ int count[16];
+    const int t = blockIdx.y;
+    if (blockIdx.x * 16 >= grp.V[t]) return;               // table shorter than the longest one in the launch (uniform)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = blockIdx.x * 16 + wave;
+    const bool live = v < grp.V[t];
+    const int d = grp.d[t], total = grp.total[t], ns = grp.n[t];
+    if (threadIdx.x < MTN_LN_MAX_GROUP) {
+#pragma unroll
+        for (int i = 0; i < MTN_LN_MAX_GROUP; ++i)           // static indices into the kernel argument
+            if ((int)threadIdx.x == i && i < ns) {
+                int which = 0;
+#pragma unroll
+                for (int q = 0; q < MTN_LN_MAX_GROUP; ++q)
+                    if (q == t) which = grp.idx[q][i];
+#pragma unroll
+                for (int q = 0; q < MTN_LN_MAX_GROUP; ++q)
+                    if (q == which) {
+                        st[i].tokens = grp.s[q].tokens; st[i].dx = grp.s[q].dx; st[i].emb_scale = grp.s[q].emb_scale;
+                        st[i].ds = drop_init(grp.s[q].drop);
+                    }
+#pragma unroll
+                for (int q = 0; q < MTN_LN_MAX_GROUP; ++q)
+                    if (q == t) st[i].first = grp.first[q][i];
+            }
+    }
+    const bool one_chunk = total <= EMB_CH;
+    auto stage = [&](int ch, int cnt) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 1024) {
+            const int g = ch + i;
+            int si = 0;
+            while (si + 1 < ns && g >= st[si + 1].first) ++si;
+            tok[i] = (int)st[si].tokens[g - st[si].first];
+        }
+        __syncthreads();
+    };
+    __syncthreads();
+    // pass 1: occurrences of this wave's entry
+    int mine = 0;
+    for (int ch = 0; ch < total; ch += EMB_CH) {
+        const int cnt = min(EMB_CH, total - ch);
+        stage(ch, cnt);
+        if (live)
+            for (int b = 0; b < cnt; b += 64) mine += __popcll(__ballot(b + lane < cnt && tok[b + lane] == v));
+    }
+    if (lane == 0) count[wave] = live ? mine : 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < d; c0 += 512) {                  // 8 columns per lane per pass (one pass for d <= 512)
+        // pass 2: entries with few occurrences, one wave each
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const bool light = live && mine > 0 && mine <= EMB_HEAVY;
+        for (int ch = 0; ch < total; ch += EMB_CH) {
+            const int cnt = min(EMB_CH, total - ch);
+            if (!one_chunk) stage(ch, cnt);
+            if (light)
+                for (int b = 0; b < cnt; b += 64)
+                    emb_add_rows(__ballot(b + lane < cnt && tok[b + lane] == v), ch + b, st, ns, d, c0, lane, acc);
+        }
+        if (light) {
+            float* dst = grp.dlut[t] + (size_t)v * d + c0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = lane * 4 + 256 * (j >> 2) + (j & 3);
+                if (c0 + c < d) dst[c] += acc[j];
+            }
+        }
+        // pass 3: frequent entries, all 16 waves on one entry at a time
+        for (int h = 0; h < 16; ++h) {
+            if (count[h] <= EMB_HEAVY) continue;           // uniform over the workgroup
+            const int vh = blockIdx.x * 16 + h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            for (int ch = 0; ch < total; ch += EMB_CH) {
+                const int cnt = min(EMB_CH, total - ch);
+                if (!one_chunk) stage(ch, cnt);
+                for (int b = wave * 64; b < cnt; b += 16 * 64)
+                    emb_add_rows(__ballot(b + lane < cnt && tok[b + lane] == vh), ch + b, st, ns, d, c0, lane, acc);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part_sum[wave][lane * 4 + 256 * (j >> 2) + (j & 3)] = acc[j];
+            __syncthreads();
+            if (threadIdx.x < 512 && c0 + (int)threadIdx.x < d) {
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sum += part_sum[q][threadIdx.x];
+                grp.dlut[t][(size_t)vh * d + c0 + threadIdx.x] += sum;
+            }
+        }
+    }
+}
+
 extern "C" int mtn_embed_bwd_group(int count, const mtn_embed_bwd_desc* descs, void* stream) {
     MTN_CHECK_ARG(count >= 1 && count <= MTN_LN_MAX_GROUP && descs, "bad group");
+    const char* det_env = getenv("MTN_EMBED_DETERMINISTIC");     // opt-in: 1-3 % of a cfg2 step slower than the atomic adds
+    bool det = det_env && det_env[0] != '0';
+    for (int i = 0; i < count; ++i) det = det && descs[i].lut_rows > 0;
+    if (det) {
+        EmbedDetGroup g;
+        memset(&g, 0, sizeof(g));
+        int vmax = 0;
+        for (int i = 0; i < count; ++i) {
+            MTN_CHECK_ARG(descs[i].rows > 0 && descs[i].d > 0 && descs[i].tokens && descs[i].dx && descs[i].dlut, "bad descriptor");
+            MTN_CHECK_ARG(descs[i].d % 4 == 0, "d must be a multiple of 4");
+            g.s[i] = descs[i];
+            int t = 0;
+            while (t < g.n_lut && g.dlut[t] != descs[i].dlut) ++t;
+            if (t == g.n_lut) { g.dlut[t] = descs[i].dlut; g.V[t] = descs[i].lut_rows; g.d[t] = descs[i].d; ++g.n_lut; }
+            MTN_CHECK_ARG(g.V[t] == descs[i].lut_rows && g.d[t] == descs[i].d, "streams of one table disagree on its shape");
+            g.idx[t][g.n[t]] = i;
+            g.first[t][g.n[t]] = g.total[t];
+            g.total[t] += descs[i].rows;
+            g.first[t][++g.n[t]] = g.total[t];
+            if (g.V[t] > vmax) vmax = g.V[t];
+        }
+        hipLaunchKernelGGL(embed_bwd_det_kernel, dim3((vmax + 15) / 16, g.n_lut), dim3(1024), 0, (hipStream_t)stream, g);
+        MTN_CHECK_LAUNCH();
+        return MTN_OK;
+    }
     EmbedBwdGroup grp;
     memset(&grp, 0, sizeof(grp));
     grp.count = count;

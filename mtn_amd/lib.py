@@ -86,7 +86,7 @@ class LnFwdDesc(C.Structure):
 
 class EmbedBwdDesc(C.Structure):
     _fields_ = [("rows", C.c_int), ("d", C.c_int), ("tokens", C.c_void_p), ("dx", C.c_void_p), ("emb_scale", C.c_float),
-                ("drop", Dropout), ("dlut", C.c_void_p)]
+                ("drop", Dropout), ("dlut", C.c_void_p), ("lut_rows", C.c_int)]
 
 
 class LnBwdDesc(C.Structure):

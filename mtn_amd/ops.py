@@ -711,6 +711,7 @@ class EmbedNormFn(torch.autograd.Function):
             E.rows, E.d, E.tokens, E.dx, E.emb_scale = sv["rows"], sv["d"], sv["tok"].data_ptr(), dx.data_ptr(), float(st["scale"])
             E.drop = _drop(st["p"], st["salt"], spec["seed"])
             E.dlut = dluts[st["lut"]].data_ptr()
+            E.lut_rows = luts[st["lut"]].size(0)
         if ln_descs:
             arr = (L.LnBwdDesc * len(ln_descs))(*ln_descs)
             L.check(lib.mtn_layernorm_bwd_group(len(ln_descs), arr, L.stream_ptr()))

@@ -111,6 +111,41 @@ def test_layernorm_fwd_bwd(dev, rows, d):
     assert relmax(bd.grad, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("d", [512, 640, 96])
+def test_embedding_backward_is_deterministic(dev, d, monkeypatch):
+    """Table gradient without atomics (csrc/layernorm.hip embed_bwd_det_kernel): same bits on every run, exact sums against
+    fp64 index_add — with a frequent id (40 % pads), more tokens than one staged chunk, d above one 512-column pass."""
+    import ctypes as C
+    import math
+    from mtn_amd import lib as L
+    lib = L.load()
+    monkeypatch.setenv("MTN_EMBED_DETERMINISTIC", "1")
+    V = 300
+    g = torch.Generator().manual_seed(11)
+    shapes = [(6, 1400), (5, 1800), (3, 333)]               # 8400 + 9000 + 999 rows > one 16384-token chunk
+    toks, dxs = [], []
+    for B, Lq in shapes:
+        t = torch.randint(0, V, (B, Lq), generator=g)
+        t[torch.rand(B, Lq, generator=g) < 0.4] = 1
+        toks.append(t.to(dev).reshape(-1).contiguous())
+        dxs.append(torch.randn(B * Lq, d, generator=g).to(dev))
+    want = torch.zeros(V, d, dtype=torch.float64, device=dev)
+    for t, x in zip(toks, dxs):
+        want.index_add_(0, t, x.double() * math.sqrt(d))
+    outs = []
+    for _ in range(3):
+        dlut = torch.zeros(V, d, device=dev)
+        descs = (L.EmbedBwdDesc * len(toks))()
+        for E, t, x in zip(descs, toks, dxs):
+            E.rows, E.d, E.tokens, E.dx, E.emb_scale = t.numel(), d, t.data_ptr(), x.data_ptr(), math.sqrt(d)
+            E.dlut, E.lut_rows = dlut.data_ptr(), V
+        L.check(lib.mtn_embed_bwd_group(len(toks), descs, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(dlut)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert relmax(outs[0].double(), want) < 1e-5
+
+
 def test_fused_embedding_streams(dev):
     """Embeddings * sqrt(d) + positional encoding (+ dropout) (+ Encoder LayerNorm) for several token streams in one grouped
     launch (mtn.py:288-289, 307-309, 83-101): outputs, table / LayerNorm gradients, and dropout-mask consistency."""
