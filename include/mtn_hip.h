@@ -62,6 +62,26 @@ typedef struct {
  * Constraints: A,B are lowp of `dtype`; K, lda, ldb multiples of 8; 16-byte aligned bases.
  * Up to MTN_GEMM_MAX_GROUP independent problems are executed by ONE launch.
  * ------------------------------------------------------------------------------------------ */
+/* Optional optimiser epilogue of a parameter-gradient GEMM (dW = dY^T X, a_trans = b_trans = 1): C is not stored as a
+ * gradient; it IS the gradient of the parameter block p[M,N] (row stride ldc, the same element offsets as out_f32), and the
+ * Adam update of mtn_adam_step is applied to it tile by tile while the accumulators are still in registers:
+ *   g = C * *grad_scale;  m,v updated;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps);
+ *   p_lp[i*ldc+j] = lowp(p)   (optional; the compute-dtype weight copy)
+ *   p_lpT[j*ldT+i] = lowp(p)  (optional; the transposed copy the dX GEMMs read)
+ * This removes the gradient's HBM round trip (8 B/param), the separate transpose pass, and hides the optimiser's 26 B/param
+ * behind the contraction.  Only valid when this GEMM is the ONLY contribution to that gradient in the step (no residual /
+ * accumulation, no gradient exchange between ranks).  write_grad != 0 also stores C to out_f32. */
+typedef struct {
+    float *p, *m, *v;
+    void* p_lp;
+    void* p_lpT;
+    int ldT;
+    int write_grad;
+    const float* state;      /* device [8]: as mtn_adam_step */
+    const float* grad_scale; /* optional device scalar */
+    float beta1, beta2, eps;
+} mtn_adam_fuse;
+
 typedef struct {
     const void* A;
     const void* B;
@@ -79,10 +99,16 @@ typedef struct {
     void* out_lp;
     int ldc;
     float* rowsum_out;
+    const mtn_adam_fuse* adam; /* HOST pointer, read during the call only; NULL = plain GEMM */
 } mtn_gemm_problem;
 
 #define MTN_GEMM_MAX_GROUP 16
 int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems /* host array */, void* stream);
+/* Table form for parameter-gradient problems (a_trans = b_trans = 1, bf16, plain C or the optimiser epilogue): up to 1024
+ * problems in ONE launch of 128 x 128 tiles, in the order given (put contractions of different length next to each other:
+ * resident workgroups then drift out of phase and the epilogue's HBM streaming overlaps other tiles' contractions).  The
+ * problem list is staged to device memory on `stream`; safe under hipGraph capture. */
+int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* problems /* host array */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm, MTN variant (mtn.py:103-114): y = a2 * (x-mean) / (std_unbiased + eps) + b2.
@@ -377,6 +403,10 @@ int mtn_transpose_group(int dtype, const void* src, void* dst, const mtn_transpo
 int mtn_noam_tick(float* state, float factor, int model_size, int warmup, float beta1, float beta2, void* stream);
 int mtn_adam_step(int dtype, long n, float* p, const float* g, float* m, float* v, void* p_lp, const float* state,
                   const float* grad_scale, float beta1, float beta2, float eps, void* stream);
+/* The same update over chunks [off[c], off[c]+len[c]) of the flat buffers (off, len: DEVICE arrays; multiples of 4, len <=
+ * 4096): the parameters that the GEMM optimiser epilogue (mtn_adam_fuse) does not cover. */
+int mtn_adam_step_chunks(int dtype, int n_chunks, const long* off, const int* len, float* p, const float* g, float* m, float* v,
+                         void* p_lp, const float* state, const float* grad_scale, float beta1, float beta2, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side batch assembly (replaces the host padding of data_handler.py:206-274 `make_batch` and the mask passes of

@@ -107,6 +107,27 @@ __device__ __forceinline__ bool drop_keep(const DropState& s, uint64_t idx) {
     return (r >> 8) >= s.thresh;
 }
 
+// ---------------------------------------------------------------- Adam (torch.optim.Adam semantics), one element
+// m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).
+// Roundings pinned with explicit fma so that every kernel that applies the update (adam_kernel, adam_chunks_kernel, the
+// optimiser epilogue of the parameter-gradient GEMMs) produces the same bits.
+struct AdamCoef { float step_size, inv_sqrt_bc2, gs, beta1, beta2, eps; };
+__device__ __forceinline__ AdamCoef adam_coef(const float* state, const float* grad_scale, float beta1, float beta2, float eps) {
+    AdamCoef c;
+    const float lr = state[1], bc1 = state[2], bc2 = state[3];
+    c.step_size = lr / bc1; c.inv_sqrt_bc2 = rsqrtf(bc2);
+    c.gs = grad_scale ? *grad_scale : 1.0f;
+    c.beta1 = beta1; c.beta2 = beta2; c.eps = eps;
+    return c;
+}
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, const AdamCoef& c) {
+    const float gk = g * c.gs;
+    m = __builtin_fmaf(c.beta1, m, (1.0f - c.beta1) * gk);
+    v = __builtin_fmaf(c.beta2, v, ((1.0f - c.beta2) * gk) * gk);
+    const float denom = __builtin_fmaf(sqrtf(v), c.inv_sqrt_bc2, c.eps);
+    p = __builtin_fmaf(-c.step_size, m / denom, p);
+}
+
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -183,15 +183,12 @@ extern "C" int mtn_noam_tick(float* state, float factor, int model_size, int war
     return MTN_OK;
 }
 
-// torch.optim.Adam semantics: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
-// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  38 B/param of HBM traffic with the bf16 copy.
+// torch.optim.Adam semantics (adam_update, common.h).  30 B/param of HBM traffic with the bf16 copy.
 template <typename T>
 __global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, T* __restrict__ p_lp, const float* __restrict__ state,
                                                    const float* __restrict__ grad_scale, float beta1, float beta2, float eps) {
-    const float lr = state[1], bc1 = state[2], bc2 = state[3];
-    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
-    const float gs = grad_scale ? *grad_scale : 1.0f;
+    const AdamCoef c = adam_coef(state, grad_scale, beta1, beta2, eps);
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         // the 16 B/param fp32 streams are touched once per step: non-temporal, so that they do not evict the bf16 weights
@@ -203,12 +200,7 @@ __global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p
         float4 mv = make_float4(m_[0], m_[1], m_[2], m_[3]), vv = make_float4(v_[0], v_[1], v_[2], v_[3]);
         float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gk = gp[k] * gs;
-            mp[k] = beta1 * mp[k] + (1.0f - beta1) * gk;
-            vp[k] = beta2 * vp[k] + (1.0f - beta2) * gk * gk;
-            pp[k] -= step_size * mp[k] / (sqrtf(vp[k]) * inv_sqrt_bc2 + eps);
-        }
+        for (int k = 0; k < 4; ++k) adam_update(pp[k], mp[k], vp[k], gp[k], c);
         __builtin_nontemporal_store(nt4{pv.x, pv.y, pv.z, pv.w}, (nt4*)(p + i * 4));
         __builtin_nontemporal_store(nt4{mv.x, mv.y, mv.z, mv.w}, (nt4*)(m + i * 4));
         __builtin_nontemporal_store(nt4{vv.x, vv.y, vv.z, vv.w}, (nt4*)(v + i * 4));
@@ -223,6 +215,50 @@ __global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p
             }
         }
     }
+}
+
+// The same update over a list of chunks of the flat buffers (what is left once the parameter-gradient GEMMs have applied
+// the optimiser to the weight matrices in their epilogues: biases, LayerNorm gains, embedding tables, the loss head).
+// chunk c = elements [off[c], off[c] + len[c]) with off, len multiples of 4 and len <= 4096; one workgroup per chunk.
+template <typename T>
+__global__ __launch_bounds__(256) void adam_chunks_kernel(const long* __restrict__ off, const int* __restrict__ len, float* __restrict__ p,
+                                                          const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          T* __restrict__ p_lp, const float* __restrict__ state,
+                                                          const float* __restrict__ grad_scale, float beta1, float beta2, float eps) {
+    const AdamCoef c = adam_coef(state, grad_scale, beta1, beta2, eps);
+    const long base = off[blockIdx.x];
+    const int n4 = len[blockIdx.x] >> 2;
+    for (int q = threadIdx.x; q < n4; q += 256) {
+        const long i = base + (long)q * 4;
+        float4 pv = *(const float4*)(p + i), gv = *(const float4*)(g + i), mv = *(const float4*)(m + i), vv = *(const float4*)(v + i);
+        float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) adam_update(pp[k], mp[k], vp[k], gp[k], c);
+        *(float4*)(p + i) = pv; *(float4*)(m + i) = mv; *(float4*)(v + i) = vv;
+        if (p_lp) {
+            if constexpr (sizeof(T) == 2) {
+                uint2 u;
+                u.x = (uint32_t)f32_to_bf16(pv.x) | ((uint32_t)f32_to_bf16(pv.y) << 16);
+                u.y = (uint32_t)f32_to_bf16(pv.z) | ((uint32_t)f32_to_bf16(pv.w) << 16);
+                *(uint2*)(p_lp + i) = u;
+            } else {
+                *(float4*)(p_lp + i) = pv;
+            }
+        }
+    }
+}
+
+extern "C" int mtn_adam_step_chunks(int dtype, int n_chunks, const long* off, const int* len, float* p, const float* g, float* m, float* v,
+                                    void* p_lp, const float* state, const float* grad_scale, float beta1, float beta2, float eps, void* stream) {
+    MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
+    MTN_CHECK_ARG(n_chunks > 0 && off && len && p && g && m && v && state, "chunk list and buffers must be non-null");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MTN_BF16)
+        hipLaunchKernelGGL((adam_chunks_kernel<bf16_t>), dim3(n_chunks), dim3(256), 0, s, off, len, p, g, m, v, (bf16_t*)p_lp, state, grad_scale, beta1, beta2, eps);
+    else
+        hipLaunchKernelGGL((adam_chunks_kernel<float>), dim3(n_chunks), dim3(256), 0, s, off, len, p, g, m, v, (float*)p_lp, state, grad_scale, beta1, beta2, eps);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
 }
 
 extern "C" int mtn_adam_step(int dtype, long n, float* p, const float* g, float* m, float* v, void* p_lp, const float* state,

@@ -19,6 +19,57 @@ struct GemmGroup {
     mtn_gemm_problem p[MTN_GEMM_MAX_GROUP];
 };
 
+// Optimiser epilogue of the parameter-gradient kernels (mtn_adam_fuse): second kernel argument of the T x T kernels only.
+struct AdamSlot { float *p, *m, *v; void* lp; void* lpT; int ldT, write_grad; };
+struct AdamGroup {
+    const float* state;
+    const float* grad_scale;
+    float beta1, beta2, eps;
+    int any;
+    int lds_epilogue;          // every slot's copies are 16-byte addressable column-wise: gemm_tt_dma128_kernel re-lays the tile out in LDS
+    AdamSlot a[MTN_GEMM_MAX_GROUP];
+};
+__device__ __forceinline__ AdamCoef adam_coef(const AdamGroup& G) { return adam_coef(G.state, G.grad_scale, G.beta1, G.beta2, G.eps); }
+// Adam on 4 consecutive columns of one row of the parameter block; g[] = the gradient (accumulator values).
+// Same arithmetic, in the same order, as adam_kernel (elementwise.hip): the two paths give the same bits.
+template <typename T>
+__device__ __forceinline__ void adam4(const AdamSlot& A, const AdamCoef& c, bool vec, size_t o, int row, int col, int nv, const float (&g)[4]) {
+    float pv[4], mv[4], vv[4];
+    typedef __attribute__((ext_vector_type(4))) float nt4;
+    if (vec) {
+        const nt4 p_ = __builtin_nontemporal_load((const nt4*)(A.p + o)), m_ = __builtin_nontemporal_load((const nt4*)(A.m + o)),
+                  v_ = __builtin_nontemporal_load((const nt4*)(A.v + o));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pv[k] = p_[k]; mv[k] = m_[k]; vv[k] = v_[k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pv[k] = k < nv ? A.p[o + k] : 0.f; mv[k] = k < nv ? A.m[o + k] : 0.f; vv[k] = k < nv ? A.v[o + k] : 0.f; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) adam_update(pv[k], mv[k], vv[k], g[k], c);
+    if (vec) {
+        __builtin_nontemporal_store(nt4{pv[0], pv[1], pv[2], pv[3]}, (nt4*)(A.p + o));
+        __builtin_nontemporal_store(nt4{mv[0], mv[1], mv[2], mv[3]}, (nt4*)(A.m + o));
+        __builtin_nontemporal_store(nt4{vv[0], vv[1], vv[2], vv[3]}, (nt4*)(A.v + o));
+    } else {
+        for (int k = 0; k < nv; ++k) { A.p[o + k] = pv[k]; A.m[o + k] = mv[k]; A.v[o + k] = vv[k]; }
+    }
+    if (A.lp) {
+        T* op = (T*)A.lp + o;
+        if (vec) {
+            if constexpr (sizeof(T) == 2)
+                *(uint2*)op = make_uint2((uint32_t)f32_to_bf16(pv[0]) | ((uint32_t)f32_to_bf16(pv[1]) << 16), (uint32_t)f32_to_bf16(pv[2]) | ((uint32_t)f32_to_bf16(pv[3]) << 16));
+            else *(float4*)op = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        } else for (int k = 0; k < nv; ++k) op[k] = LP<T>::from_f32(pv[k]);
+    }
+    if (A.lpT) {
+        T* tp = (T*)A.lpT + (size_t)col * A.ldT + row;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nv) tp[(size_t)k * A.ldT] = LP<T>::from_f32(pv[k]);
+    }
+}
+
 // XCD-aware tile mapping.  Workgroups are dealt to the 8 XCDs round-robin (id % 8) and every XCD has its own L2, so the
 // operand panels a problem's workgroups share are fetched once PER XCD that touches them.  Local workgroup t of a problem
 // (global id first_id + t) is mapped so that the workgroups of one XCD cover a contiguous band of tiles — bands of output
@@ -110,11 +161,21 @@ template <typename T, bool TR> struct Stage {
 };
 
 // Epilogue for 4 consecutive output columns of one row: v += bias; relu; dropout; gate; v += residual; store fp32 / lowp.
-template <typename T>
-__device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropState& ds, bool vec, int row, int col, int N, const f32x4_t& acc) {
+template <typename T, bool ADAM = false>
+__device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropState& ds, bool vec, int row, int col, int N, const f32x4_t& acc,
+                                          const AdamSlot* adam = nullptr, const AdamCoef* coef = nullptr) {
     float v[4] = {acc[0], acc[1], acc[2], acc[3]};
     const size_t o = (size_t)row * P.ldc + col;
     const int nv = (col + 4 <= N) ? 4 : N - col;
+    if constexpr (ADAM) {
+        if (adam->p) {                                    // the accumulators are the gradient of p[row][col..col+3]
+            adam4<T>(*adam, *coef, vec, o, row, col, nv, v);
+            if (!adam->write_grad) return;
+            if (vec) *(float4*)(P.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+            else for (int r = 0; r < nv; ++r) P.out_f32[o + r] = v[r];
+            return;
+        }
+    }
     if (P.bias) {
         if (vec) { float4 b = *(const float4*)(P.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         else for (int r = 0; r < nv; ++r) v[r] += P.bias[col + r];
@@ -161,8 +222,12 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
     }
 }
 
+struct NoAdam {};
+template <bool ON> struct AdamArg { typedef NoAdam type; };
+template <> struct AdamArg<true> { typedef AdamGroup type; };
+
 template <typename T, bool A_T, bool B_T>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp, const typename AdamArg<A_T && B_T>::type adam) {
     constexpr int BK = 128 / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE * LDSROW];
     unsigned char* sA = smem;
@@ -241,15 +306,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup grp) {
 
     // ---- epilogue: operands were swapped in the MFMAs, so a lane holds one output row (l15) x four consecutive columns
     const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+    if constexpr (A_T && B_T) {
+        AdamCoef coef;
+        if (adam.any) coef = adam_coef(adam);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = row0 + wr * 32 + i * 16 + l15;
-        if (row >= M) continue;
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + wr * 32 + i * 16 + l15;
+            if (row >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = col0 + wc * 32 + j * 16 + lg * 4;
-            if (col >= N) continue;
-            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+            for (int j = 0; j < 2; ++j) {
+                const int col = col0 + wc * 32 + j * 16 + lg * 4;
+                if (col >= N) continue;
+                epilogue4<T, true>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], &adam.a[g], &coef);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + wr * 32 + i * 16 + l15;
+            if (row >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = col0 + wc * 32 + j * 16 + lg * 4;
+                if (col >= N) continue;
+                epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+            }
         }
     }
 }
@@ -315,7 +396,7 @@ template <typename T> struct StageT128 {      // one 128-row x 128-byte contract
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tt128_kernel(const GemmGroup grp) {
+__global__ __launch_bounds__(256) void gemm_tt128_kernel(const GemmGroup grp, const AdamGroup adam) {
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int BT = 128;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * LDSROW];
@@ -387,6 +468,8 @@ __global__ __launch_bounds__(256) void gemm_tt128_kernel(const GemmGroup grp) {
     if (do_rowsum && tid < BT && row0 + tid < M) P.rowsum_out[row0 + tid] = rsum;
     const DropState ds = drop_init(P.drop);
     const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+    AdamCoef coef;
+    if (adam.any) coef = adam_coef(adam);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = row0 + wr * 64 + i * 16 + l15;
@@ -395,7 +478,7 @@ __global__ __launch_bounds__(256) void gemm_tt128_kernel(const GemmGroup grp) {
         for (int j = 0; j < 4; ++j) {
             const int col = col0 + wc * 64 + j * 16 + lg * 4;
             if (col >= N) continue;
-            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+            epilogue4<T, true>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], &adam.a[g], &coef);
         }
     }
 }
@@ -598,7 +681,7 @@ __device__ __forceinline__ uint4 ttd_frag(const unsigned char* img, int n_off, i
     return f;
 }
 
-__global__ __launch_bounds__(256) void gemm_tt_dma_kernel(const GemmGroup grp) {
+__global__ __launch_bounds__(256) void gemm_tt_dma_kernel(const GemmGroup grp, const AdamGroup adam) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -675,6 +758,8 @@ __global__ __launch_bounds__(256) void gemm_tt_dma_kernel(const GemmGroup grp) {
     }
     const DropState ds = drop_init(P.drop);
     const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+    AdamCoef coef;
+    if (adam.any) coef = adam_coef(adam);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = row0 + wr * 32 + i * 16 + l15;
@@ -683,7 +768,7 @@ __global__ __launch_bounds__(256) void gemm_tt_dma_kernel(const GemmGroup grp) {
         for (int j = 0; j < 2; ++j) {
             const int col = col0 + wc * 32 + j * 16 + lg * 4;
             if (col >= N) continue;
-            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+            epilogue4<T, true>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], &adam.a[g], &coef);
         }
     }
 }
@@ -733,20 +818,12 @@ __device__ __forceinline__ uint4 ttb_frag(const unsigned char* img, int n_off, i
     return f;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tt_dma128_kernel(const GemmGroup grp) {
+// One 128 x 128 tile of dW = dY^T X (+ optimiser epilogue): shared by the kernel-argument form and the table form below.
+__device__ __forceinline__ void tt128_tile(const mtn_gemm_problem& P, const AdamSlot& S, const bool lds_epilogue, const AdamCoef& coef,
+                                           const int row0, const int col0, unsigned char* smem) {
     typedef bf16_t T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    int g = 0;
-    while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
-    const mtn_gemm_problem& P = grp.p[g];
     const int M = P.M, N = P.N, K = P.K;
-    const int tiles_n = (N + 127) / 128;
-    const int t = (int)blockIdx.x - grp.tile_start[g];
-    const int tiles_m = (M + 128 - 1) / 128;
-    int tm_, tn_;
-    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
-    const int row0 = tm_ * 128, col0 = tn_ * 128;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
@@ -810,6 +887,86 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_dma128_kernel(const GemmGroup 
     }
     const DropState ds = drop_init(P.drop);
     const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+    if (lds_epilogue && S.p) {
+        // Optimiser epilogue through LDS (the operand stages are dead): the accumulators hold the gradient as 64-byte row
+        // pieces per lane group, which would turn the seven parameter streams into partial-line traffic.  Half a tile at a
+        // time (64 rows): gradient -> LDS [64][132] fp32; every thread then owns whole float4s of full 512-byte rows of
+        // p / m / v (coalesced non-temporal loads and stores) and of the compute-dtype copy, and parks the new weights as
+        // bf16 in a second LDS image [128 cols][72] from which the TRANSPOSED copy leaves as 128-byte column runs.
+        float* sg = (float*)smem;                                  // 64 x 132 floats = 33 792 B
+        bf16_t* st = (bf16_t*)(smem + 64 * 132 * 4);               // 128 x 72 bf16   = 18 432 B
+        typedef __attribute__((ext_vector_type(4))) float nt4;
+        const int c4 = (tid & 31) * 4, rb = tid >> 5;              // this thread: columns c4..c4+3 of rows rb*8 .. rb*8+7 of a half
+        const bool col_ok = col0 + c4 < N;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // all 24 16-byte loads of this thread's 8 rows are in flight before anything waits on them — and before the
+            // gradient goes through LDS (a load of the next row cannot be hoisted above this row's stores by the compiler: p, m,
+            // v may alias for all it knows; one HBM latency per row made the epilogue latency-bound, 50 us per tile)
+            nt4 p_[8], m_[8], v_[8];
+            bool ok[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = row0 + h * 64 + rb * 8 + q;
+                ok[q] = col_ok && row < M;
+                if (ok[q]) {
+                    const size_t o = (size_t)row * P.ldc + col0 + c4;
+                    p_[q] = __builtin_nontemporal_load((const nt4*)(S.p + o));
+                    m_[q] = __builtin_nontemporal_load((const nt4*)(S.m + o));
+                    v_[q] = __builtin_nontemporal_load((const nt4*)(S.v + o));
+                }
+            }
+            __syncthreads();
+            if (wr == h) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *(f32x4_t*)(sg + (i * 16 + l15) * 132 + wc * 64 + j * 16 + lg * 4) = acc[i][j];
+            }
+            __syncthreads();
+            uint32_t pk[4][4];                                     // the new weights as bf16: [column][row pair]
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = rb * 8 + q;
+                const int row = row0 + h * 64 + r;
+                float pv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (ok[q]) {
+                    const size_t o = (size_t)row * P.ldc + col0 + c4;
+                    const f32x4_t gq = *(const f32x4_t*)(sg + r * 132 + c4);
+                    float mv[4], vv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { pv[k] = p_[q][k]; mv[k] = m_[q][k]; vv[k] = v_[q][k]; adam_update(pv[k], mv[k], vv[k], gq[k], coef); }
+                    __builtin_nontemporal_store(nt4{pv[0], pv[1], pv[2], pv[3]}, (nt4*)(S.p + o));
+                    __builtin_nontemporal_store(nt4{mv[0], mv[1], mv[2], mv[3]}, (nt4*)(S.m + o));
+                    __builtin_nontemporal_store(nt4{vv[0], vv[1], vv[2], vv[3]}, (nt4*)(S.v + o));
+                    if (S.write_grad) *(float4*)(P.out_f32 + o) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+                    if (S.lp)
+                        *(uint2*)((T*)S.lp + o) = make_uint2((uint32_t)f32_to_bf16(pv[0]) | ((uint32_t)f32_to_bf16(pv[1]) << 16),
+                                                             (uint32_t)f32_to_bf16(pv[2]) | ((uint32_t)f32_to_bf16(pv[3]) << 16));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t bits = (uint32_t)f32_to_bf16(pv[k]);
+                    if (q & 1) pk[k][q >> 1] |= bits << 16; else pk[k][q >> 1] = bits;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(uint4*)(st + (c4 + k) * 72 + rb * 8) = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
+            __syncthreads();
+            if (S.lpT) {
+                const int r8 = (tid & 7) * 8;                       // 8 consecutive rows = 16 bytes of one column of the tile
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int c = (tid >> 3) + ps * 32;
+                    const int row = row0 + h * 64 + r8;
+                    if (col0 + c < N && row < M)                    // M % 8 == 0: the 8 rows are in or out together
+                        *(uint4*)((T*)S.lpT + (size_t)(col0 + c) * S.ldT + row) = *(const uint4*)(st + c * 72 + r8);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = row0 + wr * 64 + i * 16 + l15;
@@ -818,9 +975,79 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_dma128_kernel(const GemmGroup 
         for (int j = 0; j < 4; ++j) {
             const int col = col0 + wc * 64 + j * 16 + lg * 4;
             if (col >= N) continue;
-            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+            epilogue4<T, true>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], &S, &coef);
         }
     }
+}
+
+
+__global__ __launch_bounds__(256, 2) void gemm_tt_dma128_kernel(const GemmGroup grp, const AdamGroup adam) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
+    const mtn_gemm_problem& P = grp.p[g];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = (N + 127) / 128;
+    const int t = (int)blockIdx.x - grp.tile_start[g];
+    const int tiles_m = (M + 128 - 1) / 128;
+    int tm_, tn_;
+    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
+    const int row0 = tm_ * 128, col0 = tn_ * 128;
+    AdamCoef coef;
+    if (adam.any) coef = adam_coef(adam);
+    tt128_tile(P, adam.a[g], adam.lds_epilogue != 0, coef, row0, col0, smem);
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// Table form: ALL parameter-gradient problems of a backward pass (~200 at cfg2) in ONE launch.  The problem list does not
+// fit a kernel argument, so it lives in device memory (mtn_gemm_tt_table stages it through pinned memory): a header, the
+// problems, and a tile map (grid index -> problem, tile) in which consecutive problems have very different contraction
+// lengths.  Why: with the optimiser epilogue a tile is a compute phase (LDS-DMA pulls + MFMA) followed by a streaming phase
+// (26 B/param of HBM traffic).  Launch by launch, all tiles are in the same phase at the same time and the two costs add;
+// in one long launch the resident workgroups drift apart and one tile's streaming overlaps its neighbours' contractions.
+// --------------------------------------------------------------------------------------------------------------------
+struct TTProblem {
+    const void* A; const void* B;
+    float* out; float* rowsum;
+    float *p, *m, *v; void* lp; void* lpT;
+    int lda, ldb, M, N, K, ldc, ldT, write_grad;
+    int tiles_m, tiles_n, first_tile, pad_;
+};
+struct TTHeader {
+    const float* state; const float* grad_scale;
+    float beta1, beta2, eps;
+    int any, lds_epilogue, n_problems, n_tiles, plain_tile_order;
+    long problems_off, tilemap_off;            // byte offsets from the header
+};
+__global__ __launch_bounds__(256, 2) void gemm_tt_dma128_table_kernel(const TTHeader* __restrict__ hdr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned char* base = (const unsigned char*)hdr;
+    const uint32_t* tilemap = (const uint32_t*)(base + hdr->tilemap_off);
+    const uint32_t e = tilemap[blockIdx.x];                       // problem << 12 | tile inside the problem
+    const int g = (int)(e >> 12), t = (int)(e & 0xfff);
+    const TTProblem& Q = ((const TTProblem*)(base + hdr->problems_off))[g];
+    mtn_gemm_problem P;
+    P.A = Q.A; P.B = Q.B; P.lda = Q.lda; P.ldb = Q.ldb; P.M = Q.M; P.N = Q.N; P.K = Q.K; P.a_trans = 1; P.b_trans = 1;
+    P.bias = nullptr; P.relu = 0; P.drop.p = 0.f; P.drop.salt = 0; P.drop.seed = nullptr; P.gate = nullptr; P.gate_scale = 1.f;
+    P.residual = nullptr; P.ldr = 0; P.out_f32 = Q.out; P.out_lp = nullptr; P.ldc = Q.ldc; P.rowsum_out = Q.rowsum; P.adam = nullptr;
+    AdamSlot S;
+    S.p = Q.p; S.m = Q.m; S.v = Q.v; S.lp = Q.lp; S.lpT = Q.lpT; S.ldT = Q.ldT; S.write_grad = Q.write_grad;
+    // the problem's tiles are consecutive grid indices starting at first_tile: same XCD-aware band mapping as xcd_tile()
+    const int T = Q.tiles_m * Q.tiles_n;
+    int idx = t;
+    if (!hdr->plain_tile_order && T >= 16) {
+        const int c = t & 7, r = t >> 3;                  // class (same XCD) in order of first appearance, rank inside it
+        const int per = T >> 3, rem = T & 7;
+        idx = c * per + (c < rem ? c : rem) + r;
+    }
+    int tm_, tn_;
+    if (Q.M >= Q.N) { tm_ = idx / Q.tiles_n; tn_ = idx - tm_ * Q.tiles_n; }
+    else { tn_ = idx / Q.tiles_m; tm_ = idx - tn_ * Q.tiles_m; }
+    AdamCoef coef;
+    if (hdr->any) coef = adam_coef(hdr->state, hdr->grad_scale, hdr->beta1, hdr->beta2, hdr->eps);
+    tt128_tile(P, S, hdr->lds_epilogue != 0, coef, tm_ * 128, tn_ * 128, smem);
 }
 
 // ====================================================================================================================
@@ -930,7 +1157,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmGroup grp
 // While recording, every mtn_gemm call keeps a copy of its problem list; mtn_census_replay re-issues a recorded launch so
 // that the caller can time each of the step's GEMM launches with HIP events on the launch stream.
 #include <vector>
-struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GEMM_MAX_GROUP]; };
+struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GEMM_MAX_GROUP]; mtn_adam_fuse adam[MTN_GEMM_MAX_GROUP]; };
 static std::vector<CensusEntry> g_census;
 static bool g_census_on = false;
 static int g_variant = 0, g_variant_tiles = 0;     // set by launch_gemm: which kernel the dispatch picked
@@ -968,7 +1195,7 @@ static int retile(GemmGroup& grp, int bm, int bn) {
 }
 
 template <typename T>
-static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, bool dma_ok, hipStream_t s) {
+static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_tiles, bool at, bool bt, bool dma_ok, hipStream_t s) {
     dim3 grid(total_tiles), block(256);
     g_variant_tiles = total_tiles;
     g_variant = at ? (bt ? V_REG_TT : V_REG_TN) : (bt ? V_REG_NT : V_REG_NN);
@@ -1034,8 +1261,8 @@ static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, 
         const int t = retile(g2, 32, 32);
         if (half_force || (half_ok && t > 1024)) return launch_dma<T, 32, 32, 256>(g2, t, s);   // (measured in the step: 640 tiles 10.7 vs 10.1 us, 1280 tiles 12.7 vs 13.8 us)
         return launch_dma<T, 32, 32, 512>(g2, t, s);
-    } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp);
-    else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp);
+    } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp, NoAdam{});
+    else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp, NoAdam{});
     else if (at && bt) {
         // measured on the train step: 2 x 128x128 workgroups per CU hide latency worse than 8 x 64x64 ones (7.51 vs 7.25 ms per
         // step) although they pull half the bytes — kept behind MTN_GEMM_TT128=1 for larger batches.
@@ -1052,7 +1279,7 @@ static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, 
             t128 += ((grp.p[i].M + 127) / 128) * ((grp.p[i].N + 127) / 128);
         }
         const char* tmin = getenv("MTN_GEMM_TTB_MIN_TILES");
-        ttb = ttb && t128 >= (tmin ? atoi(tmin) : 192);
+        ttb = ttb && (t128 >= (tmin ? atoi(tmin) : 192) || adam.any);          // the coalesced optimiser epilogue lives in the 128-tile kernel
         if (ttb) {
             if constexpr (sizeof(T) == 2) {
                 static bool attr_set = false;
@@ -1063,19 +1290,28 @@ static int launch_gemm(const GemmGroup& grp, int total_tiles, bool at, bool bt, 
                 GemmGroup g2 = grp;
                 const int tiles = retile(g2, 128, 128);
                 g_variant = V_TT_DMA128; g_variant_tiles = tiles;
-                hipLaunchKernelGGL(gemm_tt_dma128_kernel, dim3(tiles), block, TTB_LDS, s, g2);
+                AdamGroup a2 = adam;
+                a2.lds_epilogue = adam.any && getenv("MTN_ADAM_EPILOGUE_DIRECT") == nullptr;
+                for (int i = 0; i < grp.count; ++i) {
+                    const AdamSlot& sl = adam.a[i];
+                    if (!sl.p) continue;
+                    if (grp.p[i].ldc % 4 != 0 || (sl.lpT && (sl.ldT % 8 != 0 || (((uintptr_t)sl.lpT) & 15) != 0)) || (((uintptr_t)sl.p) & 15) != 0 ||
+                        (sl.lp && (((uintptr_t)sl.lp) & 7) != 0))
+                        a2.lds_epilogue = 0;
+                }
+                hipLaunchKernelGGL(gemm_tt_dma128_kernel, dim3(tiles), block, TTB_LDS, s, g2, a2);
             }
         } else if (ttd) {
             g_variant = V_TT_DMA;
-            if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(gemm_tt_dma_kernel, grid, block, TTD_LDS, s, grp);
+            if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(gemm_tt_dma_kernel, grid, block, TTD_LDS, s, grp, adam);
         } else if (big) {
             GemmGroup g2 = grp;
             const int tiles = retile(g2, 128, 128);
             g_variant = V_TT128; g_variant_tiles = tiles;
-            hipLaunchKernelGGL((gemm_tt128_kernel<T>), dim3(tiles), block, 0, s, g2);
-        } else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, s, grp);
+            hipLaunchKernelGGL((gemm_tt128_kernel<T>), dim3(tiles), block, 0, s, g2, adam);
+        } else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, s, grp, adam);
     }
-    else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, s, grp);
+    else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, s, grp, NoAdam{});
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
@@ -1084,7 +1320,9 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     MTN_CHECK_ARG(dtype == MTN_F32 || dtype == MTN_BF16, "bad dtype");
     MTN_CHECK_ARG(count >= 1 && count <= MTN_GEMM_MAX_GROUP && problems, "bad problem count");
     GemmGroup grp;
+    AdamGroup adam;
     memset(&grp, 0, sizeof(grp));
+    memset(&adam, 0, sizeof(adam));
     grp.count = count;
     grp.plain_tile_order = getenv("MTN_GEMM_PLAIN_TILES") != nullptr;
     int tiles = 0;
@@ -1103,6 +1341,22 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
         grp.tile_start[i] = tiles;
         tiles += ((p.M + TILE - 1) / TILE) * ((p.N + TILE - 1) / TILE);
         grp.p[i] = p;
+        grp.p[i].adam = nullptr;                  // host pointer: never dereferenced on the device
+        if (p.adam) {
+            const mtn_adam_fuse& f = *p.adam;
+            MTN_CHECK_ARG(p.a_trans && p.b_trans, "the optimiser epilogue rides on parameter-gradient GEMMs (a_trans = b_trans = 1) only");
+            MTN_CHECK_ARG(f.p && f.m && f.v && f.state && p.out_f32, "optimiser epilogue: p, m, v, state and out_f32 are required");
+            MTN_CHECK_ARG(!p.bias && !p.relu && !p.gate && !p.residual && !p.out_lp && p.drop.p == 0.f, "optimiser epilogue: C must be the whole, plain gradient");
+            MTN_CHECK_ARG(!f.p_lpT || f.ldT >= p.M, "optimiser epilogue: ldT is the row stride of the transposed copy (>= M)");
+            if (!adam.any) {
+                adam.state = f.state; adam.grad_scale = f.grad_scale; adam.beta1 = f.beta1; adam.beta2 = f.beta2; adam.eps = f.eps;
+                adam.any = 1;
+            }
+            MTN_CHECK_ARG(adam.state == f.state && adam.grad_scale == f.grad_scale && adam.beta1 == f.beta1 && adam.beta2 == f.beta2 && adam.eps == f.eps,
+                          "optimiser epilogue: one set of hyper-parameters per launch");
+            AdamSlot& a = adam.a[i];
+            a.p = f.p; a.m = f.m; a.v = f.v; a.lp = f.p_lp; a.lpT = f.p_lpT; a.ldT = f.ldT; a.write_grad = f.write_grad;
+        }
     }
     for (int i = count; i <= MTN_GEMM_MAX_GROUP; ++i) grp.tile_start[i] = tiles;
     hipStream_t s = (hipStream_t)stream;
@@ -1116,16 +1370,118 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
         const mtn_gemm_problem& p = problems[i];
         if (p.rowsum_out || (long)p.M * p.lda * esz >= (1L << 31) || (long)p.N * p.ldb * esz >= (1L << 31)) dma_ok = false;
     }
-    const int rc = (dtype == MTN_BF16) ? launch_gemm<bf16_t>(grp, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s)
-                                       : launch_gemm<float>(grp, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s);
+    const int rc = (dtype == MTN_BF16) ? launch_gemm<bf16_t>(grp, adam, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s)
+                                       : launch_gemm<float>(grp, adam, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s);
     if (g_census_on && rc == MTN_OK) {
         CensusEntry e;
         memset(&e, 0, sizeof(e));
         e.dtype = dtype; e.count = count; e.variant = g_variant; e.tiles = g_variant_tiles;
-        for (int i = 0; i < count; ++i) e.p[i] = problems[i];
+        for (int i = 0; i < count; ++i) {
+            e.p[i] = problems[i];
+            if (problems[i].adam) e.adam[i] = *problems[i].adam;       // the caller's descriptor dies with the call
+        }
         g_census.push_back(e);
     }
     return rc;
+}
+
+// Host side of the table form.  The table is staged through pinned memory and copied with the launch stream; eager calls
+// cycle through a small ring of (pinned, device) slot pairs guarded by events, a call made while the stream is being
+// captured into a hipGraph gets a slot pair of its own that is never reused (the graph's memcpy node reads it at every replay).
+#define MTN_TT_SLOT_BYTES (256 * 1024)
+struct TTSlot { unsigned char* host; unsigned char* dev; hipEvent_t ev; bool fresh; };
+static TTSlot g_tt_ring[8];
+static int g_tt_next = 0;
+static int tt_slot_alloc(TTSlot& sl) {
+    // allocation calls are "unsafe" under a global-mode stream capture (they would invalidate it): relax the mode for this thread
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    struct Restore { hipStreamCaptureMode m; ~Restore() { (void)hipThreadExchangeStreamCaptureMode(&m); } } restore{mode};
+    if (hipHostMalloc((void**)&sl.host, MTN_TT_SLOT_BYTES, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&sl.dev, MTN_TT_SLOT_BYTES) != hipSuccess ||
+        hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) {
+        mtn_set_error("mtn_gemm_tt_table: cannot allocate a staging slot: %s", hipGetErrorString(hipGetLastError()));
+        return MTN_ERR_LAUNCH;
+    }
+    sl.fresh = true;
+    return MTN_OK;
+}
+
+extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* problems, void* stream) {
+    MTN_CHECK_ARG(dtype == MTN_BF16, "the table form is bf16 only");
+    MTN_CHECK_ARG(count >= 1 && count <= 1024 && problems, "bad problem count");
+    hipStream_t s = (hipStream_t)stream;
+    long tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        const mtn_gemm_problem& p = problems[i];
+        MTN_CHECK_ARG(p.A && p.B && p.out_f32 && p.M > 0 && p.N > 0 && p.K > 0, "null operand/output or empty problem");
+        MTN_CHECK_ARG(p.a_trans && p.b_trans, "the table form takes parameter-gradient problems (a_trans = b_trans = 1) only");
+        MTN_CHECK_ARG(!p.bias && !p.relu && !p.gate && !p.residual && !p.out_lp && p.drop.p == 0.f, "plain C = A^T B only");
+        MTN_CHECK_ARG(p.M % 8 == 0 && p.N % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0, "M, N, lda, ldb multiples of 8; ldc of 4");
+        MTN_CHECK_ARG((long)p.K * p.lda * 2 < (1L << 31) && (long)p.K * p.ldb * 2 < (1L << 31), "operands must be below 2 GiB");
+        MTN_CHECK_ARG((((uintptr_t)p.A) & 15) == 0 && (((uintptr_t)p.B) & 15) == 0 && (((uintptr_t)p.out_f32) & 15) == 0, "16-byte aligned bases");
+        const long t = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        MTN_CHECK_ARG(t <= 4095, "at most 4095 tiles per problem");
+        tiles += t;
+    }
+    const long need = (long)sizeof(TTHeader) + (long)count * sizeof(TTProblem) + tiles * 4;
+    MTN_CHECK_ARG(need <= MTN_TT_SLOT_BYTES, "problem list too large for one table");
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    TTSlot own, *sl;
+    if (cap != hipStreamCaptureStatusNone) {
+        if (tt_slot_alloc(own) != MTN_OK) return MTN_ERR_LAUNCH;       // lives as long as the process: the captured graph reads it
+        sl = &own;
+    } else {
+        sl = &g_tt_ring[g_tt_next];
+        g_tt_next = (g_tt_next + 1) % 8;
+        if (!sl->host) { if (tt_slot_alloc(*sl) != MTN_OK) return MTN_ERR_LAUNCH; }
+        else if (!sl->fresh) (void)hipEventSynchronize(sl->ev);          // its previous copy has been consumed
+    }
+    TTHeader* H = (TTHeader*)sl->host;
+    memset(H, 0, sizeof(*H));
+    H->n_problems = count; H->n_tiles = (int)tiles;
+    H->plain_tile_order = getenv("MTN_GEMM_PLAIN_TILES") != nullptr;
+    H->problems_off = sizeof(TTHeader);
+    H->tilemap_off = sizeof(TTHeader) + (long)count * sizeof(TTProblem);
+    TTProblem* Q = (TTProblem*)(sl->host + H->problems_off);
+    uint32_t* map = (uint32_t*)(sl->host + H->tilemap_off);
+    bool lds_ok = getenv("MTN_ADAM_EPILOGUE_DIRECT") == nullptr;
+    int first = 0;
+    for (int i = 0; i < count; ++i) {
+        const mtn_gemm_problem& p = problems[i];
+        TTProblem& q = Q[i];
+        memset(&q, 0, sizeof(q));
+        q.A = p.A; q.B = p.B; q.out = p.out_f32; q.rowsum = p.rowsum_out;
+        q.lda = p.lda; q.ldb = p.ldb; q.M = p.M; q.N = p.N; q.K = p.K; q.ldc = p.ldc;
+        q.tiles_m = (p.M + 127) / 128; q.tiles_n = (p.N + 127) / 128; q.first_tile = first;
+        if (p.adam) {
+            const mtn_adam_fuse& f = *p.adam;
+            MTN_CHECK_ARG(f.p && f.m && f.v && f.state, "optimiser epilogue: p, m, v and state are required");
+            MTN_CHECK_ARG(!f.p_lpT || f.ldT >= p.M, "optimiser epilogue: ldT is the row stride of the transposed copy (>= M)");
+            if (!H->any) { H->state = f.state; H->grad_scale = f.grad_scale; H->beta1 = f.beta1; H->beta2 = f.beta2; H->eps = f.eps; H->any = 1; }
+            MTN_CHECK_ARG(H->state == f.state && H->grad_scale == f.grad_scale && H->beta1 == f.beta1 && H->beta2 == f.beta2 && H->eps == f.eps,
+                          "optimiser epilogue: one set of hyper-parameters per launch");
+            q.p = f.p; q.m = f.m; q.v = f.v; q.lp = f.p_lp; q.lpT = f.p_lpT; q.ldT = f.ldT; q.write_grad = f.write_grad;
+            if ((f.p_lpT && (f.ldT % 8 != 0 || (((uintptr_t)f.p_lpT) & 15) != 0)) || (((uintptr_t)f.p) & 15) != 0 || (f.p_lp && (((uintptr_t)f.p_lp) & 7) != 0))
+                lds_ok = false;
+        }
+        const int t = q.tiles_m * q.tiles_n;
+        for (int k = 0; k < t; ++k) map[first + k] = ((uint32_t)i << 12) | (uint32_t)k;
+        first += t;
+    }
+    H->lds_epilogue = (H->any && lds_ok) ? 1 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tt_dma128_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TTB_LDS);
+        attr_set = true;
+    }
+    hipError_t e = hipMemcpyAsync(sl->dev, sl->host, (size_t)need, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) { mtn_set_error("mtn_gemm_tt_table: staging copy failed: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
+    hipLaunchKernelGGL(gemm_tt_dma128_table_kernel, dim3((unsigned)tiles), dim3(256), TTB_LDS, s, (const TTHeader*)sl->dev);
+    MTN_CHECK_LAUNCH();
+    if (cap == hipStreamCaptureStatusNone) { (void)hipEventRecord(sl->ev, s); sl->fresh = false; }
+    return MTN_OK;
 }
 
 extern "C" int mtn_census_begin(void) { g_census.clear(); g_census_on = true; return MTN_OK; }
@@ -1152,7 +1508,9 @@ extern "C" int mtn_census_replay(int i, int reps, void* stream) {
     MTN_CHECK_ARG(i >= 0 && i < (int)g_census.size() && reps >= 1, "bad census index");
     const bool was = g_census_on;
     g_census_on = false;
-    const CensusEntry e = g_census[i];
+    CensusEntry e = g_census[i];
+    for (int k = 0; k < e.count; ++k)
+        if (e.p[k].adam) e.p[k].adam = &e.adam[k];      // replays re-apply the optimiser epilogue (same cost; parameters drift by <= lr per replay)
     int rc = MTN_OK;
     for (int r = 0; r < reps && rc == MTN_OK; ++r) rc = mtn_gemm(e.dtype, e.count, e.p, stream);
     g_census_on = was;

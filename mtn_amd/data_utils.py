@@ -8,6 +8,8 @@ tensors stay on whatever device they were created on (no hard-coded ``.cuda()``)
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional
 
 import torch
@@ -100,15 +102,52 @@ class FusedAdam:
     def tick(self, factor: float, model_size: int, warmup: int):
         L.check(L.load().mtn_noam_tick(self.state.data_ptr(), factor, model_size, warmup, self.betas[0], self.betas[1], L.stream_ptr()))
 
-    def step(self):
+    def _buffers(self):
         flat, flat_lp, grad = self.model.flat_buffers()
         if self.m.data_ptr() == 0 or self.m.numel() != flat.numel() or self.m.device != flat.device:
             raise L.MtnHipError("model was re-flattened after the optimiser was built")
-        lp_ptr = None if flat_lp is flat else flat_lp.data_ptr()
+        return flat, flat_lp, grad, (None if flat_lp is flat else flat_lp.data_ptr())
+
+    def step(self):
+        flat, flat_lp, grad, lp_ptr = self._buffers()
         L.check(L.load().mtn_adam_step(L.dtype_code(self.model.compute_dtype), flat.numel(), flat.data_ptr(), grad.data_ptr(),
                                        self.m.data_ptr(), self.v.data_ptr(), lp_ptr, self.state.data_ptr(),
                                        L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
         self.model.refresh_transposed()
+
+    # ---- optimiser epilogue: the update of the sublayer weight matrices rides on their parameter-gradient GEMMs
+    def can_fuse(self) -> bool:
+        m = self.model
+        m.prepare()
+        return bool(getattr(m, "_fusable", None)) and m._rest_chunks is not None and os.environ.get("MTN_NO_FUSED_ADAM") is None
+
+    def fuse_into_backward(self, write_grad: bool = False):
+        """Arm the model's parameter-gradient queue: its next flush (the end of the coming backward pass) applies THIS
+        step's update to every sublayer weight matrix inside the dW GEMM that produces its gradient (include/mtn_hip.h
+        mtn_adam_fuse) — no gradient round trip through HBM, no separate transpose pass.  The schedule must already have
+        been advanced (tick) and ``step_rest()`` must follow the backward pass.  Single-rank only: with data parallelism
+        the gradients are exchanged between backward and the update."""
+        flat, flat_lp, grad, lp_ptr = self._buffers()
+        m = self.model
+        esz = flat_lp.element_size()
+        self._armed = dict(fusable=m._fusable, starts=[t[0] for t in m._fusable], numel=sum(r * c for _, r, c in m._fusable),
+                           grad=grad.data_ptr(), p=flat.data_ptr(), m=self.m.data_ptr(), v=self.v.data_ptr(), lp=lp_ptr,
+                           lpT=m._flat_lpT.data_ptr() if m._flat_lpT is not None else None, esz=esz, write_grad=write_grad,
+                           state=self.state.data_ptr(), grad_scale=L.ptr(self.grad_scale), betas=self.betas, eps=self.eps, applied=False)
+        m._queue.adam = self._armed
+
+    def step_rest(self):
+        """After a backward pass armed by fuse_into_backward(): the update of everything the GEMM epilogues did not touch."""
+        m = self.model
+        armed, m._queue.adam = m._queue.adam, None
+        if armed is None or not armed["applied"]:
+            raise L.MtnHipError("optimiser epilogue was armed but the backward pass did not run its parameter-gradient GEMMs")
+        flat, flat_lp, grad, lp_ptr = self._buffers()
+        off, ln, n = m._rest_chunks
+        L.check(L.load().mtn_adam_step_chunks(L.dtype_code(m.compute_dtype), n, off.data_ptr(), ln.data_ptr(), flat.data_ptr(),
+                                              grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), lp_ptr, self.state.data_ptr(),
+                                              L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
+        m.refresh_transposed(rest_only=True)
 
     def zero_grad(self, set_to_none: bool = False):
         self.model.zero_glue_grads()
@@ -149,6 +188,16 @@ class NoamOpt:
         self._step += 1
         self.optimizer.tick(self.factor, self.model_size, self.warmup)
         self.optimizer.step()
+
+    def begin_fused_step(self, write_grad: bool = False):
+        """step() split around the backward pass (FusedAdam.fuse_into_backward): advance the schedule and arm the epilogue
+        before it, finish_fused_step() after it.  Same arithmetic as step(), element for element."""
+        self._step += 1
+        self.optimizer.tick(self.factor, self.model_size, self.warmup)
+        self.optimizer.fuse_into_backward(write_grad)
+
+    def finish_fused_step(self):
+        self.optimizer.step_rest()
 
     def state_dict(self):
         return {"step": self._step, "optimizer": self.optimizer.state_dict()}

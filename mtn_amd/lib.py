@@ -20,13 +20,20 @@ class Dropout(C.Structure):
     _fields_ = [("p", C.c_float), ("salt", C.c_uint32), ("seed", C.c_void_p)]
 
 
+class AdamFuse(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("p_lp", C.c_void_p), ("p_lpT", C.c_void_p),
+                ("ldT", C.c_int), ("write_grad", C.c_int), ("state", C.c_void_p), ("grad_scale", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+
+
 class GemmProblem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("lda", C.c_int), ("ldb", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_trans", C.c_int), ("b_trans", C.c_int),
                 ("bias", C.c_void_p), ("relu", C.c_int), ("drop", Dropout),
                 ("gate", C.c_void_p), ("gate_scale", C.c_float),
                 ("residual", C.c_void_p), ("ldr", C.c_int),
-                ("out_f32", C.c_void_p), ("out_lp", C.c_void_p), ("ldc", C.c_int), ("rowsum_out", C.c_void_p)]
+                ("out_f32", C.c_void_p), ("out_lp", C.c_void_p), ("ldc", C.c_int), ("rowsum_out", C.c_void_p),
+                ("adam", C.POINTER(AdamFuse))]
 
 
 class AttnArgs(C.Structure):
@@ -135,6 +142,7 @@ SYMBOLS = {
     "mtn_last_error": (C.c_char_p, []),
     "mtn_version": (C.c_int, []),
     "mtn_gemm": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
+    "mtn_gemm_tt_table": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
     "mtn_layernorm_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mtn_layernorm_fwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(LnFwdDesc), _P]),
     "mtn_embed_bwd_group": (C.c_int, [C.c_int, C.POINTER(EmbedBwdDesc), _P]),
@@ -166,6 +174,7 @@ SYMBOLS = {
     "mtn_transpose_group": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, _P]),
     "mtn_noam_tick": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     "mtn_adam_step": (C.c_int, [C.c_int, C.c_long, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
+    "mtn_adam_step_chunks": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P]),
 }
 
 _lib = None

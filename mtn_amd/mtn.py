@@ -555,6 +555,7 @@ class EncoderDecoder(nn.Module):
         self._flat_version = -1
         self._flat_lpT = torch.zeros(total, device=dev, dtype=lp) if dev.type == "cuda" else None
         tdescs = []          # (offset, rows, cols) of every 2-D path weight that gets a transposed copy
+        fusable = []         # ... of those, the sublayer weights whose gradient is ONE deferred GEMM (optimiser epilogue)
         if dev.type == "cuda":
             if self._seed is None or self._seed.device != dev:
                 self._seed = torch.full((1,), torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, device=dev, dtype=torch.int64)
@@ -583,6 +584,7 @@ class EncoderDecoder(nn.Module):
                     m._fused["w_qkv_lpT"] = self._flat_lpT[oq:oq + 3 * d * d].view(d, 3 * d)
                     m._fused["w_o_lpT"] = self._flat_lpT[oo:oo + d * d].view(d, d)
                     tdescs += [(oq, 3 * d, d), (oo, d, d)]
+                    fusable += [(oq, 3 * d, d), (oo, d, d)]
             elif isinstance(m, PositionwiseFeedForward) and id(m.w_1.weight) in path_off:
                 w1, w1l, g1 = views(m.w_1.weight); b1, _, gb1 = views(m.w_1.bias)
                 w2, w2l, g2 = views(m.w_2.weight); b2, _, gb2 = views(m.w_2.bias)
@@ -594,6 +596,7 @@ class EncoderDecoder(nn.Module):
                     m._fused["w1_lpT"] = self._flat_lpT[o1:o1 + ffd * dm].view(dm, ffd)
                     m._fused["w2_lpT"] = self._flat_lpT[o2:o2 + ffd * dm].view(ffd, dm)
                     tdescs += [(o1, ffd, dm), (o2, dm, ffd)]
+                    fusable += [(o1, ffd, dm), (o2, dm, ffd)]
             elif isinstance(m, Generator):
                 o_w, o_b = path_off[id(m.proj.weight)], path_off[id(m.proj.bias)]
                 nw, nb = m.proj.weight.numel(), m.proj.bias.numel()
@@ -607,16 +610,33 @@ class EncoderDecoder(nn.Module):
                 m._grads = (views(m.a_2)[2], views(m.b_2)[2])
                 m._lp_dtype = lp
                 m._queue = self._queue
-        self._tdesc = None
-        if tdescs:
-            import ctypes as C
-            arr = (L.TransposeDesc * len(tdescs))()
+        def tdesc_table(descs):
+            if not descs:
+                return None
+            arr = (L.TransposeDesc * len(descs))()
             tiles = 0
-            for i, (o, r, c) in enumerate(tdescs):
+            for i, (o, r, c) in enumerate(descs):
                 arr[i].off, arr[i].rows, arr[i].cols, arr[i].tile_start = o, r, c, tiles
                 tiles += ((r + 63) // 64) * ((c + 63) // 64)
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-            self._tdesc = (raw, len(tdescs), tiles)
+            return (raw, len(descs), tiles)
+
+        self._tdesc = tdesc_table(tdescs)
+        # optimiser-epilogue bookkeeping (ops.ParamGradQueue / data_utils.FusedAdam): the fusable weights sorted by offset,
+        # the transposed copies that still need the transpose pass, and the rest of the flat buffer as <= 4096-element chunks
+        self._fusable = sorted(fusable)
+        fus = set(fusable)
+        self._tdesc_rest = tdesc_table([t for t in tdescs if t not in fus])
+        self._rest_chunks = None
+        if dev.type == "cuda" and fusable:
+            offs_c, lens_c, cur = [], [], 0
+            for o, r, c in self._fusable + [(total, 0, 0)]:
+                assert o % 4 == 0 and (r * c) % 4 == 0
+                while cur < o:
+                    n = min(4096, o - cur)
+                    offs_c.append(cur); lens_c.append(n); cur += n
+                cur = o + r * c
+            self._rest_chunks = (torch.tensor(offs_c, dtype=torch.int64).to(dev), torch.tensor(lens_c, dtype=torch.int32).to(dev), len(offs_c))
         if dev.type == "cuda" and self.multi_stream:
             n_side = max(len(l.auto_encoder_vid_attn) for l in self.decoder.layers)
             self._streams = [torch.cuda.Stream(device=dev) for _ in range(n_side)]
@@ -657,11 +677,13 @@ class EncoderDecoder(nn.Module):
             self.refresh_transposed()
         return self
 
-    def refresh_transposed(self):
-        """Rewrite the transposed compute-dtype weight copies from the current weights (one grouped kernel)."""
-        if self._tdesc is None:
+    def refresh_transposed(self, rest_only: bool = False):
+        """Rewrite the transposed compute-dtype weight copies from the current weights (one grouped kernel).
+        ``rest_only``: just the ones the optimiser epilogue of the parameter-gradient GEMMs does not write itself."""
+        table = self._tdesc_rest if rest_only else self._tdesc
+        if table is None:
             return
-        raw, n, tiles = self._tdesc
+        raw, n, tiles = table
         L.check(L.load().mtn_transpose_group(L.dtype_code(self.compute_dtype), self._flat_lp.data_ptr(), self._flat_lpT.data_ptr(),
                                              raw.data_ptr(), n, tiles, L.stream_ptr()))
 

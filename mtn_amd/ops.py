@@ -90,6 +90,49 @@ class ParamGradQueue:
         self.dtype = None
         self.side_streams = []
         self._armed = False
+        self.adam = None            # set by FusedAdam.fuse_into(): the next flush applies the optimiser in the GEMM epilogues
+
+    def _attach_adam(self):
+        """Optimiser epilogue (include/mtn_hip.h mtn_adam_fuse): every dW problem whose target is (a row block of) a fusable
+        sublayer weight updates that weight, its moments and both compute-dtype copies in place instead of storing a gradient.
+        Raises unless the fusable weights are covered exactly once — a silent partial update would corrupt training."""
+        import bisect
+        A = self.adam
+        table, starts = A["fusable"], A["starts"]
+        esz = A["esz"]
+        covered, keep = 0, []
+        seen = set()
+        for p in self.gemm:
+            if not (p.a_trans and p.b_trans and p.out_f32):
+                continue
+            off = (p.out_f32 - A["grad"]) // 4
+            i = bisect.bisect_right(starts, off) - 1
+            if i < 0:
+                continue
+            o, rows, cols = table[i]
+            if not (o <= off < o + rows * cols):
+                continue
+            rel = off - o
+            ok = (not p.residual and p.ldc == cols and p.N == cols and rel % cols == 0 and rel // cols + p.M <= rows and off not in seen)
+            if not ok:
+                raise L.MtnHipError("optimiser epilogue: a parameter-gradient GEMM does not cover its weight block once and whole")
+            seen.add(off)
+            r0 = rel // cols
+            f = L.AdamFuse()
+            f.p, f.m, f.v = A["p"] + 4 * off, A["m"] + 4 * off, A["v"] + 4 * off
+            f.p_lp = A["lp"] + esz * off if A["lp"] else None
+            f.p_lpT = A["lpT"] + esz * (o + r0) if A["lpT"] else None
+            f.ldT = rows
+            f.write_grad = 1 if A["write_grad"] else 0
+            f.state, f.grad_scale = A["state"], A["grad_scale"]
+            f.beta1, f.beta2, f.eps = A["betas"][0], A["betas"][1], A["eps"]
+            p.adam = C.pointer(f)
+            keep.append(f)
+            covered += p.M * p.N
+        if covered != A["numel"]:
+            raise L.MtnHipError(f"optimiser epilogue: {covered} of {A['numel']} fusable weight elements received a gradient GEMM")
+        A["applied"] = True
+        return keep
 
     def add(self, dtype, problems, ln_desc, keep):
         assert self.dtype in (None, dtype)
@@ -112,8 +155,24 @@ class ParamGradQueue:
             cur.wait_stream(s)
         for t in self.keep:
             t.record_stream(cur)
+        adam_keep = self._attach_adam() if self.adam is not None else None      # noqa: F841 (descriptors live until the launches)
         # a grouped launch lasts as long as its longest contraction: keep the long ones (memories: K = B*m rows) together
         self.gemm.sort(key=lambda p: -p.K)
+        table = (self.adam is not None or os.environ.get("MTN_TT_TABLE") == "1") and os.environ.get("MTN_TT_TABLE") != "0"
+        if table and self.dtype == L.MTN_BF16:
+            # with the optimiser epilogue: ALL parameter-gradient problems in one launch, long and short contractions side by
+            # side, so that the tiles' streaming epilogues overlap other tiles' contractions (csrc/gemm.hip, table form)
+            tt = [p for p in self.gemm if p.a_trans and p.b_trans and p.M % 8 == 0 and p.N % 8 == 0 and not p.residual]
+            if tt and len(tt) <= 1024:
+                order, lo, hi = [], 0, len(tt) - 1
+                while lo <= hi:
+                    order.append(tt[lo]); lo += 1
+                    if lo <= hi:
+                        order.append(tt[hi]); hi -= 1
+                arr = (L.GemmProblem * len(order))(*order)
+                L.check(lib.mtn_gemm_tt_table(self.dtype, len(order), arr, cur.cuda_stream))
+                taken = set(id(p) for p in tt)
+                self.gemm = [p for p in self.gemm if id(p) not in taken]
         # ... and at most 512 of the 128x128 tiles (two resident workgroups per CU x 256 CUs) per launch: a launch that
         # spills into a second round pays for a whole extra round
         chunk, tiles = [], 0

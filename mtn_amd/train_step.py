@@ -22,10 +22,13 @@ from .data_utils import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
 class TrainStep:
     def __init__(self, model, batch, vocab: int, pad: int = 1, warmup: int = 4000, factor: float = 1.0, lam: float = 1.0,
                  smoothing: float = 0.1, grad_sync=None, use_graph: bool = True, overlap: Optional[bool] = None, opt=None,
-                 dynamic_norms: bool = False):
+                 dynamic_norms: bool = False, fuse_optimizer: Optional[bool] = None):
         """``opt``: share an existing NoamOpt (several TrainSteps over one model, e.g. one per batch shape).
         ``dynamic_norms``: the batch tensors are refilled in place between steps, so the loss normalisers (token counts,
-        train.py:35-39) are recomputed from them inside the step instead of once at construction."""
+        train.py:35-39) are recomputed from them inside the step instead of once at construction.
+        ``fuse_optimizer``: None = on one rank, apply Adam to the sublayer weight matrices inside their parameter-gradient
+        GEMMs (FusedAdam.fuse_into_backward; those gradients are then never written to ``.grad``); False = always the
+        separate optimiser pass (gradients of every parameter are left in ``.grad`` after the step)."""
         self.model, self.batch = model, batch
         self.opt = opt if opt is not None else NoamOpt(model.decoder.layers[0].size, factor, warmup, FusedAdam(model))
         self.dynamic_norms = dynamic_norms
@@ -41,6 +44,7 @@ class TrainStep:
         self.overlap = bool(overlap) and grad_sync is not None
         self._g_seg = None
         self._st = None
+        self._fuse_opt = False if fuse_optimizer is False else None
         ae_y = batch.cap if model.auto_encoder_ft in ("caption", "summary") else batch.query
         self._ae_y = ae_y
         # loss normalisers (train.py:35-39).  Under DP they are all-reduced ONCE here for a static batch so that
@@ -66,17 +70,34 @@ class TrainStep:
             self.grad_sync.all_reduce_scalars(n)
             self._norms.copy_(n)
 
-    def _fwd_bwd(self):
+    def _fwd_bwd(self, fuse: bool = False):
         m, b = self.model, self.batch
         self._refresh_norms()
         m.zero_glue_grads()
-        out, ae_out = m.forward(b)
-        loss = self.lc.loss(out, b.trg_y, self._norms[0], ae_out, self._ae_y, self._norms[1])
-        loss.backward()
+        if fuse:
+            self.opt.begin_fused_step()
+        try:
+            out, ae_out = m.forward(b)
+            loss = self.lc.loss(out, b.trg_y, self._norms[0], ae_out, self._ae_y, self._norms[1])
+            loss.backward()
+        except BaseException:
+            m._queue.adam = None
+            raise
         return loss.detach()
 
     def _optim(self):
         self.opt.step()
+
+    def _fused(self) -> bool:
+        """One rank: the optimiser rides on the parameter-gradient GEMMs (no gradient exchange to wait for)."""
+        if self._fuse_opt is None:
+            self._fuse_opt = self.grad_sync is None and hasattr(self.opt, "begin_fused_step") and self.opt.optimizer.can_fuse()
+        return self._fuse_opt
+
+    def _step_fused(self):
+        loss = self._fwd_bwd(fuse=True)
+        self.opt.finish_fused_step()
+        return loss
 
     # ---- layer-segmented backward (data parallel, overlapped exchange)
     def _segments(self):
@@ -174,8 +195,11 @@ class TrainStep:
         self._g_fb = torch.cuda.CUDAGraph()
         if self.grad_sync is None:
             with torch.cuda.graph(self._g_fb):
-                self._loss = self._fwd_bwd()
-                self._optim()
+                if self._fused():
+                    self._loss = self._step_fused()
+                else:
+                    self._loss = self._fwd_bwd()
+                    self._optim()
         else:
             with torch.cuda.graph(self._g_fb):
                 self._loss = self._fwd_bwd()
@@ -190,6 +214,8 @@ class TrainStep:
             if self.overlap:
                 self._run_segmented(self._segments())
                 loss = self._loss_t
+            elif self._fused():
+                return self._step_fused()
             else:
                 loss = self._fwd_bwd()
                 if self.grad_sync is not None:

@@ -78,7 +78,7 @@ def test_two_rank_dp_equals_single_rank_on_concatenated_batch(tmp_path, use_grap
     c = dict(fx.GOLDEN_CONFIGS["cfg1_query"], B=4)
     raw = fx.det_batch(c["vocab"], c["B"], c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=3)
     model = _make(c, dev, "fp32")
-    step = TrainStep(model, _batch(c, raw, dev), c["vocab"], pad=fx.PAD, warmup=10, use_graph=False)
+    step = TrainStep(model, _batch(c, raw, dev), c["vocab"], pad=fx.PAD, warmup=10, use_graph=False, fuse_optimizer=False)   # keeps .grad
     losses = [float(step())]
     torch.cuda.synchronize()
     gref = model._flat_grad.cpu().clone()

@@ -476,3 +476,38 @@ def test_checkpoint_resume_continues_the_same_trajectory(dev, tmp_path):
     #  would show as ~1e-1)
     assert max(abs(a - r) / abs(a) for a, r in zip(cont, resumed)) < 3e-3, (cont, resumed)
     assert t2.opt._step == 6 and abs(t2.opt.rate() - t1.opt.rate()) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+def test_optimiser_epilogue_equals_separate_adam(dev, dtype, use_graph, monkeypatch):
+    """One rank: the Adam update of every sublayer weight matrix rides on the GEMM that produces its gradient (mtn_adam_fuse)
+    and the rest of the flat buffer is updated chunk-wise.  Same arithmetic in the same order as the separate whole-buffer
+    pass: parameters, both moments, the compute-dtype copy and its transposed copy must come out bit for bit the same over
+    several steps (with the atomic-free table gradient, so that nothing else differs between two runs)."""
+    from mtn_amd.train_step import TrainStep
+    monkeypatch.setenv("MTN_EMBED_DETERMINISTIC", "1")
+    c = fx.GOLDEN_CONFIGS["cfg1_query"]
+    b = dev_batch(raw_batch(c), dev)
+    res = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("MTN_NO_FUSED_ADAM", raising=False)
+        else:
+            monkeypatch.setenv("MTN_NO_FUSED_ADAM", "1")
+        m = build_model(c, dtype, dev, dropout=0.1, attn_dropout=0.1).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        ts = TrainStep(m, b, c["vocab"], pad=fx.PAD, warmup=10, use_graph=use_graph)
+        m.prepare()
+        m._seed.fill_(99)
+        losses = [float(ts()) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert ts._fused() == fused
+        res.append((losses, m._flat.clone(), ts.opt.optimizer.m.clone(), ts.opt.optimizer.v.clone(), m._flat_lp.clone(), m._flat_lpT.clone()))
+    (la, *ta), (lb, *tb) = res
+    assert la == lb
+    for x, y in zip(ta, tb):
+        assert torch.equal(x, y)
+    assert la[2] < la[0]

@@ -3,7 +3,7 @@ from collections import defaultdict
 db = sorted(glob.glob(sys.argv[1] + '/**/*_results.db', recursive=True))[-1]
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end, grid_x, workgroup_x, queue_id from kernels order by start").fetchall()
-adam = [i for i,r in enumerate(rows) if 'adam_kernel' in r[0]]
+adam = [i for i,r in enumerate(rows) if 'adam_kernel' in r[0] or 'adam_chunks_kernel' in r[0]]
 step = rows[adam[-2]+1:adam[-1]+1]
 t0, t1 = step[0][1], step[-1][2]
 iv = sorted((r[1], r[2]) for r in step)
