@@ -1156,16 +1156,19 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmGroup grp
 // ---------------------------------------------------------------- launch census (measurement support, bench.py)
 // While recording, every mtn_gemm call keeps a copy of its problem list; mtn_census_replay re-issues a recorded launch so
 // that the caller can time each of the step's GEMM launches with HIP events on the launch stream.
+#include <algorithm>
 #include <vector>
-struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GEMM_MAX_GROUP]; mtn_adam_fuse adam[MTN_GEMM_MAX_GROUP]; };
+struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GEMM_MAX_GROUP]; mtn_adam_fuse adam[MTN_GEMM_MAX_GROUP]; int table; };
+struct CensusTable { std::vector<mtn_gemm_problem> p; std::vector<mtn_adam_fuse> adam; };     // a table-form launch (any number of problems)
 static std::vector<CensusEntry> g_census;
+static std::vector<CensusTable> g_census_tables;
 static bool g_census_on = false;
 static int g_variant = 0, g_variant_tiles = 0;     // set by launch_gemm: which kernel the dispatch picked
-enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_DMA128, V_DMA64H, V_DMA32H, V_COUNT };
+enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_DMA128, V_DMA64H, V_DMA32H, V_TT_TABLE, V_COUNT };
 static const char* const g_variant_name[V_COUNT] = {
     "gemm_kernel<N,N> 64x64 reg-staged", "gemm_kernel<N,T>", "gemm_kernel<T,N>", "gemm_kernel<T,T> 64x64 reg-staged",
     "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
-    "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages"};
+    "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages", "gemm_tt_dma128_table_kernel"};
 
 template <typename T, int BM, int BN, int ROWB>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
@@ -1375,7 +1378,7 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     if (g_census_on && rc == MTN_OK) {
         CensusEntry e;
         memset(&e, 0, sizeof(e));
-        e.dtype = dtype; e.count = count; e.variant = g_variant; e.tiles = g_variant_tiles;
+        e.dtype = dtype; e.count = count; e.variant = g_variant; e.tiles = g_variant_tiles; e.table = -1;
         for (int i = 0; i < count; ++i) {
             e.p[i] = problems[i];
             if (problems[i].adam) e.adam[i] = *problems[i].adam;       // the caller's descriptor dies with the call
@@ -1441,7 +1444,6 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
     TTHeader* H = (TTHeader*)sl->host;
     memset(H, 0, sizeof(*H));
     H->n_problems = count; H->n_tiles = (int)tiles;
-    H->plain_tile_order = getenv("MTN_GEMM_PLAIN_TILES") != nullptr;
     H->problems_off = sizeof(TTHeader);
     H->tilemap_off = sizeof(TTHeader) + (long)count * sizeof(TTProblem);
     TTProblem* Q = (TTProblem*)(sl->host + H->problems_off);
@@ -1466,11 +1468,52 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
             if ((f.p_lpT && (f.ldT % 8 != 0 || (((uintptr_t)f.p_lpT) & 15) != 0)) || (((uintptr_t)f.p) & 15) != 0 || (f.p_lp && (((uintptr_t)f.p_lp) & 7) != 0))
                 lds_ok = false;
         }
-        const int t = q.tiles_m * q.tiles_n;
-        for (int k = 0; k < t; ++k) map[first + k] = ((uint32_t)i << 12) | (uint32_t)k;
-        first += t;
+        first += q.tiles_m * q.tiles_n;
     }
     H->lds_epilogue = (H->any && lds_ok) ? 1 : 0;
+    // Tile map.  Workgroups are dealt to the 8 XCDs round-robin by grid index and each XCD has its own L2, so a problem whose
+    // tiles are spread over all XCDs has its operand panels fetched from HBM by each of them (measured: 1.5 GB of operand
+    // traffic per launch for 0.44 GB of operands).  Here every problem is given to ONE XCD: grid index i holds a tile of the
+    // queue of XCD i % 8; problems are dealt to the queues longest-processing-time-first on an estimate of their cost
+    // (tiles x (contraction rows + the epilogue's bytes in row equivalents)), which balances the queues to within one problem.
+    if (getenv("MTN_TT_TABLE_SPREAD") != nullptr) {
+        H->plain_tile_order = getenv("MTN_GEMM_PLAIN_TILES") != nullptr;
+        int pos = 0;
+        for (int i = 0; i < count; ++i)
+            for (int k = 0; k < Q[i].tiles_m * Q[i].tiles_n; ++k) map[pos++] = ((uint32_t)i << 12) | (uint32_t)k;
+    } else {
+        H->plain_tile_order = 1;                                          // inside a problem: plain order, one L2 sees them all
+        std::vector<int> order(count);
+        std::vector<double> cost(count);
+        for (int i = 0; i < count; ++i) {
+            order[i] = i;
+            cost[i] = (double)Q[i].tiles_m * Q[i].tiles_n * (Q[i].K + (Q[i].p ? 896.0 : 128.0));
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+        std::vector<int> owner(count);
+        double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < count; ++k) {
+            int c = 0;
+            for (int x = 1; x < 8; ++x) if (load[x] < load[c]) c = x;
+            owner[order[k]] = c;
+            load[c] += cost[order[k]];
+        }
+        std::vector<uint32_t> queue[8];                                    // in the caller's order: long and short contractions alternate
+        for (int i = 0; i < count; ++i)
+            for (int k = 0; k < Q[i].tiles_m * Q[i].tiles_n; ++k) queue[owner[i]].push_back(((uint32_t)i << 12) | (uint32_t)k);
+        size_t head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (long i = 0; i < tiles; ++i) {
+            int c = (int)(i & 7);
+            if (head[c] >= queue[c].size()) {                              // this XCD's queue is done: help the one with most left
+                int best = -1;
+                size_t left = 0;
+                for (int x = 0; x < 8; ++x)
+                    if (queue[x].size() - head[x] > left) { left = queue[x].size() - head[x]; best = x; }
+                c = best;
+            }
+            map[i] = queue[c][head[c]++];
+        }
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tt_dma128_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TTB_LDS);
@@ -1481,10 +1524,22 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
     hipLaunchKernelGGL(gemm_tt_dma128_table_kernel, dim3((unsigned)tiles), dim3(256), TTB_LDS, s, (const TTHeader*)sl->dev);
     MTN_CHECK_LAUNCH();
     if (cap == hipStreamCaptureStatusNone) { (void)hipEventRecord(sl->ev, s); sl->fresh = false; }
+    if (g_census_on) {
+        CensusTable t;
+        t.p.assign(problems, problems + count);
+        t.adam.resize(count);
+        for (int i = 0; i < count; ++i)
+            if (problems[i].adam) t.adam[i] = *problems[i].adam;
+        CensusEntry e;
+        memset(&e, 0, sizeof(e));
+        e.dtype = dtype; e.count = count; e.variant = V_TT_TABLE; e.tiles = (int)tiles; e.table = (int)g_census_tables.size();
+        g_census_tables.push_back(t);
+        g_census.push_back(e);
+    }
     return MTN_OK;
 }
 
-extern "C" int mtn_census_begin(void) { g_census.clear(); g_census_on = true; return MTN_OK; }
+extern "C" int mtn_census_begin(void) { g_census.clear(); g_census_tables.clear(); g_census_on = true; return MTN_OK; }
 extern "C" int mtn_census_end(void) { g_census_on = false; return (int)g_census.size(); }
 extern "C" const char* mtn_census_variant_name(int variant) { return (variant >= 0 && variant < V_COUNT) ? g_variant_name[variant] : "?"; }
 
@@ -1494,6 +1549,20 @@ extern "C" int mtn_census_info(int i, mtn_census_launch* out) {
     const double esz = (e.dtype == MTN_BF16) ? 2.0 : 4.0;
     memset(out, 0, sizeof(*out));
     out->dtype = e.dtype; out->count = e.count; out->variant = e.variant; out->workgroups = e.tiles;
+    if (e.table >= 0) {
+        // algorithmic bytes: operands once, and per output element either the stored gradient (4 B) or the optimiser
+        // epilogue's streams: p, m, v read and written (24 B) + the two compute-dtype copies (2 x 2 B)
+        const CensusTable& t = g_census_tables[e.table];
+        for (int k = 0; k < e.count; ++k) {
+            const mtn_gemm_problem& p = t.p[k];
+            out->flops += 2.0 * p.M * p.N * p.K;
+            double per = 4.0;
+            if (p.adam) per = 24.0 + (t.adam[k].p_lp ? esz : 0.0) + (t.adam[k].p_lpT ? esz : 0.0) + (t.adam[k].write_grad ? 4.0 : 0.0);
+            out->bytes += ((double)p.M + p.N) * p.K * esz + (double)p.M * p.N * per;
+            if (k < 4) { out->M[k] = p.M; out->N[k] = p.N; out->K[k] = p.K; }
+        }
+        return MTN_OK;
+    }
     for (int k = 0; k < e.count; ++k) {
         const mtn_gemm_problem& p = e.p[k];
         out->flops += 2.0 * p.M * p.N * p.K;
@@ -1509,6 +1578,16 @@ extern "C" int mtn_census_replay(int i, int reps, void* stream) {
     const bool was = g_census_on;
     g_census_on = false;
     CensusEntry e = g_census[i];
+    if (e.table >= 0) {
+        CensusTable t = g_census_tables[e.table];
+        for (int k = 0; k < e.count; ++k)
+            if (t.p[k].adam) t.p[k].adam = &t.adam[k];
+        g_census_on = false;
+        int rc = MTN_OK;
+        for (int r = 0; r < reps && rc == MTN_OK; ++r) rc = mtn_gemm_tt_table(e.dtype, e.count, t.p.data(), stream);
+        g_census_on = was;
+        return rc;
+    }
     for (int k = 0; k < e.count; ++k)
         if (e.p[k].adam) e.p[k].adam = &e.adam[k];      // replays re-apply the optimiser epilogue (same cost; parameters drift by <= lr per replay)
     int rc = MTN_OK;

@@ -158,12 +158,14 @@ class ParamGradQueue:
         adam_keep = self._attach_adam() if self.adam is not None else None      # noqa: F841 (descriptors live until the launches)
         # a grouped launch lasts as long as its longest contraction: keep the long ones (memories: K = B*m rows) together
         self.gemm.sort(key=lambda p: -p.K)
-        table = (self.adam is not None or os.environ.get("MTN_TT_TABLE") == "1") and os.environ.get("MTN_TT_TABLE") != "0"
-        if table and self.dtype == L.MTN_BF16:
-            # with the optimiser epilogue: ALL parameter-gradient problems in one launch, long and short contractions side by
-            # side, so that the tiles' streaming epilogues overlap other tiles' contractions (csrc/gemm.hip, table form)
+        if os.environ.get("MTN_TT_TABLE") != "0" and self.dtype == L.MTN_BF16:
+            # ALL parameter-gradient problems in one launch of 128x128 tiles (csrc/gemm.hip, table form), long and short
+            # contractions side by side: no launch boundaries or partial rounds (296 vs 430 us at cfg2), and with the optimiser
+            # epilogue the tiles' streaming phases overlap other tiles' contractions.  Without the epilogue only when the
+            # problems fill 128-wide tiles (tiny test models keep the 64-wide kernels).
             tt = [p for p in self.gemm if p.a_trans and p.b_trans and p.M % 8 == 0 and p.N % 8 == 0 and not p.residual]
-            if tt and len(tt) <= 1024:
+            big = all(p.M >= 128 and p.N >= 128 for p in tt) and sum(((p.M + 127) // 128) * ((p.N + 127) // 128) for p in tt) >= 192
+            if tt and len(tt) <= 1024 and (self.adam is not None or big):
                 order, lo, hi = [], 0, len(tt) - 1
                 while lo <= hi:
                     order.append(tt[lo]); lo += 1

@@ -23,8 +23,9 @@ def short(name):
 
 
 def one_step(rows):
-    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-    return rows[adam[-2] + 1: adam[-1] + 1]
+    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] or "adam_chunks_kernel" in r["Kernel_Name"]]
+    cands = [rows[adam[i] + 1: adam[i + 1] + 1] for i in range(max(0, len(adam) - 4), len(adam) - 1)]
+    return min(cands, key=len)          # a replayed graph step (bench.py's eager census pass has extra kernels)
 
 
 def per_kernel(rows):
@@ -38,8 +39,10 @@ def per_kernel(rows):
 
 fetch_dir, write_dir, out, n_params = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
 F, W = per_kernel(one_step(load(fetch_dir, "FETCH_SIZE"))), per_kernel(one_step(load(write_dir, "WRITE_SIZE")))
-adam_f = next(v for k, v in F.items() if "adam_kernel" in k[0])
-adam_w = next(v for k, v in W.items() if "adam_kernel" in k[0])
+# (with the optimiser epilogue the whole-buffer adam_kernel is gone: calibrate on adam_chunks_kernel, same bytes per element,
+#  and pass the number of elements IT covers as <n_params_padded>)
+adam_f = next(v for k, v in F.items() if "adam_kernel" in k[0] or "adam_chunks_kernel" in k[0])
+adam_w = next(v for k, v in W.items() if "adam_kernel" in k[0] or "adam_chunks_kernel" in k[0])
 fetch_corr = 2.0                                                 # guide: wide coalesced reads are tallied at half
 write_cal = (14.0 * n_params) / (adam_w[1] / adam_w[0])           # known bytes / raw counter
 fetch_check = (16.0 * n_params) / (fetch_corr * adam_f[1] / adam_f[0])

@@ -1,0 +1,22 @@
+set -x
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pj_stats -- python $R/bench.py --no-cpu-baseline --steps 10 > /tmp/pj_b.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pj_fetch -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /tmp/pj_f.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pj_write -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /tmp/pj_w.log 2>&1
+cd $R
+NREST=$(python - <<'PY'
+import torch, sys
+sys.path.insert(0, ".")
+from mtn_amd import make_model
+from mtn_amd.synthetic import CONFIGS
+cfg = CONFIGS["cfg2"]
+m = make_model(cfg["vocab"], cfg["vocab"], N=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"], dropout=0.1, ft_sizes=cfg["ft_sizes"], diff_encoder=True, auto_encoder_ft="query", compute_dtype=torch.bfloat16).cuda()
+m.prepare()
+print(int(m._rest_chunks[1].sum()))
+PY
+)
+echo NREST=$NREST
+python tools/prof_summary.py /tmp/pj_stats gpurun_out/r01_j_kernel_stats.csv 2>&1 | tail -3
+python tools/prof_breakdown.py /tmp/pj_stats 60 > gpurun_out/r01_j_one_step_breakdown.txt
+python tools/pmc_summary.py /tmp/pj_fetch /tmp/pj_write gpurun_out/r01_j_pmc_traffic.json $NREST 2>&1 | tail -20
