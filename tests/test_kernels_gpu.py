@@ -427,3 +427,74 @@ def test_gemm_dma_128_tile_row_major(dev, M, N, K):
         del os.environ["MTN_GEMM_NTB_MIN_TILES"]
     ref = torch.relu(lp_round(a, dtype).double() @ lp_round(b, dtype).double().t() + bias.double()) + res.double()
     assert relmax(out, ref) < 1e-4 and relmax(out_lp.float(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("with_adam", [False, True], ids=["plain", "optimiser-epilogue"])
+def test_gemm_tt_table_form(dev, with_adam):
+    """All parameter-gradient problems in one launch (mtn_gemm_tt_table): ragged output sizes (partial 128-tiles), ragged
+    contraction, row sums, many problems; with the optimiser epilogue (mtn_adam_fuse) the result is Adam applied to the weight
+    block — p, m, v, the compute-dtype copy and the TRANSPOSED copy, including a row block of a taller weight (ldT > M) —
+    checked against the same update done in fp64 on the host; launched twice (the second launch reuses a staging slot)."""
+    import ctypes as C
+    from mtn_amd import lib as L
+    lib = L.load()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    shapes = [(512, 512, 640), (1536, 512, 100), (200, 136, 333), (128, 2048, 1000), (8, 8, 8), (384, 128, 64)] + [(128, 128, 96)] * 20
+    state = torch.tensor([3.0, 2e-3, 1 - 0.9 ** 3, 1 - 0.98 ** 3, 0, 0, 0, 0], device=dev)
+    probs, keep, checks = [], [], []
+    for idx, (M, N, K) in enumerate(shapes):
+        a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        A, B = a.t().contiguous().to(dev, dtype), b.t().contiguous().to(dev, dtype)
+        out = torch.full((M, N), float("nan"), device=dev)
+        rs = torch.full((M,), float("nan"), device=dev)
+        p = _gemm_problem(L, A, B, M, N, K, 1, 1, M, N)
+        p.out_f32, p.ldc, p.rowsum_out = out.data_ptr(), N, rs.data_ptr()
+        ar, br = lp_round(a, dtype).double(), lp_round(b, dtype).double()
+        ref = ar @ br.t()
+        entry = dict(out=out, rs=rs, ref=ref, rsum=ar.sum(1))
+        if with_adam:
+            rows_total, r0 = (M + 64, 24) if idx % 2 else (M, 0)         # odd problems: a row block of a taller weight
+            w = torch.randn(M, N, generator=g).to(dev)
+            m0, v0 = (0.01 * torch.randn(M, N, generator=g)).to(dev), (1e-4 * torch.rand(M, N, generator=g)).to(dev)
+            p_, m_, v_ = w.clone(), m0.clone(), v0.clone()
+            lp = torch.zeros(M, N, device=dev, dtype=dtype)
+            lpT = torch.full((N, rows_total), 7.0, device=dev, dtype=dtype)
+            f = L.AdamFuse()
+            f.p, f.m, f.v, f.p_lp = p_.data_ptr(), m_.data_ptr(), v_.data_ptr(), lp.data_ptr()
+            f.p_lpT, f.ldT = lpT.data_ptr() + 2 * r0, rows_total
+            f.write_grad, f.state, f.grad_scale, f.beta1, f.beta2, f.eps = (idx % 3 == 0), state.data_ptr(), None, 0.9, 0.98, 1e-9
+            p.adam = C.pointer(f)
+            entry.update(w=w, m0=m0, v0=v0, p=p_, m=m_, v=v_, lp=lp, lpT=lpT, r0=r0, wg=bool(f.write_grad))
+            keep.append(f)
+        probs.append(p)
+        keep += [A, B]
+        checks.append(entry)
+    arr = (L.GemmProblem * len(probs))(*probs)
+    for launch in range(2):
+        L.check(lib.mtn_gemm_tt_table(L.dtype_code(dtype), len(probs), arr, L.stream_ptr()))
+        torch.cuda.synchronize()
+        for e in checks:
+            assert relmax(e["rs"], e["rsum"]) < 1e-4
+            if not with_adam:
+                assert relmax(e["out"], e["ref"]) < 1e-4
+                continue
+            gref = e["ref"]
+            if launch == 0:
+                e["wm"], e["mm"], e["vm"] = e["w"].double().cpu(), e["m0"].double().cpu(), e["v0"].double().cpu()
+            mm = 0.9 * e["mm"] + 0.1 * gref
+            vv = 0.98 * e["vm"] + 0.02 * gref * gref
+            lr, bc1, bc2 = 2e-3, 1 - 0.9 ** 3, 1 - 0.98 ** 3
+            ww = e["wm"] - (lr / bc1) * mm / (vv.sqrt() / math.sqrt(bc2) + 1e-9)
+            e["wm"], e["mm"], e["vm"] = ww, mm, vv
+            assert relmax(e["m"], mm) < 1e-5 and relmax(e["v"], vv) < 1e-5
+            assert absmax(e["p"], ww) < 2e-6 * max(1.0, float(ww.abs().max()))
+            M = e["p"].size(0)
+            assert torch.equal(e["lp"], e["p"].to(dtype))
+            assert torch.equal(e["lpT"][:, e["r0"]:e["r0"] + M], e["p"].to(dtype).t())
+            rest = torch.cat([e["lpT"][:, :e["r0"]], e["lpT"][:, e["r0"] + M:]], dim=1)
+            assert bool((rest == 7.0).all())                                   # nothing outside the block was touched
+            if e["wg"]:
+                assert relmax(e["out"], gref) < 1e-4
+            else:
+                assert bool(torch.isnan(e["out"]).all())                       # the gradient never went to memory
