@@ -1519,7 +1519,20 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
         (void)hipFuncSetAttribute((const void*)gemm_tt_dma128_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TTB_LDS);
         attr_set = true;
     }
-    hipError_t e = hipMemcpyAsync(sl->dev, sl->host, (size_t)need, hipMemcpyHostToDevice, s);
+    hipError_t e;
+    if (cap != hipStreamCaptureStatusNone) {
+        // under capture the table is constant for the life of the graph: copy it NOW (synchronously, outside the graph) instead
+        // of recording a copy node that every replay would re-execute (5.5 us per step)
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        static hipStream_t copy_stream = nullptr;                 // non-blocking: no implicit dependency on the capturing stream
+        e = copy_stream ? hipSuccess : hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemcpyAsync(sl->dev, sl->host, (size_t)need, hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(copy_stream);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+    } else {
+        e = hipMemcpyAsync(sl->dev, sl->host, (size_t)need, hipMemcpyHostToDevice, s);
+    }
     if (e != hipSuccess) { mtn_set_error("mtn_gemm_tt_table: staging copy failed: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
     hipLaunchKernelGGL(gemm_tt_dma128_table_kernel, dim3((unsigned)tiles), dim3(256), TTB_LDS, s, (const TTHeader*)sl->dev);
     MTN_CHECK_LAUNCH();
