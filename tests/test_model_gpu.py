@@ -478,6 +478,26 @@ def test_checkpoint_resume_continues_the_same_trajectory(dev, tmp_path):
     assert t2.opt._step == 6 and abs(t2.opt.rate() - t1.opt.rate()) < 1e-12
 
 
+@pytest.mark.parametrize("name", [n for n in fx.GOLDEN_CONFIGS if n != "cfg1_query"])
+def test_optimiser_epilogue_covers_every_model_variant(dev, name, monkeypatch):
+    """The other reference configurations (caption / summary auto-encoder, shared encoder, separate embeddings and generators):
+    every sublayer weight matrix receives exactly one parameter-gradient GEMM (the epilogue raises otherwise) and two fused
+    steps equal two separate-optimiser steps bit for bit."""
+    from mtn_amd.train_step import TrainStep
+    monkeypatch.setenv("MTN_EMBED_DETERMINISTIC", "1")
+    c = fx.GOLDEN_CONFIGS[name]
+    b = dev_batch(raw_batch(c), dev)
+    res = []
+    for fused in (True, False):
+        m = build_model(c, torch.bfloat16, dev, dropout=0.0, attn_dropout=0.0).train()
+        ts = TrainStep(m, b, c["vocab"], pad=fx.PAD, warmup=10, use_graph=False, fuse_optimizer=None if fused else False)
+        losses = [float(ts()) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert ts._fused() == fused
+        res.append((losses, m._flat.clone(), m._flat_lpT.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
 def test_optimiser_epilogue_equals_separate_adam(dev, dtype, use_graph, monkeypatch):
