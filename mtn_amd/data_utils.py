@@ -119,7 +119,12 @@ class FusedAdam:
     def can_fuse(self) -> bool:
         m = self.model
         m.prepare()
-        return bool(getattr(m, "_fusable", None)) and m._rest_chunks is not None and os.environ.get("MTN_NO_FUSED_ADAM") is None
+        ok = bool(getattr(m, "_fusable", None)) and m._flat.is_cuda and os.environ.get("MTN_NO_FUSED_ADAM") is None
+        if ok:      # build the two expected "rest" tables now: they are device tensors and the step may be under graph capture later
+            every = frozenset(t[0] for t in m._fusable)
+            m.rest_tables(every)
+            m.rest_tables(every - m._fusable_optional)
+        return ok
 
     def fuse_into_backward(self, write_grad: bool = False):
         """Arm the model's parameter-gradient queue: its next flush (the end of the coming backward pass) applies THIS
@@ -130,7 +135,7 @@ class FusedAdam:
         flat, flat_lp, grad, lp_ptr = self._buffers()
         m = self.model
         esz = flat_lp.element_size()
-        self._armed = dict(fusable=m._fusable, starts=[t[0] for t in m._fusable], numel=sum(r * c for _, r, c in m._fusable),
+        self._armed = dict(fusable=m._fusable, starts=[t[0] for t in m._fusable], optional=m._fusable_optional, covered=frozenset(),
                            grad=grad.data_ptr(), p=flat.data_ptr(), m=self.m.data_ptr(), v=self.v.data_ptr(), lp=lp_ptr,
                            lpT=m._flat_lpT.data_ptr() if m._flat_lpT is not None else None, esz=esz, write_grad=write_grad,
                            state=self.state.data_ptr(), grad_scale=L.ptr(self.grad_scale), betas=self.betas, eps=self.eps, applied=False)
@@ -143,11 +148,12 @@ class FusedAdam:
         if armed is None or not armed["applied"]:
             raise L.MtnHipError("optimiser epilogue was armed but the backward pass did not run its parameter-gradient GEMMs")
         flat, flat_lp, grad, lp_ptr = self._buffers()
-        off, ln, n = m._rest_chunks
+        (off, ln, n), trest = m.rest_tables(armed["covered"])
         L.check(L.load().mtn_adam_step_chunks(L.dtype_code(m.compute_dtype), n, off.data_ptr(), ln.data_ptr(), flat.data_ptr(),
                                               grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), lp_ptr, self.state.data_ptr(),
                                               L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
-        m.refresh_transposed(rest_only=True)
+        if trest is not None:
+            m.refresh_transposed(trest)
 
     def zero_grad(self, set_to_none: bool = False):
         self.model.zero_glue_grads()
@@ -246,7 +252,8 @@ class SimpleLossCompute:
             pass
         spec = dict(targets=ys, norms=[n if torch.is_tensor(n) else torch.tensor(float(n), device=x.device) for n in norms], coefs=coefs,
                     gens=[(f["w_lp"], f["bias"], f["grad_w"], f["grad_b"], f.get("w_lpT")) for f in fused], vocab=self.criterion.size,
-                    pad=self.criterion.padding_idx, smoothing=self.criterion.smoothing, lp_dtype=fused[0]["lp_dtype"])
+                    pad=self.criterion.padding_idx, smoothing=self.criterion.smoothing, lp_dtype=fused[0]["lp_dtype"],
+                    queue=fused[0].get("queue"))
         spec["norms"] = [n.detach().float().reshape(1) for n in spec["norms"]]
         return ops.GeneratorLossFn.apply(spec, *xs)
 

@@ -555,7 +555,8 @@ class EncoderDecoder(nn.Module):
         self._flat_version = -1
         self._flat_lpT = torch.zeros(total, device=dev, dtype=lp) if dev.type == "cuda" else None
         tdescs = []          # (offset, rows, cols) of every 2-D path weight that gets a transposed copy
-        fusable = []         # ... of those, the sublayer weights whose gradient is ONE deferred GEMM (optimiser epilogue)
+        fusable = []         # ... of those, the weights whose gradient is ONE deferred GEMM (optimiser epilogue)
+        optional = set()     # ... offsets of fusable weights that may legitimately get no deferred GEMM in a step
         if dev.type == "cuda":
             if self._seed is None or self._seed.device != dev:
                 self._seed = torch.full((1,), torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, device=dev, dtype=torch.int64)
@@ -606,37 +607,20 @@ class EncoderDecoder(nn.Module):
                 if self._flat_lpT is not None and vocab % 8 == 0 and not any(t[0] == o_w for t in tdescs):
                     m._fused["w_lpT"] = self._flat_lpT[o_w:o_w + nw].view(dm, vocab)     # dX of the loss head on the LDS-DMA path
                     tdescs.append((o_w, vocab, dm))
+                    fusable.append((o_w, vocab, dm))
+                    optional.add(o_w)            # its dW reaches the queue only through the fused loss head
+                m._fused["queue"] = self._queue
             elif isinstance(m, LayerNorm) and id(m.a_2) in path_off:
                 m._grads = (views(m.a_2)[2], views(m.b_2)[2])
                 m._lp_dtype = lp
                 m._queue = self._queue
-        def tdesc_table(descs):
-            if not descs:
-                return None
-            arr = (L.TransposeDesc * len(descs))()
-            tiles = 0
-            for i, (o, r, c) in enumerate(descs):
-                arr[i].off, arr[i].rows, arr[i].cols, arr[i].tile_start = o, r, c, tiles
-                tiles += ((r + 63) // 64) * ((c + 63) // 64)
-            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-            return (raw, len(descs), tiles)
-
-        self._tdesc = tdesc_table(tdescs)
+        self._tdesc = self._tdesc_table(tdescs)
         # optimiser-epilogue bookkeeping (ops.ParamGradQueue / data_utils.FusedAdam): the fusable weights sorted by offset,
         # the transposed copies that still need the transpose pass, and the rest of the flat buffer as <= 4096-element chunks
-        self._fusable = sorted(fusable)
-        fus = set(fusable)
-        self._tdesc_rest = tdesc_table([t for t in tdescs if t not in fus])
-        self._rest_chunks = None
-        if dev.type == "cuda" and fusable:
-            offs_c, lens_c, cur = [], [], 0
-            for o, r, c in self._fusable + [(total, 0, 0)]:
-                assert o % 4 == 0 and (r * c) % 4 == 0
-                while cur < o:
-                    n = min(4096, o - cur)
-                    offs_c.append(cur); lens_c.append(n); cur += n
-                cur = o + r * c
-            self._rest_chunks = (torch.tensor(offs_c, dtype=torch.int64).to(dev), torch.tensor(lens_c, dtype=torch.int32).to(dev), len(offs_c))
+        self._fusable = sorted(set(fusable))
+        self._fusable_optional = frozenset(optional)
+        self._tdescs_all = list(tdescs)
+        self._rest_cache = {}
         if dev.type == "cuda" and self.multi_stream:
             n_side = max(len(l.auto_encoder_vid_attn) for l in self.decoder.layers)
             self._streams = [torch.cuda.Stream(device=dev) for _ in range(n_side)]
@@ -677,10 +661,44 @@ class EncoderDecoder(nn.Module):
             self.refresh_transposed()
         return self
 
-    def refresh_transposed(self, rest_only: bool = False):
+    def _tdesc_table(self, descs):
+        """Device-side descriptor table of mtn_transpose_group for the (offset, rows, cols) weights in ``descs``."""
+        if not descs:
+            return None
+        arr = (L.TransposeDesc * len(descs))()
+        tiles = 0
+        for i, (o, r, c) in enumerate(descs):
+            arr[i].off, arr[i].rows, arr[i].cols, arr[i].tile_start = o, r, c, tiles
+            tiles += ((r + 63) // 64) * ((c + 63) // 64)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self._flat.device)
+        return (raw, len(descs), tiles)
+
+    def rest_tables(self, covered: frozenset):
+        """What is left for the separate optimiser pass when the fusable weights at offsets ``covered`` were updated by the
+        epilogue of their parameter-gradient GEMM: (chunks of <= 4096 elements of the flat buffers as device arrays
+        (offsets, lengths, count), the transposed copies that still need the transpose pass).  Cached per set."""
+        hit = self._rest_cache.get(covered)
+        if hit is None:
+            dev = self._flat.device
+            total = self._flat.numel()
+            done = [t for t in self._fusable if t[0] in covered]
+            offs_c, lens_c, cur = [], [], 0
+            for o, r, c in done + [(total, 0, 0)]:
+                assert o % 4 == 0 and (r * c) % 4 == 0
+                while cur < o:
+                    n = min(4096, o - cur)
+                    offs_c.append(cur); lens_c.append(n); cur += n
+                cur = o + r * c
+            chunks = (torch.tensor(offs_c, dtype=torch.int64).to(dev), torch.tensor(lens_c, dtype=torch.int32).to(dev), len(offs_c))
+            dset = set(done)
+            hit = (chunks, self._tdesc_table([t for t in self._tdescs_all if t not in dset]))
+            self._rest_cache[covered] = hit
+        return hit
+
+    def refresh_transposed(self, table=None):
         """Rewrite the transposed compute-dtype weight copies from the current weights (one grouped kernel).
-        ``rest_only``: just the ones the optimiser epilogue of the parameter-gradient GEMMs does not write itself."""
-        table = self._tdesc_rest if rest_only else self._tdesc
+        ``table``: a subset (rest_tables()[1]) instead of all of them."""
+        table = self._tdesc if table is None else table
         if table is None:
             return
         raw, n, tiles = table

@@ -100,7 +100,8 @@ class ParamGradQueue:
         A = self.adam
         table, starts = A["fusable"], A["starts"]
         esz = A["esz"]
-        covered, keep = 0, []
+        keep = []
+        got = {}                                     # offset of the fusable weight -> elements that received a gradient GEMM
         seen = set()
         for p in self.gemm:
             if not (p.a_trans and p.b_trans and p.out_f32):
@@ -128,9 +129,15 @@ class ParamGradQueue:
             f.beta1, f.beta2, f.eps = A["betas"][0], A["betas"][1], A["eps"]
             p.adam = C.pointer(f)
             keep.append(f)
-            covered += p.M * p.N
-        if covered != A["numel"]:
-            raise L.MtnHipError(f"optimiser epilogue: {covered} of {A['numel']} fusable weight elements received a gradient GEMM")
+            got[o] = got.get(o, 0) + p.M * p.N
+        covered = set()
+        for o, rows, cols in table:
+            n = got.get(o, 0)
+            if n == rows * cols:
+                covered.add(o)
+            elif n != 0 or o not in A["optional"]:
+                raise L.MtnHipError(f"optimiser epilogue: weight at offset {o} received gradient GEMMs for {n} of {rows * cols} elements")
+        A["covered"] = frozenset(covered)
         A["applied"] = True
         return keep
 
@@ -967,7 +974,11 @@ class GeneratorLossFn(torch.autograd.Function):
             q.gate_scale, q.out_f32, q.ldc, q.rowsum_out = 1.0, gw.data_ptr(), d, gb.data_ptr()
             p_dw.append(q)
         gemm(code, p_dx)
-        gemm(code, p_dw)
+        queue = spec.get("queue")
+        if queue is not None and queue.adam is not None:
+            queue.add(code, p_dw, None, [dlogits, x_lp])      # with the optimiser epilogue: one of the problems of the table launch
+        else:
+            gemm(code, p_dw)
         return (None,) + tuple(dx[offs[i]:offs[i] + rows[i]].view(shapes[i]) for i in range(len(rows)))
 
 

@@ -153,6 +153,7 @@ class TrainStep:
     def _capture(self):
         m = self.model
         m.prepare()
+        self._fused()                               # decides (and builds its device-side tables) outside the capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):               # allocator / autograd warm-up off the capture stream

@@ -13,7 +13,7 @@ from mtn_amd.synthetic import CONFIGS
 cfg = CONFIGS["cfg2"]
 m = make_model(cfg["vocab"], cfg["vocab"], N=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"], dropout=0.1, ft_sizes=cfg["ft_sizes"], diff_encoder=True, auto_encoder_ft="query", compute_dtype=torch.bfloat16).cuda()
 m.prepare()
-print(int(m._rest_chunks[1].sum()))
+print(int(m.rest_tables(frozenset(t[0] for t in m._fusable))[0][1].sum()))
 PY
 )
 echo NREST=$NREST
