@@ -569,10 +569,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdGroup grp)
 // Deterministic variant (no atomics, the same bits on every run).  A workgroup of 16 waves owns 16 vocabulary entries of one
 // table, one per wave.  The token lists of all streams that use the table — one virtual list, stream order then row order —
 // are staged through LDS in chunks (coalesced, once per workgroup and pass) and scanned with 64-token ballots:
-//   pass 1  each wave counts the occurrences of its entry;
-//   pass 2  a wave whose entry occurs at most EMB_HEAVY times adds those rows of dx itself, in list order, through the
-//           stream's scale and dropout mask (up to eight rows' loads in flight), and writes dlut[v] += sum, once;
-//   pass 3  a frequent entry (the pad id of a ragged batch, '.', '?', ...) would serialise thousands of rows in one wave, so
+//   pass 1  each wave counts the occurrences of its entry and, while there are at most EMB_HEAVY of them, adds those rows of dx
+//           on the spot, in list order, through the stream's scale and dropout mask (up to eight rows' loads in flight); an
+//           entry that stays at or below EMB_HEAVY writes dlut[v] += sum, once (otherwise the partial sum is dropped);
+//   pass 2  a frequent entry (the pad id of a ragged batch, '.', '?', ...) would serialise thousands of rows in one wave, so
 //           all 16 waves take it together: wave w scans ballots w, w+16, ... of every chunk, the 16 partial sums meet in LDS
 //           and are added in wave order.
 // Which wave adds which row depends only on the token values and shapes, so the rounding is the same on every run.
@@ -671,40 +671,43 @@ __global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const EmbedDetGroup
             }
     }
     const bool one_chunk = total <= EMB_CH;
-    auto stage = [&](int ch, int cnt) {
+    auto stage = [&](int ch, int cnt) {                    // stream by stream: plain strided copies, no per-token search
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += 1024) {
-            const int g = ch + i;
-            int si = 0;
-            while (si + 1 < ns && g >= st[si + 1].first) ++si;
-            tok[i] = (int)st[si].tokens[g - st[si].first];
+        for (int si = 0; si < ns; ++si) {
+            const int first = st[si].first, last = si + 1 < ns ? st[si + 1].first : total;
+            const int lo = max(first, ch), hi = min(last, ch + cnt);
+            const long* src = st[si].tokens - first;
+            for (int g = lo + (int)threadIdx.x; g < hi; g += 1024) tok[g - ch] = (int)src[g];
         }
         __syncthreads();
     };
     __syncthreads();
-    // pass 1: occurrences of this wave's entry
-    int mine = 0;
-    for (int ch = 0; ch < total; ch += EMB_CH) {
-        const int cnt = min(EMB_CH, total - ch);
-        stage(ch, cnt);
-        if (live)
-            for (int b = 0; b < cnt; b += 64) mine += __popcll(__ballot(b + lane < cnt && tok[b + lane] == v));
-    }
-    if (lane == 0) count[wave] = live ? mine : 0;
-    __syncthreads();
     for (int c0 = 0; c0 < d; c0 += 512) {                  // 8 columns per lane per pass (one pass for d <= 512)
-        // pass 2: entries with few occurrences, one wave each
+        // passes 1+2 in one scan: count the occurrences of this wave's entry and, as long as there are at most EMB_HEAVY of
+        // them, add their rows on the spot (four ballots' tokens are read from LDS before the first is tested)
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        const bool light = live && mine > 0 && mine <= EMB_HEAVY;
+        int mine = 0;
         for (int ch = 0; ch < total; ch += EMB_CH) {
             const int cnt = min(EMB_CH, total - ch);
-            if (!one_chunk) stage(ch, cnt);
-            if (light)
-                for (int b = 0; b < cnt; b += 64)
-                    emb_add_rows(__ballot(b + lane < cnt && tok[b + lane] == v), ch + b, st, ns, d, c0, lane, acc);
+            if (!one_chunk || c0 == 0) stage(ch, cnt);
+            if (live)
+                for (int b = 0; b < cnt; b += 256) {
+                    int t4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t4[k] = b + k * 64 + lane < cnt ? tok[b + k * 64 + lane] : -1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned long long m = __ballot(t4[k] == v);
+                        if (m) {
+                            mine += __popcll(m);
+                            if (mine <= EMB_HEAVY) emb_add_rows(m, ch + b + k * 64, st, ns, d, c0, lane, acc);
+                        }
+                    }
+                }
         }
+        const bool light = live && mine > 0 && mine <= EMB_HEAVY;
         if (light) {
             float* dst = grp.dlut[t] + (size_t)v * d + c0;
 #pragma unroll
@@ -713,7 +716,9 @@ __global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const EmbedDetGroup
                 if (c0 + c < d) dst[c] += acc[j];
             }
         }
-        // pass 3: frequent entries, all 16 waves on one entry at a time
+        if (lane == 0) count[wave] = live ? mine : 0;
+        __syncthreads();
+        // pass 2: frequent entries, all 16 waves on one entry at a time
         for (int h = 0; h < 16; ++h) {
             if (count[h] <= EMB_HEAVY) continue;           // uniform over the workgroup
             const int vh = blockIdx.x * 16 + h;
