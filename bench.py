@@ -75,6 +75,24 @@ def cpu_baseline(model, cfg, B, steps):
             "sample": f"{steps} train steps (after 2 warm-ups) of the same workload, batch {B}, fp32, dropout off; median step {med:.3f} s; nproc={os.cpu_count()}"}
 
 
+def decode_cpu_baseline(model, cfg, max_len, beam, live, SOS, UNK, EOS):
+    """cpu_baseline leg of bench_decode.py: the same beam search on the CPU oracle (oracle/mtn_oracle.py), one dialogue."""
+    from oracle import fixtures as fx
+    from oracle.mtn_oracle import OracleConfig, OracleMTN, beam_search
+    ocfg = OracleConfig(vocab=cfg["vocab"], n_layers=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], heads=cfg["h"],
+                        ft_sizes=tuple(cfg["ft_sizes"]), diff_encoder=True, auto_encoder_ft="query")
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items() if not k.endswith(".pe")}
+    om = OracleMTN(ocfg, sd)
+    raw = fx.det_batch(cfg["vocab"], 1, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], seed=1, ragged=False)
+    ob = fx.oracle_batch(raw)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        beam_search(om, ob, max_len, SOS, UNK, EOS, beam=beam, nbest=beam)
+        t_cpu = time.perf_counter() - t0
+    return {"value": round(live / t_cpu, 1), "unit": "hypothesis-tokens/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"1 dialogue, same search, fp32 oracle: {t_cpu:.2f} s"}
+
+
 def gemm_census_roofline(step, peak_tflops):
     """Live roofline of the step's dominant kernel family, the grouped MFMA GEMMs.  One eager pass of the step's
     forward+backward is recorded by the library's launch census (include/mtn_hip.h: mtn_census_*), then EVERY recorded GEMM

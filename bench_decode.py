@@ -93,20 +93,8 @@ def main():
         line["beam_batched"] = {"dialogues_side_by_side": D, "hypothesis_tokens_per_s": round(D * live / t_many, 1),
                                 "dialogues_per_s": round(D / t_many, 2), "ms_per_step": round(1e3 * t_many / args.max_len, 3)}
     if not args.no_cpu_baseline:
-        from oracle import fixtures as fx
-        from oracle.mtn_oracle import OracleConfig, OracleMTN, beam_search
-        ocfg = OracleConfig(vocab=cfg["vocab"], n_layers=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], heads=cfg["h"],
-                            ft_sizes=tuple(cfg["ft_sizes"]), diff_encoder=True, auto_encoder_ft="query")
-        sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items() if not k.endswith(".pe")}
-        om = OracleMTN(ocfg, sd)
-        raw = fx.det_batch(cfg["vocab"], 1, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], seed=1, ragged=False)
-        ob = fx.oracle_batch(raw)
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            beam_search(om, ob, args.max_len, SOS, UNK, EOS, beam=args.beam, nbest=args.beam)
-            t_cpu = time.perf_counter() - t0
-        line["cpu_baseline"] = {"value": round(live / t_cpu, 1), "unit": "hypothesis-tokens/s", "cores": torch.get_num_threads(),
-                                "kind": "port", "sample": f"1 dialogue, same search, fp32 oracle: {t_cpu:.2f} s"}
+        from bench import decode_cpu_baseline          # the only place outside tests/ that runs the oracle is bench.py's cpu_baseline leg
+        line["cpu_baseline"] = decode_cpu_baseline(model, cfg, args.max_len, args.beam, live, SOS, UNK, EOS)
     print(json.dumps(line), flush=True)
 
 
