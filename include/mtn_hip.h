@@ -333,6 +333,12 @@ int mtn_ffn_param_grad_work(int dtype, const mtn_ffn_args* args, mtn_gemm_proble
  * Backward always defers parameter gradients (see mtn_*_param_grad_work).
  * ------------------------------------------------------------------------------------------ */
 #define MTN_SUBLAYER_MAX_GROUP 4
+/* Forward of a group whose members are bf16 with d = 512, h = 8 (d_k = 64), a <= 64 query rows per sample and memories of
+ * <= 256 rows runs stages 1-3 as ONE launch (csrc/fused.hip: LayerNorm -> head slice of the input projections -> attention,
+ * or LayerNorm -> column slice of w_1 + ReLU + dropout, per (block of samples, head | column slice) workgroup); results and
+ * saved buffers are those of the four-launch path.  mtn_fused_enable(0) turns that off for the process (A/B measurements and
+ * the tests that compare the two paths); returns the previous setting (-1 = never set: environment MTN_FUSED=0 disables). */
+int mtn_fused_enable(int on);
 int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
 int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
 

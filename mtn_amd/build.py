@@ -3,11 +3,19 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmtn_hip.so")
-SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "elementwise.hip", "sublayer.hip", "losshead.hip", "assemble.hip"]
+SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "fused.hip", "elementwise.hip", "sublayer.hip", "losshead.hip", "assemble.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _headers_mtime() -> float:
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "mtn_hip.h")]
+    return max(os.path.getmtime(h) for h in hs if os.path.exists(h))
 
 
 def _stale() -> bool:
@@ -19,13 +27,30 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """One object per source, compiled in parallel (only the sources newer than their object, or everything when a header
+    changed), then one link."""
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libmtn_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB + ".tmp"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    ht = _headers_mtime()
+    todo = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), ht):
+            todo.append((src, obj))
+
+    def cc(job):
+        cmd = [hipcc] + FLAGS + ["-c", job[0], "-o", job[1]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max(1, min(len(todo), os.cpu_count() or 1))) as ex:
+        list(ex.map(cc, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + [os.path.join(OBJ, s[:-4] + ".o") for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -14,6 +14,10 @@
 // gradients are written straight into the caller's buffers, immediately or deferred (mtn_*_param_grad_work).
 #include "common.h"
 
+// csrc/fused.hip
+int fh_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn);
+int fh_group_fwd_stage1(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
+
 static inline const char* lp_off(const void* p, long elems, int dtype) {
     return (const char*)p + elems * (dtype == MTN_BF16 ? 2 : 4);
 }
@@ -73,7 +77,7 @@ static int check_ffn(const mtn_ffn_args* a, bool bwd) {
     return MTN_OK;
 }
 
-static void attn_args_of(const mtn_mha_args* a, int dtype, mtn_attn_args* t) {
+void attn_args_of(const mtn_mha_args* a, int dtype, mtn_attn_args* t) {
     const int d = a->d, m = a->self_attn ? a->a : a->m;
     memset(t, 0, sizeof(*t));
     t->B = a->B; t->h = a->h; t->a = a->a; t->m = m; t->dk = d / a->h;
@@ -92,8 +96,11 @@ extern "C" int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* 
     MTN_CHECK_ARG(n_mha >= 0 && n_mha <= MTN_SUBLAYER_MAX_GROUP && n_ffn >= 0 && n_ffn <= MTN_SUBLAYER_MAX_GROUP && n_mha + n_ffn > 0, "bad group size");
     for (int i = 0; i < n_mha; ++i) RUN(check_mha(&mha[i], false));
     for (int i = 0; i < n_ffn; ++i) RUN(check_ffn(&ffn[i], false));
+    // Fused first launch (csrc/fused.hip): stages 1-3 in one kernel per (sample block, head | w_1 column slice)
+    const bool fused = fh_group_eligible(dtype, n_mha, mha, n_ffn, ffn) != 0;
+    if (fused) RUN(fh_group_fwd_stage1(n_mha, mha, n_ffn, ffn, stream));
     // 1. LayerNorm(x) -> xn (compute dtype); row statistics saved for backward
-    {
+    if (!fused) {
         mtn_ln_fwd_desc L[2 * MTN_SUBLAYER_MAX_GROUP];
         int n = 0;
         for (int i = 0; i < n_mha; ++i) {
@@ -111,7 +118,7 @@ extern "C" int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* 
         RUN(mtn_layernorm_fwd_group(dtype, n, L, stream));
     }
     // 2. input projections (mtn.py:256-258) and FFN first Linear + ReLU + dropout (mtn.py:280)
-    {
+    if (!fused) {
         mtn_gemm_problem p[3 * MTN_SUBLAYER_MAX_GROUP];
         int n = 0;
         for (int i = 0; i < n_mha; ++i) {
@@ -137,7 +144,7 @@ extern "C" int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* 
         RUN(mtn_gemm(dtype, n, p, stream));
     }
     // 3. softmax(QK^T/sqrt(dk) masked) V per head (mtn.py:221-231)
-    if (n_mha) {
+    if (n_mha && !fused) {
         mtn_attn_args t[MTN_SUBLAYER_MAX_GROUP];
         for (int i = 0; i < n_mha; ++i) attn_args_of(&mha[i], dtype, &t[i]);
         RUN(mtn_attention_fwd_group(dtype, n_mha, t, stream));

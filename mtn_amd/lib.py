@@ -150,6 +150,7 @@ SYMBOLS = {
     "mtn_attention_fwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(AttnArgs), _P]),
     "mtn_attention_bwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(AttnArgs), _P]),
     "mtn_cast_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(CastDesc), _P]),
+    "mtn_fused_enable": (C.c_int, [C.c_int]),
     "mtn_sublayer_group_fwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_sublayer_group_bwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_layernorm_bwd_partial_floats": (C.c_long, [C.c_int, C.c_int]),

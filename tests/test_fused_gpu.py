@@ -1,0 +1,100 @@
+"""The fused first launch of a sublayer group (csrc/fused.hip: LayerNorm -> head slice of the projections -> attention, or
+LayerNorm -> w_1 column slice + ReLU + dropout, one kernel) against (a) the four-launch path it replaces, on identical inputs,
+weights and dropout streams, and (b) the CPU oracle, at the shapes the fused kernel is built for (d_model 512, 8 heads).
+Reference ops: mtn.py:125-127, 248-267, 221-231, 279-280."""
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from tests.test_model_gpu import build_model, dev, dev_batch, raw_batch  # noqa: F401  (dev is a fixture)
+from tests.util import relmax
+
+pytestmark = pytest.mark.gpu
+
+# d = 512 / h = 8 variants of the golden configurations' shapes (ragged lengths, an empty history row, padded frames)
+CFGS = {
+    "query_b5": dict(vocab=120, N=2, d_model=512, d_ff=2048, h=8, ft_sizes=[64, 32], B=5, Q=13, H=37, C=29, T=20, frames=[17, 9],
+                     diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query"),
+    "query_b32": dict(vocab=120, N=1, d_model=512, d_ff=2048, h=8, ft_sizes=[64, 32], B=32, Q=20, H=128, C=40, T=20, frames=[32, 32],
+                      diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query"),
+    "caption_b3": dict(vocab=90, N=1, d_model=512, d_ff=1024, h=8, ft_sizes=[48], B=3, Q=9, H=70, C=44, T=33, frames=[21],
+                       diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="caption"),
+    "shared_b7": dict(vocab=60, N=1, d_model=512, d_ff=2048, h=8, ft_sizes=[40, 24], B=7, Q=8, H=5, C=16, T=7, frames=[6, 11],
+                      diff_encoder=False, diff_embed=False, diff_gen=False, auto_encoder_ft="query"),
+}
+
+
+def _run(model, b, fused, train):
+    from mtn_amd import lib
+    prev = lib.load().mtn_fused_enable(1 if fused else 0)
+    try:
+        model.zero_grad(set_to_none=True)
+        out, ae = model.forward(b)
+        res = [out.detach().clone()] + [a.detach().clone() for a in ae]
+        grads = None
+        if train:
+            loss = (out.float() ** 2).mean() + sum((a.float() ** 2).mean() for a in ae)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        torch.cuda.synchronize()
+        return res, grads
+    finally:
+        lib.load().mtn_fused_enable(1 if prev != 0 else 0)
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+@pytest.mark.parametrize("dropout", [0.0, 0.1], ids=["nodrop", "drop"])
+def test_fused_stage_equals_four_launch_path(dev, name, dropout):
+    """Same inputs, same weights, same dropout seed: the fused kernel reproduces the four-launch path's outputs.  Both do the
+    same arithmetic in the same order (LayerNorm per row, fp32 accumulation over k in steps of 32, one bf16 rounding of
+    q/k/v/hidden), so the bar is far below the bf16 tolerance: 2e-3 relative-to-max on the decoder outputs (a different
+    MFMA accumulation grouping may flip a bf16 rounding here and there)."""
+    c = CFGS[name]
+    model = build_model(c, torch.bfloat16, dev, dropout=dropout, attn_dropout=dropout)
+    model.train() if dropout > 0 else model.eval()
+    b = dev_batch(raw_batch(c), dev)
+    model.prepare()
+    seed0 = model._seed.clone()
+    ref, _ = _run(model, b, fused=False, train=False)
+    model._seed.copy_(seed0)
+    got, _ = _run(model, b, fused=True, train=False)
+    for r, g in zip(ref, got):
+        assert torch.isfinite(g).all()
+        assert relmax(g, r) < 2e-3, (name, relmax(g, r))
+
+
+@pytest.mark.parametrize("name", ["query_b5", "caption_b3", "shared_b7"])
+def test_fused_model_matches_oracle(dev, name):
+    """d = 512 / 8 heads model with the fused launches on, eval mode, against the CPU oracle: bf16 tolerance 1e-2 (relative to
+    max) on the decoder output and the auto-encoder outputs."""
+    c = CFGS[name]
+    model = build_model(c, torch.bfloat16, dev).eval()
+    raw = raw_batch(c)
+    b = dev_batch(raw, dev)
+    oracle, _ = fx.oracle_from_config(c)
+    with torch.no_grad():
+        ref_out, ref_ae = oracle.forward(fx.oracle_batch(raw))
+        got, _ = _run(model, b, fused=True, train=False)
+    assert relmax(got[0], ref_out) < 1e-2, relmax(got[0], ref_out)
+    for g, r in zip(got[1:], ref_ae):
+        assert relmax(g, r) < 1e-2, relmax(g, r)
+
+
+@pytest.mark.parametrize("name", ["query_b5", "shared_b7"])
+def test_fused_backward_equals_four_launch_path(dev, name):
+    """Gradients of every parameter with the fused launches on vs off (dropout off): cosine >= 0.99999 and 2e-2 relative to
+    max per tensor (the backward consumes the same saved buffers either way)."""
+    c = CFGS[name]
+    model = build_model(c, torch.bfloat16, dev).train()          # dropout 0 (build_model's default)
+    b = dev_batch(raw_batch(c), dev)
+    _, gref = _run(model, b, fused=False, train=True)
+    _, ggot = _run(model, b, fused=True, train=True)
+    assert gref.keys() == ggot.keys()
+    for k in gref:
+        r, g = gref[k].float().flatten(), ggot[k].float().flatten()
+        if float(r.abs().max()) == 0.0:
+            continue
+        cos = float(torch.dot(r, g) / (r.norm() * g.norm() + 1e-30))
+        assert cos > 0.9999, (k, cos)
+        assert relmax(g, r) < 2e-2, (k, relmax(g, r))
