@@ -6,24 +6,32 @@
 // w_2 (+ bias + dropout + residual) stays a grouped GEMM launch.  bf16, d_model = 512, d_k = 64 (other shapes keep the
 // four-launch path of sublayer.hip).
 //
-// One 256-thread workgroup = (member, block of whole samples: R <= 80 rows, head h | 192-column slice of w_1):
-//   * every lane first issues the loads of ITS x rows (a wave normalises rows wave, wave+4, ...; the row stays in registers)
-//     and then all weight fragments of the slice — wave w owns output columns 16w..16w+15 of each 64-column block, as the MFMA
-//     A operand straight from global memory (16 B per lane per 32-deep step, 16 steps, up to 3 blocks = 192 VGPRs).  A wave's
-//     loads return in issue order, so the x rows land first and the LayerNorm runs while the 192 KiB weight slice streams in;
-//   * the normalised rows go to LDS as a [row][512] bf16 image (16-byte slots XOR-swizzled with row & 15: conflict-free
-//     B-operand fragment reads); the workgroup of head 0 / slice 0 also writes xn, mean, rstd for backward;
-//   * projections: acc[block][row tile] on mfma_f32_16x16x32_bf16; + bias -> q | k | v (bf16) to the saved-for-backward
-//     buffers, which the attention stage of the SAME workgroup reads back (L2 hits) with the stand-alone kernel's code
-//     (attn_mfma.h): one wave per sample of the block, or the 4 waves splitting the keys of one sample.
-// Workgroup id % 8 = head, and workgroups go to the 8 XCDs round-robin: each XCD streams only its head's weight slice.
+// These launches are chains of dependent memory round trips (~2 us each on a busy chip) around a microsecond of arithmetic, so
+// the kernel is built to make ONE round trip: a 256-thread workgroup = (member, block of whole samples: R <= 80 rows, head h |
+// 192-column slice of w_1) issues EVERYTHING it will read before it computes anything —
+//   mask bytes -> registers; K|V of a memory projected ahead of the layer loop -> LDS (LDS-DMA, 128-byte head rows); the rows of
+//   an un-projected memory -> LDS (LDS-DMA); its x rows (fp32, 16 lanes per row) -> registers; LayerNorm gains -> registers;
+//   the weight slice as MFMA A-operand fragments straight from global memory (wave w owns output columns 16w..16w+15 of each
+//   64-column block: 16 B per lane per 32-deep step, 16 steps, up to 3 blocks = 192 VGPRs).
+// A wave's loads return in issue order: the x rows land first and the LayerNorm (row sums by DPP inside 16-lane rows) runs while
+// the 192 KiB weight slice streams in.  Then, on chip only:
+//   * normalised rows -> LDS [row][512] bf16 image (16-byte slots XOR-swizzled with row & 15: conflict-free B-operand reads);
+//   * projections on mfma_f32_16x16x32_bf16, acc[block][row tile]; + bias -> bf16 -> the saved-for-backward buffers (stores the
+//     kernel never waits for) AND row-major [row][64] LDS images of this head's Q, K, V;
+//   * attention per (sample, 16 query rows) on one wave: S^T = K Q^T with the keys of a tile taken in the order that makes the
+//     C layout of P^T the standard B-operand slot order, so V needs no transposition: O^T = V^T P^T reads its A operand from the
+//     row-major V image with ds_read_b64_tr_b16; softmax max/sum across the four 16-lane rows by v_permlane16/32_swap.
+// The workgroup of head 0 / slice 0 also writes xn, mean, rstd for backward.  Workgroup id % 8 = head and workgroups go to the
+// 8 XCDs round-robin: each XCD streams only its head's weight slice.
 #include <stdlib.h>
 
-#include "attn_mfma.h"
+#include "common.h"
 
 static constexpr int FH_D = 512;          // d_model
 static constexpr int FH_DK = 64;          // head width
-static constexpr int FH_ROWB = FH_D * 2;  // bytes per LDS image row
+static constexpr int FH_ROWB = FH_D * 2;  // bytes per row of the xn / memory images
+static constexpr int FH_HROWB = FH_DK * 2;  // bytes per row of the Q / K / V head images
+static constexpr int FH_MASKB = 16;       // mask bytes a thread stages at most (4096 per workgroup)
 enum { FH_SELF = 0, FH_CROSS_READY = 1, FH_CROSS_RAW = 2, FH_FFN = 3 };
 #define FH_MAX_MEMBERS (2 * MTN_SUBLAYER_MAX_GROUP)
 
@@ -46,26 +54,93 @@ struct FhMember {
     float* mean;
     float* rstd;
     bf16_t* out;       // qkv [rows, 3d] | q [rows, d] | hid [rows, d_ff]
-    bf16_t* kv;        // FH_CROSS_RAW: [B * m, 2d]
-    mtn_dropout drop;  // FFN hidden dropout
-    mtn_attn_args attn;
+    bf16_t* kv;        // cross attention: [B * m, 2d] (read when projected ahead, written for an un-projected memory)
+    const uint8_t* mask;
+    long mask_sb, mask_sq;
+    mtn_dropout drop;  // FFN hidden dropout | attention-probability dropout
+    bf16_t* o;         // attention output [rows, d]
+    float* lse;        // {row max, 1 / row sum} per (b, head, query)
 };
 struct FhGroup {
     int count;
+    int stop;          // development: leave the kernel after stage `stop` (0 = run everything); MTN_FH_STOP
     int wg_start[FH_MAX_MEMBERS + 1];
     FhMember m[FH_MAX_MEMBERS];
 };
 
 typedef __attribute__((address_space(3))) void fh_lds_void_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 fh_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float fh_f32x2;
 
-__device__ __forceinline__ uint4 fh_xfrag(const unsigned char* img, int row, int chunk) {
-    return *(const uint4*)(img + row * FH_ROWB + ((chunk ^ (row & 15)) << 4));
+__device__ __forceinline__ uint32_t fh_pack2(float a, float b) {        // v_cvt_pk_bf16_f32: round-to-nearest-even
+    const fh_bf16x2 r = __builtin_convertvector(fh_f32x2{a, b}, fh_bf16x2);
+    return *(const uint32_t*)&r;
+}
+// sum over the 16 lanes of a DPP row (every lane gets the total)
+__device__ __forceinline__ float fh_row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
+    return v;
+}
+// combine across the four 16-lane rows of the wave (lanes with equal lane & 15)
+__device__ __forceinline__ float fh_cross_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float fh_cross_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// NP = 64-column weight blocks per workgroup (3: q|k|v or 192 FFN columns; 1: q only), MT = row tiles (16 rows) at most.
+__device__ __forceinline__ uint4 fh_xfrag(const unsigned char* img, int row, int chunk) {          // [row][512] image
+    return *(const uint4*)(img + row * FH_ROWB + ((chunk ^ (row & 15)) << 4));
+}
+__device__ __forceinline__ uint4 fh_hfrag(const unsigned char* img, int row, int chunk) {          // [row][64] image, Q / K
+    return *(const uint4*)(img + row * FH_HROWB + ((chunk ^ (row & 7)) << 4));
+}
+// A-operand fragment of V^T from the row-major V image: head columns n_off + (lane & 15), keys row0 + 8*lg .. +7
+// (ds_read_b64_tr_b16, semantics as in gemm.hip ttd_frag; 16-byte slots swizzled with (row >> 1) & 7)
+__device__ __forceinline__ uint4 fh_vfrag(const unsigned char* img, int row0, int n_off, int l15, int lg) {
+    uint4 f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int krow = row0 + 8 * lg + 4 * r + (l15 >> 2);
+        const int col = n_off + 4 * (l15 & 3);
+        const int slot = (col >> 3) ^ ((krow >> 1) & 7);
+        const unsigned addr = (unsigned)(size_t)(img + krow * FH_HROWB + slot * 16 + (col & 7) * 2);
+        unsigned long long v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        if (r == 0) { f.x = (unsigned)v; f.y = (unsigned)(v >> 32); }
+        else { f.z = (unsigned)v; f.w = (unsigned)(v >> 32); }
+    }
+    return f;
+}
+
+// LDS map (bytes), the same arithmetic on host and device
+struct FhLds { int gains, xn, xm, qi, ki, vi, mask, total; };
+__host__ __device__ inline FhLds fh_lds_map(int MT, bool raw, int key_rows, int mask_bytes) {
+    FhLds L;
+    L.gains = 0;
+    L.xn = 4096;
+    L.xm = L.xn + MT * 16 * FH_ROWB;
+    L.qi = L.xm + (raw ? MT * 16 * FH_ROWB : 0);
+    L.ki = L.qi + MT * 16 * FH_HROWB;
+    const int krows = ((key_rows + 7) & ~7) + 64;           // + one key chunk of finite padding
+    L.vi = L.ki + krows * FH_HROWB;
+    L.mask = L.vi + krows * FH_HROWB;
+    L.total = L.mask + ((mask_bytes + 15) & ~15);
+    return L;
+}
+
+// NP = 64-column weight blocks per workgroup (3: q|k|v or 192 FFN columns; 1: q only), MT = row tiles (16 rows).
 template <int NP, int MT>
 __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(const FhGroup G) {
-    constexpr int RPW = MT * 4;            // rows a wave normalises at most
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int g = 0;
     while (g + 1 < G.count && (int)blockIdx.x >= G.wg_start[g + 1]) ++g;
@@ -74,103 +149,140 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
     const int slice = t % M.nslice, rb = t / M.nslice;
     const int row0 = rb * M.rows_per_wg;
     const int R = (M.rows - row0) < M.rows_per_wg ? (M.rows - row0) : M.rows_per_wg;
-    const int mt_n = (R + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kind = M.kind;
-    unsigned char* xn_s = smem;
-    unsigned char* xm_s = smem + mt_n * 16 * FH_ROWB;
+    const bool raw = kind == FH_CROSS_RAW, ffn = kind == FH_FFN;
+    const int a = M.a, m = M.m;
+    const int nsamp = ffn ? 0 : R / a, b0 = rb * M.blk;
+    const int Rm = raw ? nsamp * m : 0, rm0 = b0 * m;
+    const int key_rows = ffn ? 0 : (kind == FH_SELF ? MT * 16 : (raw ? MT * 16 : nsamp * m));
+    const int qa = M.mask_sq ? a : 1;
+    const int mask_bytes = (ffn || !M.mask) ? 0 : nsamp * qa * m;
+    const FhLds L = fh_lds_map(MT, raw, key_rows, mask_bytes);
+    unsigned char* xn_s = smem + L.xn;
+    unsigned char* xm_s = smem + L.xm;
+    unsigned char* qi_s = smem + L.qi;
+    unsigned char* ki_s = smem + L.ki;
+    unsigned char* vi_s = smem + L.vi;
+    unsigned char* mk_s = smem + L.mask;
 
-    // ---- memory rows of an un-projected memory (x attends an auto-encoder stream, mtn.py:215): bf16 rows -> LDS by LDS-DMA
-    int Rm = 0, rm0 = 0;
-    if (kind == FH_CROSS_RAW) {
-        const int nsamp = R / M.a;
-        rm0 = rb * M.blk * M.m;
-        Rm = nsamp * M.m;
+    // ================================================================ everything this workgroup reads, issued now
+    // (1) mask bytes of the block's samples
+    uint8_t mkb[FH_MASKB];
+    const uint8_t* mask_g = M.mask ? M.mask + (size_t)b0 * M.mask_sb : nullptr;   // contiguous: mask_sb is 0 or qa * m
+#pragma unroll
+    for (int i = 0; i < FH_MASKB; ++i) {
+        const int idx = tid + 256 * i;
+        mkb[i] = 1;
+        if (idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * m)];
+    }
+    // (2) LDS-DMA: rows of an un-projected memory (x attends an auto-encoder stream, mtn.py:215), or this head's K and V
+    //     rows of a memory projected ahead of the layer loop.  Rows past the end arrive as zeros (buffer bound).
+    if (raw) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(M.mem + (size_t)rm0 * FH_D), 0, Rm * FH_ROWB, 0x00020000);
-        for (int r = wave; r < Rm; r += 4) {          // one wave-instruction = one 1 KiB row; slot `lane` receives chunk lane ^ (r & 15)
-            const unsigned voff = (unsigned)r * FH_ROWB + (unsigned)((lane ^ (r & 15)) << 4);
+        for (int r = wave; r < MT * 16; r += 4) {     // one wave-instruction = one 1 KiB row; slot `lane` receives chunk lane ^ (r & 15)
+            const unsigned voff = r < Rm ? (unsigned)r * FH_ROWB + (unsigned)((lane ^ (r & 15)) << 4) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (fh_lds_void_t*)(xm_s + r * FH_ROWB), 16, voff, 0, 0, 0);
         }
-    }
-    const int mtm_n = (Rm + 15) >> 4;
-
-    // ---- this wave's x rows (fp32), then gains, then the weight fragments: returns arrive in this order
-    const float* __restrict__ xg = M.x + (size_t)row0 * FH_D;
-    float4 xv[RPW][2];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int r = wave + 4 * i;
-        if (r < R) {
-            xv[i][0] = *(const float4*)(xg + (size_t)r * FH_D + lane * 4);
-            xv[i][1] = *(const float4*)(xg + (size_t)r * FH_D + 256 + lane * 4);
+    } else if (kind == FH_CROSS_READY) {
+        const int Kr = nsamp * m;
+        const bf16_t* kbase = M.kv + (size_t)rm0 * (2 * FH_D) + slice * FH_DK;
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (Kr - 1) * (4 * FH_D) + FH_HROWB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + FH_D), 0, (Kr - 1) * (4 * FH_D) + FH_HROWB, 0x00020000);
+        const int ninst = (((Kr + 7) & ~7) + 64) >> 3;            // 8 head rows (128 B each) per wave-instruction
+        for (int i = wave; i < ninst; i += 4) {
+            const int row = i * 8 + (lane >> 3), slot = lane & 7;
+            const unsigned vk = row < Kr ? (unsigned)row * (4 * FH_D) + (unsigned)((slot ^ (row & 7)) << 4) : 0x80000000u;
+            const unsigned vv = row < Kr ? (unsigned)row * (4 * FH_D) + (unsigned)((slot ^ ((row >> 1) & 7)) << 4) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (fh_lds_void_t*)(ki_s + i * 1024), 16, vk, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (fh_lds_void_t*)(vi_s + i * 1024), 16, vv, 0, 0, 0);
         }
     }
-    float4 ga[2], gb[2];
+    // (3) x rows: row group rg = wave + 4i holds rows 4rg .. 4rg+3, one per 16-lane row; lane l15 reads columns 64j + 4*l15
+    const float* __restrict__ xg = M.x + (size_t)row0 * FH_D;
+    float4 xv[MT][8];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        ga[j] = *(const float4*)(M.ln_a + lane * 4 + 256 * j);
-        gb[j] = *(const float4*)(M.ln_b + lane * 4 + 256 * j);
+    for (int i = 0; i < MT; ++i) {
+        const int r = 4 * (wave + 4 * i) + lg;
+        const bool ok = r < R;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            xv[i][j] = ok ? *(const float4*)(xg + (size_t)r * FH_D + 64 * j + 4 * l15) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // weight block p of this workgroup covers output columns ncol[p] .. +63 of the Linear; wave w takes 16w..16w+15 of them
+    // (4) LayerNorm gains: threads 0..127 a_2, 128..255 b_2 (one float4 each) -> LDS
+    const float4 gv = *(const float4*)((tid < 128 ? M.ln_a : M.ln_b - FH_D) + tid * 4);
+    // (5) weight fragments: block p covers output columns ncol[p] .. +63 of the Linear; wave w takes 16w..16w+15 of them
     int ncol[NP];
     bool act[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        if (kind == FH_FFN) { ncol[p] = slice * (64 * NP) + p * 64; act[p] = ncol[p] + 16 * wave < M.ncols; }
+        if (ffn) { ncol[p] = slice * (64 * NP) + p * 64; act[p] = ncol[p] + 16 * wave < M.ncols; }
         else { ncol[p] = p * FH_D + slice * FH_DK; act[p] = (p == 0) || kind != FH_CROSS_READY; }
     }
     uint4 wf[NP][16];
+    float4 bv[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
-        if (act[p]) {
-            const bf16_t* wrow = M.w + (size_t)(ncol[p] + 16 * wave + l15) * FH_D + lg * 8;
+    for (int p = 0; p < NP; ++p) {
+        const int nrow = act[p] ? ncol[p] + 16 * wave : 0;     // inactive blocks read block 0 (in bounds) and are never stored
+        const bf16_t* wrow = M.w + (size_t)(nrow + l15) * FH_D + lg * 8;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
-        }
+        for (int s = 0; s < 16; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
+        bv[p] = *(const float4*)(M.bias + nrow + 4 * lg);
+    }
     const DropState ds = drop_init(M.drop);
 
-    // ---- LayerNorm (mtn.py:111-114; same arithmetic as ln_fwd_small_kernel): row -> bf16 -> LDS image
+    // ================================================================ on chip from here
+    // masks and gains -> LDS
+#pragma unroll
+    for (int i = 0; i < FH_MASKB; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < mask_bytes) mk_s[idx] = mkb[i];
+    }
+    *(float4*)(smem + L.gains + tid * 16) = gv;
+    __syncthreads();
+
+    // ---- LayerNorm (mtn.py:111-114): 16 lanes per row, 32 elements per lane; row -> bf16 -> LDS image
     const bool save = slice == 0;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int r = wave + 4 * i;
-        if (r < R) {
-            const float4 v0 = xv[i][0], v1 = xv[i][1];
-            float s = (v0.x + v0.y) + (v0.z + v0.w);
-            s += (v1.x + v1.y) + (v1.z + v1.w);
-            const float mean = wave_sum(s) / (float)FH_D;
-            float q;
-            {
-                const float e0 = v0.x - mean, e1 = v0.y - mean, e2 = v0.z - mean, e3 = v0.w - mean;
-                q = (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
-            }
-            {
-                const float e0 = v1.x - mean, e1 = v1.y - mean, e2 = v1.z - mean, e3 = v1.w - mean;
-                q += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
-            }
-            const float std_u = sqrtf(wave_sum(q) / (float)(FH_D - 1));
-            const float rstd = 1.0f / (std_u + M.eps);
-            if (save && lane == 0) { M.mean[row0 + r] = mean; M.rstd[row0 + r] = rstd; }
+    for (int i = 0; i < MT; ++i) {
+        const int r = 4 * (wave + 4 * i) + lg;
+        float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float4 v = j ? v1 : v0;
-                float4 o;
-                o.x = ga[j].x * (v.x - mean) * rstd + gb[j].x;
-                o.y = ga[j].y * (v.y - mean) * rstd + gb[j].y;
-                o.z = ga[j].z * (v.z - mean) * rstd + gb[j].z;
-                o.w = ga[j].w * (v.w - mean) * rstd + gb[j].w;
-                uint2 u;
-                u.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
-                u.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
-                const int chunk = (lane >> 1) + 32 * j;
-                *(uint2*)(xn_s + r * FH_ROWB + ((chunk ^ (r & 15)) << 4) + (lane & 1) * 8) = u;
-                if (save) *(uint2*)(M.xn + (size_t)(row0 + r) * FH_D + lane * 4 + 256 * j) = u;
-            }
+        for (int j = 0; j < 8; ++j) s += (xv[i][j].x + xv[i][j].y) + (xv[i][j].z + xv[i][j].w);
+        const float mean = fh_row16_sum(s) * (1.0f / (float)FH_D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float e0 = xv[i][j].x - mean, e1 = xv[i][j].y - mean, e2 = xv[i][j].z - mean, e3 = xv[i][j].w - mean;
+            q += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+        }
+        const float std_u = sqrtf(fh_row16_sum(q) * (1.0f / (float)(FH_D - 1)));
+        const float rstd = 1.0f / (std_u + M.eps);
+        if (save && l15 == 0 && r < R) { M.mean[row0 + r] = mean; M.rstd[row0 + r] = rstd; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 ga = *(const float4*)(smem + L.gains + (64 * j + 4 * l15) * 4);
+            const float4 gb = *(const float4*)(smem + L.gains + 2048 + (64 * j + 4 * l15) * 4);
+            const float4 v = xv[i][j];
+            uint2 u;
+            u.x = fh_pack2(ga.x * (v.x - mean) * rstd + gb.x, ga.y * (v.y - mean) * rstd + gb.y);
+            u.y = fh_pack2(ga.z * (v.z - mean) * rstd + gb.z, ga.w * (v.w - mean) * rstd + gb.w);
+            const int chunk = 8 * j + (l15 >> 1);
+            *(uint2*)(xn_s + r * FH_ROWB + ((chunk ^ (r & 15)) << 4) + (l15 & 1) * 8) = u;
+            if (save && r < R) *(uint2*)(M.xn + (size_t)(row0 + r) * FH_D + 64 * j + 4 * l15) = u;
         }
     }
-    if (kind == FH_CROSS_RAW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the memory image (LDS-DMA) has landed
+    // zero padding behind the key images (a key chunk may run past the last key: its V rows must be finite)
+    if (!ffn && kind != FH_CROSS_READY) {
+        for (int i = tid; i < 64 * FH_HROWB / 16; i += 256) {
+            *(uint4*)(ki_s + MT * 16 * FH_HROWB + i * 16) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(vi_s + MT * 16 * FH_HROWB + i * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (raw || kind == FH_CROSS_READY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA images have landed
     __syncthreads();
+    if (G.stop == 1) return;
 
     // ---- projections: acc[p][mt] = W block p (A operand: 16 output columns) x rows of tile mt (B operand)
     f32x4_t acc[NP][MT];
@@ -178,36 +290,39 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
     for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[p][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const bool raw = kind == FH_CROSS_RAW;
+    if (!raw) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        uint4 xf[MT];
+        for (int s = 0; s < 16; ++s) {
+            uint4 xf[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            if (mt < mt_n) xf[mt] = fh_xfrag(xn_s, mt * 16 + l15, s * 4 + lg);
+            for (int mt = 0; mt < MT; ++mt) xf[mt] = fh_xfrag(xn_s, mt * 16 + l15, s * 4 + lg);
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
-            if (act[p] && !(raw && p > 0)) {
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    if (mt < mt_n) mma16<bf16_t>(acc[p][mt], wf[p][s], xf[mt]);
-            }
-    }
-    if constexpr (NP == 3) {
-        if (raw) {                          // k | v of the memory rows
+                for (int mt = 0; mt < MT; ++mt) mma16<bf16_t>(acc[p][mt], wf[p][s], xf[mt]);
+        }
+    } else if constexpr (NP == 3) {           // q from the normalised rows, k | v from the memory rows
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                uint4 xf[MT];
+        for (int s = 0; s < 16; ++s) {
+            uint4 xf[MT], mf[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    if (mt < mtm_n) xf[mt] = fh_xfrag(xm_s, mt * 16 + l15, s * 4 + lg);
+            for (int mt = 0; mt < MT; ++mt) { xf[mt] = fh_xfrag(xn_s, mt * 16 + l15, s * 4 + lg); mf[mt] = fh_xfrag(xm_s, mt * 16 + l15, s * 4 + lg); }
 #pragma unroll
-                for (int p = 1; p < NP; ++p)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        if (mt < mtm_n) mma16<bf16_t>(acc[p][mt], wf[p][s], xf[mt]);
+            for (int mt = 0; mt < MT; ++mt) {
+                mma16<bf16_t>(acc[0][mt], wf[0][s], xf[mt]);
+                mma16<bf16_t>(acc[1][mt], wf[1][s], mf[mt]);
+                mma16<bf16_t>(acc[2][mt], wf[2][s], mf[mt]);
             }
         }
+    }
+    if (G.stop == 2) {
+        float t_ = 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) t_ += acc[p][mt][0] + acc[p][mt][1] + acc[p][mt][2] + acc[p][mt][3];
+        if (t_ == 123.456f) M.mean[0] = t_;
+        return;
     }
 
     // ---- epilogue: a lane holds output row (tile row l15) x four consecutive columns 16w + 4lg .. +3 of each block
@@ -215,22 +330,20 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
     for (int p = 0; p < NP; ++p) {
         if (!act[p]) continue;
         const int col = ncol[p] + 16 * wave + 4 * lg;           // column of the Linear's output
-        const float4 bv = *(const float4*)(M.bias + col);
         const bool to_kv = raw && p > 0;
-        const int rows_p = to_kv ? Rm : R, r0_p = to_kv ? rm0 : row0, tiles = to_kv ? mtm_n : mt_n;
+        const int rows_p = to_kv ? Rm : R, r0_p = to_kv ? rm0 : row0;
         bf16_t* dst;
         int ld;
-        if (kind == FH_FFN) { dst = M.out + col; ld = M.ld_out; }
+        if (ffn) { dst = M.out + col; ld = M.ld_out; }
         else if (to_kv) { dst = M.kv + (p - 1) * FH_D + slice * FH_DK + 16 * wave + 4 * lg; ld = 2 * FH_D; }
         else if (kind == FH_SELF) { dst = M.out + col; ld = M.ld_out; }
         else { dst = M.out + slice * FH_DK + 16 * wave + 4 * lg; ld = M.ld_out; }
+        unsigned char* img = p == 0 ? qi_s : (p == 1 ? ki_s : vi_s);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            if (mt >= tiles) continue;
             const int r = mt * 16 + l15;
-            if (r >= rows_p) continue;
-            float v[4] = {acc[p][mt][0] + bv.x, acc[p][mt][1] + bv.y, acc[p][mt][2] + bv.z, acc[p][mt][3] + bv.w};
-            if (kind == FH_FFN) {
+            float v[4] = {acc[p][mt][0] + bv[p].x, acc[p][mt][1] + bv[p].y, acc[p][mt][2] + bv[p].z, acc[p][mt][3] + bv[p].w};
+            if (ffn) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
                 if (ds.on) {
@@ -239,28 +352,111 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
                     for (int k = 0; k < 4; ++k) v[k] = drop_keep(ds, idx + k) ? v[k] * ds.scale : 0.f;
                 }
             }
-            store_lp4<bf16_t>(dst + (size_t)(r0_p + r) * ld, make_float4(v[0], v[1], v[2], v[3]));
+            const uint2 u = make_uint2(fh_pack2(v[0], v[1]), fh_pack2(v[2], v[3]));
+            if (r < rows_p) *(uint2*)(dst + (size_t)(r0_p + r) * ld) = u;
+            if (!ffn) {                                             // this head's Q / K / V image: [row][64], 16-byte slots swizzled
+                const int chunk = 2 * wave + (lg >> 1);
+                const int sw = p == 2 ? ((r >> 1) & 7) : (r & 7);
+                *(uint2*)(img + r * FH_HROWB + ((chunk ^ sw) << 4) + (lg & 1) * 8) = u;
+            }
         }
     }
-    if (kind == FH_FFN) return;
+    if (ffn || G.stop == 3) return;
 
-    // ---- attention of this head over the samples of the block; q, k, v come back from L2 (written above by this workgroup)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- attention of this head, on chip.  Item = (sample, 16 query rows), one wave each.
     __syncthreads();
-    const int nsamp = R / M.a, b0 = rb * M.blk;
-    if (nsamp == 1) {
-        for (int q0 = 0; q0 < M.a; q0 += MQ) attn_fwd_mfma_body<bf16_t, FH_DK, 4>(M.attn, b0, slice, q0, wave, smem);
-    } else {
-        for (int i = wave; i < nsamp; i += 4)
-            for (int q0 = 0; q0 < M.a; q0 += MQ)
-                attn_fwd_mfma_body<bf16_t, FH_DK, 1>(M.attn, b0 + i, slice, q0, 0, smem + wave * (FH_DK * (MK * 2 + 16)));
+    const float scale = 0.125f;                    // 1 / sqrt(64)
+    const int nqt = (a + 15) >> 4;
+    const int mk = kind == FH_SELF ? a : m;        // keys (= image rows) per sample
+    for (int it = wave; it < nsamp * nqt; it += 4) {
+        const int si = it / nqt, qt = it - si * nqt;
+        const int b = b0 + si;
+        const int q = qt * 16 + l15, qc = q < a ? q : a - 1;
+        const int qrow = si * a + qc, krow0 = si * mk;
+        uint4 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = fh_hfrag(qi_s, qrow, ks * 4 + lg);
+        f32x4_t ot[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) ot[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        float mrun = -INFINITY, lrun = 0.f;
+        const unsigned char* mrow = mk_s + (size_t)(si * qa + (M.mask_sq ? qc : 0)) * mk;
+        for (int c0 = 0; c0 < mk; c0 += 64) {
+            // S^T tile kt, accumulator row i <-> key c0 + 32(kt/2) + 8(i/4) + 4(kt%2) + (i%4): a lane's values of tiles 2u, 2u+1
+            // are keys c0 + 32u + 8lg + 0..7 — the B-operand slot order of the V^T P^T contraction
+            f32x4_t st[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                int key = c0 + 32 * (kt >> 1) + 8 * (l15 >> 2) + 4 * (kt & 1) + (l15 & 3);
+                key = key < mk ? key : mk - 1;
+                st[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) mma16<bf16_t>(st[kt], fh_hfrag(ki_s, krow0 + key, ks * 4 + lg), qf[ks]);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = c0 + 32 * (kt >> 1) + 8 * lg + 4 * (kt & 1) + r;
+                    float sv = st[kt][r] * scale;
+                    if (key >= mk) sv = -INFINITY;
+                    else if (M.mask && mrow[key] == 0) sv = -1e9f;
+                    st[kt][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fh_cross_max(mx);
+            const float mn = fmaxf(mrun, mx);
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = __expf(st[kt][r] - mn);             // exp(-inf) = 0 for chunk padding
+                    psum += pv;
+                    if (ds.on) {
+                        const int key = c0 + 32 * (kt >> 1) + 8 * lg + 4 * (kt & 1) + r;
+                        const uint64_t idx = ((uint64_t)(b * (FH_D / FH_DK) + slice) * a + qc) * (uint64_t)mk + key;
+                        pv = drop_keep(ds, idx) ? pv * ds.scale : 0.f;
+                    }
+                    st[kt][r] = pv;
+                }
+            psum = fh_cross_sum(psum);
+            const float alpha = (mrun == -INFINITY) ? 0.f : __expf(mrun - mn);
+            lrun = lrun * alpha + psum;
+            mrun = mn;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { ot[nt][0] *= alpha; ot[nt][1] *= alpha; ot[nt][2] *= alpha; ot[nt][3] *= alpha; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint4 pf = make_uint4(fh_pack2(st[2 * u][0], st[2 * u][1]), fh_pack2(st[2 * u][2], st[2 * u][3]),
+                                            fh_pack2(st[2 * u + 1][0], st[2 * u + 1][1]), fh_pack2(st[2 * u + 1][2], st[2 * u + 1][3]));
+                uint4 vf[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) vf[nt] = fh_vfrag(vi_s, krow0 + c0 + 32 * u, nt * 16, l15, lg);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) mma16<bf16_t>(ot[nt], vf[nt], pf);
+            }
+        }
+        // lane holds O^T[head column 16nt + 4lg + r][query l15]
+        if (q < a) {
+            const float inv = 1.0f / lrun;
+            bf16_t* og = M.o + (size_t)(b * a + q) * FH_D + slice * FH_DK + 4 * lg;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *(uint2*)(og + nt * 16) = make_uint2(fh_pack2(ot[nt][0] * inv, ot[nt][1] * inv), fh_pack2(ot[nt][2] * inv, ot[nt][3] * inv));
+            if (M.lse && lg == 0) {
+                float* stp = M.lse + 2 * ((size_t)(b * (FH_D / FH_DK) + slice) * a + q);
+                stp[0] = mrun;
+                stp[1] = inv;
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------ host side
-static constexpr int FH_MT = 5;                   // row tiles of the big instantiation (80 rows)
-static constexpr int FH_MT_SMALL = 3;             // q-only instantiation (two workgroups per CU): 48 rows
-
 static int fh_enabled = -1;          // -1: not decided yet (environment MTN_FUSED=0 turns the fused launches off)
 extern "C" int mtn_fused_enable(int on) {
     const int prev = fh_enabled;
@@ -272,68 +468,94 @@ static bool fh_env_off() {
     return fh_enabled == 0;
 }
 
-// Samples per workgroup: whole samples, at most `rmax` rows; as few workgroups as it takes to stay within one round of the
-// chip (256 CUs), but not fewer than that: these launches are bound by the bytes each CU pulls (weight slice + x rows).
-static int fh_pick_blk(int B, int a, int rmax, int wg_per_block, int budget) {
-    int best = 1;
-    for (int blk = 1; blk * a <= rmax && blk <= B; ++blk) {
-        best = blk;
-        if (((B + blk - 1) / blk) * wg_per_block <= budget) break;
+static constexpr int FH_LDS_MAX = 160 * 1024;
+static const int fh_mt_choices[3] = {2, 3, 5};
+
+struct FhPlan { int blk, mt; };
+static int fh_member_lds(const mtn_mha_args& A, int blk, int mt) {
+    const bool self = A.self_attn != 0, raw = !self && !A.kv_ready;
+    const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
+    return fh_lds_map(mt, raw, (self || raw) ? mt * 16 : blk * m, A.mask ? blk * qa * m : 0).total;
+}
+// Rows per workgroup for an attention member: whole samples, inside the row tiles (mt_cap) and the LDS; as few workgroups as it
+// takes to stay within the member's share of one round of the chip (these launches are bound by the bytes each CU pulls:
+// weight slice + x rows), but not fewer.  Returns blk = 0 when even one sample does not fit.
+static FhPlan fh_plan_mha(const mtn_mha_args& A, int mt_cap, int budget) {
+    const bool self = A.self_attn != 0, raw = !self && !A.kv_ready;
+    const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
+    FhPlan best = {0, 0};
+    if (A.mask && A.mask_sb != 0 && A.mask_sb != (long)qa * m) return best;      // the block's mask bytes must be contiguous
+    if (A.mask && A.mask_sq != 0 && A.mask_sq != m) return best;
+    for (int blk = 1; blk <= A.B; ++blk) {
+        const int R = blk * A.a, Rm = blk * m;
+        int mt = 0;
+        for (int c = 0; c < 3; ++c)
+            if (fh_mt_choices[c] * 16 >= R && (!raw || fh_mt_choices[c] * 16 >= Rm)) { mt = fh_mt_choices[c]; break; }
+        if (!mt || mt > mt_cap) break;
+        if (A.mask && blk * qa * m > 256 * FH_MASKB) break;
+        if (fh_member_lds(A, blk, mt) > FH_LDS_MAX) break;
+        best = FhPlan{blk, mt};
+        if (((A.B + blk - 1) / blk) * (FH_D / FH_DK) <= budget) break;
     }
     return best;
 }
 
-// Can this group take the fused first launch?  (bf16, d = 512, h = 8, shapes inside the kernel's tiling)
-int fh_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn) {
-    if (fh_env_off() || dtype != MTN_BF16) return 0;
+struct FhLaunch { FhGroup G; int wgs, mt, need3; size_t lds; };
+// The whole launch plan; false = this group keeps the four-launch path.
+static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, FhLaunch& P) {
+    if (n_mha + n_ffn < 1 || n_mha + n_ffn > FH_MAX_MEMBERS) return false;
+    FhGroup& G = P.G;
+    memset(&G, 0, sizeof(G));
+    bool need3 = n_ffn > 0, any_raw = false;
     for (int i = 0; i < n_mha; ++i) {
-        const mtn_mha_args& a = mha[i];
-        if (a.d != FH_D || a.h != FH_D / FH_DK) return 0;
-        if (a.a > 64 || a.a < 1) return 0;
-        const bool raw = !a.self_attn && !a.kv_ready;
-        if (raw && a.m > 64) return 0;
-        if (!a.self_attn && a.m > 256) return 0;          // long memories: the stand-alone kernel splits keys over 8 waves
+        if (mha[i].d != FH_D || mha[i].h != FH_D / FH_DK) return false;
+        if (mha[i].self_attn || !mha[i].kv_ready) need3 = true;
+        any_raw |= !mha[i].self_attn && !mha[i].kv_ready;
     }
     for (int i = 0; i < n_ffn; ++i)
-        if (ffn[i].d != FH_D || ffn[i].d_ff % 64 != 0) return 0;
-    return 1;
-}
-
-void attn_args_of(const mtn_mha_args* a, int dtype, mtn_attn_args* t);   // sublayer.hip
-
-int fh_group_fwd_stage1(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream) {
-    MTN_CHECK_ARG(n_mha + n_ffn >= 1 && n_mha + n_ffn <= FH_MAX_MEMBERS, "bad group size");
-    FhGroup G;
-    memset(&G, 0, sizeof(G));
-    bool need3 = n_ffn > 0;
-    for (int i = 0; i < n_mha; ++i)
-        if (mha[i].self_attn || !mha[i].kv_ready) need3 = true;
-    const int rmax = need3 ? FH_MT * 16 : FH_MT_SMALL * 16;
-    // share of one round (256 workgroups) each member may take
-    int n = 0, wgs = 0;
+        if (ffn[i].d != FH_D || ffn[i].d_ff % 64 != 0) return false;
     const int members = n_mha + n_ffn;
-    const int budget = 256 / members > 8 ? 256 / members : 8;
-    int max_rows = 0;
+    const int budget = 256 / members > 8 ? 256 / members : 8;       // share of one round (256 workgroups) per member
+    const int mt_cap = any_raw ? 3 : (need3 ? 5 : 3);                // q-only kernel: two workgroups per CU, 48 rows
+    int mt = 2, blk[MTN_SUBLAYER_MAX_GROUP], ffn_rpw[MTN_SUBLAYER_MAX_GROUP];
+    for (int i = 0; i < n_mha; ++i) {
+        const FhPlan pl = fh_plan_mha(mha[i], mt_cap, budget);
+        if (pl.blk == 0) return false;
+        blk[i] = pl.blk;
+        mt = pl.mt > mt ? pl.mt : mt;
+    }
+    for (int i = 0; i < n_ffn; ++i) {
+        const int nslice = (ffn[i].d_ff + 191) / 192;
+        int rpw = 80;                                     // rows per workgroup: 32 / 48 / 80, within the member's share if possible
+        if (mt_cap < 5) rpw = 48;
+        for (int c = 1; c >= 0; --c)
+            if (((ffn[i].rows + fh_mt_choices[c] * 16 - 1) / (fh_mt_choices[c] * 16)) * nslice <= budget) rpw = fh_mt_choices[c] * 16;
+        ffn_rpw[i] = rpw;
+        mt = rpw / 16 > mt ? rpw / 16 : mt;
+    }
+    // every member runs at the launch's row-tile count: shrink blocks whose LDS map no longer fits
+    size_t lds = fh_lds_map(mt, false, 0, 0).total;
+    for (int i = 0; i < n_mha; ++i) {
+        while (blk[i] > 1 && fh_member_lds(mha[i], blk[i], mt) > FH_LDS_MAX) --blk[i];
+        const int l = fh_member_lds(mha[i], blk[i], mt);
+        if (l > FH_LDS_MAX) return false;
+        lds = (size_t)l > lds ? (size_t)l : lds;
+    }
+    int n = 0, wgs = 0;
     for (int i = 0; i < n_mha; ++i) {
         const mtn_mha_args& a = mha[i];
         FhMember& M = G.m[n];
         M.kind = a.self_attn ? FH_SELF : (a.kv_ready ? FH_CROSS_READY : FH_CROSS_RAW);
-        M.a = a.a; M.m = a.self_attn ? a.a : a.m;
-        int rm = rmax;
-        int blk = fh_pick_blk(a.B, a.a, rm, FH_D / FH_DK, budget);
-        if (M.kind == FH_CROSS_RAW)                       // the memory image shares the LDS with the x image
-            while (blk > 1 && ((blk * a.a + 15) / 16 + (blk * a.m + 15) / 16) * 16 > 144) --blk;
-        M.blk = blk;
-        M.rows = a.B * a.a; M.rows_per_wg = blk * a.a; M.nslice = FH_D / FH_DK;
+        M.a = a.a; M.m = a.self_attn ? a.a : a.m; M.blk = blk[i];
+        M.rows = a.B * a.a; M.rows_per_wg = blk[i] * a.a; M.nslice = FH_D / FH_DK;
         M.eps = a.ln_eps; M.x = a.x; M.ln_a = a.ln_a; M.ln_b = a.ln_b;
         M.w = (const bf16_t*)a.w_qkv; M.bias = a.b_qkv; M.mem = (const bf16_t*)a.mem;
         M.xn = (bf16_t*)a.xn; M.mean = a.mean; M.rstd = a.rstd;
         M.out = (bf16_t*)a.qkv; M.ld_out = a.self_attn ? 3 * FH_D : FH_D; M.kv = (bf16_t*)a.kv;
-        attn_args_of(&a, MTN_BF16, &M.attn);
+        M.mask = a.mask; M.mask_sb = a.mask_sb; M.mask_sq = a.mask_sq; M.drop = a.drop_attn;
+        M.o = (bf16_t*)a.o; M.lse = a.lse;
         G.wg_start[n] = wgs;
-        wgs += ((a.B + blk - 1) / blk) * M.nslice;
-        const int rows_lds = M.kind == FH_CROSS_RAW ? ((blk * a.a + 15) / 16 + (blk * a.m + 15) / 16) * 16 : ((blk * a.a + 15) / 16) * 16;
-        max_rows = rows_lds > max_rows ? rows_lds : max_rows;
+        wgs += ((a.B + blk[i] - 1) / blk[i]) * M.nslice;
         ++n;
     }
     for (int i = 0; i < n_ffn; ++i) {
@@ -341,47 +563,51 @@ int fh_group_fwd_stage1(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn
         FhMember& M = G.m[n];
         M.kind = FH_FFN;
         M.rows = a.rows; M.ncols = a.d_ff; M.nslice = (a.d_ff + 191) / 192;
-        int rpw = rmax;                                   // rows per workgroup: a multiple of 16, within one round if possible
-        while (rpw > 16 && ((a.rows + rpw - 16 - 1) / (rpw - 16)) * M.nslice <= budget) rpw -= 16;
-        M.rows_per_wg = rpw; M.a = 1; M.blk = rpw;
+        M.rows_per_wg = ffn_rpw[i]; M.a = 1; M.m = 1; M.blk = ffn_rpw[i];
         M.eps = a.ln_eps; M.x = a.x; M.ln_a = a.ln_a; M.ln_b = a.ln_b;
         M.w = (const bf16_t*)a.w1; M.bias = a.b1;
         M.xn = (bf16_t*)a.xn; M.mean = a.mean; M.rstd = a.rstd;
         M.out = (bf16_t*)a.hid; M.ld_out = a.d_ff; M.drop = a.drop_hidden;
         G.wg_start[n] = wgs;
-        wgs += ((a.rows + rpw - 1) / rpw) * M.nslice;
-        max_rows = rpw > max_rows ? rpw : max_rows;
+        wgs += ((a.rows + ffn_rpw[i] - 1) / ffn_rpw[i]) * M.nslice;
         ++n;
     }
     G.count = n;
     for (int i = n; i <= FH_MAX_MEMBERS; ++i) G.wg_start[i] = wgs;
-    size_t lds = (size_t)max_rows * FH_ROWB;
-    const size_t attn_lds = sizeof(float) * (4 * FH_DK * 33 + 2 * 4 * 32);        // 4-wave combine area >= 4 V^T images
-    const size_t vt_lds = 4 * (size_t)FH_DK * (MK * 2 + 16);
-    if (n_mha && lds < attn_lds) lds = attn_lds;
-    if (n_mha && lds < vt_lds) lds = vt_lds;
-    hipStream_t s = (hipStream_t)stream;
-    if (need3) {
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute((const void*)fused_head_fwd_kernel<3, FH_MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                mtn_set_error("fused_head_fwd_kernel: cannot raise the dynamic LDS limit");
-                return MTN_ERR_LAUNCH;
-            }
-            attr = true;
+    { static const int stop = [] { const char* e = getenv("MTN_FH_STOP"); return e ? atoi(e) : 0; }(); G.stop = stop; }
+    P.wgs = wgs; P.mt = mt; P.need3 = need3 ? 1 : 0; P.lds = lds;
+    return true;
+}
+
+// Can this group take the fused first launch?  (bf16, d = 512, h = 8, shapes inside the kernel's tiling)
+int fh_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn) {
+    if (fh_env_off() || dtype != MTN_BF16) return 0;
+    FhLaunch P;
+    return fh_plan(n_mha, mha, n_ffn, ffn, P) ? 1 : 0;
+}
+
+template <int NP, int MT> static int fh_launch(const FhGroup& G, int wgs, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)fused_head_fwd_kernel<NP, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX) != hipSuccess) {
+            mtn_set_error("fused_head_fwd_kernel: cannot raise the dynamic LDS limit");
+            return MTN_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL((fused_head_fwd_kernel<3, FH_MT>), dim3(wgs), dim3(256), lds, s, G);
-    } else {
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute((const void*)fused_head_fwd_kernel<1, FH_MT_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                mtn_set_error("fused_head_fwd_kernel: cannot raise the dynamic LDS limit");
-                return MTN_ERR_LAUNCH;
-            }
-            attr = true;
-        }
-        hipLaunchKernelGGL((fused_head_fwd_kernel<1, FH_MT_SMALL>), dim3(wgs), dim3(256), lds, s, G);
+        attr = true;
     }
+    hipLaunchKernelGGL((fused_head_fwd_kernel<NP, MT>), dim3(wgs), dim3(256), lds, s, G);
+    return MTN_OK;
+}
+
+int fh_group_fwd_stage1(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream) {
+    FhLaunch P;
+    MTN_CHECK_ARG(fh_plan(n_mha, mha, n_ffn, ffn, P), "group outside the fused kernel's tiling");
+    hipStream_t s = (hipStream_t)stream;
+    const int mt = P.mt;
+    int rc;
+    if (P.need3) rc = mt <= 2 ? fh_launch<3, 2>(P.G, P.wgs, P.lds, s) : (mt == 3 ? fh_launch<3, 3>(P.G, P.wgs, P.lds, s) : fh_launch<3, 5>(P.G, P.wgs, P.lds, s));
+    else rc = mt <= 2 ? fh_launch<1, 2>(P.G, P.wgs, P.lds, s) : fh_launch<1, 3>(P.G, P.wgs, P.lds, s);
+    if (rc != MTN_OK) return rc;
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
