@@ -6,18 +6,20 @@
 // w_2 (+ bias + dropout + residual) stays a grouped GEMM launch.  bf16, d_model = 512, d_k = 64 (other shapes keep the
 // four-launch path of sublayer.hip).
 //
-// These launches are chains of dependent memory round trips (~2 us each on a busy chip) around a microsecond of arithmetic, so
-// the kernel is built to make ONE round trip: a 256-thread workgroup = (member, block of whole samples: R <= 80 rows, head h |
-// 192-column slice of w_1) issues EVERYTHING it will read before it computes anything —
+// These launches are chains of dependent memory round trips (~2.5 us each on a busy chip) around a microsecond of arithmetic,
+// and a wave can keep at most 63 vector-memory instructions (1 KiB each) in flight.  So the kernel is built to make ONE round
+// trip: a 512-thread workgroup = (member, block of whole samples: R <= 80 rows, head h | 192-column slice of w_1) issues
+// EVERYTHING it will read before it computes anything, spread over 8 waves so that nobody queues behind the 63-deep counter —
 //   mask bytes -> registers; K|V of a memory projected ahead of the layer loop -> LDS (LDS-DMA, 128-byte head rows); the rows of
 //   an un-projected memory -> LDS (LDS-DMA); its x rows (fp32, 16 lanes per row) -> registers; LayerNorm gains -> registers;
-//   the weight slice as MFMA A-operand fragments straight from global memory (wave w owns output columns 16w..16w+15 of each
-//   64-column block: 16 B per lane per 32-deep step, 16 steps, up to 3 blocks = 192 VGPRs).
+//   the weight slice as MFMA A-operand fragments straight from global memory: wave w owns output columns 16(w&3)..+15 of each
+//   64-column block and HALF of the contraction (k-steps 8(w>>2)..+7): 16 B per lane per 32-deep step, <= 24 loads per wave.
 // A wave's loads return in issue order: the x rows land first and the LayerNorm (row sums by DPP inside 16-lane rows) runs while
-// the 192 KiB weight slice streams in.  Then, on chip only:
+// the weight slice streams in.  Then, on chip only:
 //   * normalised rows -> LDS [row][512] bf16 image (16-byte slots XOR-swizzled with row & 15: conflict-free B-operand reads);
-//   * projections on mfma_f32_16x16x32_bf16, acc[block][row tile]; + bias -> bf16 -> the saved-for-backward buffers (stores the
-//     kernel never waits for) AND row-major [row][64] LDS images of this head's Q, K, V;
+//   * projections on mfma_f32_16x16x32_bf16, acc[block][row tile] over the wave's half of k; the two halves meet through LDS
+//     (each wave of a pair keeps every other tile); + bias -> bf16 -> the saved-for-backward buffers (stores the kernel never
+//     waits for) AND row-major [row][64] LDS images of this head's Q, K, V;
 //   * attention per (sample, 16 query rows) on one wave: S^T = K Q^T with the keys of a tile taken in the order that makes the
 //     C layout of P^T the standard B-operand slot order, so V needs no transposition: O^T = V^T P^T reads its A operand from the
 //     row-major V image with ds_read_b64_tr_b16; softmax max/sum across the four 16-lane rows by v_permlane16/32_swap.
@@ -31,7 +33,8 @@ static constexpr int FH_D = 512;          // d_model
 static constexpr int FH_DK = 64;          // head width
 static constexpr int FH_ROWB = FH_D * 2;  // bytes per row of the xn / memory images
 static constexpr int FH_HROWB = FH_DK * 2;  // bytes per row of the Q / K / V head images
-static constexpr int FH_MASKB = 16;       // mask bytes a thread stages at most (4096 per workgroup)
+static constexpr int FH_MASKB = 8;        // mask bytes a thread stages at most (4096 per 512-thread workgroup)
+static constexpr int FH_THREADS = 512;    // 8 waves: column block (wave & 3) x half of the contraction (wave >> 2)
 enum { FH_SELF = 0, FH_CROSS_READY = 1, FH_CROSS_RAW = 2, FH_FFN = 3 };
 #define FH_MAX_MEMBERS (2 * MTN_SUBLAYER_MAX_GROUP)
 
@@ -41,6 +44,7 @@ struct FhMember {
     int rows_per_wg;   // attention: blk * a (whole samples)
     int nslice;        // heads, or 192-column slices of w_1
     int a, m, blk;     // attention: query rows per sample, memory rows per sample, samples per workgroup
+    int mt;            // row tiles (16 rows) of this member's workgroups: 2, 3 or 5
     int ncols;         // FFN: d_ff
     int ld_out;        // row stride of `out`
     float eps;
@@ -64,6 +68,9 @@ struct FhMember {
 struct FhGroup {
     int count;
     int stop;          // development: leave the kernel after stage `stop` (0 = run everything); MTN_FH_STOP
+#ifdef FH_TIMELINE
+    unsigned long long* dbg;   // tools/fh_bench.hip: 16 time stamps (100 MHz wall clock) per workgroup
+#endif
     int wg_start[FH_MAX_MEMBERS + 1];
     FhMember m[FH_MAX_MEMBERS];
 };
@@ -124,42 +131,49 @@ __device__ __forceinline__ uint4 fh_vfrag(const unsigned char* img, int row0, in
 
 // LDS map (bytes), the same arithmetic on host and device
 struct FhLds { int gains, xn, xm, qi, ki, vi, mask, total; };
-__host__ __device__ inline FhLds fh_lds_map(int MT, bool raw, int key_rows, int mask_bytes) {
+__host__ __device__ inline FhLds fh_lds_map(int mt, bool raw, int key_rows, int pad_rows, int mask_bytes) {
     FhLds L;
     L.gains = 0;
-    L.xn = 4096;
-    L.xm = L.xn + MT * 16 * FH_ROWB;
-    L.qi = L.xm + (raw ? MT * 16 * FH_ROWB : 0);
-    L.ki = L.qi + MT * 16 * FH_HROWB;
-    const int krows = ((key_rows + 7) & ~7) + 64;           // + one key chunk of finite padding
+    L.xn = 4096;                                            // also the exchange area of the two contraction halves (4*NP*mt KiB)
+    L.xm = L.xn + mt * 16 * FH_ROWB;
+    L.qi = L.xm + (raw ? mt * 16 * FH_ROWB : 0);
+    L.ki = L.qi + mt * 16 * FH_HROWB;
+    const int krows = ((key_rows + pad_rows + 7) & ~7);     // keys + finite padding up to the end of the last 64-key chunk
     L.vi = L.ki + krows * FH_HROWB;
     L.mask = L.vi + krows * FH_HROWB;
     L.total = L.mask + ((mask_bytes + 15) & ~15);
     return L;
 }
+// image rows behind the keys that a 64-key chunk of the last sample may touch
+__host__ __device__ inline int fh_pad_rows(int kind, int mk) { return kind == FH_CROSS_READY ? ((mk + 63) & ~63) - mk : 64; }
+
+#ifdef FH_TIMELINE
+#define FH_STAMP(k) do { if (tid == 0) G.dbg[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define FH_STAMP(k) do { } while (0)
+#endif
 
 // NP = 64-column weight blocks per workgroup (3: q|k|v or 192 FFN columns; 1: q only), MT = row tiles (16 rows).
 template <int NP, int MT>
-__global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(const FhGroup G) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int g = 0;
-    while (g + 1 < G.count && (int)blockIdx.x >= G.wg_start[g + 1]) ++g;
-    const FhMember& M = G.m[g];
-    const int t = (int)blockIdx.x - G.wg_start[g];
-    const int slice = t % M.nslice, rb = t / M.nslice;
+__device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, const int slice, const int rb, unsigned char* smem) {
+    constexpr int NG = (MT * 4 + 7) / 8;           // row groups (4 rows) a wave normalises at most
+    constexpr int NT = NP * MT;                    // accumulator tiles per wave
+    const int tid = threadIdx.x;
     const int row0 = rb * M.rows_per_wg;
     const int R = (M.rows - row0) < M.rows_per_wg ? (M.rows - row0) : M.rows_per_wg;
-    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave & 3, kh = wave >> 2;       // column block of 16, half of the contraction
     const int kind = M.kind;
     const bool raw = kind == FH_CROSS_RAW, ffn = kind == FH_FFN;
     const int a = M.a, m = M.m;
     const int nsamp = ffn ? 0 : R / a, b0 = rb * M.blk;
     const int Rm = raw ? nsamp * m : 0, rm0 = b0 * m;
-    const int key_rows = ffn ? 0 : (kind == FH_SELF ? MT * 16 : (raw ? MT * 16 : nsamp * m));
+    const int mk = kind == FH_SELF ? a : m;        // keys (= image rows) per sample
+    const int key_rows = ffn ? 0 : ((kind == FH_SELF || raw) ? MT * 16 : nsamp * m);
     const int qa = M.mask_sq ? a : 1;
     const int mask_bytes = (ffn || !M.mask) ? 0 : nsamp * qa * m;
-    const FhLds L = fh_lds_map(MT, raw, key_rows, mask_bytes);
+    const FhLds L = fh_lds_map(MT, raw, key_rows, fh_pad_rows(kind, mk), mask_bytes);
     unsigned char* xn_s = smem + L.xn;
     unsigned char* xm_s = smem + L.xm;
     unsigned char* qi_s = smem + L.qi;
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
     const uint8_t* mask_g = M.mask ? M.mask + (size_t)b0 * M.mask_sb : nullptr;   // contiguous: mask_sb is 0 or qa * m
 #pragma unroll
     for (int i = 0; i < FH_MASKB; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + FH_THREADS * i;
         mkb[i] = 1;
         if (idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * m)];
     }
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
     //     rows of a memory projected ahead of the layer loop.  Rows past the end arrive as zeros (buffer bound).
     if (raw) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(M.mem + (size_t)rm0 * FH_D), 0, Rm * FH_ROWB, 0x00020000);
-        for (int r = wave; r < MT * 16; r += 4) {     // one wave-instruction = one 1 KiB row; slot `lane` receives chunk lane ^ (r & 15)
+        for (int r = wave; r < MT * 16; r += 8) {     // one wave-instruction = one 1 KiB row; slot `lane` receives chunk lane ^ (r & 15)
             const unsigned voff = r < Rm ? (unsigned)r * FH_ROWB + (unsigned)((lane ^ (r & 15)) << 4) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (fh_lds_void_t*)(xm_s + r * FH_ROWB), 16, voff, 0, 0, 0);
         }
@@ -190,8 +204,8 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
         const bf16_t* kbase = M.kv + (size_t)rm0 * (2 * FH_D) + slice * FH_DK;
         const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (Kr - 1) * (4 * FH_D) + FH_HROWB, 0x00020000);
         const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + FH_D), 0, (Kr - 1) * (4 * FH_D) + FH_HROWB, 0x00020000);
-        const int ninst = (((Kr + 7) & ~7) + 64) >> 3;            // 8 head rows (128 B each) per wave-instruction
-        for (int i = wave; i < ninst; i += 4) {
+        const int ninst = ((Kr + fh_pad_rows(kind, mk) + 7) & ~7) >> 3;        // 8 head rows (128 B each) per wave-instruction
+        for (int i = wave; i < ninst; i += 8) {
             const int row = i * 8 + (lane >> 3), slot = lane & 7;
             const unsigned vk = row < Kr ? (unsigned)row * (4 * FH_D) + (unsigned)((slot ^ (row & 7)) << 4) : 0x80000000u;
             const unsigned vv = row < Kr ? (unsigned)row * (4 * FH_D) + (unsigned)((slot ^ ((row >> 1) & 7)) << 4) : 0x80000000u;
@@ -199,54 +213,65 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (fh_lds_void_t*)(vi_s + i * 1024), 16, vv, 0, 0, 0);
         }
     }
-    // (3) x rows: row group rg = wave + 4i holds rows 4rg .. 4rg+3, one per 16-lane row; lane l15 reads columns 64j + 4*l15
+    // (3) x rows: row group rg = wave + 8i holds rows 4rg .. 4rg+3, one per 16-lane row; lane l15 reads columns 64j + 4*l15
     const float* __restrict__ xg = M.x + (size_t)row0 * FH_D;
-    float4 xv[MT][8];
+    float4 xv[NG][8];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int r = 4 * (wave + 4 * i) + lg;
-        const bool ok = r < R;
+    for (int i = 0; i < NG; ++i) {
+        const int r = 4 * (wave + 8 * i) + lg;
+        const bool ok = r < R;                     // (groups past the tile range have r >= MT*16 >= R)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             xv[i][j] = ok ? *(const float4*)(xg + (size_t)r * FH_D + 64 * j + 4 * l15) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // (4) LayerNorm gains: threads 0..127 a_2, 128..255 b_2 (one float4 each) -> LDS
-    const float4 gv = *(const float4*)((tid < 128 ? M.ln_a : M.ln_b - FH_D) + tid * 4);
-    // (5) weight fragments: block p covers output columns ncol[p] .. +63 of the Linear; wave w takes 16w..16w+15 of them
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 256) gv = *(const float4*)((tid < 128 ? M.ln_a : M.ln_b - FH_D) + tid * 4);
+    // (5) weight fragments: block p covers output columns ncol[p] .. +63 of the Linear; this wave: columns 16*wc .. +15,
+    //     contraction steps 8*kh .. +7
     int ncol[NP];
     bool act[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        if (ffn) { ncol[p] = slice * (64 * NP) + p * 64; act[p] = ncol[p] + 16 * wave < M.ncols; }
+        if (ffn) { ncol[p] = slice * (64 * NP) + p * 64; act[p] = ncol[p] + 16 * wc < M.ncols; }
         else { ncol[p] = p * FH_D + slice * FH_DK; act[p] = (p == 0) || kind != FH_CROSS_READY; }
     }
-    uint4 wf[NP][16];
+    uint4 wf[NP][8];
     float4 bv[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int nrow = act[p] ? ncol[p] + 16 * wave : 0;     // inactive blocks read block 0 (in bounds) and are never stored
-        const bf16_t* wrow = M.w + (size_t)(nrow + l15) * FH_D + lg * 8;
+        if (act[p]) {
+            const bf16_t* wrow = M.w + (size_t)(ncol[p] + 16 * wc + l15) * FH_D + kh * 256 + lg * 8;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
-        bv[p] = *(const float4*)(M.bias + nrow + 4 * lg);
+            for (int s = 0; s < 8; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
+            bv[p] = *(const float4*)(M.bias + ncol[p] + 16 * wc + 4 * lg);
+        } else {                                    // inactive block (q-only member in a 3-block launch, ragged last FFN slice)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) wf[p][s] = make_uint4(0, 0, 0, 0);
+            bv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     const DropState ds = drop_init(M.drop);
+    FH_STAMP(1);                                   // everything issued
 
     // ================================================================ on chip from here
     // masks and gains -> LDS
 #pragma unroll
     for (int i = 0; i < FH_MASKB; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + FH_THREADS * i;
         if (idx < mask_bytes) mk_s[idx] = mkb[i];
     }
-    *(float4*)(smem + L.gains + tid * 16) = gv;
+    if (tid < 256) *(float4*)(smem + L.gains + tid * 16) = gv;
+    FH_STAMP(2);                                   // masks, x rows (issued before the gains) and gains have landed
     __syncthreads();
+    FH_STAMP(3);
 
     // ---- LayerNorm (mtn.py:111-114): 16 lanes per row, 32 elements per lane; row -> bf16 -> LDS image
     const bool save = slice == 0;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int r = 4 * (wave + 4 * i) + lg;
+    for (int i = 0; i < NG; ++i) {
+        if (wave + 8 * i >= MT * 4) break;
+        const int r = 4 * (wave + 8 * i) + lg;
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += (xv[i][j].x + xv[i][j].y) + (xv[i][j].z + xv[i][j].w);
@@ -275,16 +300,18 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
     }
     // zero padding behind the key images (a key chunk may run past the last key: its V rows must be finite)
     if (!ffn && kind != FH_CROSS_READY) {
-        for (int i = tid; i < 64 * FH_HROWB / 16; i += 256) {
+        for (int i = tid; i < 64 * FH_HROWB / 16; i += FH_THREADS) {
             *(uint4*)(ki_s + MT * 16 * FH_HROWB + i * 16) = make_uint4(0, 0, 0, 0);
             *(uint4*)(vi_s + MT * 16 * FH_HROWB + i * 16) = make_uint4(0, 0, 0, 0);
         }
     }
+    FH_STAMP(4);                                   // LayerNorm done
     if (raw || kind == FH_CROSS_READY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA images have landed
     __syncthreads();
+    FH_STAMP(5);
     if (G.stop == 1) return;
 
-    // ---- projections: acc[p][mt] = W block p (A operand: 16 output columns) x rows of tile mt (B operand)
+    // ---- projections: acc[p][mt] = W block p (A operand: 16 output columns) x rows of tile mt (B operand), this wave's half of k
     f32x4_t acc[NP][MT];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -292,10 +319,10 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
         for (int mt = 0; mt < MT; ++mt) acc[p][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (!raw) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < 8; ++s) {
             uint4 xf[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xf[mt] = fh_xfrag(xn_s, mt * 16 + l15, s * 4 + lg);
+            for (int mt = 0; mt < MT; ++mt) xf[mt] = fh_xfrag(xn_s, mt * 16 + l15, (kh * 8 + s) * 4 + lg);
 #pragma unroll
             for (int p = 0; p < NP; ++p)
 #pragma unroll
@@ -303,10 +330,13 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
         }
     } else if constexpr (NP == 3) {           // q from the normalised rows, k | v from the memory rows
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < 8; ++s) {
             uint4 xf[MT], mf[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) { xf[mt] = fh_xfrag(xn_s, mt * 16 + l15, s * 4 + lg); mf[mt] = fh_xfrag(xm_s, mt * 16 + l15, s * 4 + lg); }
+            for (int mt = 0; mt < MT; ++mt) {
+                xf[mt] = fh_xfrag(xn_s, mt * 16 + l15, (kh * 8 + s) * 4 + lg);
+                mf[mt] = fh_xfrag(xm_s, mt * 16 + l15, (kh * 8 + s) * 4 + lg);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 mma16<bf16_t>(acc[0][mt], wf[0][s], xf[mt]);
@@ -314,6 +344,27 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
                 mma16<bf16_t>(acc[2][mt], wf[2][s], mf[mt]);
             }
         }
+    }
+    FH_STAMP(6);                                   // this wave's half of the projections done (all weight fragments landed)
+    // ---- the two halves of the contraction meet: of each pair of waves (same columns), wave kh keeps the tiles with
+    //      (tile index & 1) == kh and hands the others over through LDS (the xn image is dead: everybody is past it)
+    __syncthreads();
+    {
+        float* ex = (float*)xn_s + (size_t)wc * (NT * 256) + lane * 4;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (((p * MT + mt) & 1) != kh) *(f32x4_t*)(ex + (p * MT + mt) * 256) = acc[p][mt];
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (((p * MT + mt) & 1) == kh) {
+                    const f32x4_t o = *(const f32x4_t*)(ex + (p * MT + mt) * 256);
+                    acc[p][mt][0] += o[0]; acc[p][mt][1] += o[1]; acc[p][mt][2] += o[2]; acc[p][mt][3] += o[3];
+                }
     }
     if (G.stop == 2) {
         float t_ = 0.f;
@@ -325,22 +376,23 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
         return;
     }
 
-    // ---- epilogue: a lane holds output row (tile row l15) x four consecutive columns 16w + 4lg .. +3 of each block
+    // ---- epilogue (the tiles this wave kept): a lane holds output row (tile row l15) x four consecutive columns 16wc + 4lg .. +3
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         if (!act[p]) continue;
-        const int col = ncol[p] + 16 * wave + 4 * lg;           // column of the Linear's output
+        const int col = ncol[p] + 16 * wc + 4 * lg;             // column of the Linear's output
         const bool to_kv = raw && p > 0;
         const int rows_p = to_kv ? Rm : R, r0_p = to_kv ? rm0 : row0;
         bf16_t* dst;
         int ld;
         if (ffn) { dst = M.out + col; ld = M.ld_out; }
-        else if (to_kv) { dst = M.kv + (p - 1) * FH_D + slice * FH_DK + 16 * wave + 4 * lg; ld = 2 * FH_D; }
+        else if (to_kv) { dst = M.kv + (p - 1) * FH_D + slice * FH_DK + 16 * wc + 4 * lg; ld = 2 * FH_D; }
         else if (kind == FH_SELF) { dst = M.out + col; ld = M.ld_out; }
-        else { dst = M.out + slice * FH_DK + 16 * wave + 4 * lg; ld = M.ld_out; }
+        else { dst = M.out + slice * FH_DK + 16 * wc + 4 * lg; ld = M.ld_out; }
         unsigned char* img = p == 0 ? qi_s : (p == 1 ? ki_s : vi_s);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            if (((p * MT + mt) & 1) != kh) continue;
             const int r = mt * 16 + l15;
             float v[4] = {acc[p][mt][0] + bv[p].x, acc[p][mt][1] + bv[p].y, acc[p][mt][2] + bv[p].z, acc[p][mt][3] + bv[p].w};
             if (ffn) {
@@ -355,20 +407,21 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
             const uint2 u = make_uint2(fh_pack2(v[0], v[1]), fh_pack2(v[2], v[3]));
             if (r < rows_p) *(uint2*)(dst + (size_t)(r0_p + r) * ld) = u;
             if (!ffn) {                                             // this head's Q / K / V image: [row][64], 16-byte slots swizzled
-                const int chunk = 2 * wave + (lg >> 1);
+                const int chunk = 2 * wc + (lg >> 1);
                 const int sw = p == 2 ? ((r >> 1) & 7) : (r & 7);
                 *(uint2*)(img + r * FH_HROWB + ((chunk ^ sw) << 4) + (lg & 1) * 8) = u;
             }
         }
     }
+    FH_STAMP(7);                                   // epilogue stores issued, images written
     if (ffn || G.stop == 3) return;
 
     // ---- attention of this head, on chip.  Item = (sample, 16 query rows), one wave each.
     __syncthreads();
+    FH_STAMP(8);
     const float scale = 0.125f;                    // 1 / sqrt(64)
     const int nqt = (a + 15) >> 4;
-    const int mk = kind == FH_SELF ? a : m;        // keys (= image rows) per sample
-    for (int it = wave; it < nsamp * nqt; it += 4) {
+    for (int it = wave; it < nsamp * nqt; it += 8) {
         const int si = it / nqt, qt = it - si * nqt;
         const int b = b0 + si;
         const int q = qt * 16 + l15, qc = q < a ? q : a - 1;
@@ -454,6 +507,24 @@ __global__ __launch_bounds__(256, NP == 3 ? 1 : 2) void fused_head_fwd_kernel(co
             }
         }
     }
+    FH_STAMP(9);
+}
+
+template <int NP>
+__global__ __launch_bounds__(FH_THREADS) void fused_head_fwd_kernel(const FhGroup G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef FH_TIMELINE
+    const int tid = threadIdx.x;
+#endif
+    FH_STAMP(0);
+    int g = 0;
+    while (g + 1 < G.count && (int)blockIdx.x >= G.wg_start[g + 1]) ++g;
+    const FhMember& M = G.m[g];
+    const int t = (int)blockIdx.x - G.wg_start[g];
+    const int slice = t % M.nslice, rb = t / M.nslice;
+    if (M.mt <= 2) fh_body<NP, 2>(G, M, slice, rb, smem);
+    else if (M.mt == 3) fh_body<NP, 3>(G, M, slice, rb, smem);
+    else fh_body<NP, 5>(G, M, slice, rb, smem);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -471,19 +542,20 @@ static bool fh_env_off() {
 static constexpr int FH_LDS_MAX = 160 * 1024;
 static const int fh_mt_choices[3] = {2, 3, 5};
 
-struct FhPlan { int blk, mt; };
+struct FhPlan { int blk, mt, lds; };
 static int fh_member_lds(const mtn_mha_args& A, int blk, int mt) {
     const bool self = A.self_attn != 0, raw = !self && !A.kv_ready;
     const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
-    return fh_lds_map(mt, raw, (self || raw) ? mt * 16 : blk * m, A.mask ? blk * qa * m : 0).total;
+    const int kind = self ? FH_SELF : (raw ? FH_CROSS_RAW : FH_CROSS_READY);
+    return fh_lds_map(mt, raw, (self || raw) ? mt * 16 : blk * m, fh_pad_rows(kind, m), A.mask ? blk * qa * m : 0).total;
 }
-// Rows per workgroup for an attention member: whole samples, inside the row tiles (mt_cap) and the LDS; as few workgroups as it
-// takes to stay within the member's share of one round of the chip (these launches are bound by the bytes each CU pulls:
+// Rows per workgroup for an attention member: whole samples, inside the row tiles (<= 80 rows) and the LDS; as few workgroups as
+// it takes to stay within the member's share of one round of the chip (these launches are bound by the bytes each CU pulls:
 // weight slice + x rows), but not fewer.  Returns blk = 0 when even one sample does not fit.
-static FhPlan fh_plan_mha(const mtn_mha_args& A, int mt_cap, int budget) {
+static FhPlan fh_plan_mha(const mtn_mha_args& A, int budget) {
     const bool self = A.self_attn != 0, raw = !self && !A.kv_ready;
     const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
-    FhPlan best = {0, 0};
+    FhPlan best = {0, 0, 0};
     if (A.mask && A.mask_sb != 0 && A.mask_sb != (long)qa * m) return best;      // the block's mask bytes must be contiguous
     if (A.mask && A.mask_sq != 0 && A.mask_sq != m) return best;
     for (int blk = 1; blk <= A.B; ++blk) {
@@ -491,63 +563,41 @@ static FhPlan fh_plan_mha(const mtn_mha_args& A, int mt_cap, int budget) {
         int mt = 0;
         for (int c = 0; c < 3; ++c)
             if (fh_mt_choices[c] * 16 >= R && (!raw || fh_mt_choices[c] * 16 >= Rm)) { mt = fh_mt_choices[c]; break; }
-        if (!mt || mt > mt_cap) break;
-        if (A.mask && blk * qa * m > 256 * FH_MASKB) break;
-        if (fh_member_lds(A, blk, mt) > FH_LDS_MAX) break;
-        best = FhPlan{blk, mt};
+        if (!mt) break;
+        if (A.mask && blk * qa * m > FH_THREADS * FH_MASKB) break;
+        const int lds = fh_member_lds(A, blk, mt);
+        if (lds > FH_LDS_MAX) break;
+        best = FhPlan{blk, mt, lds};
         if (((A.B + blk - 1) / blk) * (FH_D / FH_DK) <= budget) break;
     }
     return best;
 }
 
-struct FhLaunch { FhGroup G; int wgs, mt, need3; size_t lds; };
+struct FhLaunch { FhGroup G; int wgs, need3; size_t lds; };
 // The whole launch plan; false = this group keeps the four-launch path.
 static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, FhLaunch& P) {
     if (n_mha + n_ffn < 1 || n_mha + n_ffn > FH_MAX_MEMBERS) return false;
     FhGroup& G = P.G;
     memset(&G, 0, sizeof(G));
-    bool need3 = n_ffn > 0, any_raw = false;
+    bool need3 = n_ffn > 0;
     for (int i = 0; i < n_mha; ++i) {
         if (mha[i].d != FH_D || mha[i].h != FH_D / FH_DK) return false;
         if (mha[i].self_attn || !mha[i].kv_ready) need3 = true;
-        any_raw |= !mha[i].self_attn && !mha[i].kv_ready;
     }
     for (int i = 0; i < n_ffn; ++i)
         if (ffn[i].d != FH_D || ffn[i].d_ff % 64 != 0) return false;
     const int members = n_mha + n_ffn;
     const int budget = 256 / members > 8 ? 256 / members : 8;       // share of one round (256 workgroups) per member
-    const int mt_cap = any_raw ? 3 : (need3 ? 5 : 3);                // q-only kernel: two workgroups per CU, 48 rows
-    int mt = 2, blk[MTN_SUBLAYER_MAX_GROUP], ffn_rpw[MTN_SUBLAYER_MAX_GROUP];
-    for (int i = 0; i < n_mha; ++i) {
-        const FhPlan pl = fh_plan_mha(mha[i], mt_cap, budget);
-        if (pl.blk == 0) return false;
-        blk[i] = pl.blk;
-        mt = pl.mt > mt ? pl.mt : mt;
-    }
-    for (int i = 0; i < n_ffn; ++i) {
-        const int nslice = (ffn[i].d_ff + 191) / 192;
-        int rpw = 80;                                     // rows per workgroup: 32 / 48 / 80, within the member's share if possible
-        if (mt_cap < 5) rpw = 48;
-        for (int c = 1; c >= 0; --c)
-            if (((ffn[i].rows + fh_mt_choices[c] * 16 - 1) / (fh_mt_choices[c] * 16)) * nslice <= budget) rpw = fh_mt_choices[c] * 16;
-        ffn_rpw[i] = rpw;
-        mt = rpw / 16 > mt ? rpw / 16 : mt;
-    }
-    // every member runs at the launch's row-tile count: shrink blocks whose LDS map no longer fits
-    size_t lds = fh_lds_map(mt, false, 0, 0).total;
-    for (int i = 0; i < n_mha; ++i) {
-        while (blk[i] > 1 && fh_member_lds(mha[i], blk[i], mt) > FH_LDS_MAX) --blk[i];
-        const int l = fh_member_lds(mha[i], blk[i], mt);
-        if (l > FH_LDS_MAX) return false;
-        lds = (size_t)l > lds ? (size_t)l : lds;
-    }
     int n = 0, wgs = 0;
+    size_t lds = 0;
     for (int i = 0; i < n_mha; ++i) {
         const mtn_mha_args& a = mha[i];
+        const FhPlan pl = fh_plan_mha(a, budget);
+        if (pl.blk == 0) return false;
         FhMember& M = G.m[n];
         M.kind = a.self_attn ? FH_SELF : (a.kv_ready ? FH_CROSS_READY : FH_CROSS_RAW);
-        M.a = a.a; M.m = a.self_attn ? a.a : a.m; M.blk = blk[i];
-        M.rows = a.B * a.a; M.rows_per_wg = blk[i] * a.a; M.nslice = FH_D / FH_DK;
+        M.a = a.a; M.m = a.self_attn ? a.a : a.m; M.blk = pl.blk; M.mt = pl.mt;
+        M.rows = a.B * a.a; M.rows_per_wg = pl.blk * a.a; M.nslice = FH_D / FH_DK;
         M.eps = a.ln_eps; M.x = a.x; M.ln_a = a.ln_a; M.ln_b = a.ln_b;
         M.w = (const bf16_t*)a.w_qkv; M.bias = a.b_qkv; M.mem = (const bf16_t*)a.mem;
         M.xn = (bf16_t*)a.xn; M.mean = a.mean; M.rstd = a.rstd;
@@ -555,7 +605,8 @@ static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn
         M.mask = a.mask; M.mask_sb = a.mask_sb; M.mask_sq = a.mask_sq; M.drop = a.drop_attn;
         M.o = (bf16_t*)a.o; M.lse = a.lse;
         G.wg_start[n] = wgs;
-        wgs += ((a.B + blk[i] - 1) / blk[i]) * M.nslice;
+        wgs += ((a.B + pl.blk - 1) / pl.blk) * M.nslice;
+        lds = (size_t)pl.lds > lds ? (size_t)pl.lds : lds;
         ++n;
     }
     for (int i = 0; i < n_ffn; ++i) {
@@ -563,19 +614,24 @@ static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn
         FhMember& M = G.m[n];
         M.kind = FH_FFN;
         M.rows = a.rows; M.ncols = a.d_ff; M.nslice = (a.d_ff + 191) / 192;
-        M.rows_per_wg = ffn_rpw[i]; M.a = 1; M.m = 1; M.blk = ffn_rpw[i];
+        int mt = 5;                                       // rows per workgroup: 32 / 48 / 80, within the member's share if possible
+        for (int c = 1; c >= 0; --c)
+            if (((a.rows + fh_mt_choices[c] * 16 - 1) / (fh_mt_choices[c] * 16)) * M.nslice <= budget) mt = fh_mt_choices[c];
+        M.mt = mt; M.rows_per_wg = mt * 16; M.a = 1; M.m = 1; M.blk = mt * 16;
         M.eps = a.ln_eps; M.x = a.x; M.ln_a = a.ln_a; M.ln_b = a.ln_b;
         M.w = (const bf16_t*)a.w1; M.bias = a.b1;
         M.xn = (bf16_t*)a.xn; M.mean = a.mean; M.rstd = a.rstd;
         M.out = (bf16_t*)a.hid; M.ld_out = a.d_ff; M.drop = a.drop_hidden;
         G.wg_start[n] = wgs;
-        wgs += ((a.rows + ffn_rpw[i] - 1) / ffn_rpw[i]) * M.nslice;
+        wgs += ((a.rows + M.rows_per_wg - 1) / M.rows_per_wg) * M.nslice;
+        const size_t l = (size_t)fh_lds_map(mt, false, 0, 0, 0).total;
+        lds = l > lds ? l : lds;
         ++n;
     }
     G.count = n;
     for (int i = n; i <= FH_MAX_MEMBERS; ++i) G.wg_start[i] = wgs;
     { static const int stop = [] { const char* e = getenv("MTN_FH_STOP"); return e ? atoi(e) : 0; }(); G.stop = stop; }
-    P.wgs = wgs; P.mt = mt; P.need3 = need3 ? 1 : 0; P.lds = lds;
+    P.wgs = wgs; P.need3 = need3 ? 1 : 0; P.lds = lds;
     return true;
 }
 
@@ -586,16 +642,16 @@ int fh_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, 
     return fh_plan(n_mha, mha, n_ffn, ffn, P) ? 1 : 0;
 }
 
-template <int NP, int MT> static int fh_launch(const FhGroup& G, int wgs, size_t lds, hipStream_t s) {
+template <int NP> static int fh_launch(const FhGroup& G, int wgs, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)fused_head_fwd_kernel<NP, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)fused_head_fwd_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX) != hipSuccess) {
             mtn_set_error("fused_head_fwd_kernel: cannot raise the dynamic LDS limit");
             return MTN_ERR_LAUNCH;
         }
         attr = true;
     }
-    hipLaunchKernelGGL((fused_head_fwd_kernel<NP, MT>), dim3(wgs), dim3(256), lds, s, G);
+    hipLaunchKernelGGL((fused_head_fwd_kernel<NP>), dim3(wgs), dim3(FH_THREADS), lds, s, G);
     return MTN_OK;
 }
 
@@ -603,10 +659,7 @@ int fh_group_fwd_stage1(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn
     FhLaunch P;
     MTN_CHECK_ARG(fh_plan(n_mha, mha, n_ffn, ffn, P), "group outside the fused kernel's tiling");
     hipStream_t s = (hipStream_t)stream;
-    const int mt = P.mt;
-    int rc;
-    if (P.need3) rc = mt <= 2 ? fh_launch<3, 2>(P.G, P.wgs, P.lds, s) : (mt == 3 ? fh_launch<3, 3>(P.G, P.wgs, P.lds, s) : fh_launch<3, 5>(P.G, P.wgs, P.lds, s));
-    else rc = mt <= 2 ? fh_launch<1, 2>(P.G, P.wgs, P.lds, s) : fh_launch<1, 3>(P.G, P.wgs, P.lds, s);
+    const int rc = P.need3 ? fh_launch<3>(P.G, P.wgs, P.lds, s) : fh_launch<1>(P.G, P.wgs, P.lds, s);
     if (rc != MTN_OK) return rc;
     MTN_CHECK_LAUNCH();
     return MTN_OK;
