@@ -2,15 +2,19 @@
 """bench.py — train-step throughput of the MTN hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...            (spawns its own N ranks: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the reference's batch loop body (train.py:29-40 + data_utils.py:133-156) over one synthetic
 batch already resident in HBM: forward -> generator + label-smoothed loss (main + 2 auto-encoder terms) -> backward ->
 [RCCL all-reduce of the flat gradient] -> Adam/Noam update.  Workload at every N: BASELINE.json configs[1] shapes
-(d_model=512, 6 layers, 8 heads, d_ff=2048, |V|=3000, Q/H/C/T=20/128/40/20, 32 I3D(2048)+32 VGGish(128) frames), 32
-samples PER GPU (weak scaling), bf16 compute with fp32 master weights / residual stream / statistics, dropout 0.1 on
-(in-kernel), random-init weights, synthetic data.  Rank 0 prints ONE JSON line.
+(d_model=512, 6 layers, 8 heads, d_ff=2048, |V|=3000, Q/H/C/T=20/128/40/20, 32 I3D(2048)+32 VGGish(128) frames); N = 1:
+32 samples (cfg2 = BASELINE configs[1], the configuration the metric is quoted on); N > 1: 64 samples PER GPU (cfg3 = BASELINE
+configs[2], weak scaling); bf16 compute with fp32 master weights / residual stream / statistics, dropout 0.1 on (in-kernel),
+random-init weights, synthetic data.  Rank 0 prints ONE JSON line.  `value` comes from EXACTLY --steps steps between two
+barrier + synchronize brackets; four more windows of the same length are timed afterwards and reported beside it
+(config.window_ms_per_step, median) because one window of a 4-5 ms step is a short sample.
 """
 import argparse
 import json
@@ -27,7 +31,7 @@ import torch  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
 PEAK_FP32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-SURVEY_GFLOP_PER_SAMPLE = {"cfg2": 15.90, "cfg4": 33.22, "cfg1": 0.315}
+SURVEY_GFLOP_PER_SAMPLE = {"cfg2": 15.90, "cfg3": 15.90, "cfg4": 33.22, "cfg1": 0.315}
 
 
 def parse():
@@ -35,7 +39,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg4"])
+    ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4"],
+                    help="default: cfg2 (batch 32) on one GPU, cfg3 (batch 64 per GPU) on several")
     ap.add_argument("--batch-per-gpu", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=0.1)
@@ -43,7 +48,33 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--bf16-grad-allreduce", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--windows", type=int, default=4, help="extra timed windows of --steps steps after the one `value` comes from")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (batch-64 figure at N=1, "
+                    "exchange-free single-rank figure at N>1)")
+    args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "cfg2" if args.gpus == 1 else "cfg3"
+    return args
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: re-execute under torch.distributed.run, one rank per GPU
+    (RCCL over xGMI), rendezvous on 127.0.0.1; the ranks' output (rank 0's JSON line last) passes through."""
+    import socket
+    import subprocess
+    backend = os.environ.get("MTN_DIST_BACKEND") or "nccl"
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and n_dev < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs for RCCL, this node shows {n_dev} "
+                 f"(MTN_DIST_BACKEND=gloo runs the multi-rank control flow on fewer devices, as a dry run only)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline(model, cfg, B, steps):
@@ -180,14 +211,27 @@ def pmc_traffic(kernel_name):
     return None
 
 
+def pmc_step_traffic():
+    """Whole-step HBM-side GB from the latest committed PMC summary (profiles/*pmc_traffic.json)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    try:
+        return float(json.load(open(files[-1]))["step"]["total_GB"]) if files else None
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     from mtn_amd import dp, lib, make_model
     from mtn_amd.synthetic import CONFIGS, flops_per_sample, synthetic_batch
     from mtn_amd.train_step import TrainStep
 
     rank, world, local = dp.init_distributed()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     local = local % torch.cuda.device_count()      # (several ranks may share a GPU in a gloo dry run of the multi-rank control flow)
     torch.cuda.set_device(local)
@@ -214,43 +258,85 @@ def main():
                             device=dev, seed=1 + rank, ragged=False)
     step = TrainStep(model, batch, cfg["vocab"], pad=1, warmup=4000, grad_sync=sync, use_graph=not args.no_graph)
 
+    def timed_window(st, n_steps):
+        """n_steps steps between two (barrier + synchronize) brackets; wall seconds, max over ranks; HIP-event ms of this rank."""
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        out = None
+        for _ in range(n_steps):
+            out = st()
+        e1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item()), e0.elapsed_time(e1), out
+
     for _ in range(max(1, args.warmup)):
         loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        loss = step()
-    e1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
-    loss_val = float(loss.item()) / float(batch.ntokens)
+    elapsed, ev_total_ms, loss = timed_window(step, args.steps)              # <- `value`
+    loss_val = float(loss.item())            # TrainStep returns the normalised loss: sum of the three KL terms per target / query token
+    windows = [elapsed / args.steps * 1e3]
+    for _ in range(max(0, args.windows)):
+        windows.append(timed_window(step, args.steps)[0] / args.steps * 1e3)
+    # secondary measurements (never `value`)
+    secondary = {}
+    if not args.no_secondary and args.workload in ("cfg2", "cfg3"):
+        try:
+            if world == 1 and B != 64:
+                # BASELINE configs[2] / north_star quote the utilisation target at batch 64 per GPU: the same step at that batch
+                b64 = synthetic_batch(cfg["vocab"], 64, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=7, ragged=False)
+                st64 = TrainStep(model, b64, cfg["vocab"], pad=1, warmup=4000, grad_sync=None, use_graph=not args.no_graph)
+                for _ in range(3):
+                    st64()
+                dt64, _, _ = timed_window(st64, args.steps)
+                secondary["batch64_one_gpu"] = {"samples_per_s": round(64 * args.steps / dt64, 1), "ms_per_step": round(dt64 / args.steps * 1e3, 4),
+                                                "what": "same model and step at batch 64 (BASELINE configs[2] per-GPU batch) on this one GPU"}
+                del st64, b64
+            elif world > 1 and rank == 0:
+                pass      # (filled below: every rank must take part in the barriers of timed_window)
+            if world > 1:
+                # the same per-GPU batch on ONE rank without any exchange (graph of forward+backward+optimiser epilogue): the
+                # figure a DP rank is compared with, measured in the same job; the other ranks idle at the barriers
+                st1 = TrainStep(model, batch, cfg["vocab"], pad=1, warmup=4000, grad_sync=None, use_graph=not args.no_graph) if rank == 0 else None
+                if rank == 0:
+                    for _ in range(3):
+                        st1()
+                dt1, _, _ = timed_window(st1 if rank == 0 else (lambda: None), args.steps)
+                secondary["one_rank_no_exchange"] = {"samples_per_s": round(B * args.steps / dt1, 1), "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                                                     "what": "rank 0 alone, same per-GPU batch, no gradient exchange, optimiser fused into the dW launch"}
+        except Exception as e:  # pragma: no cover
+            secondary["error"] = str(e)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        gflop = SURVEY_GFLOP_PER_SAMPLE.get(args.workload) if (args.workload != "cfg2" or True) else None
+        gflop = SURVEY_GFLOP_PER_SAMPLE.get(args.workload)
         gflop_formula = flops_per_sample(**cfg) / 1e9
         step_tf = value * gflop / 1e3                                 # whole job
         peak = (PEAK_BF16_TFLOPS if lp == torch.bfloat16 else PEAK_FP32_TFLOPS) * world
-        ev_ms = e0.elapsed_time(e1) / args.steps
+        ev_ms = ev_total_ms / args.steps
         step_info = {"what": "whole captured train step (one hipGraph launch = one step): algorithmic GFLOP/sample x samples "
                              "per launch / HIP-event time per launch on the launch stream",
                      "achieved_TFLOPs": round(step_tf, 2), "frac": round(step_tf / peak, 5),
                      "gflop_per_sample": gflop, "gflop_per_sample_closed_form": round(gflop_formula, 3),
                      "hip_event_ms_per_step": round(ev_ms, 4),
                      "optimiser_bytes_per_step": (28 if step._fused() else 38) * sum(p.numel() for p in model.parameters())}
+        hbm = pmc_step_traffic()
+        if hbm is not None and world == 1 and args.workload == "cfg2" and B == 32:
+            # whole-step HBM-side traffic from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, gfx950 corrections) / measured step time
+            step_info["hbm_GB_per_step_pmc"] = hbm
+            step_info["hbm_GBps_measured"] = round(hbm / (ms * 1e-3), 1)
+            step_info["hbm_frac_of_8TBps"] = round(hbm / (ms * 1e-3) / PEAK_HBM_GBS, 4)
         try:
             import ctypes as C
             scratch = torch.empty(2048 * 256, device=dev, dtype=torch.float32)
@@ -303,7 +389,12 @@ def main():
                            "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                            "dropout": args.dropout, "attn_dropout": 0.1 if args.dropout > 0 else 0.0,
                            "hip_graph": not args.no_graph, "weights": "random-init (xavier), fp32 master + bf16 compute copy",
-                           "loss_per_token_last_step": round(loss_val, 4)},
+                           "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                           "dist_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                           "window_ms_per_step": [round(w, 4) for w in windows],
+                           "median_window_ms_per_step": round(sorted(windows)[len(windows) // 2], 4),
+                           "normalised_loss_last_step": round(loss_val, 4),
+                           "secondary": secondary},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             try:

