@@ -45,6 +45,7 @@ struct FhMember {
     int nslice;        // heads, or 192-column slices of w_1
     int a, m, blk;     // attention: query rows per sample, memory rows per sample, samples per workgroup
     int mt;            // row tiles (16 rows) of this member's workgroups: 2, 3 or 5
+    int hg, sg;        // XCD-aware workgroup map: the 8 XCDs form hg slice groups x sg row-block groups (hg * sg = 8)
     int ncols;         // FFN: d_ff
     int ld_out;        // row stride of `out`
     float eps;
@@ -131,13 +132,13 @@ __device__ __forceinline__ uint4 fh_vfrag(const unsigned char* img, int row0, in
 
 // LDS map (bytes), the same arithmetic on host and device
 struct FhLds { int gains, xn, xm, qi, ki, vi, mask, total; };
-__host__ __device__ inline FhLds fh_lds_map(int mt, bool raw, int key_rows, int pad_rows, int mask_bytes) {
+__host__ __device__ inline FhLds fh_lds_map(int mt, bool raw, int key_rows, int pad_rows, int mask_bytes, int ffn_blocks = 0) {
     FhLds L;
-    L.gains = 0;
-    L.xn = 4096;                                            // also the exchange area of the two contraction halves (4*NP*mt KiB)
+    L.gains = 0;                                            // a_2 | b_2 | biases of the workgroup's output columns
+    L.xn = 4096 + 1024;                                     // also the exchange area of the two contraction halves (4*NP*mt KiB)
     L.xm = L.xn + mt * 16 * FH_ROWB;
     L.qi = L.xm + (raw ? mt * 16 * FH_ROWB : 0);
-    L.ki = L.qi + mt * 16 * FH_HROWB;
+    L.ki = L.qi + mt * 16 * (ffn_blocks ? ffn_blocks * FH_HROWB : FH_HROWB);     // Q image, or the feed-forward output tile [row][64 * NP]
     const int krows = ((key_rows + pad_rows + 7) & ~7);     // keys + finite padding up to the end of the last 64-key chunk
     L.vi = L.ki + krows * FH_HROWB;
     L.mask = L.vi + krows * FH_HROWB;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     const int key_rows = ffn ? 0 : ((kind == FH_SELF || raw) ? MT * 16 : nsamp * m);
     const int qa = M.mask_sq ? a : 1;
     const int mask_bytes = (ffn || !M.mask) ? 0 : nsamp * qa * m;
-    const FhLds L = fh_lds_map(MT, raw, key_rows, fh_pad_rows(kind, mk), mask_bytes);
+    const FhLds L = fh_lds_map(MT, raw, key_rows, fh_pad_rows(kind, mk), mask_bytes, ffn ? NP : 0);
     unsigned char* xn_s = smem + L.xn;
     unsigned char* xm_s = smem + L.xm;
     unsigned char* qi_s = smem + L.qi;
@@ -234,25 +235,37 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         if (ffn) { ncol[p] = slice * (64 * NP) + p * 64; act[p] = ncol[p] + 16 * wc < M.ncols; }
-        else { ncol[p] = p * FH_D + slice * FH_DK; act[p] = (p == 0) || kind != FH_CROSS_READY; }
+        else { ncol[p] = p * FH_D + slice * FH_DK; act[p] = (p == 0) || (p < 3 && kind != FH_CROSS_READY); }
     }
+    // The MFMA A-operand layout (lane 16c + r <-> row r, 16-byte chunk c of the 64-byte step) would make every quad of
+    // adjacent lanes touch four different weight rows: the texture addresser then takes 64 cycles per wave-instruction instead
+    // of 16.  So the loads are issued COALESCED — lane 4r + c reads (row r, chunk c): a quad = 64 contiguous bytes — and the
+    // fragments are put in operand order on chip, once they have landed (4 ds_bpermute per fragment).
     uint4 wf[NP][8];
-    float4 bv[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         if (act[p]) {
-            const bf16_t* wrow = M.w + (size_t)(ncol[p] + 16 * wc + l15) * FH_D + kh * 256 + lg * 8;
+            const bf16_t* wrow = M.w + (size_t)(ncol[p] + 16 * wc + (lane >> 2)) * FH_D + kh * 256 + (lane & 3) * 8;
 #pragma unroll
             for (int s = 0; s < 8; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
-            bv[p] = *(const float4*)(M.bias + ncol[p] + 16 * wc + 4 * lg);
-        } else {                                    // inactive block (q-only member in a 3-block launch, ragged last FFN slice)
+        } else {                                    // inactive block (q-only member in a 3-block launch, attention member in a 4-block one)
 #pragma unroll
             for (int s = 0; s < 8; ++s) wf[p][s] = make_uint4(0, 0, 0, 0);
-            bv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    // biases of the workgroup's 64 * NP output columns -> LDS (behind the gains)
+    float bias_v = 0.f;
+    if (tid < 64 * NP) {
+        const int p_ = tid >> 6;
+        bool on = false;
+        int nc = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) if (p == p_) { on = act[p] || (ffn && ncol[p] + (tid & 63) < M.ncols); nc = ncol[p]; }
+        if (on) bias_v = M.bias[nc + (tid & 63)];
+    }
+    FH_STAMP(13);                                  // all loads issued
     const DropState ds = drop_init(M.drop);
-    FH_STAMP(1);                                   // everything issued
+    FH_STAMP(1);                                   // ... and the dropout key derived (one more scalar round trip)
 
     // ================================================================ on chip from here
     // masks and gains -> LDS
@@ -262,6 +275,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         if (idx < mask_bytes) mk_s[idx] = mkb[i];
     }
     if (tid < 256) *(float4*)(smem + L.gains + tid * 16) = gv;
+    if (tid < 64 * NP) *(float*)(smem + L.gains + 4096 + tid * 4) = bias_v;
     FH_STAMP(2);                                   // masks, x rows (issued before the gains) and gains have landed
     __syncthreads();
     FH_STAMP(3);
@@ -311,6 +325,18 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     FH_STAMP(5);
     if (G.stop == 1) return;
 
+    {   // weight fragments into operand order: lane 16c + r takes the 16 bytes lane 4r + c loaded
+        const int src = (4 * l15 + lg) * 4;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                wf[p][s].x = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[p][s].x);
+                wf[p][s].y = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[p][s].y);
+                wf[p][s].z = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[p][s].z);
+                wf[p][s].w = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[p][s].w);
+            }
+    }
     // ---- projections: acc[p][mt] = W block p (A operand: 16 output columns) x rows of tile mt (B operand), this wave's half of k
     f32x4_t acc[NP][MT];
 #pragma unroll
@@ -328,7 +354,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) mma16<bf16_t>(acc[p][mt], wf[p][s], xf[mt]);
         }
-    } else if constexpr (NP == 3) {           // q from the normalised rows, k | v from the memory rows
+    } else if constexpr (NP >= 3) {           // q from the normalised rows, k | v from the memory rows
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             uint4 xf[MT], mf[MT];
@@ -376,48 +402,72 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         return;
     }
 
-    // ---- epilogue (the tiles this wave kept): a lane holds output row (tile row l15) x four consecutive columns 16wc + 4lg .. +3
+    // ---- epilogue (the tiles this wave kept): a lane holds output row (tile row l15) x four consecutive columns 16wc + 4lg .. +3.
+    //      + bias (ReLU, dropout) -> bf16 -> LDS: this head's Q / K / V images ([row][64], 16-byte slots swizzled), or the
+    //      feed-forward output tile [row][64 * NP]; global memory gets them afterwards as whole rows (a lane's 8 bytes of 16
+    //      different rows per store would cost the texture addresser 64 cycles per wave-instruction)
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         if (!act[p]) continue;
         const int col = ncol[p] + 16 * wc + 4 * lg;             // column of the Linear's output
-        const bool to_kv = raw && p > 0;
-        const int rows_p = to_kv ? Rm : R, r0_p = to_kv ? rm0 : row0;
-        bf16_t* dst;
-        int ld;
-        if (ffn) { dst = M.out + col; ld = M.ld_out; }
-        else if (to_kv) { dst = M.kv + (p - 1) * FH_D + slice * FH_DK + 16 * wc + 4 * lg; ld = 2 * FH_D; }
-        else if (kind == FH_SELF) { dst = M.out + col; ld = M.ld_out; }
-        else { dst = M.out + slice * FH_DK + 16 * wc + 4 * lg; ld = M.ld_out; }
-        unsigned char* img = p == 0 ? qi_s : (p == 1 ? ki_s : vi_s);
+        unsigned char* img = p == 0 ? qi_s : (p == 1 ? ki_s : vi_s);          // (p == 3 exists for FFN members only)
+        const float4 bvp = *(const float4*)(smem + L.gains + 4096 + (p * 64 + 16 * wc + 4 * lg) * 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if (((p * MT + mt) & 1) != kh) continue;
             const int r = mt * 16 + l15;
-            float v[4] = {acc[p][mt][0] + bv[p].x, acc[p][mt][1] + bv[p].y, acc[p][mt][2] + bv[p].z, acc[p][mt][3] + bv[p].w};
+            float v[4] = {acc[p][mt][0] + bvp.x, acc[p][mt][1] + bvp.y, acc[p][mt][2] + bvp.z, acc[p][mt][3] + bvp.w};
             if (ffn) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
                 if (ds.on) {
-                    const uint64_t idx = (uint64_t)(r0_p + r) * (uint64_t)M.ncols + col;
+                    const uint64_t idx = (uint64_t)(row0 + r) * (uint64_t)M.ncols + col;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = drop_keep(ds, idx + k) ? v[k] * ds.scale : 0.f;
                 }
             }
             const uint2 u = make_uint2(fh_pack2(v[0], v[1]), fh_pack2(v[2], v[3]));
-            if (r < rows_p) *(uint2*)(dst + (size_t)(r0_p + r) * ld) = u;
-            if (!ffn) {                                             // this head's Q / K / V image: [row][64], 16-byte slots swizzled
+            if (ffn) {
+                const int chunk = p * 8 + 2 * wc + (lg >> 1);       // 16-byte chunk of the (128 * NP)-byte row
+                *(uint2*)(qi_s + r * (NP * FH_HROWB) + ((chunk ^ (r & 7)) << 4) + (lg & 1) * 8) = u;
+            } else {
                 const int chunk = 2 * wc + (lg >> 1);
                 const int sw = p == 2 ? ((r >> 1) & 7) : (r & 7);
                 *(uint2*)(img + r * FH_HROWB + ((chunk ^ sw) << 4) + (lg & 1) * 8) = u;
             }
         }
     }
-    FH_STAMP(7);                                   // epilogue stores issued, images written
-    if (ffn || G.stop == 3) return;
+    FH_STAMP(7);                                   // images / output tile written
+    __syncthreads();
+    // ---- LDS -> global, whole rows: 8 lanes per 128-byte head row (8 rows per wave-instruction), 8 * NP lanes per FFN row
+    if (ffn) {
+        constexpr int LPR = 8 * NP;                            // lanes per row (16 bytes each)
+        const int ncols_here = (M.ncols - slice * 64 * NP) < 64 * NP ? (M.ncols - slice * 64 * NP) : 64 * NP;
+        for (int r = tid / LPR; r < R; r += FH_THREADS / LPR) {
+            const int c = tid % LPR;
+            if (c * 8 < ncols_here)
+                *(uint4*)(M.out + (size_t)(row0 + r) * M.ld_out + slice * 64 * NP + c * 8) = *(const uint4*)(qi_s + r * (NP * FH_HROWB) + ((c ^ (r & 7)) << 4));
+        }
+        return;
+    }
+    {
+        const int c = tid & 7;
+        bf16_t* qdst = M.out + (size_t)row0 * M.ld_out + (kind == FH_SELF ? slice * FH_DK : slice * FH_DK) + c * 8;
+        for (int r = tid >> 3; r < R; r += FH_THREADS / 8)
+            *(uint4*)(qdst + (size_t)r * M.ld_out) = *(const uint4*)(qi_s + r * FH_HROWB + ((c ^ (r & 7)) << 4));
+        if (kind != FH_CROSS_READY) {
+            const int rows_kv = raw ? Rm : R;
+            bf16_t* kdst = raw ? M.kv + (size_t)rm0 * (2 * FH_D) + slice * FH_DK + c * 8 : M.out + (size_t)row0 * M.ld_out + FH_D + slice * FH_DK + c * 8;
+            const int ldkv = raw ? 2 * FH_D : M.ld_out;
+            for (int r = tid >> 3; r < rows_kv; r += FH_THREADS / 8) {
+                *(uint4*)(kdst + (size_t)r * ldkv) = *(const uint4*)(ki_s + r * FH_HROWB + ((c ^ (r & 7)) << 4));
+                *(uint4*)(kdst + (size_t)r * ldkv + FH_D) = *(const uint4*)(vi_s + r * FH_HROWB + ((c ^ ((r >> 1) & 7)) << 4));
+            }
+        }
+    }
+    if (G.stop == 3) return;
 
     // ---- attention of this head, on chip.  Item = (sample, 16 query rows), one wave each.
-    __syncthreads();
     FH_STAMP(8);
     const float scale = 0.125f;                    // 1 / sqrt(64)
     const int nqt = (a + 15) >> 4;
@@ -527,10 +577,25 @@ __global__ __launch_bounds__(FH_THREADS) void fused_head_fwd_kernel(const FhGrou
     while (g + 1 < G.count && (int)blockIdx.x >= G.wg_start[g + 1]) ++g;
     const FhMember& M = G.m[g];
     const int t = (int)blockIdx.x - G.wg_start[g];
-    const int slice = t % M.nslice, rb = t / M.nslice;
-    if (M.mt <= 2) fh_body<NP, 2>(G, M, slice, rb, smem);
-    else if (M.mt == 3) fh_body<NP, 3>(G, M, slice, rb, smem);
-    else fh_body<NP, 5>(G, M, slice, rb, smem);
+    // Workgroups go to the 8 XCDs round-robin (id % 8; every member starts at a multiple of 8) and each XCD has its own L2: the
+    // launch is bound by what crosses the fabric into the L2s, i.e. by how often an x row or a weight slice is pulled by
+    // DIFFERENT XCDs.  XCD (hgi, sgi) takes the slices of group hgi and the row blocks congruent to sgi mod sg: an x row is
+    // then pulled by hg XCDs instead of 8, a weight slice by sg instead of 8 (same-XCD re-reads are L2 hits).
+    const int xcd = t & 7, j = t >> 3;
+    const int hpg = M.nslice / M.hg;
+    const int slice = (xcd % M.hg) * hpg + (j % hpg), rb = (j / hpg) * M.sg + (xcd / M.hg);
+#ifdef FH_TIMELINE
+    if (tid == 0) G.dbg[(size_t)blockIdx.x * 16 + 12] = wall_clock64() + (unsigned long long)(slice + rb) * 0;   // member found, first fields read
+#endif
+    if (rb * M.rows_per_wg >= M.rows) return;                  // padding workgroup (row-block count rounded up to the map's grid)
+    if constexpr (NP == 4) {                       // 4 weight blocks: 128 VGPRs of fragments -> at most 64 rows (two row groups per wave)
+        if (M.mt <= 2) fh_body<NP, 2>(G, M, slice, rb, smem);
+        else fh_body<NP, 4>(G, M, slice, rb, smem);
+    } else {
+        if (M.mt <= 2) fh_body<NP, 2>(G, M, slice, rb, smem);
+        else if (M.mt == 3) fh_body<NP, 3>(G, M, slice, rb, smem);
+        else fh_body<NP, 5>(G, M, slice, rb, smem);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -546,7 +611,8 @@ static bool fh_env_off() {
 }
 
 static constexpr int FH_LDS_MAX = 160 * 1024;
-static const int fh_mt_choices[3] = {2, 3, 5};
+// row tiles a workgroup may have: {2, 3, 5} in the 1- and 3-block kernels, {2, 4} in the 4-block kernel
+static const int fh_mt_sets[2][3] = {{2, 3, 5}, {2, 4, 4}};
 
 struct FhPlan { int blk, mt, lds; };
 static int fh_member_lds(const mtn_mha_args& A, int blk, int mt) {
@@ -558,7 +624,8 @@ static int fh_member_lds(const mtn_mha_args& A, int blk, int mt) {
 // Rows per workgroup for an attention member: whole samples, inside the row tiles (<= 80 rows) and the LDS; as few workgroups as
 // it takes to stay within the member's share of one round of the chip (these launches are bound by the bytes each CU pulls:
 // weight slice + x rows), but not fewer.  Returns blk = 0 when even one sample does not fit.
-static FhPlan fh_plan_mha(const mtn_mha_args& A, int budget) {
+static FhPlan fh_plan_mha(const mtn_mha_args& A, int budget, int np) {
+    const int* fh_mt_choices = fh_mt_sets[np == 4];
     const bool self = A.self_attn != 0, raw = !self && !A.kv_ready;
     const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
     FhPlan best = {0, 0, 0};
@@ -579,26 +646,41 @@ static FhPlan fh_plan_mha(const mtn_mha_args& A, int budget) {
     return best;
 }
 
-struct FhLaunch { FhGroup G; int wgs, need3; size_t lds; };
+// XCD map of a member: (hg, sg) with hg * sg = 8, sg | row-block count, hg | slice count, least bytes crossing the fabric:
+// 8 XCDs x (x bytes / sg + weight bytes / hg).
+static void fh_pick_xcd_map(FhMember& M, int nrb, double x_bytes, double w_bytes) {
+    double best = 1e30;
+    M.hg = 8; M.sg = 1;
+    for (int sg = 1; sg <= 8; sg *= 2) {
+        const int hg = 8 / sg;
+        if (nrb % sg != 0 || M.nslice % hg != 0) continue;
+        const double c = x_bytes / sg + w_bytes / hg;
+        if (c < best) { best = c; M.hg = hg; M.sg = sg; }
+    }
+}
+
+struct FhLaunch { FhGroup G; int wgs, np; size_t lds; };
 // The whole launch plan; false = this group keeps the four-launch path.
 static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, FhLaunch& P) {
     if (n_mha + n_ffn < 1 || n_mha + n_ffn > FH_MAX_MEMBERS) return false;
     FhGroup& G = P.G;
     memset(&G, 0, sizeof(G));
-    bool need3 = n_ffn > 0;
+    // weight blocks (64 output columns) per workgroup: 1 = q only; 3 = q | k | v; 4 = launches with feed-forward members
+    // (256 columns of w_1 per workgroup: d_ff / 256 slices, 8 at d_ff = 2048 — one per XCD group like the heads)
+    int np = n_ffn > 0 ? 4 : 1;
     for (int i = 0; i < n_mha; ++i) {
         if (mha[i].d != FH_D || mha[i].h != FH_D / FH_DK) return false;
-        if (mha[i].self_attn || !mha[i].kv_ready) need3 = true;
+        if ((mha[i].self_attn || !mha[i].kv_ready) && np < 3) np = 3;
     }
     for (int i = 0; i < n_ffn; ++i)
-        if (ffn[i].d != FH_D || ffn[i].d_ff % 64 != 0) return false;
+        if (ffn[i].d != FH_D || ffn[i].d_ff % 256 != 0) return false;
     const int members = n_mha + n_ffn;
     const int budget = 256 / members > 8 ? 256 / members : 8;       // share of one round (256 workgroups) per member
     int n = 0, wgs = 0;
     size_t lds = 0;
     for (int i = 0; i < n_mha; ++i) {
         const mtn_mha_args& a = mha[i];
-        const FhPlan pl = fh_plan_mha(a, budget);
+        const FhPlan pl = fh_plan_mha(a, budget, np);
         if (pl.blk == 0) return false;
         FhMember& M = G.m[n];
         M.kind = a.self_attn ? FH_SELF : (a.kv_ready ? FH_CROSS_READY : FH_CROSS_RAW);
@@ -611,7 +693,9 @@ static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn
         M.mask = a.mask; M.mask_sb = a.mask_sb; M.mask_sq = a.mask_sq; M.drop = a.drop_attn;
         M.o = (bf16_t*)a.o; M.lse = a.lse;
         G.wg_start[n] = wgs;
-        wgs += ((a.B + pl.blk - 1) / pl.blk) * M.nslice;
+        const int nrb = (a.B + pl.blk - 1) / pl.blk;
+        fh_pick_xcd_map(M, nrb, (double)M.rows * FH_D * 4, (M.kind == FH_CROSS_READY ? 1.0 : 3.0) * FH_D * FH_D * 2);
+        wgs += nrb * M.nslice;                            // a multiple of 8: the next member starts on XCD 0 again
         lds = (size_t)pl.lds > lds ? (size_t)pl.lds : lds;
         ++n;
     }
@@ -619,25 +703,27 @@ static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn
         const mtn_ffn_args& a = ffn[i];
         FhMember& M = G.m[n];
         M.kind = FH_FFN;
-        M.rows = a.rows; M.ncols = a.d_ff; M.nslice = (a.d_ff + 191) / 192;
-        int mt = 5;                                       // rows per workgroup: 32 / 48 / 80, within the member's share if possible
-        for (int c = 1; c >= 0; --c)
-            if (((a.rows + fh_mt_choices[c] * 16 - 1) / (fh_mt_choices[c] * 16)) * M.nslice <= budget) mt = fh_mt_choices[c];
+        M.rows = a.rows; M.ncols = a.d_ff; M.nslice = a.d_ff / 256;
+        int mt = 4;                                       // rows per workgroup: 32 or 64; 32 if that stays within the member's share
+        if (((a.rows + 31) / 32) * M.nslice <= budget) mt = 2;
         M.mt = mt; M.rows_per_wg = mt * 16; M.a = 1; M.m = 1; M.blk = mt * 16;
         M.eps = a.ln_eps; M.x = a.x; M.ln_a = a.ln_a; M.ln_b = a.ln_b;
         M.w = (const bf16_t*)a.w1; M.bias = a.b1;
         M.xn = (bf16_t*)a.xn; M.mean = a.mean; M.rstd = a.rstd;
         M.out = (bf16_t*)a.hid; M.ld_out = a.d_ff; M.drop = a.drop_hidden;
         G.wg_start[n] = wgs;
-        wgs += ((a.rows + M.rows_per_wg - 1) / M.rows_per_wg) * M.nslice;
-        const size_t l = (size_t)fh_lds_map(mt, false, 0, 0, 0).total;
+        int nrb = (a.rows + M.rows_per_wg - 1) / M.rows_per_wg;
+        while ((nrb * M.nslice) % 8 != 0) ++nrb;          // padding row blocks (their workgroups leave at once): members start on XCD 0
+        fh_pick_xcd_map(M, nrb, (double)a.rows * FH_D * 4, (double)a.d_ff * FH_D * 2);
+        wgs += nrb * M.nslice;
+        const size_t l = (size_t)fh_lds_map(mt, false, 0, 0, 0, 4).total;
         lds = l > lds ? l : lds;
         ++n;
     }
     G.count = n;
     for (int i = n; i <= FH_MAX_MEMBERS; ++i) G.wg_start[i] = wgs;
     { static const int stop = [] { const char* e = getenv("MTN_FH_STOP"); return e ? atoi(e) : 0; }(); G.stop = stop; }
-    P.wgs = wgs; P.need3 = need3 ? 1 : 0; P.lds = lds;
+    P.wgs = wgs; P.np = np; P.lds = lds;
     return true;
 }
 
@@ -665,7 +751,7 @@ int fh_group_fwd_stage1(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn
     FhLaunch P;
     MTN_CHECK_ARG(fh_plan(n_mha, mha, n_ffn, ffn, P), "group outside the fused kernel's tiling");
     hipStream_t s = (hipStream_t)stream;
-    const int rc = P.need3 ? fh_launch<3>(P.G, P.wgs, P.lds, s) : fh_launch<1>(P.G, P.wgs, P.lds, s);
+    const int rc = P.np == 4 ? fh_launch<4>(P.G, P.wgs, P.lds, s) : (P.np == 3 ? fh_launch<3>(P.G, P.wgs, P.lds, s) : fh_launch<1>(P.G, P.wgs, P.lds, s));
     if (rc != MTN_OK) return rc;
     MTN_CHECK_LAUNCH();
     return MTN_OK;

@@ -22,7 +22,7 @@ struct Case { const char* name; int n_mha, n_ffn; int self[3], ready[3], m[3]; }
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 32, a = 20, d = 512, ff = 2048;
-    const int NSET = 96;                                   // weight sets: 96 x (1.5 + 2) MiB x 3 members > 256 MiB
+    const int NSET = argc > 2 ? atoi(argv[2]) : 96;        // weight sets: 96 x (1.5 + 2) MiB x 3 members > 256 MiB (1 = warm weights)
     const Case cases[] = {
         {"g0 self x3", 3, 0, {1, 1, 1}, {0, 0, 0}, {20, 20, 20}},
         {"g1 cross-ready x3 (128,32,32)", 3, 0, {0, 0, 0}, {1, 1, 1}, {128, 32, 32}},
@@ -69,7 +69,8 @@ int main(int argc, char** argv) {
         };
         set_w(0);
         if (!fh_plan(c.n_mha, mha, c.n_ffn, ffn, P)) { printf("%s: not eligible\n", c.name); continue; }
-        const int iters = 2 * NSET;
+        const int iters = NSET > 8 ? 2 * NSET : 64;
+        const int skip = iters / 2;
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         float best = 1e9f, tot = 0.f;
         for (int it = 0; it < iters; ++it) {
@@ -77,12 +78,12 @@ int main(int argc, char** argv) {
             fh_plan(c.n_mha, mha, c.n_ffn, ffn, P);
             P.G.dbg = dbg;
             CK(hipEventRecord(e0, st));
-            const int rc = P.need3 ? fh_launch<3>(P.G, P.wgs, P.lds, st) : fh_launch<1>(P.G, P.wgs, P.lds, st);
+            const int rc = P.np == 4 ? fh_launch<4>(P.G, P.wgs, P.lds, st) : (P.np == 3 ? fh_launch<3>(P.G, P.wgs, P.lds, st) : fh_launch<1>(P.G, P.wgs, P.lds, st));
             CK(hipGetLastError());
             CK(hipEventRecord(e1, st));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            if (it >= NSET) { tot += ms; best = std::min(best, ms); }
+            if (it >= skip) { tot += ms; best = std::min(best, ms); }
             (void)rc;
         }
         std::vector<unsigned long long> h((size_t)P.wgs * 16);
@@ -90,9 +91,9 @@ int main(int argc, char** argv) {
         unsigned long long t0 = ~0ull;
         for (int w = 0; w < P.wgs; ++w) t0 = std::min(t0, h[(size_t)w * 16]);
         const int nst = 10;
-        printf("%-34s wgs %4d np %d lds %6zu B blk/mt", c.name, P.wgs, P.need3 ? 3 : 1, P.lds);
-        for (int i = 0; i < P.G.count; ++i) printf(" %d/%d", P.G.m[i].blk, P.G.m[i].mt);
-        printf(": avg %.2f us  best %.2f us (event pair, incl. launch)\n", tot / NSET * 1e3f, best * 1e3f);
+        printf("%-34s wgs %4d np %d lds %6zu B blk/mt", c.name, P.wgs, P.np, P.lds);
+        for (int i = 0; i < P.G.count; ++i) printf(" %d/%d(%dx%d)", P.G.m[i].blk, P.G.m[i].mt, P.G.m[i].hg, P.G.m[i].sg);
+        printf(": avg %.2f us  best %.2f us (event pair, incl. launch)\n", tot / (iters - skip) * 1e3f, best * 1e3f);
         // median / max over workgroups of each stamp, relative to the first workgroup's start (us)
         printf("    stamp:   start  issued  landed   bar1   LNend   bar2   projd   epil    bar3    end\n");
         for (int pass = 0; pass < 3; ++pass) {
@@ -105,6 +106,14 @@ int main(int argc, char** argv) {
                 printf(" %7.2f", pass == 0 ? v.front() : (pass == 1 ? v[v.size() / 2] : v.back()));
             }
             printf("\n");
+        }
+        {   // entry -> member found -> loads issued -> dropout key (medians, us)
+            double v12 = 0, v13 = 0, v1 = 0; int nn = 0;
+            for (int w = 0; w < P.wgs; ++w) {
+                const unsigned long long* q = &h[(size_t)w * 16];
+                if (q[12] >= q[0] && q[13] >= q[12]) { v12 += (q[12] - q[0]) * 0.01; v13 += (q[13] - q[0]) * 0.01; v1 += (q[1] - q[0]) * 0.01; ++nn; }
+            }
+            if (nn) printf("    mean since workgroup entry: member found %.2f us, loads issued %.2f us, dropout key %.2f us\n", v12 / nn, v13 / nn, v1 / nn);
         }
         {   // shader clock: cycles between the first and the last stamp of a workgroup that ran to the end / wall time between them
             double mhz = 0; int nn = 0;
