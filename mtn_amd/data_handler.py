@@ -11,9 +11,10 @@ host, `np.load`s the feature files, uploads, and derives masks with several torc
 * ``make_batch`` describes a batch by the ids of its items (one small H2D copy) and builds all padded tensors AND their
   masks with two grouped HIP launches (csrc/assemble.hip) — no host padding, no per-step file I/O, no mask passes.
 
-Dataset parsing itself (json / .npy reading, vocabulary) is out of scope (no GPU work there): ``data`` is the
-dict the reference's ``load`` returns, with in-memory arrays as feature values (the reference accepts those too,
-data_handler.py:158).
+``get_vocabulary`` / ``load`` read the DSTC7-AVSD json + per-video .npy features into that layout (host work, once per run;
+reference data_handler.py:45-148): ``data`` is the dict the reference's ``load`` returns, except that the feature values are
+the arrays themselves instead of (path, frames) pairs — the reference's planner accepts both (data_handler.py:158) and the
+corpus goes to the device whole anyway.
 """
 from __future__ import annotations
 
@@ -25,6 +26,104 @@ import torch
 
 from . import lib as L
 from .data_utils import Batch
+
+SPECIALS = {"<unk>": 0, "<blank>": 1, "<sos>": 2, "<eos>": 3}          # data_handler.py:46
+
+
+def _caption_text(dialog: dict, include_caption: str):
+    if include_caption in ("caption", "summary"):
+        return dialog[include_caption]
+    if include_caption == "caption,summary":
+        return dialog["caption"] + dialog["summary"]      # (no separator: the reference concatenates the two strings as they are)
+    return None
+
+
+def get_vocabulary(dataset_file: str, cutoff: int = 1, include_caption: str = "none") -> Dict[str, int]:
+    """data_handler.py:45-76.  Word ids in order of first appearance (caption, then all questions, then all answers of each
+    dialog).  The reference ignores its ``cutoff`` argument: it loops over cutoffs 1..5 and returns the LAST vocabulary, i.e.
+    words seen more than 5 times — reproduced here (``cutoff`` is accepted for signature compatibility)."""
+    import json
+    freq: Dict[str, int] = {}
+    for dialog in json.load(open(dataset_file, "r"))["dialogs"]:
+        cap = _caption_text(dialog, include_caption)
+        if cap is not None:
+            for w in cap.split():
+                freq[w] = freq.get(w, 0) + 1
+        for key in ("question", "answer"):
+            for turn in dialog["dialog"]:
+                for w in turn[key].split():
+                    freq[w] = freq.get(w, 0) + 1
+    vocab = dict(SPECIALS)
+    for w, n in freq.items():
+        if n > 5:
+            vocab[w] = len(vocab)
+    return vocab
+
+
+def words2ids(text: str, vocab: Dict[str, int]) -> np.ndarray:
+    """<sos> w1 .. wn <eos>, unknown words -> <unk> (data_handler.py:78-88)."""
+    unk = vocab["<unk>"]
+    return np.array([vocab["<sos>"]] + [vocab.get(w, unk) for w in text.split()] + [vocab["<eos>"]], dtype=np.int32)
+
+
+def load(fea_types, fea_path: str, dataset_file: str, vocab: Dict[str, int], include_caption: str = "none",
+         separate_caption: bool = False, max_history_length: int = -1, merge_source: bool = False, undisclosed_only: bool = False,
+         read_features: bool = True) -> dict:
+    """data_handler.py:90-148: one item [vid, qa_id, history, question, answer_in, answer_out(, caption)] per dialog turn; the
+    history of turn n is the caption (or a single <blank> when the caption is kept apart) followed by the question+answer
+    pairs of turns max(0, n - max_history_length) .. n-1.  ``features``: one dict per feature type, vid -> float32
+    [frames, F] array read from fea_path with <FeaType> / <ImageID> substituted (.npy)."""
+    import json
+    raw = json.load(open(dataset_file, "r"))
+    blank = np.array([vocab["<blank>"]], dtype=np.int32)
+    has_cap = include_caption in ("caption", "summary", "caption,summary")
+    items, vids, qa_id = [], [], 0
+    for dialog in raw["dialogs"]:
+        cap_text = _caption_text(dialog, include_caption)
+        caption = words2ids(cap_text, vocab) if cap_text is not None else blank
+        questions = [words2ids(t["question"], vocab) for t in dialog["dialog"]]
+        answers = [words2ids(t["answer"], vocab) for t in dialog["dialog"]]
+        pairs = [np.concatenate((q, a)).astype(np.int32) for q, a in zip(questions, answers)]
+        vid = dialog["image_id"]
+        if vid not in vids:
+            vids.append(vid)
+        turns = range(len(questions) - 1, len(questions)) if undisclosed_only else range(len(questions))
+        for n in turns:
+            if undisclosed_only:
+                assert dialog["dialog"][n]["answer"] == "__UNDISCLOSED__"
+            first = blank if (has_cap and separate_caption) else caption
+            start = max(0, n - max_history_length) if max_history_length > 0 else 0
+            history = np.concatenate([first] + pairs[start:n]) if n > start else first
+            question = questions[n]
+            if merge_source:
+                question = np.concatenate((caption, history, question))
+            item = [vid, qa_id, history, question, answers[n][:-1], answers[n][1:]]
+            if has_cap and separate_caption:
+                item.append(caption)
+            items.append(item)
+            qa_id += 1
+    data = {"dialogs": items, "vocab": vocab, "features": [], "original": raw}
+    if fea_types is not None and fea_types[0] != "none":
+        for ftype in fea_types:
+            base = fea_path.replace("<FeaType>", ftype)
+            feats = {}
+            for vid in vids:
+                path = base.replace("<ImageID>", vid)
+                feats[vid] = np.load(path).astype(np.float32, copy=False) if read_features else (path, int(np.load(path, mmap_mode="r").shape[0]))
+            data["features"].append(feats)
+    else:
+        data["features"] = None
+    return data
+
+
+def feature_shape(data: dict) -> List[int]:
+    """Feature width of every feature type (data_handler.py:277-285)."""
+    out = []
+    for feat in data["features"] or []:
+        v = next(iter(feat.values()))
+        out.append(int(np.load(v[0], mmap_mode="r").shape[-1]) if isinstance(v, tuple) else int(v.shape[-1]))
+    return out
+
 
 _FIELDS = (("his", 2), ("query", 3), ("trg", 4), ("trg_y", 5), ("cap", 6))     # dialog item columns (data_handler.py:130-133)
 

@@ -205,8 +205,16 @@ class NoamOpt:
     def finish_fused_step(self):
         self.optimizer.step_rest()
 
+    def step_count(self) -> int:
+        """Optimiser steps taken so far.  The schedule lives on the device (FusedAdam.state[0]) and advances on every replay
+        of a captured step, which the host-side counter does not see: read it there (one small D2H copy; checkpoints / logs only)."""
+        st = getattr(self.optimizer, "state", None)
+        if torch.is_tensor(st) and st.numel() > 0:
+            self._step = int(round(float(st[0].item())))
+        return self._step
+
     def state_dict(self):
-        return {"step": self._step, "optimizer": self.optimizer.state_dict()}
+        return {"step": self.step_count(), "optimizer": self.optimizer.state_dict()}
 
     def load_state_dict(self, sd):
         self._step = int(sd["step"])
@@ -214,7 +222,7 @@ class NoamOpt:
 
     def rate(self, step=None):
         if step is None:
-            step = self._step
+            step = self.step_count()
         return self.factor * (self.model_size ** (-0.5) * min(step ** (-0.5), step * self.warmup ** (-1.5)))
 
 

@@ -152,6 +152,14 @@ class ParamGradQueue:
             self._armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
+    def reset(self):
+        """Drop everything queued and disarm.  A backward pass that raises never reaches the engine's final callbacks, so the
+        queue would stay armed with stale problems and no later backward would register a flush: the step's error path and
+        the start of every step call this."""
+        self.gemm, self.ln, self.keep = [], [], []
+        self._armed = False
+        self.adam = None
+
     def flush(self):
         self._armed = False
         if not self.gemm and not self.ln:

@@ -2,10 +2,15 @@
 """Training entry point with the reference's model/optimiser flags (train.py:57-96), so that the `python train.py ...`
 line of run.sh:109-140 can launch this implementation:  python -m mtn_amd.train --nb-blocks 6 --d-model 512 ...
 
-Dataset I/O (data_handler.py: DSTC7-AVSD json + .npy features) is out of the hot-path scope; without
-``--train-set`` the loop runs on synthetic batches of the reference's shapes.  Dataset flags are accepted and ignored
-with a notice, so existing command lines keep working.  One process per GPU under torchrun gives data parallelism
-(RCCL all-reduce of the flat gradient buffer).
+Three modes:
+  * ``--train-set <json> --train-path <.../<FeaType>/<ImageID>.npy>`` (what run.sh passes): the reference's pipeline —
+    vocabulary from the training annotations, DSTC7-AVSD json + per-video .npy features loaded once and uploaded whole
+    (mtn_amd.data_handler), length-bucketed batches, an epoch loop on captured graphs per padded shape (or ``--eager``),
+    validation loss after every epoch, <model>.conf / <model>_params.txt / <model>_N.pth.tar / <model>_best.pth.tar written
+    as train.py:166-225 does (checkpoints are state_dicts in the reference's key schema);
+  * ``--corpus-videos N``: the same loop on a synthetic ragged corpus;
+  * neither: one fixed-shape synthetic batch replayed (throughput runs).
+One process per GPU under torchrun gives data parallelism (RCCL all-reduce of the flat gradient buffer).
 """
 import argparse
 import logging
@@ -21,7 +26,7 @@ from .train_step import TrainStep
 def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpu", "-g", default=0, type=int)
-    # data flags of the reference (accepted; synthetic data is used when --train-set is empty)
+    # data flags of the reference (train.py:59-73); synthetic data is used when --train-set is empty
     for f in ("--fea-type",):
         p.add_argument(f, nargs="+", type=str, default=["i3d_rgb", "vggish"])
     for f in ("--train-path", "--train-set", "--valid-path", "--valid-set", "--model"):
@@ -106,13 +111,18 @@ def run_epoch_graphed(trainer, indices, epoch, report_interval, rank, rng):
     t0, tok0 = time.time(), 0
     for j, k in enumerate(order):
         loss, b = trainer.step(indices[k])
-        loss_sum += loss * b._ntok[0]            # the step's loss is already divided by its token counts (train.py:36)
-        tok_sum += b._ntok[0]
+        # the step's loss is already divided by the token count of the step over ALL ranks (train.py:36; dp.py): weight it
+        # with that same count; the ranks' sums add up to the epoch mean of the global batches
+        n_glob = b._norms_global[0].to(torch.int64)
+        loss_sum += loss * n_glob
+        tok_sum += n_glob
         if (j + 1) % report_interval == 0 and rank == 0:
             ntok = int(tok_sum)
             dt = time.time() - t0
             print("Epoch: %d Step: %d Loss: %f Tokens per Sec: %f" % (epoch + 1, j + 1, float(loss), (ntok - tok0) / dt))
             t0, tok0 = time.time(), ntok
+    if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        torch.distributed.all_reduce(loss_sum)
     return float(loss_sum) / max(1, int(tok_sum))
 
 
@@ -136,17 +146,31 @@ def validate(corpus, indices, model, criterion, ae_ft, lam):
     return float(total) / max(1, int(tokens))
 
 
+def global_norms(b, ae_y, sync):
+    """[target tokens, auto-encoder tokens] of this step over ALL ranks (device tensor), and this rank's target tokens."""
+    norms = torch.stack([b.ntokens, (ae_y != 1).sum()]).float()
+    local_ntok = float(norms[0])
+    if sync is not None and getattr(sync, "world", 1) > 1:
+        sync.all_reduce_scalars(norms)
+    return norms, local_ntok
+
+
 def run_epoch(corpus, indices, model, loss_compute, ae_ft, epoch, report_interval, rank, rng):
-    """train.py:23-50: shuffle the planned batches, assemble each on the device, forward, loss + backward + optimiser."""
+    """train.py:23-50: shuffle the planned batches, assemble each on the device, forward, loss + backward + optimiser.
+    Data parallel: the loss normalisers are the GLOBAL token counts of the step (all ranks' batches), so that the summed
+    gradients are those of one rank on the concatenated batch (dp.py) — as the captured schedule does (TrainStep._norms)."""
     from .data_handler import make_batch
     order = list(range(len(indices)))
     rng.shuffle(order)
     t0, tokens, total_loss, total_tokens = time.time(), 0, 0.0, 0
+    sync = loss_compute.grad_sync
     for j, k in enumerate(order):
         b = make_batch(corpus, indices[k], 1, separate_caption=True)
         out, ae_out = model.forward(b)
         ae_y = b.cap if ae_ft in ("caption", "summary") else b.query
-        loss = loss_compute(out, b.trg_y, b.ntokens, ae_out, ae_y, (ae_y != 1).sum())
+        norms, local_ntok = global_norms(b, ae_y, sync)
+        loss = loss_compute(out, b.trg_y, norms[0], ae_out, ae_y, norms[1])     # = normalised loss x global target tokens
+        loss = loss * local_ntok / float(norms[0])                              # this rank's share, for the epoch mean below
         total_loss += loss
         total_tokens += int(b.ntokens)
         tokens += int(b.ntokens)
@@ -164,8 +188,35 @@ def main(argv=None):
     local = local % torch.cuda.device_count()      # (several ranks may share a GPU in a gloo dry run)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    train_data = valid_data = vocab = None
     if args.train_set:
-        logging.warning("dataset loading is outside this implementation's scope; running on synthetic batches instead")
+        from . import data_handler as dh
+        sep_cap = bool(args.separate_caption) and args.include_caption != "none"
+        logging.info("Extracting words from " + args.train_set)
+        vocab = dh.get_vocabulary(args.train_set, include_caption=args.include_caption)
+        kw = dict(include_caption=args.include_caption, separate_caption=bool(args.separate_caption), vocab=vocab,
+                  max_history_length=args.max_history_length, merge_source=bool(args.merge_source))
+        logging.info("Loading training data from " + args.train_set)
+        train_data = dh.load(args.fea_type, args.train_path, args.train_set, **kw)
+        if args.valid_set:
+            logging.info("Loading validation data from " + args.valid_set)
+            valid_data = dh.load(args.fea_type, args.valid_path or args.train_path, args.valid_set, **kw)
+        if not sep_cap:
+            raise SystemExit("mtn_amd.train: the model needs the caption as its own stream (--separate-caption 1 with "
+                             "--include-caption caption|summary|caption,summary), as run.sh sets it; the reference crashes "
+                             "without it too (mtn.py:52)")
+        args.vocab_size = len(vocab)
+        args.ft_sizes = dh.feature_shape(train_data)
+        logging.info("Detected feature dims: %s  #vocab = %d", args.ft_sizes, len(vocab))
+        if args.model and rank == 0:                                  # train.py:166-172
+            import os
+            import pickle
+            os.makedirs(os.path.dirname(args.model) or ".", exist_ok=True)
+            with open(args.model + ".conf", "wb") as f:
+                pickle.dump((vocab, args), f, -1)
+            with open(args.model + "_params.txt", "w") as f:
+                for arg in vars(args):
+                    f.write("{}={}\n".format(arg, getattr(args, arg)))
     torch.manual_seed(args.rand_seed)
     model = make_model(args.vocab_size, args.vocab_size, N=args.nb_blocks, d_model=args.d_model, d_ff=args.d_ff, h=args.att_h,
                        dropout=args.dropout, separate_his_embed=bool(args.separate_his_embed), separate_cap_embed=bool(args.separate_cap_embed),
@@ -179,12 +230,14 @@ def main(argv=None):
         sync.broadcast_(model._flat)
         model._flat_version = -1
         model.prepare()
-    if args.corpus_videos > 0:
+    if args.corpus_videos > 0 or train_data is not None:
         import random
         from .data_handler import DeviceCorpus, make_batch_indices
         from .data_utils import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
-        data = synthetic_corpus(args.corpus_videos, args.vocab_size, args.ft_sizes, args.rand_seed)
-        indices, n_samples = make_batch_indices(data, batchsize=args.batch_size, max_length=256, separate_caption=True)  # train.py:126
+        synthetic = train_data is None
+        max_len = 256 if synthetic else args.max_length         # (run.sh passes 256, the parser's default is the reference's 20)
+        data = synthetic_corpus(args.corpus_videos, args.vocab_size, args.ft_sizes, args.rand_seed) if synthetic else train_data
+        indices, n_samples = make_batch_indices(data, batchsize=args.batch_size, max_length=max_len, separate_caption=True)  # train.py:126
         indices = indices[:len(indices) // world * world][rank::world]   # data parallel: equal shares of the planned batches (every
                                                                          # rank must issue the same number of gradient exchanges)
         corpus = DeviceCorpus(data, dev)
@@ -200,9 +253,9 @@ def main(argv=None):
             trainer = BucketedTrainer(model, corpus, args.vocab_size, pad=1, warmup=args.warmup_steps, lam=args.loss_l,
                                       bucket=args.bucket, grad_sync=sync)
         valid = None
-        if args.valid_videos > 0:
-            vdata = synthetic_corpus(args.valid_videos, args.vocab_size, args.ft_sizes, args.rand_seed + 1000)
-            vidx, vn = make_batch_indices(vdata, batchsize=args.batch_size, max_length=256, separate_caption=True)
+        if args.valid_videos > 0 or valid_data is not None:
+            vdata = valid_data if valid_data is not None else synthetic_corpus(args.valid_videos, args.vocab_size, args.ft_sizes, args.rand_seed + 1000)
+            vidx, vn = make_batch_indices(vdata, batchsize=args.batch_size, max_length=max_len, separate_caption=True)
             valid = (DeviceCorpus(vdata, dev), vidx)
             logging.info("#validation sample = %d  #validation batch = %d", vn, len(vidx))
         min_valid = 1.0e10
@@ -211,7 +264,7 @@ def main(argv=None):
             model.load_state_dict(torch.load(args.resume + ".pth.tar", map_location=dev), strict=False)
             model.prepare()
             the_opt.load_state_dict(torch.load(args.resume + "_opt.pth.tar"))
-            logging.info("resumed from %s at optimiser step %d", args.resume, the_opt._step)
+            logging.info("resumed from %s at optimiser step %d", args.resume, the_opt.step_count())
         for epoch in range(args.num_epochs):
             if args.eager:
                 mean = run_epoch(corpus, indices, model, lc, args.auto_encoder_ft, epoch, args.report_interval, rank, rng)

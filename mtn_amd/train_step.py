@@ -74,6 +74,8 @@ class TrainStep:
         m, b = self.model, self.batch
         self._refresh_norms()
         m.zero_glue_grads()
+        if m._queue is not None and (m._queue.gemm or m._queue.ln or m._queue._armed):
+            m._queue.reset()               # left over from a step that raised: never mix it into this one
         if fuse:
             self.opt.begin_fused_step()
         try:
@@ -81,7 +83,8 @@ class TrainStep:
             loss = self.lc.loss(out, b.trg_y, self._norms[0], ae_out, self._ae_y, self._norms[1])
             loss.backward()
         except BaseException:
-            m._queue.adam = None
+            if m._queue is not None:
+                m._queue.reset()
             raise
         return loss.detach()
 
@@ -210,7 +213,9 @@ class TrainStep:
         # the warm-up/capture passes did not run the optimiser outside capture: parameters are untouched
 
     def __call__(self) -> torch.Tensor:
-        """Runs one step; returns the (device) loss tensor of data_utils.py:156 without synchronising."""
+        """Runs one step; returns the device tensor of the NORMALISED loss (main KL / global target tokens + lambda * sum of the
+        auto-encoder KLs / global query tokens: the `loss` of data_utils.py:135-144, before the `* norm` of :156), without
+        synchronising."""
         if not self.use_graph:
             if self.overlap:
                 self._run_segmented(self._segments())
@@ -271,4 +276,5 @@ class BucketedTrainer:
         else:
             make_batch(self.corpus, pidx, self.pad, separate_caption=True, out=hit[0])
         hit[1].refresh_norms_eager()
+        hit[0]._norms_global = hit[1]._norms        # [target tokens, auto-encoder tokens] the step's loss is divided by (all ranks)
         return hit[1](), hit[0]

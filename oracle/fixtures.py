@@ -196,3 +196,23 @@ def det_corpus(n_videos: int = 5, turns: int = 3, vocab: int = 60, ft_sizes: Seq
             d[v] = arr
         feats.append(d)
     return {"dialogs": dialogs, "features": feats, "vocab": {"<blank>": PAD, "<unk>": UNK, "<sos>": SOS, "<eos>": EOS}}
+
+
+def det_avsd_json(n_dialogs: int = 7, seed: int = 5) -> dict:
+    """A deterministic miniature of the DSTC7-AVSD annotation file (the json schema data_handler.get_vocabulary / load read:
+    dialogs[*] = {image_id, caption, summary, dialog: [{question, answer}]}).  Words come from a small pool so that some pass
+    the reference's frequency cut (> 5 occurrences) and others become <unk>."""
+    rs = np.random.RandomState(seed)
+    common = "a the man woman is are in on room kitchen holding walks sits looks at book cup phone does he she yes no".split()
+    rare = [f"rare{i}" for i in range(40)]
+
+    def sent(lo, hi):
+        n = rs.randint(lo, hi + 1)
+        ws = [common[rs.randint(len(common))] if rs.rand() < 0.85 else rare[rs.randint(len(rare))] for _ in range(n)]
+        return " ".join(ws)
+
+    dialogs = []
+    for d in range(n_dialogs):
+        turns = [{"question": sent(2, 8) + " ?", "answer": sent(1, 9) + " ."} for _ in range(rs.randint(1, 6))]
+        dialogs.append({"image_id": f"VID{d:02d}", "caption": sent(6, 16) + " .", "summary": sent(5, 12) + " .", "dialog": turns})
+    return {"type": "mini", "version": "det", "dialogs": dialogs}

@@ -224,13 +224,63 @@ def run_batch_assembly():
     print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")
 
 
+DATASET_VARIANTS = [dict(include_caption="none", separate_caption=False, max_history_length=-1, merge_source=False),
+                    dict(include_caption="caption", separate_caption=True, max_history_length=-1, merge_source=False),
+                    dict(include_caption="caption,summary", separate_caption=True, max_history_length=2, merge_source=False),
+                    dict(include_caption="summary", separate_caption=False, max_history_length=1, merge_source=True)]
+
+
+def run_dataset_frontend():
+    """The reference's dataset front end (data_handler.py:45-148: get_vocabulary, words2ids, load, feature_shape) on the
+    deterministic mini annotation file of fixtures.det_avsd_json -> tests/golden/mini_avsd.json (the INPUT, our own synthetic
+    text) and tests/golden/dataset_frontend.npz (the reference's OUTPUTS: vocabulary in id order, every item's arrays)."""
+    import json
+    import tempfile
+    from oracle.fixtures import det_avsd_json
+    import data_handler as ref_dh        # noqa
+    raw = det_avsd_json()
+    jpath = os.path.join(ROOT, "tests", "golden", "mini_avsd.json")
+    json.dump(raw, open(jpath, "w"), indent=0)
+    tmp = tempfile.mkdtemp(prefix="mtn_golden_ds_")
+    rs = np.random.RandomState(3)
+    dims = {"i3d": 12, "vgg": 5}
+    for ft, F in dims.items():
+        os.makedirs(os.path.join(tmp, ft))
+        for d in raw["dialogs"]:
+            np.save(os.path.join(tmp, ft, d["image_id"] + ".npy"), rs.randn(rs.randint(3, 9), F).astype(np.float32))
+    fea_path = os.path.join(tmp, "<FeaType>", "<ImageID>.npy")
+    out = {}
+    for vi, kw in enumerate(DATASET_VARIANTS):
+        vocab = ref_dh.get_vocabulary(jpath, include_caption=kw["include_caption"])
+        words = sorted(vocab, key=vocab.get)
+        assert [vocab[w] for w in words] == list(range(len(words)))
+        out[f"v{vi}.vocab"] = np.array(words)
+        data = ref_dh.load(list(dims), fea_path, jpath, vocab, **kw)
+        out[f"v{vi}.n_items"] = np.array(len(data["dialogs"]))
+        out[f"v{vi}.vids"] = np.array([it[0] for it in data["dialogs"]])
+        out[f"v{vi}.qa_ids"] = np.array([it[1] for it in data["dialogs"]], dtype=np.int64)
+        for col, name in ((2, "his"), (3, "query"), (4, "ans_in"), (5, "ans_out"), (6, "cap")):
+            if col < len(data["dialogs"][0]):
+                out[f"v{vi}.{name}.flat"] = np.concatenate([np.asarray(it[col]).ravel() for it in data["dialogs"]]).astype(np.int64)
+                out[f"v{vi}.{name}.len"] = np.array([len(it[col]) for it in data["dialogs"]], dtype=np.int64)
+        out[f"v{vi}.frames"] = np.array([[data["features"][f][v][1] for v in sorted(data["features"][f])] for f in range(len(dims))], dtype=np.int64)
+        out[f"v{vi}.feature_dims"] = np.array(ref_dh.feature_shape(data), dtype=np.int64)
+    path = os.path.join(ROOT, "tests", "golden", "dataset_frontend.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", jpath, "and", path, len(out), "arrays", os.path.getsize(path), "bytes")
+
+
 def main():
     ref_mtn, ref_du, ref_ls = import_reference()
     torch.set_num_threads(8)
     if "--batch-assembly-only" in sys.argv:
         run_batch_assembly()
         return
+    if "--dataset-only" in sys.argv:
+        run_dataset_frontend()
+        return
     run_batch_assembly()
+    run_dataset_frontend()
     for name, c in GOLDEN_CONFIGS.items():
         run_config(name, c, ref_mtn, ref_du, ref_ls)
 

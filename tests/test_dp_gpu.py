@@ -92,3 +92,62 @@ def test_two_rank_dp_equals_single_rank_on_concatenated_batch(tmp_path, use_grap
     dp_losses = [a + b for a, b in zip(r0["losses"], r1["losses"])]
     for a, b in zip(dp_losses, losses):
         assert abs(a - b) < 2e-3 * abs(b), (dp_losses, losses)
+
+
+def _eager_worker(rank, world, port, out_dir):
+    """The eager data-parallel loop body of mtn_amd.train.run_epoch (forward, global normalisers, SimpleLossCompute with the
+    gradient exchange between backward and the optimiser step) on this rank's half of the batch."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from mtn_amd import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute, dp
+    from mtn_amd.train import global_norms
+    from oracle import fixtures as fx
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = dict(fx.GOLDEN_CONFIGS["cfg1_query"], B=4)
+    raw = fx.det_batch(c["vocab"], c["B"], c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=3)
+    s, e = dp.shard_range(c["B"], rank, world)
+    shard = {k: (v[s:e] if k != "fts" else [f[s:e] for f in v]) for k, v in raw.items()}
+    model = _make(c, dev, "fp32")
+    model.prepare()
+    sync = dp.GradSync(lambda: model.flat_buffers()[2], n_buckets=3)
+    opt = NoamOpt(c["d_model"], 1, 10, FusedAdam(model))
+    lc = SimpleLossCompute(model.generator, model.auto_encoder_generator, LabelSmoothing(c["vocab"], fx.PAD, 0.1), opt=opt, grad_sync=sync)
+    b = _batch(c, shard, dev)
+    model.zero_glue_grads()
+    out, ae_out = model.forward(b)
+    norms, _ = global_norms(b, b.query, sync)
+    lc(out, b.trg_y, norms[0], ae_out, b.query, norms[1])
+    torch.cuda.synchronize()
+    torch.save({"grad1": model._flat_grad.cpu().clone(), "flat": model._flat.cpu().clone()}, os.path.join(out_dir, f"eager{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eager_two_rank_dp_equals_single_rank_on_concatenated_batch(tmp_path):
+    """The eager loop (python -m mtn_amd.train --eager under torchrun) normalises by the global token counts: the summed
+    gradient of two ranks on half batches is the gradient of one rank on the whole batch."""
+    import torch.multiprocessing as mp
+    from mtn_amd import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
+    from oracle import fixtures as fx
+    port = _free_port()
+    mp.start_processes(_eager_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "eager0.pt"), torch.load(tmp_path / "eager1.pt")
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["grad1"], r1["grad1"])
+    dev = torch.device("cuda:0")
+    c = dict(fx.GOLDEN_CONFIGS["cfg1_query"], B=4)
+    raw = fx.det_batch(c["vocab"], c["B"], c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=3)
+    model = _make(c, dev, "fp32")
+    model.prepare()
+    opt = NoamOpt(c["d_model"], 1, 10, FusedAdam(model))
+    lc = SimpleLossCompute(model.generator, model.auto_encoder_generator, LabelSmoothing(c["vocab"], fx.PAD, 0.1), opt=opt)
+    b = _batch(c, raw, dev)
+    model.zero_glue_grads()
+    out, ae_out = model.forward(b)
+    lc(out, b.trg_y, b.ntokens, ae_out, b.query, (b.query != fx.PAD).sum())
+    torch.cuda.synchronize()
+    gref = model._flat_grad.cpu()
+    err = float((r0["grad1"] - gref).abs().max() / gref.abs().max())
+    assert err < 1e-5, err
