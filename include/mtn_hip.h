@@ -196,7 +196,8 @@ int mtn_layernorm_bwd(int rows, int d, float eps, const float* x, const float* a
  *   o  : lowp [(b*a+i)*ldo + h*dk + c];  lse: float2 per (b,head,i) at lse[2*((b*h+hh)*a+i)] = {row max, 1/row sum}
  *        (kept apart: a fully masked row has max = -1e9, where max + log(sum) would lose log(sum))
  * bwd: d_o lowp (same layout as o) -> dq (ldq layout), dk/dv (ldkv layout), all lowp.
- *      Gradient does not flow through masked scores (masked_fill).
+ *      Gradient does not flow through masked scores (masked_fill).  Any number of query rows (the PE table of the
+ *      reference goes to 5000, mtn.py:293): the MFMA kernel walks them in passes of 32.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int B, h, a, m, dk;
@@ -211,6 +212,9 @@ typedef struct {
     /* backward only */
     const void* d_o;
     void *dq, *dk_out, *dv_out;
+    /* backward, set by the library (callers leave them 0): one launch covers query rows q0 .. q0+qn-1 of every sequence;
+       sequences longer than 32 rows are walked in several passes, kv_accum != 0 = add dk/dv to the earlier passes' sums */
+    int q0, qn, kv_accum;
 } mtn_attn_args;
 #define MTN_ATTN_MAX_GROUP 4
 /* Grouped forms: up to MTN_ATTN_MAX_GROUP independent attention problems (different shapes allowed) per launch. */

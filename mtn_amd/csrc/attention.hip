@@ -392,14 +392,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
     if ((int)blockIdx.x >= A.B * A.h) return;
     const int b = blockIdx.x / A.h, hh = blockIdx.x % A.h;
     const int a = A.a, m = A.m;
+    // one pass covers query rows qo .. qo+an-1 of every sample (an <= 32); sequences longer than 32 rows take several passes,
+    // the later ones adding their dK / dV to what the earlier ones stored (mtn_attention_bwd_group)
+    const int qo = A.q0, an = A.qn > 0 ? A.qn : (a - A.q0 < BQ ? a - A.q0 : BQ);
     const bool solo = (NW == 1) || (m <= BK);          // one key tile: one wave (see the forward kernel)
     if (NW > 1 && solo && wave > 0) return;
     const float scale = rsqrtf((float)DK);
-    const T* qg = (const T*)A.q + (size_t)b * a * A.ldq + hh * DK;
+    const T* qg = (const T*)A.q + ((size_t)b * a + qo) * A.ldq + hh * DK;
     const T* kg = (const T*)A.k + (size_t)b * m * A.ldkv + hh * DK;
     const T* vg = (const T*)A.v + (size_t)b * m * A.ldkv + hh * DK;
-    const T* og = (const T*)A.o + (size_t)b * a * A.ldo + hh * DK;
-    const T* dog = (const T*)A.d_o + (size_t)b * a * A.ldo + hh * DK;
+    const T* og = (const T*)A.o + ((size_t)b * a + qo) * A.ldo + hh * DK;
+    const T* dog = (const T*)A.d_o + ((size_t)b * a + qo) * A.ldo + hh * DK;
     const DropState ds = drop_init(A.drop);
 
     // ---- prologue: A-operand fragments of Q and dO (rows = queries), transposed images, D_q
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         int q = qt * 16 + l15;
-        q = q < a ? q : a - 1;
+        q = q < an ? q : an - 1;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const bool ok = ks * KSTEP + lg * EPV < DK;
@@ -418,8 +421,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
     constexpr int NBT = ((32 / 4) * (DK / 4) + 63) / 64;     // 4x4 blocks per lane for a 32-row transposed image
     if (wave == 0) {                                          // the shared images are built by wave 0 (small: 2 x 32 x DK)
         TStage<T, NBT> sdo, sq;
-        sdo.load(dog, A.ldo, 0, BQ, a, DK, lane);
-        sq.load(qg, A.ldq, 0, BQ, a, DK, lane);
+        sdo.load(dog, A.ldo, 0, BQ, an, DK, lane);
+        sq.load(qg, A.ldq, 0, BQ, an, DK, lane);
         sdo.store(dOt, ROWB, BQ, DK, lane);
         sq.store(Qt, ROWB, BQ, DK, lane);
     }
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
         int q = lane >> 1;
         const int half = lane & 1;
         float sacc = 0.f;
-        if (q < a) {
+        if (q < an) {
             const T* dp = dog + (size_t)q * A.ldo + half * (DK / 2);
             const T* op = og + (size_t)q * A.ldo + half * (DK / 2);
 #pragma unroll
@@ -446,8 +449,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = qt * 16 + 4 * lg + r;
-            const int qc = q < a ? q : a - 1;
-            const float* stp = A.lse + 2 * ((size_t)(b * A.h + hh) * a + qc);
+            const int qc = q < an ? q : an - 1;
+            const float* stp = A.lse + 2 * ((size_t)(b * A.h + hh) * a + qo + qc);
             mxq[qt][r] = stp[0];
             invq[qt][r] = stp[1];
             Dq[qt][r] = Ds[q];
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) dqt[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    T* dqg = (T*)A.dq + (size_t)b * a * A.ldq + hh * DK;
+    T* dqg = (T*)A.dq + ((size_t)b * a + qo) * A.ldq + hh * DK;
     T* dkg = (T*)A.dk_out + (size_t)b * m * A.ldkv + hh * DK;
     T* dvg = (T*)A.dv_out + (size_t)b * m * A.ldkv + hh * DK;
 
@@ -495,8 +498,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             int q = qt * 16 + 4 * lg + r;
-                            q = q < a ? q : a - 1;
-                            w |= (uint32_t)(A.mask[(size_t)b * A.mask_sb + (size_t)q * A.mask_sq + key] != 0) << (8 * r);
+                            q = q < an ? q : an - 1;
+                            w |= (uint32_t)(A.mask[(size_t)b * A.mask_sb + (size_t)(qo + q) * A.mask_sq + key] != 0) << (8 * r);
                         }
                     }
                 }
@@ -529,14 +532,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
                 for (int r = 0; r < 4; ++r) {
                     const int q = qt * 16 + 4 * lg + r;
                     float pd = 0.f, dsv = 0.f;
-                    if (key < m && q < a) {
+                    if (key < m && q < an) {
                         const bool keep_score = ((mk[qt][kt] >> (8 * r)) & 0xffu) != 0;
                         const float sv = keep_score ? sc[qt][kt][r] * scale : -1e9f;
                         const float p = __expf(sv - mxq[qt][r]) * invq[qt][r];
                         float dpd = dp[qt][kt][r];
                         pd = p;
                         if (ds.on) {
-                            const uint64_t idx = ((uint64_t)(b * A.h + hh) * a + q) * (uint64_t)m + key;
+                            const uint64_t idx = ((uint64_t)(b * A.h + hh) * a + qo + q) * (uint64_t)m + key;
                             const bool kp = drop_keep(ds, idx);
                             pd = kp ? p * ds.scale : 0.f;
                             dpd = kp ? dpd * ds.scale : 0.f;
@@ -563,8 +566,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
                     mma16<T>(ak, frag_from_tlds<T>(Qt, ROWB, dt * 16 + l15, u, lg), sf);
                 }
                 if (key < m) {   // lane holds rows (head columns) dt*16 + 4lg + r of key column `key`
-                    store4<T>(dvg + (size_t)key * A.ldkv + dt * 16 + 4 * lg, make_float4(av[0], av[1], av[2], av[3]));
-                    store4<T>(dkg + (size_t)key * A.ldkv + dt * 16 + 4 * lg, make_float4(ak[0] * scale, ak[1] * scale, ak[2] * scale, ak[3] * scale));
+                    T* pv = dvg + (size_t)key * A.ldkv + dt * 16 + 4 * lg;
+                    T* pk = dkg + (size_t)key * A.ldkv + dt * 16 + 4 * lg;
+                    float4 ov = make_float4(av[0], av[1], av[2], av[3]);
+                    float4 ok_ = make_float4(ak[0] * scale, ak[1] * scale, ak[2] * scale, ak[3] * scale);
+                    if (A.kv_accum) {                       // a later query-block pass: add to the earlier passes' sums
+                        const float4 pv0 = load4<T>(pv), pk0 = load4<T>(pk);
+                        ov.x += pv0.x; ov.y += pv0.y; ov.z += pv0.z; ov.w += pv0.w;
+                        ok_.x += pk0.x; ok_.y += pk0.y; ok_.z += pk0.z; ok_.w += pk0.w;
+                    }
+                    store4<T>(pv, ov);
+                    store4<T>(pk, ok_);
                 }
             }
         }
@@ -588,7 +600,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int q = qt * 16 + l15;
-            if (q < a) {
+            if (q < an) {
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
                     const f32x4_t v = dqt[dt][qt];
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
         __syncthreads();
         for (int idx = threadIdx.x; idx < 32 * (DK / 4); idx += 64 * NW) {
             const int q = idx & 31, d4 = (idx >> 5) * 4;
-            if (q >= a) continue;
+            if (q >= an) continue;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < NW; ++w)
@@ -663,7 +675,6 @@ static int check_attn(const mtn_attn_args* A, bool bwd) {
     MTN_CHECK_ARG(A->q && A->k && A->v && A->o, "null tensor");
     if (bwd) {
         MTN_CHECK_ARG(A->d_o && A->dq && A->dk_out && A->dv_out && A->lse, "null backward tensor");
-        MTN_CHECK_ARG(A->a <= AMAX_B, "attention backward supports at most 64 query rows per sequence");
     }
     return MTN_OK;
 }
@@ -736,32 +747,52 @@ extern "C" int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args
     for (int i = 0; i < count; ++i) {
         if (int rc = check_attn(&args[i], true)) return rc;
         G.a[i] = args[i];
-        size_t l = bwd_lds_bytes(args[i].a, args[i].dk);
+        size_t l = bwd_lds_bytes(args[i].a < AMAX_B ? args[i].a : AMAX_B, args[i].dk);      // (VALU fallback only)
         if (l > lds) lds = l;
         if (args[i].B * args[i].h > gx) gx = args[i].B * args[i].h;
     }
     MTN_CHECK_ARG(lds <= 160 * 1024, "attention backward tile does not fit LDS");
     dim3 grid(gx, 1, count), block(256);
     hipStream_t s = (hipStream_t)stream;
-    {   // MFMA path: same supported head size everywhere, query blocks of at most 32 rows
+    {   // MFMA path: same supported head size everywhere; query rows in passes of 32 (a pass takes the members that still
+        // have rows left; passes after the first add their dK / dV to the stored sums)
         bool ok = getenv("MTN_ATTN_VALU") == nullptr;
         const int dk = args[0].dk;
-        for (int i = 0; i < count; ++i)
-            ok = ok && args[i].dk == dk && (dk == 16 || dk == 32 || dk == 64 || dk == 128) && args[i].a <= BQ && args[i].ldq % 8 == 0 &&
+        int amax = 0;
+        for (int i = 0; i < count; ++i) {
+            ok = ok && args[i].dk == dk && (dk == 16 || dk == 32 || dk == 64 || dk == 128) && args[i].ldq % 8 == 0 &&
                  args[i].ldkv % 8 == 0 && args[i].ldo % 8 == 0;
+            amax = args[i].a > amax ? args[i].a : amax;
+        }
         if (ok) {
-            int nw = 1;
-            for (int i = 0; i < count; ++i) { const int t = (args[i].m + BK - 1) / BK; nw = t > nw ? t : nw; }
-            // 2 waves up to 8 key tiles: a 226-register wave leaves room for 2 per SIMD, and a group's one-tile members
-            // (one live wave each) then share the CU with the long member instead of waiting for a second round
-            int wgs = 0;
-            for (int i = 0; i < count; ++i) wgs += args[i].B * args[i].h;
-            nw = nw <= 1 ? 1 : (nw <= 8 ? 2 : ((wgs <= 256) ? 8 : 4));
-            if (const char* f = getenv("MTN_ATTN_BWD_NW")) nw = atoi(f);
-            int rc = (dtype == MTN_BF16) ? dispatch_bwd_mfma<bf16_t>(dk, G, grid, nw, s) : dispatch_bwd_mfma<float>(dk, G, grid, nw, s);
+            int rc = MTN_OK;
+            for (int q0 = 0; q0 < amax && rc == MTN_OK; q0 += BQ) {
+                AttnGroup P;
+                memset(&P, 0, sizeof(P));
+                int nw = 1, wgs = 0, px = 0;
+                for (int i = 0; i < count; ++i) {
+                    if (args[i].a <= q0) continue;
+                    mtn_attn_args& t = P.a[P.count++];
+                    t = args[i];
+                    t.q0 = q0; t.qn = args[i].a - q0 < BQ ? args[i].a - q0 : BQ; t.kv_accum = q0 > 0;
+                    const int kt = (t.m + BK - 1) / BK;
+                    nw = kt > nw ? kt : nw;
+                    wgs += t.B * t.h;
+                    px = t.B * t.h > px ? t.B * t.h : px;
+                }
+                // 2 waves up to 8 key tiles: a 226-register wave leaves room for 2 per SIMD, and a group's one-tile members
+                // (one live wave each) then share the CU with the long member instead of waiting for a second round
+                nw = nw <= 1 ? 1 : (nw <= 8 ? 2 : ((wgs <= 256) ? 8 : 4));
+                if (const char* f = getenv("MTN_ATTN_BWD_NW")) nw = atoi(f);
+                const dim3 pgrid(px, 1, P.count);
+                rc = (dtype == MTN_BF16) ? dispatch_bwd_mfma<bf16_t>(dk, P, pgrid, nw, s) : dispatch_bwd_mfma<float>(dk, P, pgrid, nw, s);
+                if (rc != MTN_OK && q0 > 0) return rc;          // (a first-pass refusal falls through to the VALU kernel)
+            }
             if (rc == MTN_OK) { MTN_CHECK_LAUNCH(); return MTN_OK; }
         }
     }
+    for (int i = 0; i < count; ++i)
+        MTN_CHECK_ARG(args[i].a <= AMAX_B, "attention backward (VALU fallback: d_k outside {16,32,64,128}) supports at most 64 query rows per sequence");
     if (dtype == MTN_BF16) {
         if (int rc = set_lds(attn_bwd_kernel<bf16_t>, lds)) return rc;
         hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), grid, block, lds, s, G);

@@ -41,7 +41,8 @@ class AttnArgs(C.Structure):
                 ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("ldq", C.c_int), ("ldkv", C.c_int),
                 ("mask", C.c_void_p), ("mask_sb", C.c_long), ("mask_sq", C.c_long), ("drop", Dropout),
                 ("o", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p),
-                ("d_o", C.c_void_p), ("dq", C.c_void_p), ("dk_out", C.c_void_p), ("dv_out", C.c_void_p)]
+                ("d_o", C.c_void_p), ("dq", C.c_void_p), ("dk_out", C.c_void_p), ("dv_out", C.c_void_p),
+                ("q0", C.c_int), ("qn", C.c_int), ("kv_accum", C.c_int)]
 
 
 class MhaArgs(C.Structure):
