@@ -87,6 +87,10 @@ GOLDEN_CONFIGS: Dict[str, dict] = {
                          frames=[32, 32], diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="caption"),
     "small_shared": dict(vocab=60, N=2, d_model=64, d_ff=128, h=4, ft_sizes=[96, 32], B=3, Q=11, H=37, C=23, T=9,
                          frames=[17, 40], diff_encoder=False, diff_embed=False, diff_gen=False, auto_encoder_ft="query"),
+    # d_model 512 / 8 heads (d_k = 64): the widths of BASELINE configs[1..4], so that the kernel instantiations the benchmark
+    # runs (and the fused projection + attention kernel, which only exists at this width) are pinned to the REFERENCE
+    "wide_n1": dict(vocab=96, N=1, d_model=512, d_ff=2048, h=8, ft_sizes=[64, 32], B=3, Q=12, H=24, C=16, T=12,
+                    frames=[10, 6], diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query"),
     "small_diffall": dict(vocab=60, N=1, d_model=64, d_ff=128, h=2, ft_sizes=[96], B=2, Q=7, H=5, C=13, T=6,
                           frames=[9], diff_encoder=True, diff_embed=True, diff_gen=True, auto_encoder_ft="summary"),
 }

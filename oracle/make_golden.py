@@ -279,6 +279,10 @@ def main():
     if "--dataset-only" in sys.argv:
         run_dataset_frontend()
         return
+    if "--only" in sys.argv:
+        name = sys.argv[sys.argv.index("--only") + 1]
+        run_config(name, GOLDEN_CONFIGS[name], ref_mtn, ref_du, ref_ls)
+        return
     run_batch_assembly()
     run_dataset_frontend()
     for name, c in GOLDEN_CONFIGS.items():

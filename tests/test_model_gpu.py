@@ -169,7 +169,7 @@ def test_model_forward_matches_reference_golden(dev, dtype, name):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("name", ["cfg1_query", "small_shared", "small_diffall"])
+@pytest.mark.parametrize("name", ["cfg1_query", "small_shared", "small_diffall", "wide_n1"])
 def test_model_loss_and_grads_match_reference_golden(dev, dtype, name):
     from mtn_amd import LabelSmoothing, SimpleLossCompute
     c = fx.GOLDEN_CONFIGS[name]
