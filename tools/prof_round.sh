@@ -1,9 +1,9 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pj_stats -- python $R/bench.py --no-cpu-baseline --steps 10 > /tmp/pj_b.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pj_fetch -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /tmp/pj_f.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pj_write -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /tmp/pj_w.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pj_stats -- python $R/bench.py --no-cpu-baseline --no-secondary --windows 0 --steps 10 > /tmp/pj_b.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pj_fetch -- python $R/bench.py --no-cpu-baseline --no-secondary --windows 0 --steps 3 --warmup 1 > /tmp/pj_f.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pj_write -- python $R/bench.py --no-cpu-baseline --no-secondary --windows 0 --steps 3 --warmup 1 > /tmp/pj_w.log 2>&1
 cd $R
 NREST=$(python - <<'PY'
 import torch, sys
@@ -17,6 +17,6 @@ print(int(m.rest_tables(frozenset(t[0] for t in m._fusable))[0][1].sum()))
 PY
 )
 echo NREST=$NREST
-python tools/prof_summary.py /tmp/pj_stats gpurun_out/r01_k_kernel_stats.csv 2>&1 | tail -3
-python tools/prof_breakdown.py /tmp/pj_stats 60 > gpurun_out/r01_k_one_step_breakdown.txt
-python tools/pmc_summary.py /tmp/pj_fetch /tmp/pj_write gpurun_out/r01_k_pmc_traffic.json $NREST 2>&1 | tail -20
+python tools/prof_summary.py /tmp/pj_stats gpurun_out/r02_a_kernel_stats.csv 2>&1 | tail -3
+python tools/prof_breakdown.py /tmp/pj_stats 60 > gpurun_out/r02_a_one_step_breakdown.txt
+python tools/pmc_summary.py /tmp/pj_fetch /tmp/pj_write gpurun_out/r02_a_pmc_traffic.json $NREST 2>&1 | tail -20
