@@ -115,6 +115,24 @@ class FusedAdam:
                                        L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
         self.model.refresh_transposed()
 
+    def step_range(self, off: int, n: int):
+        """The update on flat elements [off, off+n) only (data parallel: this rank's shard of a gradient slice,
+        dp.ShardedOptimizerSync).  The compute-dtype copies are NOT written: the caller refreshes them once all shards of all
+        ranks have arrived (refresh_copies)."""
+        flat, flat_lp, grad, lp_ptr = self._buffers()
+        assert off % 4 == 0 and n > 0
+        L.check(L.load().mtn_adam_step(L.dtype_code(self.model.compute_dtype), n, flat.data_ptr() + 4 * off, grad.data_ptr() + 4 * off,
+                                       self.m.data_ptr() + 4 * off, self.v.data_ptr() + 4 * off, None, self.state.data_ptr(),
+                                       L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
+
+    def refresh_copies(self):
+        """Compute-dtype weight copy + transposed copies from the fp32 master (after a sharded update + all-gather)."""
+        m = self.model
+        flat, flat_lp, _, lp_ptr = self._buffers()
+        if lp_ptr is not None:
+            L.check(L.load().mtn_cast_f32_to_lp(L.dtype_code(m.compute_dtype), flat.numel(), flat.data_ptr(), lp_ptr, L.stream_ptr()))
+        m.refresh_transposed()
+
     # ---- optimiser epilogue: the update of the sublayer weight matrices rides on their parameter-gradient GEMMs
     def can_fuse(self) -> bool:
         m = self.model
@@ -163,6 +181,10 @@ class FusedAdam:
         stored per parameter NAME, so a checkpoint survives a different flat layout; ``schedule`` is the device-side Noam /
         bias-correction state [step, lr, 1-b1^t, 1-b2^t]."""
         off = 0
+        sh = getattr(self, "_sharded", None)
+        if sh is not None:          # data parallel with a sharded optimiser: every rank holds the moments of its shards only
+            sh.gather(self.m)
+            sh.gather(self.v)
         out = {"schedule": self.state.detach().cpu().clone(), "exp_avg": {}, "exp_avg_sq": {}}
         names = {id(p): n for n, p in self.model.named_parameters()}
         for p, o in zip(self.model._flat_params, self.model._flat_offsets):
@@ -204,6 +226,12 @@ class NoamOpt:
 
     def finish_fused_step(self):
         self.optimizer.step_rest()
+
+    def begin_sharded_step(self):
+        """Data parallel with a sharded optimiser (dp.ShardedOptimizerSync): advance the schedule now; the per-shard updates
+        (FusedAdam.step_range) follow slice by slice, refresh_copies() at the end."""
+        self._step += 1
+        self.optimizer.tick(self.factor, self.model_size, self.warmup)
 
     def step_count(self) -> int:
         """Optimiser steps taken so far.  The schedule lives on the device (FusedAdam.state[0]) and advances on every replay

@@ -111,3 +111,103 @@ class GradSync:
                 chunk.copy_(c16)
             else:
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+
+
+class ShardedOptimizerSync:
+    """Data parallelism without a replicated optimiser pass (ZeRO-1 style), slice by slice:
+
+        reduce-scatter of a gradient slice  ->  optimiser update of THIS rank's 1/N of the slice  ->  all-gather of the updated
+        fp32 master weights of the slice
+
+    instead of  all-reduce -> the full Adam pass on every rank.  The bytes on the links are those of the all-reduce (a ring
+    all-reduce IS a reduce-scatter followed by an all-gather), but every rank streams 38 B/param of optimiser state for 1/N of
+    the parameters instead of all of them, and the replicas are identical by construction (every element is summed and updated
+    exactly once, then copied).  With the layer-segmented backward (train_step.TrainStep) slice k's three stages run on the
+    communication / side streams while the compute stream is already in the backward of layer k-1; only the last slice's
+    chain is exposed.  After the last slice, ``finish()`` waits and the caller refreshes the compute-dtype copies (cast +
+    transposes of everything: 10 B/param, local).
+
+    ``update(off, n)`` applies the optimiser to flat elements [off, off+n) (HIP: mtn_adam_step on the sub-buffers; the CPU
+    tests pass a torch reference).  Slices whose length is not a multiple of 4*world leave a tail of < 4*world elements that
+    is all-reduced and updated redundantly on every rank.
+    Collectives: RCCL in-place reduce_scatter_tensor / all_gather_into_tensor; other backends (gloo on CUDA tensors in the
+    single-GPU tests) take an all-reduce + per-shard broadcasts with the same results."""
+
+    def __init__(self, flat_fn, grad_fn, update, group=None):
+        self.flat_fn, self.grad_fn, self.update, self.group = flat_fn, grad_fn, update, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.native = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.side = None
+        self._works = []
+        self.slices = set()             # every (lo, hi) this object has been asked to handle (for gather())
+
+    def gather(self, buf: torch.Tensor):
+        """Make a per-element optimiser buffer (Adam moments) complete on every rank: each rank only ever updates its shards.
+        Blocking; checkpoints only."""
+        if self.world == 1:
+            return buf
+        for lo, hi in sorted(self.slices):
+            per, own, tail = self.split(lo, hi)
+            for r in range(self.world if per > 0 else 0):
+                dist.broadcast(buf[lo + r * per: lo + (r + 1) * per], src=r, group=self.group)
+        return buf
+
+    def split(self, lo: int, hi: int):
+        """(elements per rank, first element of this rank's shard, first element of the replicated tail)"""
+        per = ((hi - lo) // (self.world * 4)) * 4
+        return per, lo + self.rank * per, lo + per * self.world
+
+    def reduce_update(self, lo: int, hi: int):
+        """Issue the chain for flat[lo:hi] behind everything queued on the current stream; does not block the current stream."""
+        if hi <= lo:
+            return
+        self.slices.add((lo, hi))
+        flat, grad = self.flat_fn(), self.grad_fn()
+        per, own, tail = self.split(lo, hi)
+        cuda = grad.is_cuda
+        if cuda and self.side is None:
+            self.side = torch.cuda.Stream()
+        if self.world == 1:
+            emu = int(os.environ.get("MTN_DP_EMULATE_WORLD", "1"))     # TIMING ONLY (1-GPU boxes): update 1/emu of the slice, as a
+            n = hi - lo                                                # rank of an emu-GPU job would (the result is wrong)
+            self.update(lo, n if emu <= 1 else max(4, (n // (emu * 4)) * 4))
+            return
+        works = []
+        if per > 0:
+            if self.native:
+                w = dist.reduce_scatter_tensor(grad[own:own + per], grad[lo:tail], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                w = dist.all_reduce(grad[lo:tail], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            works.append(w)
+        if tail < hi:
+            works.append(dist.all_reduce(grad[tail:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+        def chain():
+            for w in works:
+                w.wait()                           # the current (side) stream waits; the host does not
+            if per > 0:
+                self.update(own, per)
+            if tail < hi:
+                self.update(tail, hi - tail)       # replicated: identical inputs -> identical results on every rank
+            if per > 0:
+                if self.native:
+                    self._works.append(dist.all_gather_into_tensor(flat[lo:tail], flat[own:own + per], group=self.group, async_op=True))
+                else:
+                    for r in range(self.world):
+                        self._works.append(dist.broadcast(flat[lo + r * per: lo + (r + 1) * per], src=r, group=self.group, async_op=True))
+
+        if cuda:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                chain()
+        else:
+            chain()
+
+    def finish(self):
+        """The current stream waits for every chain issued since the last finish()."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)

@@ -42,6 +42,15 @@ class TrainStep:
         if overlap is None:
             overlap = os.environ.get("MTN_DP_OVERLAP", "1") != "0"
         self.overlap = bool(overlap) and grad_sync is not None
+        # data parallel: reduce-scatter + optimiser on this rank's shard + all-gather of the master weights
+        # (dp.ShardedOptimizerSync) instead of all-reduce + the full optimiser pass on every rank; MTN_DP_SHARDED=0 = the latter
+        self.sharded = None
+        if grad_sync is not None and os.environ.get("MTN_DP_SHARDED", "1") != "0" and hasattr(self.opt.optimizer, "step_range"):
+            from .dp import ShardedOptimizerSync
+            adam = self.opt.optimizer
+            self.sharded = ShardedOptimizerSync(lambda: model.flat_buffers()[0], lambda: model.flat_buffers()[2], adam.step_range,
+                                                group=getattr(grad_sync, "group", None))
+            adam._sharded = self.sharded
         self._g_seg = None
         self._st = None
         self._fuse_opt = False if fuse_optimizer is False else None
@@ -147,6 +156,13 @@ class TrainStep:
         return segs
 
     def _run_segmented(self, runners):
+        if self.sharded is not None:
+            self.opt.begin_sharded_step()
+            for run, (lo, hi) in runners:
+                run()
+                self.sharded.reduce_update(lo, hi)
+            self.sharded.finish()
+            return
         works = []
         for run, (lo, hi) in runners:
             run()
@@ -192,7 +208,10 @@ class TrainStep:
         self._loss = self._loss_t
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt, pool=pool):
-            self._optim()
+            if self.sharded is not None:
+                self.opt.optimizer.refresh_copies()          # the updates ran shard by shard between the segment graphs
+            else:
+                self._optim()
         self._g_fb = self._g_seg[0]
 
     def _capture_simple(self):
@@ -209,7 +228,10 @@ class TrainStep:
                 self._loss = self._fwd_bwd()
             self._g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
-                self._optim()
+                if self.sharded is not None:
+                    self.opt.optimizer.refresh_copies()
+                else:
+                    self._optim()
         # the warm-up/capture passes did not run the optimiser outside capture: parameters are untouched
 
     def __call__(self) -> torch.Tensor:
@@ -224,9 +246,14 @@ class TrainStep:
                 return self._step_fused()
             else:
                 loss = self._fwd_bwd()
-                if self.grad_sync is not None:
+                if self.sharded is not None:
+                    self._whole_buffer_sharded()
+                elif self.grad_sync is not None:
                     self.grad_sync()
-            self._optim()
+            if self.sharded is not None:
+                self.opt.optimizer.refresh_copies()
+            else:
+                self._optim()
             return loss
         if self._g_fb is None:
             self._capture()
@@ -235,10 +262,21 @@ class TrainStep:
             self._g_opt.replay()
             return self._loss
         self._g_fb.replay()
-        if self.grad_sync is not None:
+        if self.sharded is not None:
+            self._whole_buffer_sharded()
+            self._g_opt.replay()
+        elif self.grad_sync is not None:
             self.grad_sync()
             self._g_opt.replay()
         return self._loss
+
+    def _whole_buffer_sharded(self):
+        """The simple schedule (MTN_DP_OVERLAP=0) with the sharded optimiser: the flat gradient in a few large slices."""
+        self.opt.begin_sharded_step()
+        n = self.model._flat_grad.numel()
+        for lo, hi in self.grad_sync.buckets(n):
+            self.sharded.reduce_update(lo, hi)
+        self.sharded.finish()
 
 
 class BucketedTrainer:

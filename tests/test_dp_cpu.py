@@ -93,3 +93,51 @@ def test_shard_range_and_buckets():
     gs = dp.GradSync(lambda: None, n_buckets=4)
     bk = gs.buckets(106_650_000)
     assert bk[0][0] == 0 and bk[-1][1] == 106_650_000 and all(a[1] == b[0] for a, b in zip(bk, bk[1:])) and len(bk) == 4
+
+
+def _ref_adam(p, g, m, v, lr, b1=0.9, b2=0.98, eps=1e-9, t=1):
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.sub_(lr / (1 - b1 ** t) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps))
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mtn_amd import dp
+    dp.init_distributed("gloo")
+    n = 10_007                                             # not a multiple of 4 * world: exercises the replicated tail
+    g0 = torch.Generator().manual_seed(1)
+    flat = torch.randn(n, generator=g0)                    # identical replicas
+    m, v = torch.zeros(n), torch.zeros(n)
+    cuts = [0, 1000, 1003, 6000, n]                         # slices in backward order (last first), one of them 3 elements long
+    sh = dp.ShardedOptimizerSync(lambda: flat, lambda: grad, None)
+    for t in range(1, 4):
+        grad = torch.randn(n, generator=torch.Generator().manual_seed(100 * t + rank))     # this rank's local gradient
+        sh.update = lambda off, cnt, t=t: _ref_adam(flat[off:off + cnt], grad[off:off + cnt], m[off:off + cnt], v[off:off + cnt], 1e-2, t=t)
+        for lo, hi in list(zip(cuts[:-1], cuts[1:]))[::-1]:
+            sh.reduce_update(lo, hi)
+        sh.finish()
+    sh.gather(m); sh.gather(v)
+    torch.save({"flat": flat, "m": m, "v": v}, os.path.join(out_dir, f"sh{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_optimizer_exchange_equals_allreduce_plus_full_update(tmp_path):
+    """dp.ShardedOptimizerSync (reduce-scatter -> update of the own shard -> all-gather, with a replicated tail) on two gloo
+    ranks, three steps: the replicas are BIT-identical (parameters and, after gather(), both moments) and equal to one process
+    that sums the two gradients and updates everything."""
+    port = _free_port()
+    mp.start_processes(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "sh0.pt"), torch.load(tmp_path / "sh1.pt")
+    for k in ("flat", "m", "v"):
+        assert torch.equal(r0[k], r1[k]), k
+    n = 10_007
+    flat = torch.randn(n, generator=torch.Generator().manual_seed(1))
+    m, v = torch.zeros(n), torch.zeros(n)
+    for t in range(1, 4):
+        g = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 * t + r)) for r in range(2))
+        _ref_adam(flat, g, m, v, 1e-2, t=t)
+    assert torch.allclose(r0["flat"], flat, rtol=0, atol=1e-6) and torch.allclose(r0["m"], m, atol=1e-6) and torch.allclose(r0["v"], v, atol=1e-6)

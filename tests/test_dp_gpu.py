@@ -37,9 +37,10 @@ def _batch(c, raw, dev):
     return Batch(t(raw["query"]), t(raw["his"]), None, [t(f) for f in raw["fts"]], t(raw["cap"]), t(raw["trg"]), t(raw["trg_y"]), pad=fx.PAD, device=dev)
 
 
-def _worker(rank, world, port, out_dir, use_graph):
+def _worker(rank, world, port, out_dir, use_graph, sharded=True):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      MTN_DP_SHARDED="1" if sharded else "0")
     import torch.distributed as dist
     from mtn_amd import dp
     from mtn_amd.train_step import TrainStep
@@ -53,6 +54,7 @@ def _worker(rank, world, port, out_dir, use_graph):
     model = _make(c, dev, "fp32")
     sync = dp.GradSync(lambda: model.flat_buffers()[2], n_buckets=3)
     step = TrainStep(model, _batch(c, shard, dev), c["vocab"], pad=fx.PAD, warmup=10, grad_sync=sync, use_graph=use_graph)
+    assert (step.sharded is not None) == sharded
     losses = [float(step())]
     torch.cuda.synchronize()
     grad1 = model._flat_grad.cpu().clone()          # reduced gradient of step 1 (the optimiser does not touch it)
@@ -64,14 +66,17 @@ def _worker(rank, world, port, out_dir, use_graph):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("sharded", [True, False], ids=["sharded-optimiser", "allreduce-full-optimiser"])
 @pytest.mark.parametrize("use_graph", [True, False])
-def test_two_rank_dp_equals_single_rank_on_concatenated_batch(tmp_path, use_graph):
+def test_two_rank_dp_equals_single_rank_on_concatenated_batch(tmp_path, use_graph, sharded):
+    """Both exchange schemes: reduce-scatter + optimiser on the own shard + all-gather of the master weights
+    (dp.ShardedOptimizerSync, the default), and all-reduce + the full optimiser pass on every rank (MTN_DP_SHARDED=0)."""
     import torch.multiprocessing as mp
     from mtn_amd.train_step import TrainStep
     from oracle import fixtures as fx
     assert torch.cuda.is_available()
     port = _free_port()
-    mp.start_processes(_worker, args=(2, port, str(tmp_path), use_graph), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(2, port, str(tmp_path), use_graph, sharded), nprocs=2, join=True, start_method="spawn")
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0["flat"], r1["flat"])                       # replicas stay identical
     dev = torch.device("cuda:0")
