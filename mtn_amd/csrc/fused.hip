@@ -25,18 +25,7 @@
 //     row-major V image with ds_read_b64_tr_b16; softmax max/sum across the four 16-lane rows by v_permlane16/32_swap.
 // The workgroup of head 0 / slice 0 also writes xn, mean, rstd for backward.  Workgroup id % 8 = head and workgroups go to the
 // 8 XCDs round-robin: each XCD streams only its head's weight slice.
-#include <stdlib.h>
-
-#include "common.h"
-
-static constexpr int FH_D = 512;          // d_model
-static constexpr int FH_DK = 64;          // head width
-static constexpr int FH_ROWB = FH_D * 2;  // bytes per row of the xn / memory images
-static constexpr int FH_HROWB = FH_DK * 2;  // bytes per row of the Q / K / V head images
-static constexpr int FH_MASKB = 8;        // mask bytes a thread stages at most (4096 per 512-thread workgroup)
-static constexpr int FH_THREADS = 512;    // 8 waves: column block (wave & 3) x half of the contraction (wave >> 2)
-enum { FH_SELF = 0, FH_CROSS_READY = 1, FH_CROSS_RAW = 2, FH_FFN = 3 };
-#define FH_MAX_MEMBERS (2 * MTN_SUBLAYER_MAX_GROUP)
+#include "fused_common.h"
 
 struct FhMember {
     int kind;
@@ -75,60 +64,6 @@ struct FhGroup {
     int wg_start[FH_MAX_MEMBERS + 1];
     FhMember m[FH_MAX_MEMBERS];
 };
-
-typedef __attribute__((address_space(3))) void fh_lds_void_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 fh_bf16x2;
-typedef __attribute__((ext_vector_type(2))) float fh_f32x2;
-
-__device__ __forceinline__ uint32_t fh_pack2(float a, float b) {        // v_cvt_pk_bf16_f32: round-to-nearest-even
-    const fh_bf16x2 r = __builtin_convertvector(fh_f32x2{a, b}, fh_bf16x2);
-    return *(const uint32_t*)&r;
-}
-// sum over the 16 lanes of a DPP row (every lane gets the total)
-__device__ __forceinline__ float fh_row16_sum(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
-    return v;
-}
-// combine across the four 16-lane rows of the wave (lanes with equal lane & 15)
-__device__ __forceinline__ float fh_cross_max(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float fh_cross_sum(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-__device__ __forceinline__ uint4 fh_xfrag(const unsigned char* img, int row, int chunk) {          // [row][512] image
-    return *(const uint4*)(img + row * FH_ROWB + ((chunk ^ (row & 15)) << 4));
-}
-__device__ __forceinline__ uint4 fh_hfrag(const unsigned char* img, int row, int chunk) {          // [row][64] image, Q / K
-    return *(const uint4*)(img + row * FH_HROWB + ((chunk ^ (row & 7)) << 4));
-}
-// A-operand fragment of V^T from the row-major V image: head columns n_off + (lane & 15), keys row0 + 8*lg .. +7
-// (ds_read_b64_tr_b16, semantics as in gemm.hip ttd_frag; 16-byte slots swizzled with (row >> 1) & 7)
-__device__ __forceinline__ uint4 fh_vfrag(const unsigned char* img, int row0, int n_off, int l15, int lg) {
-    uint4 f;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int krow = row0 + 8 * lg + 4 * r + (l15 >> 2);
-        const int col = n_off + 4 * (l15 & 3);
-        const int slot = (col >> 3) ^ ((krow >> 1) & 7);
-        const unsigned addr = (unsigned)(size_t)(img + krow * FH_HROWB + slot * 16 + (col & 7) * 2);
-        unsigned long long v;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
-        if (r == 0) { f.x = (unsigned)v; f.y = (unsigned)(v >> 32); }
-        else { f.z = (unsigned)v; f.w = (unsigned)(v >> 32); }
-    }
-    return f;
-}
 
 // LDS map (bytes), the same arithmetic on host and device
 struct FhLds { int gains, xn, xm, qi, ki, vi, mask, total; };
@@ -609,6 +544,8 @@ static bool fh_env_off() {
     if (fh_enabled < 0) { const char* e = getenv("MTN_FUSED"); fh_enabled = (e && e[0] == '0') ? 0 : 1; }
     return fh_enabled == 0;
 }
+
+int fh_is_enabled() { return fh_env_off() ? 0 : 1; }
 
 static constexpr int FH_LDS_MAX = 160 * 1024;
 // row tiles a workgroup may have: {2, 3, 5} in the 1- and 3-block kernels, {2, 4} in the 4-block kernel

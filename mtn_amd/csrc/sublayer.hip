@@ -17,6 +17,10 @@
 // csrc/fused.hip
 int fh_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn);
 int fh_group_fwd_stage1(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
+// csrc/fused_bwd.hip
+struct FbIo { const void* dyl; void *dq, *dk, *dv; int ldq, ldkv; };
+int fb_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, const FbIo* io);
+int fb_group_bwd_stage(int n_mha, const mtn_mha_args* mha, const FbIo* io, void* stream);
 
 static inline const char* lp_off(const void* p, long elems, int dtype) {
     return (const char*)p + elems * (dtype == MTN_BF16 ? 2 : 4);
@@ -226,11 +230,24 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
             if (!ffn[i].dyl_ready) c[n++] = mtn_cast_desc{(long)ffn[i].rows * ffn[i].d, ffn[i].dy, ffn_ws(&ffn[i], dtype).dyl, ffn[i].drop_out};
         if (n) RUN(mtn_cast_group(dtype, n, c, stream));
     }
+    // Fused stage 2 + 3 of the attention members (csrc/fused_bwd.hip): dO of a head and the head's attention backward in one
+    // kernel per (sample block, head); dO never goes to HBM
+    FbIo io[MTN_SUBLAYER_MAX_GROUP];
+    for (int i = 0; i < n_mha; ++i) {
+        const mtn_mha_args* a = &mha[i];
+        const MhaWs w = mha_ws(a, dtype);
+        const int d = a->d;
+        io[i].dyl = w.dyl; io[i].dq = w.dqkv;
+        if (a->self_attn) { io[i].dk = lp_off(w.dqkv, d, dtype); io[i].dv = lp_off(w.dqkv, 2 * d, dtype); io[i].ldq = io[i].ldkv = 3 * d; }
+        else { io[i].dk = w.dkv; io[i].dv = lp_off(w.dkv, d, dtype); io[i].ldq = d; io[i].ldkv = 2 * d; }
+    }
+    const bool fb = n_mha > 0 && fb_group_eligible(dtype, n_mha, mha, io) != 0;
+    if (fb) RUN(fb_group_bwd_stage(n_mha, mha, io, stream));
     // 2. dO = dyl Wo ;  dh = (dyl W2) * relu'(h) * hidden-dropout mask (both recovered from the saved hidden: hid > 0)
-    {
+    if (!fb || n_ffn > 0) {
         mtn_gemm_problem p[2 * MTN_SUBLAYER_MAX_GROUP];
         int n = 0;
-        for (int i = 0; i < n_mha; ++i) {
+        for (int i = 0; i < n_mha && !fb; ++i) {
             const mtn_mha_args* a = &mha[i];
             const MhaWs w = mha_ws(a, dtype);
             const int d = a->d, rows = a->B * a->a;
@@ -249,7 +266,7 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
         RUN(run_gemms(dtype, n, p, stream));
     }
     // 3. attention core backward -> dq, dk, dv
-    if (n_mha) {
+    if (n_mha && !fb) {
         mtn_attn_args t[MTN_SUBLAYER_MAX_GROUP];
         for (int i = 0; i < n_mha; ++i) {
             const mtn_mha_args* a = &mha[i];
