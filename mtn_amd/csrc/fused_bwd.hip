@@ -57,8 +57,8 @@ __host__ __device__ inline FbLds fb_lds_map(int mt, int key_rows, int mask_bytes
     const int krows = ((key_rows + 7) & ~7) + 32;          // + one key tile of finite padding
     L.vi = L.ki + krows * FH_HROWB;
     L.mask = L.vi + krows * FH_HROWB;
-    L.scratch = L.mask + ((mask_bytes + 15) & ~15);
-    L.total = L.scratch + 8 * FB_WAVE_SCRATCH;
+    L.total = L.mask + ((mask_bytes + 15) & ~15);
+    L.scratch = L.dy;                                      // the waves' dS tile images reuse the dy image (dead once dO exists): 8 x 2.6 KiB
     return L;
 }
 
@@ -197,7 +197,7 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                 *(uint2*)(doi_s + r * FH_HROWB + (((2 * wc + (lg >> 1)) ^ (r & 7)) << 4) + (lg & 1) * 8) = u;
             }
     }
-    __syncthreads();
+    __syncthreads();                                            // dO image complete; the exchange area (in the dy image) is dead too
 
     // ---- attention backward, one wave per sample of the block
     const float scale = 0.125f;
@@ -307,20 +307,27 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                 const int key = j0 + kt * 16 + l15;
                 const uint4 pf = fb_frag_from_c(sc[0][kt], sc[1][kt]);
                 const uint4 sf = fb_frag_from_c(dp[0][kt], dp[1][kt]);
-                uint4 dot_[4], qt_[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) { dot_[nt] = fb_tfrag(doi_s, qrow0, nt * 16, l15, lg); qt_[nt] = fb_tfrag(qi_s, qrow0, nt * 16, l15, lg); }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
+                for (int nh = 0; nh < 2; ++nh) {                  // head columns in two halves of 32 (register pressure)
+                    uint4 dot_[2], qt_[2];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    f32x4_t av = f32x4_t{0.f, 0.f, 0.f, 0.f}, ak = av;
-                    mma16<bf16_t>(av, dot_[nt], pf);
-                    mma16<bf16_t>(ak, qt_[nt], sf);
-                    if (key < mk) {   // lane holds head columns nt*16 + 4lg + r of key column `key`
-                        const size_t go = (krow_g0 + krow0 + key) * M.ldkv + slice * FH_DK + nt * 16 + 4 * lg;
-                        *(uint2*)(M.dv + go) = make_uint2(fh_pack2(av[0], av[1]), fh_pack2(av[2], av[3]));
-                        *(uint2*)(M.dk + go) = make_uint2(fh_pack2(ak[0] * scale, ak[1] * scale), fh_pack2(ak[2] * scale, ak[3] * scale));
+                    for (int n2 = 0; n2 < 2; ++n2) {
+                        dot_[n2] = fb_tfrag(doi_s, qrow0, (2 * nh + n2) * 16, l15, lg);
+                        qt_[n2] = fb_tfrag(qi_s, qrow0, (2 * nh + n2) * 16, l15, lg);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n2 = 0; n2 < 2; ++n2) {
+                        const int nt = 2 * nh + n2;
+                        f32x4_t av = f32x4_t{0.f, 0.f, 0.f, 0.f}, ak = av;
+                        mma16<bf16_t>(av, dot_[n2], pf);
+                        mma16<bf16_t>(ak, qt_[n2], sf);
+                        if (key < mk) {   // lane holds head columns nt*16 + 4lg + r of key column `key`
+                            const size_t go = (krow_g0 + krow0 + key) * M.ldkv + slice * FH_DK + nt * 16 + 4 * lg;
+                            *(uint2*)(M.dv + go) = make_uint2(fh_pack2(av[0], av[1]), fh_pack2(av[2], av[3]));
+                            *(uint2*)(M.dk + go) = make_uint2(fh_pack2(ak[0] * scale, ak[1] * scale), fh_pack2(ak[2] * scale, ak[3] * scale));
+                        }
                     }
                 }
             }
