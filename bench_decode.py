@@ -30,10 +30,13 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch-dialogues", type=int, default=8, help="also time D dialogues decoded side by side (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--kv-cache", default="auto", choices=["auto", "on", "off"],
+                    help="prefix K/V cache of the target self-attention (auto: on beyond 32 tokens, mtn_amd.decode.KV_CACHE_FROM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     from mtn_amd import lib, make_model
     from mtn_amd.decode import beam_search_decode, beam_search_decode_many, greedy_decode
+    KV = {"auto": None, "on": True, "off": False}[args.kv_cache]
     from mtn_amd.synthetic import CONFIGS, synthetic_batch
     assert torch.cuda.is_available(), "bench_decode.py needs a GPU (the HIP path has no CPU fallback)"
     dev = torch.device("cuda", 0)
@@ -49,7 +52,7 @@ def main():
                                device=dev, seed=100 + i, ragged=False) for i in range(args.dialogues)]
 
     def run_beam(b):
-        return beam_search_decode(model, b, args.max_len, SOS, UNK, EOS, PAD, beam=args.beam, nbest=args.beam,
+        return beam_search_decode(model, b, args.max_len, SOS, UNK, EOS, PAD, beam=args.beam, nbest=args.beam, kv_cache=KV,
                                   use_graph=not args.no_graph)
 
     run_beam(batches[0])                                   # warm-up (allocator, first graph capture)
@@ -62,11 +65,11 @@ def main():
     live = 1 + (args.max_len - 1) * args.beam              # step 0 extends <sos> only, later steps `beam` hypotheses
     tok_beam = args.dialogues * live / t_beam
 
-    greedy_decode(model, batches[0], args.max_len, SOS, PAD, use_graph=not args.no_graph)
+    greedy_decode(model, batches[0], args.max_len, SOS, PAD, use_graph=not args.no_graph, kv_cache=KV)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for b in batches:
-        greedy_decode(model, b, args.max_len, SOS, PAD, use_graph=not args.no_graph)
+        greedy_decode(model, b, args.max_len, SOS, PAD, use_graph=not args.no_graph, kv_cache=KV)
     torch.cuda.synchronize()
     t_greedy = time.perf_counter() - t0
 
@@ -82,7 +85,7 @@ def main():
     if args.batch_dialogues > 0:
         D = args.batch_dialogues
         big = synthetic_batch(cfg["vocab"], D, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=300, ragged=True)
-        many = lambda: beam_search_decode_many(model, big, args.max_len, SOS, UNK, EOS, PAD, beam=args.beam, nbest=args.beam, use_graph=not args.no_graph)
+        many = lambda: beam_search_decode_many(model, big, args.max_len, SOS, UNK, EOS, PAD, beam=args.beam, nbest=args.beam, use_graph=not args.no_graph, kv_cache=KV)
         many()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -9,8 +9,11 @@ the dialogue (query/caption, video), never on the target prefix.  Here:
 * all live hypotheses are decoded together, as the batch dimension of one target-stream pass
   (``DecoderLayer.forward_target``: 4 text attentions + F attend-to-auto-encoder + FFN per layer);
 * the pass has a FIXED shape — (width, max_len) tokens under the causal mask, log-probabilities read at position l — so the
-  whole pass is ONE hipGraph replayed per token (≈170 launches of a few µs: launch-latency-bound; a K/V cache would not
-  shorten it at the reference's max_len = 20, it would only shrink kernels that are already at the latency floor);
+  whole pass is ONE hipGraph replayed per token (launch-latency-bound at the reference's max_len = 20);
+* for longer searches (``kv_cache``, default above KV_CACHE_FROM tokens) the pass covers only the NEWEST position: every layer
+  keeps K|V of the target prefix per hypothesis, the new row's K|V are projected into it, and the self-attention of that row is
+  a cross-attention over the cache (keys 0..l enabled); a beam step re-orders hypotheses, so the cache rows follow their
+  parents by one gather per token.  Same n-best lists as the full-prefix pass (tested), O(l) instead of O(l^2) work per token;
 * hypothesis bookkeeping stays on the host exactly as in the reference (same candidate order, same tie behaviour).
 """
 from __future__ import annotations
@@ -27,8 +30,9 @@ class DecodeSession:
     """Everything about one dialogue that does not depend on the target prefix, plus the replayable target-stream pass.
     A session is reusable for further dialogues of the same shapes (``load``): buffers and the captured graph persist."""
 
-    def __init__(self, model, batch, max_len: int, width: int, pad: int = 1, use_graph: bool = True):
+    def __init__(self, model, batch, max_len: int, width: int, pad: int = 1, use_graph: bool = True, kv_cache: bool = False):
         self.model, self.width, self.max_len, self.pad = model, width, max_len, pad
+        self.kv_cache = bool(kv_cache)
         self.use_graph = use_graph and batch.query.is_cuda
         dev = batch.query.device
         self.q = self.cp = self.hs = self.aes = self.masks = None
@@ -41,6 +45,22 @@ class DecodeSession:
         self.logp = None
         self._graph = None
         self.load(batch)
+        if self.kv_cache:
+            # Prefix K/V cache of the target self-attention (the reference recomputes the whole prefix for every hypothesis and
+            # token, data_utils.py:197-205): per layer (W, L, 2d) in the compute dtype, TWO copies — a beam step re-orders the
+            # hypotheses, so the rows of the cache follow their parents by one gather from the other copy per token.
+            W, L, d = self.D * width, max_len, model.decoder.layers[0].size
+            lp = model.compute_dtype
+            nl = len(model.decoder.layers)
+            self._cache = [torch.zeros(nl, W, L, 2 * d, device=dev, dtype=lp) for _ in range(2)]
+            self._cur = 0
+            self._parent = torch.arange(W, device=dev)
+            self._self_mem = torch.zeros(W, L, d, device=dev, dtype=torch.float32)      # shape carrier (never read: K|V are ready)
+            self._self_mem._mtn_lp = torch.zeros(W, L, d, device=dev, dtype=lp) if lp != torch.float32 else self._self_mem
+            self._self_mask = torch.zeros(W, 1, L, dtype=torch.bool, device=dev)
+            self._self_mask._mtn_u8 = torch.zeros(W, 1, L, dtype=torch.uint8, device=dev)
+            self._prev = None                                                            # prefixes of the previous step, per dialogue
+            self._graphs = {}
 
     @staticmethod
     def signature(model, batch, max_len, width):
@@ -107,6 +127,67 @@ class DecodeSession:
         last = x.index_select(1, self.pos).squeeze(1)               # (width, d): the position being extended
         self.logp = m.generator(last).float()                       # (width, V) log-probabilities (mtn.py:68-69)
 
+    def _pass_cached(self, cur: int):
+        """One target position (self.pos) for every hypothesis, against the prefix cache: gather the cache rows of the parents
+        (copy 1-cur -> cur), embed the newest token, per layer project its K|V into the cache and run the layer on that one row."""
+        m = self.model
+        cap_mask, his_mask, q_mask = self.masks
+        src, dst = self._cache[1 - cur], self._cache[cur]
+        torch.index_select(src, 1, self._parent, out=dst)
+        tok = self.tokens.index_select(1, self.pos)                                  # (W, 1)
+        emb, pos_enc = m.tgt_embed[0], m.tgt_embed[1]
+        x = emb(tok) + pos_enc.pe[0].index_select(0, self.pos).unsqueeze(0)           # lut * sqrt(d) + PE[l]   (mtn.py:289, 308; eval: no dropout)
+        ar = torch.arange(self.max_len, device=x.device)
+        self._self_mask._mtn_u8.copy_((ar <= self.pos).view(1, 1, -1).expand_as(self._self_mask))
+        m.attach_memory_kv(self._kv_pairs)
+        try:
+            for k, layer in enumerate(m.decoder.layers):
+                kv_new = layer.self_kv_of_new_rows(x)                                # (W, 1, 2d)
+                dst[k].index_copy_(1, self.pos, kv_new)
+                x = layer.forward_target_cached(x, self.cp, cap_mask, self.hs, his_mask, self.q, q_mask, self.aes[k], m.auto_encoder_ft,
+                                                dst[k].view(-1, dst.size(-1)), self._self_mem, self._self_mask)
+        finally:
+            m.clear_memory_kv()
+        x = m.decoder.norm(x)
+        self.logp = m.generator(x.squeeze(1)).float()
+
+    def _step_cached(self, prefix_lists):
+        l = len(prefix_lists[0][0])
+        W = self.width
+        host_tok = torch.full((self.D * W, self.max_len), self.pad, dtype=torch.long)
+        parent = torch.arange(self.D * W)
+        for d, prefixes in enumerate(prefix_lists):
+            host_tok[d * W:d * W + len(prefixes), :l] = torch.tensor(prefixes, dtype=torch.long)
+            if l > 1:
+                prev = self._prev[d]
+                for i, p in enumerate(prefixes):                    # the hypothesis this one extends (same tokens but the last)
+                    parent[d * W + i] = d * W + prev.index(list(p[:-1]))
+        self._prev = [[list(p) for p in prefixes] for prefixes in prefix_lists]
+        self.tokens.copy_(host_tok)
+        self._parent.copy_(parent)
+        self.pos.fill_(l - 1)
+        cur = self._cur
+        with torch.no_grad():
+            if not self.use_graph:
+                self._pass_cached(cur)
+            else:
+                g = self._graphs.get(cur)
+                if g is None:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        self._pass_cached(cur)
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._pass_cached(cur)
+                    g = self._graphs[cur] = (g, self.logp)          # each graph writes its own output buffer
+                g[0].replay()
+                self.logp = g[1]
+        self._cur = 1 - cur
+        return [self.logp[d * W:d * W + len(p)] for d, p in enumerate(prefix_lists)]
+
     def step(self, prefixes: Sequence[Sequence[int]]) -> torch.Tensor:
         """Log-probabilities (n, V) of the next token after each prefix of ONE dialogue (all prefixes have the same length)."""
         return self.step_many([prefixes])[0]
@@ -119,6 +200,8 @@ class DecodeSession:
         l = len(prefix_lists[0][0])
         if max(len(p) for p in prefix_lists) > self.width or l > self.max_len:
             raise ValueError("more hypotheses / longer prefix than the session was built for")
+        if self.kv_cache:
+            return self._step_cached(prefix_lists)
         host = torch.full((self.D * self.width, self.max_len), self.pad, dtype=torch.long)
         for d, prefixes in enumerate(prefix_lists):
             host[d * self.width:d * self.width + len(prefixes), :l] = torch.tensor(prefixes, dtype=torch.long)
@@ -143,12 +226,14 @@ class DecodeSession:
 
 
 _SESSIONS: dict = {}
+KV_CACHE_FROM = 32      # prefix K/V cache by default for searches longer than this (at the reference's max_len = 20 the full-prefix
+                        # pass is launch-latency-bound and as fast; the cache makes a token cost O(l) instead of O(l^2) work beyond it)
 
 
-def _session(model, batch, max_len, width, pad, use_graph) -> DecodeSession:
+def _session(model, batch, max_len, width, pad, use_graph, kv_cache=False) -> DecodeSession:
     """Sessions are kept per (model, shapes): a dialogue with the shapes of an earlier one reuses its buffers and graph.
     The cache is dropped when the model's weights change (prepare() version) or it grows past a few shapes."""
-    key = DecodeSession.signature(model, batch, max_len, width) + (bool(use_graph),)
+    key = DecodeSession.signature(model, batch, max_len, width) + (bool(use_graph), bool(kv_cache))
     model.prepare()
     ver = getattr(model, "_flat_version", None)
     hit = _SESSIONS.get(key)
@@ -157,7 +242,7 @@ def _session(model, batch, max_len, width, pad, use_graph) -> DecodeSession:
         return hit[0]
     if len(_SESSIONS) >= 8:
         _SESSIONS.clear()
-    sess = DecodeSession(model, batch, max_len, width, pad=pad, use_graph=use_graph)
+    sess = DecodeSession(model, batch, max_len, width, pad=pad, use_graph=use_graph, kv_cache=kv_cache)
     _SESSIONS[key] = (sess, ver)
     return sess
 
@@ -215,11 +300,13 @@ class _Beam:
 
 
 def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam=5, penalty=1.0,
-                            nbest=5, min_len=1, use_graph=True):
+                            nbest=5, min_len=1, use_graph=True, kv_cache=None):
     """beam_search_decode for a Batch of D dialogues at once: the D x beam live hypotheses are the batch dimension of ONE
     target-stream pass per generated token (the pass is launch-latency-bound, so D dialogues cost little more than one).
     Returns a list of D (n-best list, best score) pairs, each equal to what the single-dialogue search returns."""
-    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph)
+    if kv_cache is None:
+        kv_cache = max_len > KV_CACHE_FROM
+    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph, kv_cache)
     beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
     k = beam + 2
     for l in range(max_len):
@@ -245,20 +332,20 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
 
 
 def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam=5, penalty=1.0,
-                       nbest=5, min_len=1, use_graph=True):
+                       nbest=5, min_len=1, use_graph=True, kv_cache=None):
     """data_utils.py:188-242, same arguments and return value: (n-best list of (token list, score) sorted by score,
     best score).  A hypothesis ending with <eos> at length k scores logp + penalty * k; <unk> and <eos> never extend
     a hypothesis; candidates are visited in descending log-probability exactly as the reference does (data_utils.py:219)."""
     if batch.query.size(0) != 1:
         raise ValueError("beam_search_decode works on one dialogue (data_utils.py:188); use beam_search_decode_many for a batch")
     return beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam, penalty, nbest,
-                                   min_len, use_graph)[0]
+                                   min_len, use_graph, kv_cache)[0]
 
 
-def greedy_decode(model, batch, max_len, start_symbol, pad_symbol=1, use_graph=True):
+def greedy_decode(model, batch, max_len, start_symbol, pad_symbol=1, use_graph=True, kv_cache=None):
     """data_utils.py:159-186 (the reference's own greedy_decode cannot run: it calls decode() with the wrong arity, SURVEY
     §8c) — pinned to: argmax of the generator's log-probabilities at every step, (1, max_len) tokens incl. <sos>."""
-    sess = _session(model, batch, max_len, 1, pad_symbol, use_graph)
+    sess = _session(model, batch, max_len, 1, pad_symbol, use_graph, max_len > KV_CACHE_FROM if kv_cache is None else kv_cache)
     ys = [start_symbol]
     for _ in range(max_len - 1):
         nxt = int(sess.step([ys]).argmax(dim=-1)[0])

@@ -302,6 +302,45 @@ class DecoderLayer(nn.Module):
             x = self._run_group([(sl[7 + 4 * i], self.auto_encoder_attn[i], aes[i], ae_mask, x)])[0]
         return self._run_group([(sl[4 + 4 * nF], self.feed_forward, None, None, x)])[0]
 
+    def self_kv_of_new_rows(self, x):
+        """K|V projection of the target self-attention (sublayer 0) for NEW target rows x (W, n, d): LayerNorm(x) w_k|w_v^T + b
+        -> (W, n, 2d) in the compute dtype (decode with a prefix K/V cache: mtn.py:183 applied to one position)."""
+        sc, attn = self.sublayer[0], self.self_attn
+        lp = sc._ctx()[0]
+        f = attn.fused()
+        d = x.size(-1)
+        _, xn_lp = ops.layer_norm(x, sc.norm.a_2, sc.norm.b_2, sc.norm.eps, lp)
+        w = f["w_qkv_lp"] if f["w_qkv_lp"] is not None else ops.cast_to_lp(f["w_qkv"], lp)
+        rows = x.numel() // d
+        out = torch.empty(rows, 2 * d, device=x.device, dtype=lp)
+        pr = ops.L.GemmProblem()
+        pr.A, pr.B, pr.lda, pr.ldb, pr.M, pr.N, pr.K = xn_lp.data_ptr(), w.data_ptr() + d * d * w.element_size(), d, d, rows, 2 * d, d
+        pr.bias, pr.gate_scale, pr.out_lp, pr.ldc = f["b_qkv"].data_ptr() + d * f["b_qkv"].element_size(), 1.0, out.data_ptr(), 2 * d
+        ops.gemm(ops.L.dtype_code(lp), [pr])
+        return out.view(x.size(0), x.size(1), 2 * d)
+
+    def forward_target_cached(self, x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, aes, ae_features,
+                              self_kv, self_mem, self_mask):
+        """forward_target for the NEWEST target position only (x: (W, 1, d)) against a prefix K/V cache of this layer's target
+        self-attention: ``self_kv`` (W * L, 2d) already holds K|V of positions 0..l (the new row included), ``self_mask``
+        (W, 1, L) enables keys 0..l, ``self_mem`` is a (W, L, d) placeholder that only carries the shape.  The self-attention
+        of mtn.py:183 on the last row is then a cross-attention of that row over the cache — same weights, same arithmetic."""
+        sl = self.sublayer
+        nF = len(aes)
+        text, _, _, ae_mask = self._plan(cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, None, [None] * nF,
+                                         [None] * nF, ae_features)
+        prev = getattr(sl[0], "_kv_ready", None)
+        object.__setattr__(sl[0], "_kv_ready", self_kv)
+        try:
+            x = self._run_group([(sl[0], self.self_attn, self_mem, self_mask, x)])[0]
+        finally:
+            object.__setattr__(sl[0], "_kv_ready", prev)
+        for j in range(1, 4):
+            x = self._run_group([text[j] + (x,)])[0]
+        for i in range(nF):
+            x = self._run_group([(sl[7 + 4 * i], self.auto_encoder_attn[i], aes[i], ae_mask, x)])[0]
+        return self._run_group([(sl[4 + 4 * nF], self.feed_forward, None, None, x)])[0]
+
     def forward(self, x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask,
                 ae_fts, ae_features):
         owner = getattr(self, "_owner", None)

@@ -26,15 +26,18 @@ def one_dialogue(c, seed=2):
     return fx.det_batch(c["vocab"], 1, c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=seed, ragged=False)
 
 
+@pytest.mark.parametrize("kv_cache", [False, True], ids=["full-prefix", "kv-cache"])
 @pytest.mark.parametrize("use_graph", [True, False])
 @pytest.mark.parametrize("name", list(fx.GOLDEN_CONFIGS))
-def test_beam_search_matches_reference_nbest(dev, name, use_graph):
+def test_beam_search_matches_reference_nbest(dev, name, use_graph, kv_cache):
+    """The reference's own n-best lists (beam 5): with the full-prefix pass and with the prefix K/V cache (one new position
+    per token, the cache rows following their parent hypotheses)."""
     from mtn_amd.decode import beam_search_decode
     c = fx.GOLDEN_CONFIGS[name]
     g = dict(np.load(os.path.join(GOLD, name + ".npz")))
     model = build_model(c, torch.float32, dev).eval()
     b = dev_batch(one_dialogue(c), dev)
-    nbest, best = beam_search_decode(model, b, 8, fx.SOS, fx.UNK, fx.EOS, fx.PAD, use_graph=use_graph)
+    nbest, best = beam_search_decode(model, b, 8, fx.SOS, fx.UNK, fx.EOS, fx.PAD, use_graph=use_graph, kv_cache=kv_cache)
     assert len(nbest) == int(g["beam.n"])
     for i, (toks, score) in enumerate(nbest):
         assert list(toks) == list(g[f"beam.tokens.{i}"]), i
@@ -119,3 +122,32 @@ def test_beam_search_many_dialogues_equals_one_by_one(dev):
     for (nb1, best1), (nbm, bestm) in zip(singles, many):
         assert [list(t) for t, _ in nbm] == [list(t) for t, _ in nb1]
         assert max(abs(a[1] - b[1]) for a, b in zip(nbm, nb1)) < 1e-3 and abs(best1 - bestm) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_kv_cache_decode_equals_full_prefix_decode_on_a_long_search(dev, dtype):
+    """max_len 48 (beyond KV_CACHE_FROM: the cache is the default there), d_model 512 so that the fused forward kernel serves
+    both passes: beam 4 over 3 dialogues side by side.  fp32 mode: identical n-best token lists and scores within 1e-4; bf16:
+    best score within 1e-2 and greedy token chains equal."""
+    from mtn_amd.decode import beam_search_decode_many, greedy_decode
+    c = dict(vocab=96, N=2, d_model=512, d_ff=1024, h=8, ft_sizes=[64, 32], B=3, Q=9, H=30, C=14, T=8, frames=[11, 7],
+             diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query")
+    model = build_model(c, dtype, dev).eval()
+    raw = fx.det_batch(c["vocab"], c["B"], c["Q"], c["H"], c["C"], c["T"], c["frames"], c["ft_sizes"], seed=2, ragged=True)
+    b = dev_batch(raw, dev)
+    L = 48
+    full = beam_search_decode_many(model, b, L, fx.SOS, fx.UNK, fx.EOS, fx.PAD, beam=4, nbest=4, kv_cache=False)
+    cached = beam_search_decode_many(model, b, L, fx.SOS, fx.UNK, fx.EOS, fx.PAD, beam=4, nbest=4)          # default: cache on
+    for (nf, bf), (nc, bc) in zip(full, cached):
+        if dtype == torch.float32:
+            assert [t for t, _ in nf] == [t for t, _ in nc]
+            assert all(abs(sf - sc) < 1e-4 * max(1.0, abs(sf)) for (_, sf), (_, sc) in zip(nf, nc))
+        else:
+            assert abs(bf - bc) < 1e-2 * max(1.0, abs(bf))
+    one = dev_batch({k: (v[:1] if k != "fts" else [f[:1] for f in v]) for k, v in raw.items()}, dev)
+    g_full = greedy_decode(model, one, L, fx.SOS, fx.PAD, kv_cache=False)
+    g_cache = greedy_decode(model, one, L, fx.SOS, fx.PAD)
+    if dtype == torch.float32:
+        assert torch.equal(g_full, g_cache)
+    else:
+        assert float((g_full == g_cache).float().mean()) > 0.5      # bf16 near-ties may fork the chain late

@@ -398,8 +398,9 @@ class _NoSync:
         pass
 
 
+@pytest.mark.parametrize("sharded", [False, True], ids=["allreduce", "sharded-optimiser"])
 @pytest.mark.parametrize("name", ["cfg1_query", "cfg1_caption", "small_shared"])
-def test_layer_segmented_backward_equals_monolithic(dev, name):
+def test_layer_segmented_backward_equals_monolithic(dev, name, sharded, monkeypatch):
     """TrainStep under data parallelism cuts backward at the decoder-layer boundaries (forward_segmented) so that each
     layer's gradient slice can be exchanged while the next layer's backward runs: same loss, same gradients, and the slices
     handed to the exchange tile the flat gradient buffer exactly once."""
@@ -411,7 +412,9 @@ def test_layer_segmented_backward_equals_monolithic(dev, name):
             mod.p = 0.0
     b = dev_batch(raw_batch(c), dev)
     sync = _NoSync()
+    monkeypatch.setenv("MTN_DP_SHARDED", "1" if sharded else "0")
     ts = TrainStep(model, b, c["vocab"], pad=fx.PAD, grad_sync=sync, use_graph=False, overlap=True)
+    assert (ts.sharded is not None) == sharded
     model.prepare()
     model._seed.fill_(4242)
     l1 = ts._fwd_bwd()
@@ -429,7 +432,7 @@ def test_layer_segmented_backward_equals_monolithic(dev, name):
     else:
         assert relmax(g1[n_glue:], g2[n_glue:]) < 1e-5
     assert relmax(g1[:n_glue], g2[:n_glue]) < 1e-5
-    covered = sorted(sync.ranges)
+    covered = sorted(ts.sharded.slices) if sharded else sorted(sync.ranges)     # what was handed to the exchange
     assert covered[0][0] == 0 and covered[-1][1] == g1.numel()
     assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
 
