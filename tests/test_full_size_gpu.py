@@ -227,11 +227,17 @@ def test_cfg2_loss_and_gradients_match_oracle_through_the_captured_step():
         assert cos > (0.999999 if dtype == torch.float32 else 0.9995), (dtype, cos)
 
 
-def test_cfg2_two_fused_steps_match_oracle_adam():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_cfg2_two_fused_steps_match_oracle_adam(dtype):
     """Two CAPTURED steps with the optimiser applied inside the parameter-gradient table launch (the schedule the benchmark
     times) against two oracle steps of Adam(0.9, 0.98, 1e-9) under the Noam rate (train.py:190, data_utils.py:92-117), fp32
     mode, dropout off.  The first Adam step only sees the sign of a gradient; the second mixes two gradients, so the update
-    p2 - p0 of every weight matrix is compared: cosine >= 0.999 per tensor, and the loss of the second step within 1e-3."""
+    p2 - p0 of every weight matrix is compared: cosine >= 0.999 per tensor, and the loss of the second step within 1e-3.
+    bf16 mode (bf16 operands, fp32 master weights / moments — the benchmark's arithmetic, fused forward and backward kernels on):
+    second-step loss within 1e-2; update cosine >= 0.99 over all weight matrices together (measured 0.9941, the same with the
+    fused kernels off: it is what bf16 operands do to Adam's normalised step) and >= 0.85 per tensor (measured worst 0.90: the
+    query projection of the top layer's target self-attention, whose gradient over 80 target tokens is tiny and is then
+    normalised by Adam)."""
     from mtn_amd import make_model
     from mtn_amd.synthetic import CONFIGS
     from mtn_amd.train_step import TrainStep
@@ -243,7 +249,7 @@ def test_cfg2_two_fused_steps_match_oracle_adam():
     b = dev_batch(raw, dev)
     torch.manual_seed(0)
     m = make_model(cfg["vocab"], cfg["vocab"], N=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"], dropout=0.0,
-                   ft_sizes=cfg["ft_sizes"], diff_encoder=True, auto_encoder_ft="query", compute_dtype=torch.float32, attn_dropout=0.0).to(dev).train()
+                   ft_sizes=cfg["ft_sizes"], diff_encoder=True, auto_encoder_ft="query", compute_dtype=dtype, attn_dropout=0.0).to(dev).train()
     om, sd = _cfg2_oracle(m, raw, cfg)
     p0 = {k: v.detach().clone() for k, v in sd.items()}
     ob = fx.oracle_batch(raw)
@@ -262,17 +268,23 @@ def test_cfg2_two_fused_steps_match_oracle_adam():
     got_losses = [float(ts()), float(ts())]
     torch.cuda.synchronize()
     assert ts._fused(), "the optimiser epilogue should be on for a single rank"
-    assert abs(got_losses[1] - want_losses[1]) < 1e-3 * abs(want_losses[1]), (got_losses, want_losses)
+    f32 = dtype == torch.float32
+    assert abs(got_losses[1] - want_losses[1]) < (1e-3 if f32 else 1e-2) * abs(want_losses[1]), (got_losses, want_losses)
     got = {k: v.detach().float().cpu() for k, v in m.state_dict().items() if not k.endswith(".pe")}
-    checked = 0
+    checked, dot, n1, n2, worst, worst_k = 0, 0.0, 0.0, 0.0, 1.0, ""
     for k, w in sd.items():
         if w.dim() != 2 or "lut" in k:
             continue
         du_w, du_g = (w.detach() - p0[k]).double().flatten(), (got[k] - p0[k]).double().flatten()
         cos = float(torch.dot(du_w, du_g) / (du_w.norm() * du_g.norm() + 1e-30))
-        assert cos > 0.999, (k, cos)
+        assert cos > (0.999 if f32 else 0.85), (k, cos)
+        if cos < worst:
+            worst, worst_k = cos, k
+        dot += float(torch.dot(du_w, du_g)); n1 += float(du_w.norm()) ** 2; n2 += float(du_g.norm()) ** 2
         checked += 1
     assert checked > 150
+    assert dot / (n1 ** 0.5 * n2 ** 0.5) > (0.9999 if f32 else 0.99)
+    print(f"{dtype}: worst per-tensor update cosine {worst:.5f} ({worst_k}), overall {dot / (n1 ** 0.5 * n2 ** 0.5):.6f}")
 
 
 def test_cfg3_batch64_step_properties():
