@@ -153,6 +153,20 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
 #pragma unroll
         for (int s = 0; s < 8; ++s) wf[s] = *(const uint4*)(wrow + s * 32);
     }
+    // softmax statistics {row max, 1 / row sum} of this wave's first sample (queries 8lg + 4qt + r): in flight with everything else
+    float mxq[2][4], invq[2][4];
+    {
+        const int si0 = wave < nsamp ? wave : 0;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
+                const float2 st = *(const float2*)(M.lse + 2 * ((size_t)((b0 + si0) * (FH_D / FH_DK) + slice) * a + qc));
+                mxq[qt][r] = st.x;
+                invq[qt][r] = st.y;
+            }
+    }
     const DropState ds = drop_init(M.drop);
 
     // ================================================================ on chip from here
@@ -229,15 +243,17 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
             }
         }
         __builtin_amdgcn_wave_barrier();
-        float mxq[2][4], invq[2][4], Dq[2][4];
+        float Dq[2][4];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
-                const float* stp = M.lse + 2 * ((size_t)(b * (FH_D / FH_DK) + slice) * a + qc);
-                mxq[qt][r] = stp[0];
-                invq[qt][r] = stp[1];
+                if (si != wave) {                                  // (blocks of more than 8 samples: later rounds load theirs here)
+                    const float2 st = *(const float2*)(M.lse + 2 * ((size_t)(b * (FH_D / FH_DK) + slice) * a + qc));
+                    mxq[qt][r] = st.x;
+                    invq[qt][r] = st.y;
+                }
                 Dq[qt][r] = Ds[q < 32 ? q : 31];
             }
         f32x4_t dqt[4][2];
