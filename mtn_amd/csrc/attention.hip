@@ -404,6 +404,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
     const T* og = (const T*)A.o + ((size_t)b * a + qo) * A.ldo + hh * DK;
     const T* dog = (const T*)A.d_o + ((size_t)b * a + qo) * A.ldo + hh * DK;
     const DropState ds = drop_init(A.drop);
+    const DropBase dbase = drop_base((uint64_t)(b * A.h + hh) * (uint64_t)a * (uint64_t)m);   // P-dropout index of (q, key) = base + q * m + key
 
     // ---- prologue: A-operand fragments of Q and dO (rows = queries), transposed images, D_q
     uint4 qf[2][NKS], dof[2][NKS];
@@ -539,8 +540,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
                         float dpd = dp[qt][kt][r];
                         pd = p;
                         if (ds.on) {
-                            const uint64_t idx = ((uint64_t)(b * A.h + hh) * a + qo + q) * (uint64_t)m + key;
-                            const bool kp = drop_keep(ds, idx);
+                            const bool kp = drop_keep_at(ds, dbase, (uint32_t)((qo + q) * m + key));
                             pd = kp ? p * ds.scale : 0.f;
                             dpd = kp ? dpd * ds.scale : 0.f;
                         }

@@ -169,6 +169,7 @@ __device__ __forceinline__ void attn_fwd_mfma_body(const mtn_attn_args& A, const
     const T* kg = (const T*)A.k + (size_t)b * m * A.ldkv + hh * DK;
     const T* vg = (const T*)A.v + (size_t)b * m * A.ldkv + hh * DK;
     const DropState ds = drop_init(A.drop);
+    const DropBase dbase = drop_base((uint64_t)(b * A.h + hh) * (uint64_t)a * (uint64_t)m);   // P-dropout index of (q, key) = base + q * m + key
 
     uint4 qf[2][NKS];
 #pragma unroll
@@ -264,8 +265,7 @@ __device__ __forceinline__ void attn_fwd_mfma_body(const mtn_attn_args& A, const
                     psum += pv;
                     if (ds.on) {
                         const int key = j0 + kt * 16 + 4 * lg + r;
-                        const uint64_t idx = ((uint64_t)(b * A.h + hh) * a + qc) * (uint64_t)m + key;
-                        pv = drop_keep(ds, idx) ? pv * ds.scale : 0.f;
+                        pv = drop_keep_at(ds, dbase, (uint32_t)(qc * m + key)) ? pv * ds.scale : 0.f;
                     }
                     st[kt][qt][r] = pv;
                 }

@@ -100,10 +100,25 @@ __device__ __forceinline__ DropState drop_init(const mtn_dropout& d) {
     }
     return s;
 }
+// keep(idx) = lowbias32((lo(idx) ^ k0) + hi(idx) * DROP_HI_MUL) ^ k1, top 24 bits against p * 2^24: one 32-bit mixer per element
+// (two integer multiplies — they run at quarter rate on the vector ALU, and the attention kernels hash 16 elements per lane per tile)
+static constexpr uint32_t DROP_HI_MUL = 0x9E3779B1u;
 __device__ __forceinline__ bool drop_keep(const DropState& s, uint64_t idx) {
-    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-    uint32_t r = mix32(lo ^ s.k0) ^ mix32(hi + s.k1);
-    r = mix32(r + s.k1);
+    const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    const uint32_t r = mix32((lo ^ s.k0) + hi * DROP_HI_MUL) ^ s.k1;
+    return (r >> 8) >= s.thresh;
+}
+// The same function for idx = base + off with a (wave-)uniform 64-bit base and a 32-bit offset: the high word's term is prepared once
+struct DropBase { uint32_t lo, hic; };
+__device__ __forceinline__ DropBase drop_base(uint64_t base) {
+    DropBase b;
+    b.lo = (uint32_t)base;
+    b.hic = (uint32_t)(base >> 32) * DROP_HI_MUL;
+    return b;
+}
+__device__ __forceinline__ bool drop_keep_at(const DropState& s, const DropBase& b, uint32_t off) {
+    const uint32_t lo = b.lo + off;
+    const uint32_t r = mix32((lo ^ s.k0) + b.hic + (lo < b.lo ? DROP_HI_MUL : 0u)) ^ s.k1;
     return (r >> 8) >= s.thresh;
 }
 

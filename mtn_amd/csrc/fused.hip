@@ -356,9 +356,9 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
                 if (ds.on) {
-                    const uint64_t idx = (uint64_t)(row0 + r) * (uint64_t)M.ncols + col;
+                    const DropBase db = drop_base((uint64_t)(row0 + r) * (uint64_t)M.ncols + col);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = drop_keep(ds, idx + k) ? v[k] * ds.scale : 0.f;
+                    for (int k = 0; k < 4; ++k) v[k] = drop_keep_at(ds, db, k) ? v[k] * ds.scale : 0.f;
                 }
             }
             const uint2 u = make_uint2(fh_pack2(v[0], v[1]), fh_pack2(v[2], v[3]));
@@ -409,6 +409,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     for (int it = wave; it < nsamp * nqt; it += 8) {
         const int si = it / nqt, qt = it - si * nqt;
         const int b = b0 + si;
+        const DropBase dbase = drop_base((uint64_t)(b * (FH_D / FH_DK) + slice) * (uint64_t)a * (uint64_t)mk);   // P-dropout index of (q, key) = base + q * mk + key
         const int q = qt * 16 + l15, qc = q < a ? q : a - 1;
         const int qrow = si * a + qc, krow0 = si * mk;
         uint4 qf[2];
@@ -454,8 +455,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
                     psum += pv;
                     if (ds.on) {
                         const int key = c0 + 32 * (kt >> 1) + 8 * lg + 4 * (kt & 1) + r;
-                        const uint64_t idx = ((uint64_t)(b * (FH_D / FH_DK) + slice) * a + qc) * (uint64_t)mk + key;
-                        pv = drop_keep(ds, idx) ? pv * ds.scale : 0.f;
+                        pv = drop_keep_at(ds, dbase, (uint32_t)(qc * mk + key)) ? pv * ds.scale : 0.f;
                     }
                     st[kt][r] = pv;
                 }

@@ -9,10 +9,13 @@
 // everything it reads up front — dy rows (bf16, [row][512]) and the head's q, k, v, o rows (128 bytes each) by LDS-DMA, mask bytes,
 // the 64 rows of W_o^T it needs as coalesced loads (8 waves = 4 column blocks x 2 halves of the contraction, fragments put in
 // MFMA operand order with ds_bpermute) — then works on chip: dO on mfma_f32_16x16x32_bf16 (halves met through LDS) -> bf16 LDS
-// image (dO never goes to HBM), then one wave per sample runs the attention backward over key tiles of 32:
-//     S = Q K^T, dP = dO V^T (row-major images, A rows permuted so that P's C layout is the standard B-operand slot order),
-//     P from the saved {row max, 1 / row sum}, dropout regenerated, dS = P (dP - D),
-//     dV^T = dO^T P, dK^T = Q^T dS (A operands by ds_read_b64_tr_b16 from the row-major images), dQ^T += K^T dS^T (dS through LDS).
+// image (dO never goes to HBM), then the attention backward over key tiles of 32, a team of FOUR waves per sample (a single wave
+// issues one vector instruction per ~5 clocks, and the per-score work — exp, dropout hash, selects — is ~50 instructions):
+//     phase 1, wave = 16 x 16 quadrant of the score tile: S = Q K^T, dP = dO V^T (A rows permuted so that a lane's four scores are
+//              consecutive queries), P from the saved {row max, 1 / row sum}, dropout regenerated, dS = P (dP - D);
+//              P^T and dS^T go to the team's [key][query] LDS images (8-byte writes; double-buffered, one barrier per tile);
+//     phase 2, wave = 16 head columns: dV^T = dO^T P, dK^T = Q^T dS, dQ^T += K^T dS^T — A operands by ds_read_b64_tr_b16 from the
+//              row-major q / dO / k images, B operands straight (or transposed-read) from the tile images; no cross-wave reduction.
 #include "fused_common.h"
 
 #define FB_MAX_MEMBERS MTN_SUBLAYER_MAX_GROUP
@@ -37,14 +40,25 @@ struct FbMember {
     bf16_t* dk;
     bf16_t* dv;
 };
+#ifdef FB_TIMELINE
+// development build (tools/fb_timeline.py): 16 wall-clock stamps (100 MHz) per workgroup of the launch selected with MTN_FB_TL_LAUNCH
+__device__ unsigned long long fb_timeline[256 * 16];
+#define FB_STAMP(k) do { if (tl && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) fb_timeline[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define FB_STAMP(k) do { } while (0)
+#endif
 struct FbGroup {
     int count;
+    int tl;                    // FB_TIMELINE builds: this launch records its stamps
+    int stop;                  // development: leave after stage `stop` (1 loads landed, 2 dO image, 3 attention math; 0 = everything); MTN_FB_STOP
     int wg_start[FB_MAX_MEMBERS + 1];
     FbMember m[FB_MAX_MEMBERS];
 };
 
-static constexpr int FB_DSROW = 80;        // bytes per row of a wave's dS tile image [32 queries][32 keys] (+ 16 pad)
-static constexpr int FB_WAVE_SCRATCH = 32 * FB_DSROW + 32 * 4;
+static constexpr int FB_DSROW = 80;        // bytes per row of a tile image [32 keys][32 queries] bf16 (+ 16 pad)
+static constexpr int FB_TILE_IMG = 32 * FB_DSROW;
+static constexpr int FB_TEAM_SCRATCH = 4 * FB_TILE_IMG;   // a team's {P^T, dS^T} images, double-buffered over key tiles
+static constexpr int FB_SCRATCH = 2 * FB_TEAM_SCRATCH + 8 * 128;      // ... two teams, then D_q[32] of each wave: 21.0 KiB
 
 struct FbLds { int dy, qi, oi, doi, ki, vi, mask, scratch, total; };
 __host__ __device__ inline FbLds fb_lds_map(int mt, int key_rows, int mask_bytes) {
@@ -58,7 +72,7 @@ __host__ __device__ inline FbLds fb_lds_map(int mt, int key_rows, int mask_bytes
     L.vi = L.ki + krows * FH_HROWB;
     L.mask = L.vi + krows * FH_HROWB;
     L.total = L.mask + ((mask_bytes + 15) & ~15);
-    L.scratch = L.dy;                                      // the waves' dS tile images reuse the dy image (dead once dO exists): 8 x 2.6 KiB
+    L.scratch = L.dy;                                      // the teams' tile images reuse the dy image (dead once dO exists; >= 32 KiB)
     return L;
 }
 
@@ -89,8 +103,21 @@ __device__ __forceinline__ uint4 fb_tfrag(const unsigned char* img, int row0, in
     }
     return f;
 }
-__device__ __forceinline__ uint4 fb_frag_from_c(const f32x4_t& lo, const f32x4_t& hi) {
-    return make_uint4(fh_pack2(lo[0], lo[1]), fh_pack2(lo[2], lo[3]), fh_pack2(hi[0], hi[1]), fh_pack2(hi[2], hi[3]));
+// the same transposing read on a tile image [32 rows][32 columns] with FB_DSROW-byte rows (no swizzle): columns n_off + (lane & 15),
+// rows 8*lg .. +7
+__device__ __forceinline__ uint4 fb_tfrag_img(const unsigned char* img, int n_off, int l15, int lg) {
+    uint4 f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int krow = 8 * lg + 4 * r + (l15 >> 2);
+        const int col = n_off + 4 * (l15 & 3);
+        const unsigned addr = (unsigned)(size_t)(img + krow * FB_DSROW + col * 2);
+        unsigned long long v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        if (r == 0) { f.x = (unsigned)v; f.y = (unsigned)(v >> 32); }
+        else { f.z = (unsigned)v; f.w = (unsigned)(v >> 32); }
+    }
+    return f;
 }
 __device__ __forceinline__ float fb_dot8(const uint4& x, const uint4& y) {
     float s = 0.f;
@@ -102,8 +129,9 @@ __device__ __forceinline__ float fb_dot8(const uint4& x, const uint4& y) {
 }
 
 template <int MT>
-__device__ __forceinline__ void fb_body(const FbMember& M, const int slice, const int rb, unsigned char* smem) {
+__device__ __forceinline__ void fb_body(const FbMember& M, const int slice, const int rb, unsigned char* smem, const int stop, const int tl) {
     const int tid = threadIdx.x;
+    FB_STAMP(0);
     const int row0 = rb * M.rows_per_wg;
     const int R = (M.rows - row0) < M.rows_per_wg ? (M.rows - row0) : M.rows_per_wg;
     const int lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
@@ -114,8 +142,8 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     const int Kr = nsamp * mk;                             // key rows of the block
     const size_t krow_g0 = M.self_attn ? (size_t)row0 : (size_t)b0 * M.m;     // first key row of the block in k / v / dk / dv
     const int qa = M.mask_sq ? a : 1;
-    const int mask_bytes = M.mask ? nsamp * qa * mk : 0;
-    const FbLds L = fb_lds_map(MT, M.self_attn ? MT * 16 : M.blk * M.m, M.mask ? M.blk * qa * mk : 0);
+    const int mask_bytes = nsamp * qa * mk;                // the mask image always exists (all ones without a mask): no branch per score
+    const FbLds L = fb_lds_map(MT, M.self_attn ? MT * 16 : M.blk * M.m, M.blk * qa * mk);
     unsigned char* dy_s = smem + L.dy;
     unsigned char* qi_s = smem + L.qi;
     unsigned char* oi_s = smem + L.oi;
@@ -123,8 +151,11 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     unsigned char* ki_s = smem + L.ki;
     unsigned char* vi_s = smem + L.vi;
     unsigned char* mk_s = smem + L.mask;
-    unsigned char* ds_s = smem + L.scratch + wave * FB_WAVE_SCRATCH;      // this wave's dS tile image
-    float* Ds = (float*)(ds_s + 32 * FB_DSROW);                           // ... and D_q of its sample
+    // attention stage: a team of four waves per sample; wave w4 of the team = quadrant (query tile qt, key sub-tile kt) of a 32 x 32
+    // score tile in the first phase, head columns 16 w4 .. +15 of dq, dk, dv in the second
+    const int team = wave >> 2, w4 = wave & 3, qt = w4 & 1, kt = w4 >> 1;
+    unsigned char* tm_s = smem + L.scratch + team * FB_TEAM_SCRATCH;
+    float* Ds = (float*)(smem + L.scratch + 2 * FB_TEAM_SCRATCH + wave * 128);    // D_q of the wave's sample
 
     // ================================================================ everything this workgroup reads, issued now
     uint8_t mkb[FH_MASKB];
@@ -133,7 +164,7 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     for (int i = 0; i < FH_MASKB; ++i) {
         const int idx = tid + FH_THREADS * i;
         mkb[i] = 1;
-        if (idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * mk)];
+        if (M.mask && idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * mk)];
     }
     {   // dy rows [R][512] (rows past R: zeros), 16-byte slots swizzled with row & 15
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(M.dyl + (size_t)row0 * FH_D), 0, R * FH_ROWB, 0x00020000);
@@ -153,21 +184,20 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
 #pragma unroll
         for (int s = 0; s < 8; ++s) wf[s] = *(const uint4*)(wrow + s * 32);
     }
-    // softmax statistics {row max, 1 / row sum} of this wave's first sample (queries 8lg + 4qt + r): in flight with everything else
-    float mxq[2][4], invq[2][4];
+    // softmax statistics {row max, 1 / row sum} of the team's first sample (queries 8lg + 4qt + r): in flight with everything else
+    float mxq[4], invq[4];
     {
-        const int si0 = wave < nsamp ? wave : 0;
+        const int si0 = team < nsamp ? team : 0;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
-                const float2 st = *(const float2*)(M.lse + 2 * ((size_t)((b0 + si0) * (FH_D / FH_DK) + slice) * a + qc));
-                mxq[qt][r] = st.x;
-                invq[qt][r] = st.y;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int q = 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
+            const float2 st = *(const float2*)(M.lse + 2 * ((size_t)((b0 + si0) * (FH_D / FH_DK) + slice) * a + qc));
+            mxq[r] = st.x;
+            invq[r] = st.y;
+        }
     }
     const DropState ds = drop_init(M.drop);
+    FB_STAMP(1);
 
     // ================================================================ on chip from here
 #pragma unroll
@@ -177,6 +207,8 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // LDS-DMA images and weight fragments have landed
     __syncthreads();
+    FB_STAMP(2);
+    if (stop == 1) return;
     {
         const int src = (4 * l15 + lg) * 4;
 #pragma unroll
@@ -195,6 +227,7 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     for (int s = 0; s < 8; ++s)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) mma16<bf16_t>(acc[mt], wf[s], fh_xfrag(dy_s, mt * 16 + l15, (kh * 8 + s) * 4 + lg));
+    FB_STAMP(3);
     __syncthreads();                                            // everybody is past the dy image: it becomes the exchange area
     {
         float* ex = (float*)dy_s + (size_t)wc * (MT * 256) + lane * 4;
@@ -212,169 +245,144 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
             }
     }
     __syncthreads();                                            // dO image complete; the exchange area (in the dy image) is dead too
+    FB_STAMP(4);
+    if (stop == 2) return;
 
-    // ---- attention backward, one wave per sample of the block
+    // ---- attention backward: two samples at a time, a team of four waves each; one workgroup barrier per key tile of 32
     const float scale = 0.125f;
-    for (int si = wave; si < nsamp; si += 8) {
-        const int b = b0 + si, qrow0 = si * a, krow0 = si * mk;
-        // D_q = sum_c dO[q][c] O[q][c]: lanes 2q, 2q+1 each take half a row
-        {
-            const int q = lane >> 1, half = lane & 1, row = qrow0 + q;
-            float sacc = 0.f;
-            if (q < a) {
+    const int nrounds = (nsamp + 1) >> 1;
+    int buf = 0;
+    for (int rd = 0; rd < nrounds; ++rd) {
+        const int si = 2 * rd + team;
+        const bool live = si < nsamp;                              // team-uniform; an idle team only keeps the barriers
+        const int sic = live ? si : nsamp - 1;
+        const int b = b0 + sic, qrow0 = sic * a, krow0 = sic * mk;
+        const DropBase dbase = drop_base((uint64_t)(b * (FH_D / FH_DK) + slice) * (uint64_t)a * (uint64_t)mk);   // P-dropout index of (q, key) = base + q * mk + key
+        uint4 qf[2], dof[2];
+        float Dq[4];
+        f32x4_t dqt[2];                                            // dQ^T[head column 16 w4 + 4lg + r][query 16 qt' + l15]
+        dqt[0] = dqt[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            // D_q = sum_c dO[q][c] O[q][c]: lanes 2q, 2q+1 each take half a row (every wave of the team, for its own use)
+            {
+                const int q = lane >> 1, half = lane & 1, row = qrow0 + q;
+                float sacc = 0.f;
+                if (q < a) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    sacc += fb_dot8(fh_hfrag(doi_s, row, half * 4 + c), fh_hfrag(oi_s, row, half * 4 + c));
+                    for (int c = 0; c < 4; ++c)
+                        sacc += fb_dot8(fh_hfrag(doi_s, row, half * 4 + c), fh_hfrag(oi_s, row, half * 4 + c));
+                }
+                sacc += __shfl_xor(sacc, 1, 64);
+                if (half == 0) Ds[q] = sacc;
             }
-            sacc += __shfl_xor(sacc, 1, 64);
-            if (half == 0) Ds[q] = sacc;
-        }
-        // A fragments of Q and dO: accumulator row i of query tile qt <-> query 8(i/4) + 4qt + (i%4), so that a lane's C values of the
-        // two tiles are queries 8lg + 0..7 — the B-operand slot order of the contractions over the query index
-        uint4 qf[2][2], dof[2][2];
+            // A fragments of Q and dO: accumulator row i of query tile qt <-> query 8(i/4) + 4qt + (i%4), so that the C values of the
+            // two query tiles at one lane group are queries 8lg + 0..7 — the B-operand slot order of the contractions over the query
+            {
+                int q = 8 * (l15 >> 2) + 4 * qt + (l15 & 3);
+                q = q < a ? q : a - 1;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            int q = 8 * (l15 >> 2) + 4 * qt + (l15 & 3);
-            q = q < a ? q : a - 1;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                qf[qt][ks] = fh_hfrag(qi_s, qrow0 + q, ks * 4 + lg);
-                dof[qt][ks] = fh_hfrag(doi_s, qrow0 + q, ks * 4 + lg);
+                for (int ks = 0; ks < 2; ++ks) {
+                    qf[ks] = fh_hfrag(qi_s, qrow0 + q, ks * 4 + lg);
+                    dof[ks] = fh_hfrag(doi_s, qrow0 + q, ks * 4 + lg);
+                }
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-        float Dq[2][4];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
-                if (si != wave) {                                  // (blocks of more than 8 samples: later rounds load theirs here)
+                if (rd != 0) {                                     // (later rounds load their statistics here)
                     const float2 st = *(const float2*)(M.lse + 2 * ((size_t)(b * (FH_D / FH_DK) + slice) * a + qc));
-                    mxq[qt][r] = st.x;
-                    invq[qt][r] = st.y;
+                    mxq[r] = st.x;
+                    invq[r] = st.y;
                 }
-                Dq[qt][r] = Ds[q < 32 ? q : 31];
+                Dq[r] = Ds[q];
             }
-        f32x4_t dqt[4][2];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) dqt[nt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        if (rd == 0) FB_STAMP(5);
 
-        for (int j0 = 0; j0 < mk; j0 += 32) {
-            uint4 kf[2][2], vf[2][2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                int key = j0 + kt * 16 + l15;
-                key = key < mk ? key : mk - 1;
+        for (int j0 = 0; j0 < mk; j0 += 32, buf ^= 1) {
+            unsigned char* pt_s = tm_s + buf * (2 * FB_TILE_IMG);  // P^T (dropped out) [key][query]
+            unsigned char* dst_s = pt_s + FB_TILE_IMG;             // dS^T [key][query]
+            if (live) {
+                // ---- phase 1: this wave's 16 x 16 quadrant of S = Q K^T and dP = dO V^T, then P and dS
+                const int key = j0 + kt * 16 + l15, kc = key < mk ? key : mk - 1;
+                uint4 kf[2], vf[2];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    kf[kt][ks] = fh_hfrag(ki_s, krow0 + key, ks * 4 + lg);
-                    vf[kt][ks] = fh_hfrag(vi_s, krow0 + key, ks * 4 + lg);
+                    kf[ks] = fh_hfrag(ki_s, krow0 + kc, ks * 4 + lg);
+                    vf[ks] = fh_hfrag(vi_s, krow0 + kc, ks * 4 + lg);
                 }
+                f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = sc;   // C layout: rows q = 8lg + 4qt + r, column key
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    mma16<bf16_t>(sc, qf[ks], kf[ks]);
+                    mma16<bf16_t>(dp, dof[ks], vf[ks]);
+                }
+                if (rd == 0 && j0 == 0) FB_STAMP(6);
+                // straight-line code (clamped indices and selects), so that the four elements' dependent chains overlap
+                float pd[4], dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
+                    const bool valid = key < mk && q < a;
+                    const bool keep_score = mk_s[(sic * qa + (M.mask_sq ? qc : 0)) * mk + kc] != 0;
+                    const float sv = keep_score ? sc[r] * scale : -1e9f;
+                    const float p = __expf(sv - mxq[r]) * invq[r];
+                    const bool kp = drop_keep_at(ds, dbase, (uint32_t)(qc * mk + kc));     // dropout off: threshold 0, scale 1
+                    const float pdr = kp ? p * ds.scale : 0.f;
+                    const float dpd = kp ? dp[r] * ds.scale : 0.f;
+                    pd[r] = valid ? pdr : 0.f;
+                    dsv[r] = (valid && keep_score) ? p * (dpd - Dq[r]) : 0.f;
+                }
+                const int off = (kt * 16 + l15) * FB_DSROW + (8 * lg + 4 * qt) * 2;      // the lane's four queries are consecutive
+                *(uint2*)(pt_s + off) = make_uint2(fh_pack2(pd[0], pd[1]), fh_pack2(pd[2], pd[3]));
+                *(uint2*)(dst_s + off) = make_uint2(fh_pack2(dsv[0], dsv[1]), fh_pack2(dsv[2], dsv[3]));
+                if (rd == 0 && j0 == 0) FB_STAMP(7);
             }
-            // S = Q K^T, dP = dO V^T   (C layout: rows q = 8lg + 4qt + r, column key = j0 + 16kt + l15)
-            f32x4_t sc[2][2], dp[2][2];
+            __syncthreads();                                       // the tile's images are complete (the other buffer may still be read)
+            if (live) {
+                // ---- phase 2: head columns 16 w4 .. +15.  dV^T = dO^T P, dK^T = Q^T dS (contraction over the 32 queries, per key
+                // sub-tile), dQ^T += K^T dS^T (contraction over the tile's 32 keys); A operands by transposing reads of the row-major images
+                const uint4 dot_ = fb_tfrag(doi_s, qrow0, w4 * 16, l15, lg);
+                const uint4 qt_ = fb_tfrag(qi_s, qrow0, w4 * 16, l15, lg);
+                const uint4 kt_ = fb_tfrag(ki_s, krow0 + j0, w4 * 16, l15, lg);
+                uint4 pf[2], sf[2], sfq[2];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    sc[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    dp[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        mma16<bf16_t>(sc[qt][kt], qf[qt][ks], kf[kt][ks]);
-                        mma16<bf16_t>(dp[qt][kt], dof[qt][ks], vf[kt][ks]);
-                    }
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    pf[k2] = *(const uint4*)(pt_s + (k2 * 16 + l15) * FB_DSROW + lg * 16);      // keys 16 k2 + l15, queries 8lg .. +7
+                    sf[k2] = *(const uint4*)(dst_s + (k2 * 16 + l15) * FB_DSROW + lg * 16);
+                    sfq[k2] = fb_tfrag_img(dst_s, k2 * 16, l15, lg);                           // queries 16 k2 + l15, keys 8lg .. +7
                 }
-            // P, dS in registers (sc <- dropped-out P, dp <- dS); dS also goes to LDS as [q][key]
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    const int key = j0 + kt * 16 + l15;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int q = 8 * lg + 4 * qt + r;
-                        float pd = 0.f, dsv = 0.f;
-                        if (key < mk && q < a) {
-                            const bool keep_score = !M.mask || mk_s[(size_t)(si * qa + (M.mask_sq ? q : 0)) * mk + key] != 0;
-                            const float sv = keep_score ? sc[qt][kt][r] * scale : -1e9f;
-                            const float p = __expf(sv - mxq[qt][r]) * invq[qt][r];
-                            float dpd = dp[qt][kt][r];
-                            pd = p;
-                            if (ds.on) {
-                                const uint64_t idx = ((uint64_t)(b * (FH_D / FH_DK) + slice) * a + q) * (uint64_t)mk + key;
-                                const bool kp = drop_keep(ds, idx);
-                                pd = kp ? p * ds.scale : 0.f;
-                                dpd = kp ? dpd * ds.scale : 0.f;
-                            }
-                            dsv = keep_score ? p * (dpd - Dq[qt][r]) : 0.f;
-                        }
-                        sc[qt][kt][r] = pd;
-                        dp[qt][kt][r] = dsv;
-                        *(bf16_t*)(ds_s + q * FB_DSROW + (kt * 16 + l15) * 2) = f32_to_bf16(dsv);
-                    }
-                }
-            // dV^T = dO^T Pdrop, dK^T = Q^T dS (contraction over the 32 query rows), written per key tile
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const int key = j0 + kt * 16 + l15;
-                const uint4 pf = fb_frag_from_c(sc[0][kt], sc[1][kt]);
-                const uint4 sf = fb_frag_from_c(dp[0][kt], dp[1][kt]);
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh) {                  // head columns in two halves of 32 (register pressure)
-                    uint4 dot_[2], qt_[2];
-#pragma unroll
-                    for (int n2 = 0; n2 < 2; ++n2) {
-                        dot_[n2] = fb_tfrag(doi_s, qrow0, (2 * nh + n2) * 16, l15, lg);
-                        qt_[n2] = fb_tfrag(qi_s, qrow0, (2 * nh + n2) * 16, l15, lg);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int n2 = 0; n2 < 2; ++n2) {
-                        const int nt = 2 * nh + n2;
-                        f32x4_t av = f32x4_t{0.f, 0.f, 0.f, 0.f}, ak = av;
-                        mma16<bf16_t>(av, dot_[n2], pf);
-                        mma16<bf16_t>(ak, qt_[n2], sf);
-                        if (key < mk) {   // lane holds head columns nt*16 + 4lg + r of key column `key`
-                            const size_t go = (krow_g0 + krow0 + key) * M.ldkv + slice * FH_DK + nt * 16 + 4 * lg;
-                            *(uint2*)(M.dv + go) = make_uint2(fh_pack2(av[0], av[1]), fh_pack2(av[2], av[3]));
-                            *(uint2*)(M.dk + go) = make_uint2(fh_pack2(ak[0] * scale, ak[1] * scale), fh_pack2(ak[2] * scale, ak[3] * scale));
-                        }
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();                   // the dS tile image is complete (same wave, in-order LDS)
-            // dQ^T += K^T dS^T (contraction over the 32 keys of the tile): B = dS rows (query qt*16 + l15), keys 8lg .. 8lg+7
-            {
-                uint4 sfq[2], kft[4];
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) sfq[qt] = *(const uint4*)(ds_s + (qt * 16 + l15) * FB_DSROW + lg * 16);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) kft[nt] = fb_tfrag(ki_s, krow0 + j0, nt * 16, l15, lg);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) mma16<bf16_t>(dqt[nt][qt], kft[nt], sfq[qt]);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // dQ: lane holds dQ^T[head column nt*16 + 4lg + r][query qt*16 + l15]
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int q = qt * 16 + l15;
-            if (q < a) {
-                bf16_t* dqg = M.dq + (size_t)(row0 + qrow0 + q) * M.ldq + slice * FH_DK + 4 * lg;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    *(uint2*)(dqg + nt * 16) = make_uint2(fh_pack2(dqt[nt][qt][0] * scale, dqt[nt][qt][1] * scale), fh_pack2(dqt[nt][qt][2] * scale, dqt[nt][qt][3] * scale));
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    f32x4_t av = f32x4_t{0.f, 0.f, 0.f, 0.f}, ak = av;
+                    mma16<bf16_t>(av, dot_, pf[k2]);
+                    mma16<bf16_t>(ak, qt_, sf[k2]);
+                    mma16<bf16_t>(dqt[k2], kt_, sfq[k2]);
+                    const int key = j0 + k2 * 16 + l15;
+                    if (key < mk && stop != 3) {   // lane holds head columns 16 w4 + 4lg + r of key column `key`
+                        const size_t go = (krow_g0 + krow0 + key) * M.ldkv + slice * FH_DK + w4 * 16 + 4 * lg;
+                        *(uint2*)(M.dv + go) = make_uint2(fh_pack2(av[0], av[1]), fh_pack2(av[2], av[3]));
+                        *(uint2*)(M.dk + go) = make_uint2(fh_pack2(ak[0] * scale, ak[1] * scale), fh_pack2(ak[2] * scale, ak[3] * scale));
+                    }
+                }
+                if (rd == 0 && j0 == 0) FB_STAMP(8);
             }
         }
+        if (rd == 0) FB_STAMP(10);
+        if (live) {
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int q = q2 * 16 + l15;
+                if (q < a && stop != 3) {
+                    bf16_t* dqg = M.dq + (size_t)(row0 + qrow0 + q) * M.ldq + slice * FH_DK + w4 * 16 + 4 * lg;
+                    *(uint2*)dqg = make_uint2(fh_pack2(dqt[q2][0] * scale, dqt[q2][1] * scale), fh_pack2(dqt[q2][2] * scale, dqt[q2][3] * scale));
+                }
+            }
+        }
+        if (rd == 0) FB_STAMP(11);
     }
 }
 
@@ -388,9 +396,9 @@ __global__ __launch_bounds__(FH_THREADS) void fused_head_bwd_kernel(const FbGrou
     const int hpg = (FH_D / FH_DK) / M.hg;
     const int slice = (xcd % M.hg) * hpg + (j % hpg), rb = (j / hpg) * M.sg + (xcd / M.hg);
     if (rb * M.rows_per_wg >= M.rows) return;
-    if (M.mt <= 2) fb_body<2>(M, slice, rb, smem);
-    else if (M.mt == 3) fb_body<3>(M, slice, rb, smem);
-    else fb_body<5>(M, slice, rb, smem);
+    if (M.mt <= 2) fb_body<2>(M, slice, rb, smem, G.stop, G.tl);
+    else if (M.mt == 3) fb_body<3>(M, slice, rb, smem, G.stop, G.tl);
+    else fb_body<5>(M, slice, rb, smem, G.stop, G.tl);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -405,6 +413,7 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
     if (n_mha < 1 || n_mha > FB_MAX_MEMBERS) return false;
     FbGroup& G = P.G;
     memset(&G, 0, sizeof(G));
+    { static const int stop = [] { const char* e = getenv("MTN_FB_STOP"); return e ? atoi(e) : 0; }(); G.stop = stop; }
     const int budget = 256 / n_mha > 8 ? 256 / n_mha : 8;
     const int mts[3] = {2, 3, 5};
     int wgs = 0;
@@ -423,7 +432,7 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
                 if (mts[c] * 16 >= b * A.a) { t = mts[c]; break; }
             if (!t) break;
             if (A.mask && b * qa * m > FH_THREADS * FH_MASKB) break;
-            const int need = fb_lds_map(t, self ? t * 16 : b * m, A.mask ? b * qa * m : 0).total;
+            const int need = fb_lds_map(t, self ? t * 16 : b * m, b * qa * m).total;
             if (need > FB_LDS_MAX) break;
             blk = b; mt = t; l = need;
             if (((A.B + b - 1) / b) * (FH_D / FH_DK) <= budget) break;
@@ -477,7 +486,25 @@ int fb_group_bwd_stage(int n_mha, const mtn_mha_args* mha, const FbIo* io, void*
         }
         attr = true;
     }
+#ifdef FB_TIMELINE
+    {
+        static int launch = 0;
+        static const int want = [] { const char* e = getenv("MTN_FB_TL_LAUNCH"); return e ? atoi(e) : 0; }();
+        P.G.tl = (launch++ == want);
+        if (P.G.tl) {
+            fprintf(stderr, "fb timeline: launch %d, %d workgroups, %zu B LDS\n", want, P.wgs, P.lds);
+            for (int i = 0; i < P.G.count; ++i)
+                fprintf(stderr, "  member %d: wgs %d..%d a=%d m=%d blk=%d mt=%d self=%d mask=%d\n", i, P.G.wg_start[i], P.G.wg_start[i + 1], P.G.m[i].a,
+                        P.G.m[i].m, P.G.m[i].blk, P.G.m[i].mt, P.G.m[i].self_attn, P.G.m[i].mask != nullptr);
+        }
+    }
+#endif
     hipLaunchKernelGGL(fused_head_bwd_kernel, dim3(P.wgs), dim3(FH_THREADS), P.lds, (hipStream_t)stream, P.G);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
+#ifdef FB_TIMELINE
+extern "C" int mtn_fb_timeline_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_timeline), sizeof(unsigned long long) * 256 * 16) == hipSuccess ? MTN_OK : MTN_ERR_LAUNCH;
+}
+#endif

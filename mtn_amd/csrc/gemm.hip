@@ -182,9 +182,9 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
     }
     if (P.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     if (ds.on) {
-        const uint64_t idx = (uint64_t)row * (uint64_t)N + col;
+        const DropBase db = drop_base((uint64_t)row * (uint64_t)N + col);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = drop_keep(ds, idx + r) ? v[r] * ds.scale : 0.f;
+        for (int r = 0; r < 4; ++r) v[r] = drop_keep_at(ds, db, r) ? v[r] * ds.scale : 0.f;
     }
     if (P.gate) {
         const T* gp = (const T*)P.gate + o;
