@@ -108,7 +108,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     const int mk = kind == FH_SELF ? a : m;        // keys (= image rows) per sample
     const int key_rows = ffn ? 0 : ((kind == FH_SELF || raw) ? MT * 16 : nsamp * m);
     const int qa = M.mask_sq ? a : 1;
-    const int mask_bytes = (ffn || !M.mask) ? 0 : nsamp * qa * m;
+    const int mask_bytes = ffn ? 0 : nsamp * qa * m;   // the mask image always exists (all ones without a mask): no branch per score
     const FhLds L = fh_lds_map(MT, raw, key_rows, fh_pad_rows(kind, mk), mask_bytes, ffn ? NP : 0);
     unsigned char* xn_s = smem + L.xn;
     unsigned char* xm_s = smem + L.xm;
@@ -125,7 +125,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     for (int i = 0; i < FH_MASKB; ++i) {
         const int idx = tid + FH_THREADS * i;
         mkb[i] = 1;
-        if (idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * m)];
+        if (M.mask && idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * m)];
     }
     // (2) LDS-DMA: rows of an un-projected memory (x attends an auto-encoder stream, mtn.py:215), or this head's K and V
     //     rows of a memory projected ahead of the layer loop.  Rows past the end arrive as zeros (buffer bound).
@@ -423,42 +423,45 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         for (int c0 = 0; c0 < mk; c0 += 64) {
             // S^T tile kt, accumulator row i <-> key c0 + 32(kt/2) + 8(i/4) + 4(kt%2) + (i%4): a lane's values of tiles 2u, 2u+1
             // are keys c0 + 32u + 8lg + 0..7 — the B-operand slot order of the V^T P^T contraction
+            const bool wide = mk - c0 > 32;                        // keys 32..63 of the chunk exist (uniform): short memories skip that half
             f32x4_t st[4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
+                st[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (kt >= 2 && !wide) continue;
                 int key = c0 + 32 * (kt >> 1) + 8 * (l15 >> 2) + 4 * (kt & 1) + (l15 & 3);
                 key = key < mk ? key : mk - 1;
-                st[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) mma16<bf16_t>(st[kt], fh_hfrag(ki_s, krow0 + key, ks * 4 + lg), qf[ks]);
             }
+            // straight-line per score (clamped indices, selects): the lane's dependent chains have to overlap each other
             float mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= 2 && !wide) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = c0 + 32 * (kt >> 1) + 8 * lg + 4 * (kt & 1) + r;
-                    float sv = st[kt][r] * scale;
-                    if (key >= mk) sv = -INFINITY;
-                    else if (M.mask && mrow[key] == 0) sv = -1e9f;
+                    const int key = c0 + 32 * (kt >> 1) + 8 * lg + 4 * (kt & 1) + r, kc = key < mk ? key : mk - 1;
+                    float sv = mrow[kc] != 0 ? st[kt][r] * scale : -1e9f;
+                    sv = key < mk ? sv : -INFINITY;
                     st[kt][r] = sv;
                     mx = fmaxf(mx, sv);
                 }
+            }
             mx = fh_cross_max(mx);
             const float mn = fmaxf(mrun, mx);
             float psum = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= 2 && !wide) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pv = __expf(st[kt][r] - mn);             // exp(-inf) = 0 for chunk padding
+                    const int key = c0 + 32 * (kt >> 1) + 8 * lg + 4 * (kt & 1) + r, kc = key < mk ? key : mk - 1;
+                    const float pv = __expf(st[kt][r] - mn);       // exp(-inf) = 0 for chunk padding
                     psum += pv;
-                    if (ds.on) {
-                        const int key = c0 + 32 * (kt >> 1) + 8 * lg + 4 * (kt & 1) + r;
-                        pv = drop_keep_at(ds, dbase, (uint32_t)(qc * mk + key)) ? pv * ds.scale : 0.f;
-                    }
-                    st[kt][r] = pv;
+                    st[kt][r] = drop_keep_at(ds, dbase, (uint32_t)(qc * mk + kc)) ? pv * ds.scale : 0.f;     // dropout off: threshold 0, scale 1
                 }
+            }
             psum = fh_cross_sum(psum);
             const float alpha = (mrun == -INFINITY) ? 0.f : __expf(mrun - mn);
             lrun = lrun * alpha + psum;
@@ -467,6 +470,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             for (int nt = 0; nt < 4; ++nt) { ot[nt][0] *= alpha; ot[nt][1] *= alpha; ot[nt][2] *= alpha; ot[nt][3] *= alpha; }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !wide) continue;
                 const uint4 pf = make_uint4(fh_pack2(st[2 * u][0], st[2 * u][1]), fh_pack2(st[2 * u][2], st[2 * u][3]),
                                             fh_pack2(st[2 * u + 1][0], st[2 * u + 1][1]), fh_pack2(st[2 * u + 1][2], st[2 * u + 1][3]));
                 uint4 vf[4];
@@ -556,7 +560,7 @@ static int fh_member_lds(const mtn_mha_args& A, int blk, int mt) {
     const bool self = A.self_attn != 0, raw = !self && !A.kv_ready;
     const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
     const int kind = self ? FH_SELF : (raw ? FH_CROSS_RAW : FH_CROSS_READY);
-    return fh_lds_map(mt, raw, (self || raw) ? mt * 16 : blk * m, fh_pad_rows(kind, m), A.mask ? blk * qa * m : 0).total;
+    return fh_lds_map(mt, raw, (self || raw) ? mt * 16 : blk * m, fh_pad_rows(kind, m), blk * qa * m).total;
 }
 // Rows per workgroup for an attention member: whole samples, inside the row tiles (<= 80 rows) and the LDS; as few workgroups as
 // it takes to stay within the member's share of one round of the chip (these launches are bound by the bytes each CU pulls:
