@@ -322,6 +322,9 @@ typedef struct {
     const void* dyl_ready;
     void* next_dyl;
     mtn_dropout next_drop;
+    /* forward, optional: compute-dtype copy of y [rows,d], written by the same epilogue — for an output that a later sublayer
+       attends as un-projected memory (an auto-encoder stream, mtn.py:215), which otherwise costs a cast launch */
+    void* y_lp;
 } mtn_ffn_args;
 int mtn_ffn_sublayer_fwd(int dtype, const mtn_ffn_args* args, void* stream);
 int mtn_ffn_sublayer_bwd(int dtype, const mtn_ffn_args* args, void* stream);

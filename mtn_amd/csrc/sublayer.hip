@@ -166,7 +166,7 @@ extern "C" int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* 
         for (int i = 0; i < n_ffn; ++i) {
             const mtn_ffn_args* a = &ffn[i];
             p[n] = gemm_init(a->hid, a->d_ff, a->w2, a->d_ff, a->rows, a->d, a->d_ff, 0, 0);
-            p[n].bias = a->b2; p[n].drop = a->drop_out; p[n].residual = a->x; p[n].ldr = a->d; p[n].out_f32 = a->y; p[n].ldc = a->d; ++n;
+            p[n].bias = a->b2; p[n].drop = a->drop_out; p[n].residual = a->x; p[n].ldr = a->d; p[n].out_f32 = a->y; p[n].out_lp = a->y_lp; p[n].ldc = a->d; ++n;
         }
         RUN(mtn_gemm(dtype, n, p, stream));
     }

@@ -71,7 +71,7 @@ class FfnArgs(C.Structure):
                 ("d_ln_a", C.c_void_p), ("d_ln_b", C.c_void_p), ("d_w1", C.c_void_p), ("d_b1", C.c_void_p),
                 ("d_w2", C.c_void_p), ("d_b2", C.c_void_p),
                 ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int),
-                ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout)]
+                ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout), ("y_lp", C.c_void_p)]
 
 
 class LossHeadArgs(C.Structure):

@@ -213,12 +213,14 @@ class DecoderLayer(nn.Module):
         self.sublayer = nn.ModuleList([SublayerConnection(size, dropout) for _ in range(5 + 4 * len(auto_encoder_vid_attn))])
 
     @staticmethod
-    def _run_group(items):
+    def _run_group(items, raw_memory_outputs=False):
         """items: [(sublayer_connection, module, mem, mask, input)] that do not depend on each other -> their outputs,
-        computed by one lockstep group (ops.SublayerGroupFn: shared launches)."""
+        computed by one lockstep group (ops.SublayerGroupFn: shared launches).  raw_memory_outputs: the feed-forward outputs are
+        attended as un-projected memory later (the auto-encoder streams, mtn.py:215): they also leave in the compute dtype."""
         members, tensors = [], []
         for sc, mod, mem, mask, inp in items:
             mb = sc.member(mod, mem, mask)
+            mb.want_lp = raw_memory_outputs and mb.kind == "ffn"
             kv = getattr(sc, "_kv_ready", None)        # K|V of a constant memory projected ahead of the layer loop
             if kv is not None and mb.kind == "mha" and mem is not None and kv.size(0) == mem.size(0) * mem.size(1):
                 mb.kv_ready = kv
@@ -235,6 +237,8 @@ class DecoderLayer(nn.Module):
             res[k] = outs[pos]
             if members[k].holder is not None:
                 outs[pos]._mtn_next = members[k].holder
+            if members[k].out_lp is not None:
+                outs[pos]._mtn_lp = members[k].out_lp
         return res
 
     def _plan(self, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask, ae_features):
@@ -270,7 +274,7 @@ class DecoderLayer(nn.Module):
         aes = [ae_fts[i] if isinstance(ae_fts, (list, tuple)) else ae_fts for i in range(nF)]
         for j in range(3):
             items = [text[j] + (x,)] + [chains[i][j] + (aes[i],) for i in range(nF)]
-            outs = run(items)
+            outs = run(items, raw_memory_outputs=(j == 2))
             x, aes = outs[0], list(outs[1:])
         x = run([text[3] + (x,)])[0]
         for i in range(nF):
@@ -287,7 +291,7 @@ class DecoderLayer(nn.Module):
         nF = len(vid_fts)
         aes = [ae_fts[i] if isinstance(ae_fts, (list, tuple)) else ae_fts for i in range(nF)]
         for j in range(3):
-            aes = self._run_group([chains[i][j] + (aes[i],) for i in range(nF)])
+            aes = self._run_group([chains[i][j] + (aes[i],) for i in range(nF)], raw_memory_outputs=(j == 2))
         return aes
 
     def forward_target(self, x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, aes, ae_features):

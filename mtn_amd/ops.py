@@ -485,6 +485,8 @@ class GroupMember:
     holder: Optional[dict] = None
     feeds: Optional[dict] = None
     kv_ready: Optional[torch.Tensor] = None     # K|V of a constant memory, projected ahead of the layer loop (project_memories)
+    want_lp: bool = False                       # 'ffn': also write the output in the compute dtype (-> out_lp): it is attended as raw memory
+    out_lp: Optional[torch.Tensor] = None
 
 
 class SublayerGroupFn(torch.autograd.Function):
@@ -573,6 +575,9 @@ class SublayerGroupFn(torch.autograd.Function):
                 A.w1, A.b1, A.w2, A.b2 = cfg.w1_lp.data_ptr(), mb.params[2].data_ptr(), cfg.w2_lp.data_ptr(), mb.params[3].data_ptr()
                 A.w1_t, A.w2_t = L.ptr(cfg.w1_lpT), L.ptr(cfg.w2_lpT)
                 A.y, A.xn, A.mean, A.rstd, A.hid = y.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), hid.data_ptr()
+                if mb.want_lp and lp != torch.float32:
+                    mb.out_lp = torch.empty(y.shape, device=dev, dtype=lp)
+                    A.y_lp = mb.out_lp.data_ptr()
                 saved.append(dict(x=x, xn=xn, mean=mean, rstd=rstd, hid=hid))
             ys.append(y)
         L.check(lib.mtn_sublayer_group_fwd(code, n_mha, mha_args, n_ffn, ffn_args, L.stream_ptr()))

@@ -23,3 +23,7 @@ for r in step:
 tot = sum(sum(v) for v in agg.values())
 for k,v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:int(sys.argv[2]) if len(sys.argv)>2 else 30]:
     print(f"{k[0]:46s} wgs={k[1]:6d} n={len(v):4d} avg={sum(v)/len(v):8.2f} us  total={sum(v):8.1f} ({100*sum(v)/tot:4.1f}%)")
+if len(sys.argv) > 3:      # the step's launches in order: index, start offset, duration, workgroups, name
+    with open(sys.argv[3], "w") as f:
+        for i, r in enumerate(step):
+            f.write(f"{i:3d} {(r[1]-t0)/1e3:8.1f} {(r[2]-r[1])/1e3:7.2f} us wgs={r[3]//max(1,r[4]):5d}  {r[0].split('(')[0][-60:]}\n")
