@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const AttnGro
 }
 
 template <typename T, int DK, int NW> static int launch_fwd_mfma_nw(const AttnGroup& G, dim3 grid, hipStream_t s) {
-    const size_t vt = (size_t)DK * (MK * sizeof(T) + 16);
+    const size_t vt = (size_t)DK * (MK * sizeof(T) + tpad<T>());
     if constexpr (NW == 1) {
         hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, DK, 1>), grid, dim3(64), vt, s, G);
     } else {
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
     constexpr int NDT = DK / 16;
     constexpr int TPK = KSTEP / 16;                    // C tiles per contraction step over a 32-long index (bf16 2, fp32 1)
     constexpr int NU = 32 / KSTEP;                     // contraction steps over 32 queries / 32 keys (bf16 1, fp32 2)
-    constexpr int ROWB = 32 * (int)sizeof(T) + 16;     // bytes per row of the transposed images (32 entries + pad)
+    constexpr int ROWB = 32 * (int)sizeof(T) + tpad<T>();     // bytes per row of the transposed images (32 entries + pad)
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
 }
 
 template <typename T, int DK, int NW> static int launch_bwd_mfma_nw(const AttnGroup& G, dim3 grid, hipStream_t s) {
-    const size_t rowb = 32 * sizeof(T) + 16;
+    const size_t rowb = 32 * sizeof(T) + tpad<T>();
     const size_t shared = 2 * (size_t)DK * rowb + 32 * sizeof(float), per_wave = ((size_t)DK + 32) * rowb;
     if constexpr (NW == 1) {
         hipLaunchKernelGGL((attn_bwd_mfma_kernel<T, DK, 1>), grid, dim3(64), shared + per_wave, s, G);

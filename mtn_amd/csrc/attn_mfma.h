@@ -27,13 +27,29 @@ template <typename T> __device__ __forceinline__ uint4 load_frag(const T* base, 
     return valid ? *(const uint4*)base : make_uint4(0, 0, 0, 0);
 }
 
+// Row pad of a transposed image and the lane -> 4x4 block map of its staging.  ds_write_b64 is served in groups of 16 contiguous
+// lanes over 32 banks: with 16 column blocks per row (d_k = 64) a group takes 4 column blocks x 4 row blocks, and with a pitch of
+// 8 (mod 32) bytes their 8-byte pieces (column block * 4 rows * pitch + row block * 8) fall on 16 different bank pairs; the plain
+// map (16 column blocks of one row block per group) with a pitch of 16 (mod 32) put them on 2 (SQ_LDS_BANK_CONFLICT 0.6-0.76).
+template <typename T> __host__ __device__ constexpr int tpad() { return sizeof(T) == 2 ? 8 : 16; }
+__device__ __forceinline__ void tblk(int blk, int cb_n, int& kb, int& cb) {
+    if (cb_n == 16) {
+        cb = (blk & 3) | (((blk >> 4) & 3) << 2);
+        kb = ((blk >> 2) & 3) | ((blk >> 6) << 2);
+    } else {
+        kb = blk / cb_n;
+        cb = blk - kb * cb_n;
+    }
+}
+
 // 4x4 block transpose staging: src rows [r0, r0+nrows) x ncols (row stride ld, rows clamped to rmax-1) -> dst[col][row]
 template <typename T>
 __device__ __forceinline__ void stage_transposed(unsigned char* dst, int dst_row_bytes, const T* src, int ld, int r0, int nrows,
                                                  int rmax, int ncols, int lane) {
     const int cb_n = ncols >> 2, nblk = (nrows >> 2) * cb_n;
     for (int blk = lane; blk < nblk; blk += 64) {
-        const int kb = blk / cb_n, cb = blk - kb * cb_n;
+        int kb, cb;
+        tblk(blk, cb_n, kb, cb);
         if constexpr (sizeof(T) == 2) {
             uint2 v[4];
 #pragma unroll
@@ -74,7 +90,8 @@ template <typename T, int NB> struct TStage {
         for (int i = 0; i < NB; ++i) {
             const int blk = lane + 64 * i;
             if (blk < nblk) {
-                const int kb = blk / cb_n, cb = blk - kb * cb_n;
+                int kb, cb;
+        tblk(blk, cb_n, kb, cb);
                 if constexpr (sizeof(T) == 2) {
                     uint2 t[4];
 #pragma unroll
@@ -102,7 +119,8 @@ template <typename T, int NB> struct TStage {
         for (int i = 0; i < NB; ++i) {
             const int blk = lane + 64 * i;
             if (blk < nblk) {
-                const int kb = blk / cb_n, cb = blk - kb * cb_n;
+                int kb, cb;
+        tblk(blk, cb_n, kb, cb);
                 if constexpr (sizeof(T) == 2) {
                     const uint32_t a0 = v[i][0].x, a1 = v[i][0].y, b0 = v[i][0].z, b1 = v[i][0].w;   // rows k0 (a), k1 (b)
                     const uint32_t c0 = v[i][1].x, c1 = v[i][1].y, d0 = v[i][1].z, d1 = v[i][1].w;   // rows k2 (c), k3 (d)
@@ -156,7 +174,7 @@ __device__ __forceinline__ void attn_fwd_mfma_body(const mtn_attn_args& A, const
     constexpr int NDT = DK / 16;                      // 16-column tiles of the head dimension
     constexpr int TPK = KSTEP / 16;                   // 16-key C tiles per contraction step over keys (bf16 2, fp32 1)
     constexpr int NU = MK / KSTEP;                    // contraction steps per key tile
-    constexpr int VT_ROW = MK * (int)sizeof(T) + 16;  // bytes per row of the transposed V image
+    constexpr int VT_ROW = MK * (int)sizeof(T) + tpad<T>();  // bytes per row of the transposed V image
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
     unsigned char* vt = fsm + (size_t)wave * DK * VT_ROW;
     const int a = A.a, m = A.m;
