@@ -83,15 +83,24 @@ def test_fused_model_matches_oracle(dev, name):
 
 
 @pytest.mark.parametrize("name", ["query_b5", "shared_b7"])
-def test_fused_backward_equals_four_launch_path(dev, name):
-    """Gradients of every parameter with the fused launches on vs off (dropout off): cosine >= 0.9999 and 5e-2 relative to max
-    per tensor.  The backward consumes the saved buffers of whichever forward ran; a hidden unit whose pre-activation sits at a
-    bf16 rounding boundary of zero switches its ReLU gate between the two forwards, which moves single entries of the w_1
-    gradient by a few percent of the largest entry (measured 3e-2) while the direction of every tensor stays the same."""
+@pytest.mark.parametrize("dropout", [0.0, 0.1], ids=["nodrop", "drop"])
+def test_fused_backward_equals_four_launch_path(dev, name, dropout):
+    """Gradients of every parameter with the fused launches on vs off — without dropout, and with the same dropout streams (the
+    backward kernel regenerates the attention-dropout mask from the seed).  The backward consumes the saved buffers of whichever
+    forward ran, so the two gradients differ by the forward's bf16 rounding differences; a hidden unit whose pre-activation sits
+    at a rounding boundary of zero switches its ReLU gate, which moves single entries of the w_1 gradient by a few percent of the
+    largest entry.  Measured over 6 seeds x 2 shapes (tools/dbg_fused_bwd_spread.py): per-tensor cosine 0.99986-0.99996 and
+    ||diff|| / ||ref|| 0.9-1.7e-2 under dropout (cosine > 0.9999 without), single entries <= 1.5e-2 of the largest (w_1: <= 5.8e-2).
+    Bars: cosine 0.9999 (0.9997 under dropout), ||diff||/||ref|| 2.5e-2, single entries 5e-2 (w_1: 1e-1)."""
     c = CFGS[name]
-    model = build_model(c, torch.bfloat16, dev).train()          # dropout 0 (build_model's default)
+    torch.manual_seed(0)
+    model = build_model(c, torch.bfloat16, dev, dropout=dropout, attn_dropout=dropout).train()
     b = dev_batch(raw_batch(c), dev)
+    model.prepare()
+    model._seed.fill_(1234)                    # (the dropout seed defaults to torch.initial_seed(): pin it)
+    seed0 = model._seed.clone()
     _, gref = _run(model, b, fused=False, train=True)
+    model._seed.copy_(seed0)
     _, ggot = _run(model, b, fused=True, train=True)
     assert gref.keys() == ggot.keys()
     for k in gref:
@@ -99,5 +108,6 @@ def test_fused_backward_equals_four_launch_path(dev, name):
         if float(r.abs().max()) == 0.0 or k.endswith("linears.1.bias"):
             continue        # key-projection biases: mathematically zero gradient (a key bias shifts every score of a row equally) = rounding noise
         cos = float(torch.dot(r, g) / (r.norm() * g.norm() + 1e-30))
-        assert cos > 0.9999, (k, cos)
-        assert relmax(g, r) < 5e-2, (k, relmax(g, r))
+        assert cos > (0.9997 if dropout > 0 else 0.9999), (k, cos)
+        assert float((g - r).norm() / r.norm()) < 2.5e-2, (k, float((g - r).norm() / r.norm()))
+        assert relmax(g, r) < (1e-1 if ".w_1." in k else 5e-2), (k, relmax(g, r))
