@@ -430,6 +430,9 @@ class Decoder(nn.Module):
         for layer in self.layers:
             x, auto_encoded_ft = layer(x, cap_memory, cap_mask, his_memory, his_mask, query_memory, query_mask, tgt_mask,
                                        vid_ft, vid_mask, auto_encoded_ft, auto_encoded_features)
+        if x.is_cuda and len(auto_encoded_ft) == len(self.ae_norm) and all(t.size(-1) == x.size(-1) for t in auto_encoded_ft):
+            ys = ops.layer_norm_group([x] + list(auto_encoded_ft), [self.norm] + list(self.ae_norm))      # one launch each way
+            return ys[0], ys[1:]
         return self.norm(x), [self.ae_norm[i](ft) for i, ft in enumerate(auto_encoded_ft)]
 
 

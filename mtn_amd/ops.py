@@ -255,6 +255,93 @@ class LayerNormFn(torch.autograd.Function):
         return dx, ret_a, ret_b, None, None, None, None, None
 
 
+class LayerNormGroupFn(torch.autograd.Function):
+    """Several independent LayerNorms (mtn.py:111-114; the decoder's final norms, mtn.py:164) in ONE launch each way.
+    spec: norms = [(a2, b2, eps, grad_a, grad_b)] (grad_* = fp32 destinations or None), lp_dtype, queue.  With a compute dtype the
+    outputs also go, in order, to consecutive row ranges of one buffer (spec['_lp_rows'], [sum rows, d]) — the operand of the
+    loss head's GEMM, which then needs no cast launch.  Parameter gradients are written to grad_* (deferred through the queue)
+    or, without destinations, returned through autograd as usual."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        lib = L.load()
+        n = len(spec["norms"])
+        xs = [t.contiguous() for t in tensors[:n]]
+        _require_cuda(*xs)
+        dev = xs[0].device
+        lp = spec["lp_dtype"]
+        want_lp = lp is not None and lp != torch.float32
+        code = L.dtype_code(lp) if want_lp else L.MTN_F32
+        d = xs[0].size(-1)
+        rows = [x.numel() // d for x in xs]
+        y_lp = torch.empty(sum(rows), d, device=dev, dtype=lp) if want_lp else None
+        descs = (L.LnFwdDesc * n)()
+        ys, saved, off = [], [], 0
+        for i, (x, (a2, b2, eps, _ga, _gb)) in enumerate(zip(xs, spec["norms"])):
+            y = torch.empty_like(x)
+            mean = torch.empty(rows[i], device=dev, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            D = descs[i]
+            D.rows, D.d, D.eps, D.x, D.a2, D.b2 = rows[i], d, eps, x.data_ptr(), a2.data_ptr(), b2.data_ptr()
+            D.y_f32, D.y_lp, D.mean, D.rstd = y.data_ptr(), (y_lp[off:].data_ptr() if want_lp else None), mean.data_ptr(), rstd.data_ptr()
+            ys.append(y)
+            saved.append((x, mean, rstd))
+            off += rows[i]
+        L.check(lib.mtn_layernorm_fwd_group(code, n, descs, L.stream_ptr()))
+        spec["_lp_rows"] = y_lp
+        ctx.spec, ctx.saved, ctx.rows, ctx.d = spec, saved, rows, d
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        lib = L.load()
+        spec, saved, rows, d = ctx.spec, ctx.saved, ctx.rows, ctx.d
+        n = len(saved)
+        queue = spec.get("queue")
+        descs = (L.LnBwdDesc * n)()
+        dxs, finals, keep, rets = [], [], [], []
+        for i, ((x, mean, rstd), (a2, _b2, eps, ga, gb)) in enumerate(zip(saved, spec["norms"])):
+            g = gs[i].contiguous() if gs[i] is not None else torch.zeros_like(x)
+            dx = torch.empty_like(x)
+            partial = torch.empty(lib.mtn_layernorm_bwd_partial_floats(rows[i], d), device=x.device, dtype=torch.float32)
+            B_ = descs[i]
+            B_.rows, B_.d, B_.eps, B_.x, B_.a2, B_.mean, B_.rstd = rows[i], d, eps, x.data_ptr(), a2.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+            B_.g, B_.dx, B_.partial = g.data_ptr(), dx.data_ptr(), partial.data_ptr()
+            da = ga if ga is not None else torch.empty_like(a2)
+            db = gb if gb is not None else torch.empty_like(a2)
+            finals.append((L.LnFinalizeDesc(partial.data_ptr(), lib.mtn_layernorm_bwd_nparts(rows[i]), d, da.data_ptr(), db.data_ptr()), partial, ga is not None))
+            rets.append((None if ga is not None else da, None if gb is not None else db))
+            dxs.append(dx)
+            keep += [g, partial]
+        L.check(lib.mtn_layernorm_bwd_group(n, descs, L.stream_ptr()))
+        now = []
+        for desc, partial, has_dest in finals:
+            if queue is not None and has_dest:
+                queue.add(queue.dtype, [], desc, [partial])
+            else:
+                now.append(desc)
+        if now:
+            L.check(lib.mtn_layernorm_bwd_finalize(len(now), (L.LnFinalizeDesc * len(now))(*now), L.stream_ptr()))
+        ctx.keep = keep
+        return (None,) + tuple(dxs) + tuple(r[0] for r in rets) + tuple(r[1] for r in rets)
+
+
+def layer_norm_group(xs, modules):
+    """-> [y_i fp32] for independent LayerNorm modules (mtn_amd.mtn.LayerNorm) in one launch; each output carries
+    `_mtn_lp_rows = (buffer, first row, rows)`: its compute-dtype copy inside one [sum rows, d] buffer (None in fp32 mode)."""
+    spec = dict(norms=[(m.a_2, m.b_2, m.eps) + (tuple(m._grads) if m._grads is not None else (None, None)) for m in modules],
+                lp_dtype=modules[0]._lp_dtype, queue=modules[0]._queue)
+    params = [m.a_2 for m in modules] + [m.b_2 for m in modules]        # autograd inputs (gradients returned when no destination is set)
+    ys = LayerNormGroupFn.apply(spec, *xs, *params)
+    buf, off = spec.get("_lp_rows"), 0
+    for y in ys:
+        r = y.numel() // y.size(-1)
+        if buf is not None:
+            y._mtn_lp_rows = (buf, off, r)
+        off += r
+    return list(ys)
+
+
 def layer_norm(x, a2, b2, eps=1e-6, lp_dtype=None, grad_a=None, grad_b=None, queue=None):
     """-> (y fp32, y in the compute dtype).  grad_a/grad_b: optional fp32 destinations for da2/db2."""
     y, y_lp = LayerNormFn.apply(x, a2, b2, eps, lp_dtype, grad_a, grad_b, queue)
@@ -917,7 +1004,17 @@ class GeneratorLossFn(torch.autograd.Function):
         d, V = xs[0].size(-1), spec["vocab"]
         rows = [x.numel() // d for x in xs]
         R = sum(rows)
-        x_lp = torch.empty(R, d, device=dev, dtype=lp)
+        # inputs that are consecutive row ranges of one compute-dtype buffer already (layer_norm_group): no cast
+        ready, off = None, 0
+        for i, x in enumerate(xs):
+            tag = getattr(x, "_mtn_lp_rows", None)
+            if tag is None or tag[1] != off or tag[2] != rows[i] or tag[0].dtype != lp or (ready is not None and tag[0] is not ready):
+                ready = None
+                break
+            ready, off = tag[0], off + rows[i]
+        if ready is not None and ready.size(0) != R:
+            ready = None
+        x_lp = ready if ready is not None else torch.empty(R, d, device=dev, dtype=lp)
         logits = torch.empty(R, V, device=dev, dtype=torch.float32)
         casts = (L.CastDesc * len(xs))()
         off = 0
@@ -929,7 +1026,9 @@ class GeneratorLossFn(torch.autograd.Function):
             offs.append(off)
             off += rows[i]
             ctx_keep = xc
-        if lp == torch.float32:
+        if ready is not None:
+            pass
+        elif lp == torch.float32:
             for i, x in enumerate(xs):
                 x_lp[offs[i]:offs[i] + rows[i]].copy_(x.reshape(rows[i], d))
         else:
