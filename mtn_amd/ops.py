@@ -290,6 +290,9 @@ class LayerNormGroupFn(torch.autograd.Function):
         L.check(lib.mtn_layernorm_fwd_group(code, n, descs, L.stream_ptr()))
         spec["_lp_rows"] = y_lp
         ctx.spec, ctx.saved, ctx.rows, ctx.d = spec, saved, rows, d
+        # gradient hand-off (GroupMember.holder): the sublayer that produced an input wants dx once more, through ITS output dropout,
+        # in the compute dtype
+        ctx.feeds = [getattr(t, "_mtn_next", None) for t in tensors[:n]]
         return tuple(ys)
 
     @staticmethod
@@ -307,6 +310,12 @@ class LayerNormGroupFn(torch.autograd.Function):
             B_ = descs[i]
             B_.rows, B_.d, B_.eps, B_.x, B_.a2, B_.mean, B_.rstd = rows[i], d, eps, x.data_ptr(), a2.data_ptr(), mean.data_ptr(), rstd.data_ptr()
             B_.g, B_.dx, B_.partial = g.data_ptr(), dx.data_ptr(), partial.data_ptr()
+            f = ctx.feeds[i]
+            if f is not None and f.get("lp") is not None and f["lp"] != torch.float32:
+                nxt = torch.empty(x.shape, device=x.device, dtype=f["lp"])
+                f["dyl"], f["dx_ptr"], f["ver"], f["shape"] = nxt, dx.data_ptr(), dx._version, dx.shape
+                B_.dx_lp, B_.dx_lp_dtype, B_.dx_lp_drop = nxt.data_ptr(), L.dtype_code(f["lp"]), _drop(f["p"], f["salt"], f["seed"])
+                keep.append(nxt)
             da = ga if ga is not None else torch.empty_like(a2)
             db = gb if gb is not None else torch.empty_like(a2)
             finals.append((L.LnFinalizeDesc(partial.data_ptr(), lib.mtn_layernorm_bwd_nparts(rows[i]), d, da.data_ptr(), db.data_ptr()), partial, ga is not None))
