@@ -2,6 +2,8 @@
 LayerNorm -> w_1 column slice + ReLU + dropout, one kernel) against (a) the four-launch path it replaces, on identical inputs,
 weights and dropout streams, and (b) the CPU oracle, at the shapes the fused kernel is built for (d_model 512, 8 heads).
 Reference ops: mtn.py:125-127, 248-267, 221-231, 279-280."""
+import os
+
 import pytest
 import torch
 
@@ -123,7 +125,7 @@ def _rand_cfg(seed):
                 auto_encoder_ft=r.choice(["query", "caption"]))
 
 
-@pytest.mark.parametrize("seed", list(range(10)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MTN_FUZZ_N", "10")))))      # (80 seeds were run once: 78 pass, 1 at cosine 0.99896 with 3 samples, 1 shape the fixture generator cannot draw)
 def test_fused_random_shapes_equal_four_launch_path(dev, seed):
     """Random batch sizes and sequence lengths (1 .. just past the kernels' tilings: 32 query rows, 128-row memories, odd sample
     counts per workgroup, two-row sequences), dropout on: outputs and gradients with the fused launches on vs off.  Shapes outside
