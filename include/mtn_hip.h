@@ -457,6 +457,14 @@ typedef struct {
 int mtn_assemble_features(int count, const mtn_assemble_features_desc* descs /* host array */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Candidate selection of the beam search (data_utils.py:219 argsorts each hypothesis' vocabulary row on the host).
+ * Per row of x [rows, V] (row stride ldx): the k largest entries in descending order (equal values: ascending column),
+ * packed as out[row] = { k values, k column indices as floats, x[row][extra_col] } (2k+1 floats; extra_col < 0: 0).
+ * 1 <= k <= 16, V < 2^24.
+ * ------------------------------------------------------------------------------------------ */
+int mtn_topk_rows(const float* x, int rows, int V, long ldx, int k, int extra_col, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement support (bench.py `roofline`): a census of the GEMM launches of one step.  Between mtn_census_begin() and
  * mtn_census_end() (returns the number of launches) every mtn_gemm call is recorded on the host (no device work, no
  * change to the launch); mtn_census_info() describes launch i — which kernel the dispatch picked, its workgroup count,

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 
 from . import ops
@@ -30,9 +32,14 @@ class DecodeSession:
     """Everything about one dialogue that does not depend on the target prefix, plus the replayable target-stream pass.
     A session is reusable for further dialogues of the same shapes (``load``): buffers and the captured graph persist."""
 
-    def __init__(self, model, batch, max_len: int, width: int, pad: int = 1, use_graph: bool = True, kv_cache: bool = False):
+    def __init__(self, model, batch, max_len: int, width: int, pad: int = 1, use_graph: bool = True, kv_cache: bool = False,
+                 select=None):
         self.model, self.width, self.max_len, self.pad = model, width, max_len, pad
         self.kv_cache = bool(kv_cache)
+        # select = (k, column): the pass also leaves, per row, its k largest log-probabilities, their columns and that column's
+        # value in self.top (ops.topk_rows, inside the captured graph): the beam search reads only that
+        self.select = select if (select is not None and batch.query.is_cuda) else None
+        self.top = None
         self.use_graph = use_graph and batch.query.is_cuda
         dev = batch.query.device
         self.q = self.cp = self.hs = self.aes = self.masks = None
@@ -101,6 +108,19 @@ class DecodeSession:
             kvs = model.hoist_memory_kv(self.cp, self.hs, self.q, [], outs=None if first else self._kvs)
             if kvs is not None:
                 self._kvs, self._kv_pairs = kvs, list(model._kv_targets)
+                # ... and of the auto-encoder outputs the target stream attends un-projected (mtn.py:215): they do not change
+                # with the prefix either, so their K|V leave the per-token pass as well (2 x N projections of Q rows per token)
+                items, scs = [], []
+                for k, layer in enumerate(model.decoder.layers):
+                    for i, mem in enumerate(self.aes[k]):
+                        f = layer.auto_encoder_attn[i].fused()
+                        if f.get("w_qkv_lp") is None or mem._mtn_lp.dtype != lp:
+                            continue
+                        items.append((mem._mtn_lp, f["w_qkv_lp"], f["b_qkv"]))
+                        scs.append(layer.sublayer[7 + 4 * i])
+                if items:
+                    self._ae_kvs = ops.project_memories(items, lp, None if first else getattr(self, "_ae_kvs", None))
+                    self._kv_pairs += list(zip(scs, self._ae_kvs))
             model.clear_memory_kv()
             new_masks = (b.cap_mask, b.his_mask, b.query_mask)
             rep = lambda mk: mk.repeat_interleave(width, dim=0)
@@ -126,6 +146,8 @@ class DecodeSession:
         x = m.decoder.norm(x)
         last = x.index_select(1, self.pos).squeeze(1)               # (width, d): the position being extended
         self.logp = m.generator(last).float()                       # (width, V) log-probabilities (mtn.py:68-69)
+        if self.select is not None:
+            self.top = ops.topk_rows(self.logp, min(self.select[0], self.logp.size(1)), self.select[1])
 
     def _pass_cached(self, cur: int):
         """One target position (self.pos) for every hypothesis, against the prefix cache: gather the cache rows of the parents
@@ -150,6 +172,8 @@ class DecodeSession:
             m.clear_memory_kv()
         x = m.decoder.norm(x)
         self.logp = m.generator(x.squeeze(1)).float()
+        if self.select is not None:
+            self.top = ops.topk_rows(self.logp, min(self.select[0], self.logp.size(1)), self.select[1])
 
     def _step_cached(self, prefix_lists):
         l = len(prefix_lists[0][0])
@@ -182,9 +206,9 @@ class DecodeSession:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self._pass_cached(cur)
-                    g = self._graphs[cur] = (g, self.logp)          # each graph writes its own output buffer
+                    g = self._graphs[cur] = (g, self.logp, self.top)          # each graph writes its own output buffers
                 g[0].replay()
-                self.logp = g[1]
+                self.logp, self.top = g[1], g[2]
         self._cur = 1 - cur
         return [self.logp[d * W:d * W + len(p)] for d, p in enumerate(prefix_lists)]
 
@@ -230,10 +254,10 @@ KV_CACHE_FROM = 32      # prefix K/V cache by default for searches longer than t
                         # pass is launch-latency-bound and as fast; the cache makes a token cost O(l) instead of O(l^2) work beyond it)
 
 
-def _session(model, batch, max_len, width, pad, use_graph, kv_cache=False) -> DecodeSession:
+def _session(model, batch, max_len, width, pad, use_graph, kv_cache=False, select=None) -> DecodeSession:
     """Sessions are kept per (model, shapes): a dialogue with the shapes of an earlier one reuses its buffers and graph.
     The cache is dropped when the model's weights change (prepare() version) or it grows past a few shapes."""
-    key = DecodeSession.signature(model, batch, max_len, width) + (bool(use_graph), bool(kv_cache))
+    key = DecodeSession.signature(model, batch, max_len, width) + (bool(use_graph), bool(kv_cache), select)
     model.prepare()
     ver = getattr(model, "_flat_version", None)
     hit = _SESSIONS.get(key)
@@ -242,7 +266,7 @@ def _session(model, batch, max_len, width, pad, use_graph, kv_cache=False) -> De
         return hit[0]
     if len(_SESSIONS) >= 8:
         _SESSIONS.clear()
-    sess = DecodeSession(model, batch, max_len, width, pad=pad, use_graph=use_graph, kv_cache=kv_cache)
+    sess = DecodeSession(model, batch, max_len, width, pad=pad, use_graph=use_graph, kv_cache=kv_cache, select=select)
     _SESSIONS[key] = (sess, ver)
     return sess
 
@@ -306,20 +330,28 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
     Returns a list of D (n-best list, best score) pairs, each equal to what the single-dialogue search returns."""
     if kv_cache is None:
         kv_cache = max_len > KV_CACHE_FROM
-    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph, kv_cache)
-    beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
     k = beam + 2
+    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph, kv_cache, select=(k + 1, end_symbol))
+    beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
     for l in range(max_len):
         logps = sess.step_many([bm.prefixes() for bm in beams])
-        allp = torch.cat(logps, 0)
-        tv, ti = torch.topk(allp, min(k + 1, allp.size(1)), dim=-1)          # device-side selection: only the heads of the rows travel
-        packed = torch.cat([tv.double(), ti.double(), allp[:, end_symbol:end_symbol + 1].double()], 1).cpu().numpy()
-        kk = tv.size(1)
+        if sess.top is not None:
+            # device-side selection inside the pass (csrc/select.hip): only the heads of the rows travel, in one copy
+            full = sess.top.cpu().numpy().astype("float64")
+            live = [r for d, lp in enumerate(logps) for r in range(d * sess.width, d * sess.width + lp.size(0))]
+            packed = full[live]
+            kk = (packed.shape[1] - 1) // 2
+            allp = None
+        else:
+            allp = torch.cat(logps, 0)
+            tv, ti = torch.topk(allp, min(k + 1, allp.size(1)), dim=-1)
+            packed = torch.cat([tv.double(), ti.double(), allp[:, end_symbol:end_symbol + 1].double()], 1).cpu().numpy()
+            kk = tv.size(1)
         vals, idx, eos = packed[:, :kk], packed[:, kk:2 * kk].astype("int64"), packed[:, 2 * kk]
         # exact ties inside a row's head would make the visiting order depend on the selection algorithm: the reference's
         # order (argsort, data_utils.py:219) is then taken from the full row
         tie = bool((vals[:, 1:] == vals[:, :-1]).any())
-        host = allp.double().cpu().numpy() if tie else None
+        host = (allp if allp is not None else torch.cat(logps, 0)).double().cpu().numpy() if tie else None
         o = 0
         for bm, lp in zip(beams, logps):
             n = lp.size(0)

@@ -782,6 +782,16 @@ class SublayerGroupFn(torch.autograd.Function):
         return (None, *grads_out)
 
 
+def topk_rows(x, k, extra_col=-1):
+    """x (rows, V) fp32 -> (rows, 2k+1) fp32: per row its k largest entries in descending order, their column indices (as floats)
+    and x[row, extra_col] — the part of a log-probability row the beam search looks at (data_utils.py:219), csrc/select.hip."""
+    _require_cuda(x)
+    x = x.contiguous()
+    out = torch.empty(x.size(0), 2 * k + 1, device=x.device, dtype=torch.float32)
+    L.check(L.load().mtn_topk_rows(x.data_ptr(), x.size(0), x.size(1), x.stride(0), k, extra_col, out.data_ptr(), L.stream_ptr()))
+    return out
+
+
 # ------------------------------------------------------------------------------------------ memory K/V, ahead of the layers
 def project_memories(items, lp_dtype, outs=None):
     """K|V projections (mtn.py:257-258) of CONSTANT memories for many sublayers at once: items = [(mem_lp (B,m,d) compute dtype,

@@ -500,3 +500,22 @@ def test_gemm_tt_table_form(dev, with_adam):
                 assert relmax(e["out"], gref) < 1e-4
             else:
                 assert bool(torch.isnan(e["out"]).all())                       # the gradient never went to memory
+
+
+@pytest.mark.parametrize("rows,V,k,ld_pad", [(1, 7, 3, 0), (5, 3000, 7, 0), (8, 3000, 1, 5), (3, 5000, 6, 0), (2, 16, 16, 0)])
+def test_topk_rows_matches_sort(dev, rows, V, k, ld_pad):
+    """csrc/select.hip against a stable descending sort (equal values in ascending column order): values, columns and the
+    extra column; rows with repeated values; a row stride larger than V; rows longer than the register path (V > 4096)."""
+    from mtn_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(rows * 1000 + V + k)
+    x = torch.randn(rows, V + ld_pad, generator=g)
+    x[0, : min(V, 5)] = 1.5                                   # ties at the top of a row
+    if rows > 1:
+        x[1].round_(decimals=1)                               # many repeated values
+    xd = x.to(dev)[:, :V]
+    out = ops.topk_rows(xd, k, extra_col=min(3, V - 1)).cpu()
+    ref = x[:, :V].double()
+    order = torch.argsort(-ref, dim=1, stable=True)[:, :k]
+    assert torch.equal(out[:, k:2 * k].long(), order)
+    assert torch.equal(out[:, :k].double(), torch.gather(ref, 1, order))
+    assert torch.equal(out[:, 2 * k].double(), ref[:, min(3, V - 1)])
