@@ -293,6 +293,14 @@ class LayerNormGroupFn(torch.autograd.Function):
         # gradient hand-off (GroupMember.holder): the sublayer that produced an input wants dx once more, through ITS output dropout,
         # in the compute dtype
         ctx.feeds = [getattr(t, "_mtn_next", None) for t in tensors[:n]]
+        # an input that a sublayer attends as memory too (the last layer's auto-encoder outputs): the two gradients meet in one
+        # buffer (protocol of SublayerGroupFn: `_mtn_gacc`) instead of an autograd add
+        ctx.xaccs = []
+        for t in tensors[:n]:
+            xg = getattr(t, "_mtn_gacc", None) if (_XACC and t.requires_grad) else None
+            if xg is not None:
+                xg["remaining"] += 1
+            ctx.xaccs.append(xg)
         return tuple(ys)
 
     @staticmethod
@@ -311,7 +319,7 @@ class LayerNormGroupFn(torch.autograd.Function):
             B_.rows, B_.d, B_.eps, B_.x, B_.a2, B_.mean, B_.rstd = rows[i], d, eps, x.data_ptr(), a2.data_ptr(), mean.data_ptr(), rstd.data_ptr()
             B_.g, B_.dx, B_.partial = g.data_ptr(), dx.data_ptr(), partial.data_ptr()
             f = ctx.feeds[i]
-            if f is not None and f.get("lp") is not None and f["lp"] != torch.float32:
+            if f is not None and f.get("lp") is not None and f["lp"] != torch.float32 and ctx.xaccs[i] is None:   # (a shared gradient buffer is not final here)
                 nxt = torch.empty(x.shape, device=x.device, dtype=f["lp"])
                 f["dyl"], f["dx_ptr"], f["ver"], f["shape"] = nxt, dx.data_ptr(), dx._version, dx.shape
                 B_.dx_lp, B_.dx_lp_dtype, B_.dx_lp_drop = nxt.data_ptr(), L.dtype_code(f["lp"]), _drop(f["p"], f["salt"], f["seed"])
@@ -323,6 +331,18 @@ class LayerNormGroupFn(torch.autograd.Function):
             dxs.append(dx)
             keep += [g, partial]
         L.check(lib.mtn_layernorm_bwd_group(n, descs, L.stream_ptr()))
+        for i, xg in enumerate(ctx.xaccs):
+            if xg is None:
+                continue
+            xg["remaining"] -= 1
+            if xg["buf"] is None and xg["remaining"] > 0:
+                xg["buf"], dxs[i] = dxs[i], None                  # first writer: the memory-role users accumulate into our dx
+            elif xg["buf"] is not None:
+                buf = xg["buf"]
+                buf.add_(dxs[i])
+                dxs[i] = None
+                if xg["remaining"] == 0:
+                    dxs[i], xg["buf"] = buf, None
         now = []
         for desc, partial, has_dest in finals:
             if queue is not None and has_dest:

@@ -90,12 +90,18 @@ class TrainStep:
         try:
             out, ae_out = m.forward(b)
             loss = self.lc.loss(out, b.trg_y, self._norms[0], ae_out, self._ae_y, self._norms[1])
-            loss.backward()
+            loss.backward(self._unit_grad(loss))          # (a kept ones scalar: autograd would launch a fill for the implicit one)
         except BaseException:
             if m._queue is not None:
                 m._queue.reset()
             raise
         return loss.detach()
+
+    def _unit_grad(self, loss):
+        g = getattr(self, "_one", None)
+        if g is None or g.device != loss.device or g.dtype != loss.dtype:
+            g = self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        return g
 
     def _optim(self):
         self.opt.step()
@@ -133,7 +139,7 @@ class TrainStep:
             st = m.forward_segmented(b)
             self._st = st
             loss = self.lc.loss(st["out"], b.trg_y, self._norms[0], st["ae_out"], self._ae_y, self._norms[1])
-            loss.backward()                                     # loss head + final LayerNorms
+            loss.backward(self._unit_grad(loss))                # loss head + final LayerNorms
             ins, outs = st["layers"][N - 1]
             bwd(outs, st["top_in"])                             # top decoder layer
             self._loss_t = loss.detach()
