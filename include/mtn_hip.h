@@ -98,6 +98,8 @@ typedef struct {
     float* out_f32;
     void* out_lp;
     int ldc;
+    int lp_drop_after_residual; /* != 0: `drop` is NOT applied to v; it is applied to the out_lp copy only, after the residual
+                                   (an accumulated gradient leaving also as the masked compute-dtype operand of its consumer) */
     float* rowsum_out;
     const mtn_adam_fuse* adam; /* HOST pointer, read during the call only; NULL = plain GEMM */
 } mtn_gemm_problem;
@@ -279,6 +281,11 @@ typedef struct {
     /* forward, cross attention: 1 = `kv` already holds K|V of the memory (projected ahead of the layer loop for every layer
        that attends the same constant memory, one grouped GEMM): the sublayer skips that projection.  Backward is unchanged. */
     int kv_ready;
+    /* backward, optional: the memory gradient after THIS sublayer's contribution is final (the caller knows: last user of a
+       shared gradient buffer) and its producer wants it once more through its output dropout in the compute dtype
+       [B*m, d] — written by the dmem GEMM's epilogue instead of a cast launch */
+    void* dmem_lp;
+    mtn_dropout dmem_lp_drop;
 } mtn_mha_args;
 int mtn_mha_sublayer_fwd(int dtype, const mtn_mha_args* args, void* stream);
 int mtn_mha_sublayer_bwd(int dtype, const mtn_mha_args* args, void* stream);

@@ -181,7 +181,7 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
         else for (int r = 0; r < nv; ++r) v[r] += P.bias[col + r];
     }
     if (P.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-    if (ds.on) {
+    if (ds.on && !P.lp_drop_after_residual) {
         const DropBase db = drop_base((uint64_t)row * (uint64_t)N + col);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = drop_keep_at(ds, db, r) ? v[r] * ds.scale : 0.f;
@@ -212,6 +212,11 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
     }
     if (P.out_lp) {
         T* op = (T*)P.out_lp + o;
+        if (ds.on && P.lp_drop_after_residual) {          // the stored f32 value stays whole; only this copy goes through the dropout
+            const DropBase db = drop_base((uint64_t)row * (uint64_t)N + col);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = drop_keep_at(ds, db, r) ? v[r] * ds.scale : 0.f;
+        }
         if (vec) {
             if constexpr (sizeof(T) == 2) {
                 *(uint2*)op = make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16), (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));

@@ -297,6 +297,7 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
                     p[n] = a->w_qkv_t ? gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv_t, d, dtype), 3 * d, rows_m, d, 2 * d, 0, 0)
                                       : gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv, (long)d * d, dtype), d, rows_m, d, 2 * d, 0, 1);
                     if (a->dmem_accumulate) { p[n].residual = a->dmem; p[n].ldr = d; }
+                    if (a->dmem_lp) { p[n].out_lp = a->dmem_lp; p[n].drop = a->dmem_lp_drop; p[n].lp_drop_after_residual = 1; }
                     p[n].out_f32 = a->dmem; p[n].ldc = d; ++n;
                 }
             }

@@ -32,7 +32,8 @@ class GemmProblem(C.Structure):
                 ("bias", C.c_void_p), ("relu", C.c_int), ("drop", Dropout),
                 ("gate", C.c_void_p), ("gate_scale", C.c_float),
                 ("residual", C.c_void_p), ("ldr", C.c_int),
-                ("out_f32", C.c_void_p), ("out_lp", C.c_void_p), ("ldc", C.c_int), ("rowsum_out", C.c_void_p),
+                ("out_f32", C.c_void_p), ("out_lp", C.c_void_p), ("ldc", C.c_int), ("lp_drop_after_residual", C.c_int),
+                ("rowsum_out", C.c_void_p),
                 ("adam", C.POINTER(AdamFuse))]
 
 
@@ -57,7 +58,8 @@ class MhaArgs(C.Structure):
                 ("d_ln_a", C.c_void_p), ("d_ln_b", C.c_void_p),
                 ("d_w_qkv", C.c_void_p), ("d_b_qkv", C.c_void_p), ("d_w_o", C.c_void_p), ("d_b_o", C.c_void_p),
                 ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int),
-                ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout), ("kv_ready", C.c_int)]
+                ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout), ("kv_ready", C.c_int),
+                ("dmem_lp", C.c_void_p), ("dmem_lp_drop", Dropout)]
 
 
 class FfnArgs(C.Structure):

@@ -20,6 +20,7 @@ from . import lib as L
 
 # ------------------------------------------------------------------------------------------ helpers
 _XACC = os.environ.get("MTN_NO_XACC") != "1"
+_HANDOFF_MEM = os.environ.get("MTN_NO_MEM_HANDOFF") != "1"     # a memory's final gradient also leaves its last dmem GEMM as the producer's masked dy
 
 
 def _drop(p: float, salt: int, seed: Optional[torch.Tensor]) -> L.Dropout:
@@ -675,7 +676,8 @@ class SublayerGroupFn(torch.autograd.Function):
                         mem_t._mtn_gacc = gacc
                     gacc["remaining"] += 1
                 saved.append(dict(x=x, mem_lp=mem_lp, mask=mask_u8, xn=xn, mean=mean, rstd=rstd, qkv=qkv, kv=kv, o=o, lse=lse,
-                                  need_dmem=need_dmem, gacc=gacc, m=m))
+                                  need_dmem=need_dmem, gacc=gacc, m=m,
+                                  mem_next=getattr(mem_t, "_mtn_next", None) if need_dmem else None))   # the memory's producer (hand-off holder)
             else:
                 rows = x.numel() // d
                 ff = cfg.w1_lp.size(0)
@@ -750,6 +752,7 @@ class SublayerGroupFn(torch.autograd.Function):
                 A = mha_args[im]; im += 1
                 B, a, d, m = A.B, A.a, A.d, sv["m"]
                 dmem, dmem_ret, accumulate = None, None, 0
+                A.dmem_lp = None
                 if sv["need_dmem"]:
                     gacc = sv["gacc"]
                     if gacc["buf"] is None:
@@ -760,6 +763,13 @@ class SublayerGroupFn(torch.autograd.Function):
                     gacc["remaining"] -= 1
                     if gacc["remaining"] == 0:       # last user (first in forward order): hand the sum to autograd once
                         dmem_ret, gacc["buf"] = dmem, None
+                        # ... and, through the dmem GEMM's epilogue, to the sublayer that produced the memory: the sum once
+                        # more, through that sublayer's output dropout, in the compute dtype (its backward then needs no cast)
+                        fm = sv.get("mem_next")
+                        if fm is not None and fm.get("lp") == cfg.lp_dtype and cfg.lp_dtype != torch.float32 and _HANDOFF_MEM:
+                            dmem_lp = torch.empty(dmem.shape, device=dev, dtype=cfg.lp_dtype)
+                            fm["dyl"], fm["dx_ptr"], fm["ver"], fm["shape"] = dmem_lp, dmem.data_ptr(), dmem._version, dmem.shape
+                            A.dmem_lp, A.dmem_lp_drop = dmem_lp.data_ptr(), _drop(fm["p"], fm["salt"], fm["seed"])
                 ws_lp = torch.empty(lib.mtn_mha_bwd_ws_lp_elems(B, a, m, d, A.self_attn), device=dev, dtype=cfg.lp_dtype)
                 ws_f32 = torch.empty(lib.mtn_mha_bwd_ws_f32_floats(B, a, m, d), device=dev, dtype=torch.float32)
                 A.dy, A.dx, A.dmem, A.dmem_accumulate = dy.data_ptr(), dx.data_ptr(), L.ptr(dmem), accumulate
