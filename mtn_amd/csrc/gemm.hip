@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_dma128_table_kernel(const TTHe
     mtn_gemm_problem P;
     P.A = Q.A; P.B = Q.B; P.lda = Q.lda; P.ldb = Q.ldb; P.M = Q.M; P.N = Q.N; P.K = Q.K; P.a_trans = 1; P.b_trans = 1;
     P.bias = nullptr; P.relu = 0; P.drop.p = 0.f; P.drop.salt = 0; P.drop.seed = nullptr; P.gate = nullptr; P.gate_scale = 1.f;
-    P.residual = nullptr; P.ldr = 0; P.out_f32 = Q.out; P.out_lp = nullptr; P.ldc = Q.ldc; P.rowsum_out = Q.rowsum; P.adam = nullptr;
+    P.residual = nullptr; P.ldr = 0; P.out_f32 = Q.out; P.out_lp = nullptr; P.ldc = Q.ldc; P.lp_drop_after_residual = 0; P.rowsum_out = Q.rowsum; P.adam = nullptr;
     AdamSlot S;
     S.p = Q.p; S.m = Q.m; S.v = Q.v; S.lp = Q.lp; S.lpT = Q.lpT; S.ldT = Q.ldT; S.write_grad = Q.write_grad;
     // the problem's tiles are consecutive grid indices starting at first_tile: same XCD-aware band mapping as xcd_tile()
