@@ -930,8 +930,12 @@ class EncoderDecoder(nn.Module):
             x_in, ae_in = cut(x_out), [cut(a) for a in ae_out]
         self.clear_memory_kv()
         top_in = [x_in] + ae_in
-        out = self.decoder.norm(x_in)
-        ae_fin = [self.decoder.ae_norm[i](a) for i, a in enumerate(ae_in)]
+        if x_in.is_cuda and len(ae_in) == len(self.decoder.ae_norm):
+            ys = ops.layer_norm_group([x_in] + list(ae_in), [self.decoder.norm] + list(self.decoder.ae_norm))    # as Decoder.forward
+            out, ae_fin = ys[0], ys[1:]
+        else:
+            out = self.decoder.norm(x_in)
+            ae_fin = [self.decoder.ae_norm[i](a) for i, a in enumerate(ae_in)]
         return dict(enc_out=enc_out, enc_leaf=enc_leaf, layers=layers, top_in=top_in, out=out, ae_out=ae_fin)
 
     def decode(self, encoded_vid_features, his_memory, cap_memory, query_memory, vid_features_mask, his_mask, cap_mask,
