@@ -19,6 +19,8 @@ struct GemmGroup {
     mtn_gemm_problem p[MTN_GEMM_MAX_GROUP];
 };
 
+int gemm_k512_try(int count, const mtn_gemm_problem* p, int min_tiles, hipStream_t s, int* tiles_out);      // gemm_k512.hip
+
 // Optimiser epilogue of the parameter-gradient kernels (mtn_adam_fuse): second kernel argument of the T x T kernels only.
 struct AdamSlot { float *p, *m, *v; void* lp; void* lpT; int ldT, write_grad; };
 struct AdamGroup {
@@ -1169,11 +1171,11 @@ static std::vector<CensusEntry> g_census;
 static std::vector<CensusTable> g_census_tables;
 static bool g_census_on = false;
 static int g_variant = 0, g_variant_tiles = 0;     // set by launch_gemm: which kernel the dispatch picked
-enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_DMA128, V_DMA64H, V_DMA32H, V_TT_TABLE, V_COUNT };
+enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_DMA128, V_DMA64H, V_DMA32H, V_TT_TABLE, V_K512, V_COUNT };
 static const char* const g_variant_name[V_COUNT] = {
     "gemm_kernel<N,N> 64x64 reg-staged", "gemm_kernel<N,T>", "gemm_kernel<T,N>", "gemm_kernel<T,T> 64x64 reg-staged",
     "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
-    "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages", "gemm_tt_dma128_table_kernel"};
+    "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages", "gemm_tt_dma128_table_kernel", "gemm_k512_kernel"};
 
 template <typename T, int BM, int BN, int ROWB>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
@@ -1378,8 +1380,15 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
         const mtn_gemm_problem& p = problems[i];
         if (p.rowsum_out || (long)p.M * p.lda * esz >= (1L << 31) || (long)p.N * p.ldb * esz >= (1L << 31)) dma_ok = false;
     }
-    const int rc = (dtype == MTN_BF16) ? launch_gemm<bf16_t>(grp, adam, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s)
-                                       : launch_gemm<float>(grp, adam, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s);
+    // many large problems with the short contraction K = 512 (the memories' K|V projections for all layers): csrc/gemm_k512.hip
+    int rc = 1, k512_tiles = 0;
+    static const int k512_min = [] { const char* e = getenv("MTN_GEMM_K512_MIN_TILES"); return e ? atoi(e) : 512; }();
+    const int took = (dtype == MTN_BF16 && k512_min > 0) ? gemm_k512_try(count, problems, k512_min, s, &k512_tiles) : 0;
+    if (took < 0) { mtn_set_error("gemm_k512_kernel: launch failed"); return MTN_ERR_LAUNCH; }
+    if (took == 1) { g_variant = V_K512; g_variant_tiles = k512_tiles; rc = MTN_OK; }
+    else
+        rc = (dtype == MTN_BF16) ? launch_gemm<bf16_t>(grp, adam, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s)
+                                 : launch_gemm<float>(grp, adam, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s);
     if (g_census_on && rc == MTN_OK) {
         CensusEntry e;
         memset(&e, 0, sizeof(e));

@@ -519,3 +519,35 @@ def test_topk_rows_matches_sort(dev, rows, V, k, ld_pad):
     assert torch.equal(out[:, k:2 * k].long(), order)
     assert torch.equal(out[:, :k].double(), torch.gather(ref, 1, order))
     assert torch.equal(out[:, 2 * k].double(), ref[:, min(3, V - 1)])
+
+
+def test_gemm_k512_many_large_problems(dev):
+    """csrc/gemm_k512.hip (taken for launches of >= 512 output tiles of 128 x 128 with K = 512, plain bias epilogue into a bf16
+    output — the memories' K|V projections): several problems in one launch, row counts that are not multiples of the tile, a
+    narrow N, row strides larger than the row, against fp32 matmul of the same bf16 operands (one bf16 rounding of the result)."""
+    import ctypes as C
+    from mtn_amd import lib as L
+    lib = L.load()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    shapes = [(4096, 1024, 512, 1024), (1000, 1024, 512, 1024), (640, 520, 640, 528), (4096, 1024, 512, 1024), (4096, 1024, 512, 1024), (1280, 1024, 512, 1024)]
+    probs = (L.GemmProblem * len(shapes))()
+    keep, refs = [], []
+    for i, (M, N, lda, ldc) in enumerate(shapes):
+        a = (torch.randn(M, lda, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+        w = (torch.randn(N, 512, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+        b = torch.randn(N, generator=g).to(dev)
+        out = torch.full((M, ldc), 7.0, device=dev, dtype=torch.bfloat16)
+        p = probs[i]
+        p.A, p.B, p.lda, p.ldb, p.M, p.N, p.K = a.data_ptr(), w.data_ptr(), lda, 512, M, N, 512
+        p.bias, p.gate_scale, p.out_lp, p.ldc = b.data_ptr(), 1.0, out.data_ptr(), ldc
+        keep += [a, w, b]
+        refs.append((out, a[:, :512].float() @ w.float().t() + b, N))
+    lib.mtn_census_begin()
+    L.check(lib.mtn_gemm(L.MTN_BF16, len(shapes), probs, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert lib.mtn_census_end() == 1
+    info = L.CensusLaunch(); lib.mtn_census_info(0, C.byref(info))
+    assert lib.mtn_census_variant_name(info.variant).decode() == "gemm_k512_kernel"
+    for out, ref, N in refs:
+        assert relmax(out[:, :N].float(), ref) < 1e-2
+        assert bool((out[:, N:].float() == 7.0).all())             # nothing written past the problem's columns
