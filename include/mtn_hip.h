@@ -183,7 +183,7 @@ typedef struct {
     int nparts, d;
     float *da2, *db2;
 } mtn_ln_finalize_desc;
-#define MTN_LN_FINALIZE_MAX_GROUP 64
+#define MTN_LN_FINALIZE_MAX_GROUP 112 /* descriptors per launch (3.6 KB of kernel arguments): all LayerNorms of a cfg2 step in one */
 int mtn_layernorm_bwd_finalize(int count, const mtn_ln_finalize_desc* descs /* host array */, void* stream);
 int mtn_layernorm_bwd(int rows, int d, float eps, const float* x, const float* a2, const float* mean,
                       const float* rstd, const float* g, const float* dres, float* dx, float* da2, float* db2,
