@@ -80,7 +80,8 @@ class DecodeSession:
         (rows d*width .. d*width+width-1 belong to dialogue d)."""
         model, width, b = self.model, self.width, batch
         self.D = D = b.query.size(0)
-        model.eval()
+        if model.training:                       # (nn.Module.eval() walks every submodule: ~1 ms of Python per dialogue)
+            model.eval()
         model.prepare()
         lp = model.compute_dtype
         with torch.no_grad():
