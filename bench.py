@@ -49,8 +49,10 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--bf16-grad-allreduce", action="store_true")
     ap.add_argument("--windows", type=int, default=4, help="extra timed windows of --steps steps after the one `value` comes from")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (batch-64 figure at N=1, "
-                    "exchange-free single-rank figure at N>1)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (batch-64 figure, one-rank RCCL "
+                    "schedule and decode figures at N=1, exchange-free single-rank figure at N>1)")
+    ap.add_argument("--no-record", action="store_true", help="development probe: allows MTN_DP_EMULATE_WORLD (a rank updates 1/N of "
+                    "every slice as in an N-GPU job — WRONG parameters, timing only); the line is then marked \"record\": false")
     args = ap.parse_args()
     if args.workload is None:
         args.workload = "cfg2" if args.gpus == 1 else "cfg3"
@@ -124,6 +126,80 @@ def decode_cpu_baseline(model, cfg, max_len, beam, live, SOS, UNK, EOS):
             "kind": "port", "sample": f"1 dialogue, same search, fp32 oracle: {t_cpu:.2f} s"}
 
 
+def decode_measure(model, cfg, dev, beam=4, max_len=20, dialogues=4, batch_dialogues=8, cpu_steps=5, use_graph=True, cpu=True):
+    """BASELINE configs[4] (cfg5) on the model of the train-step line: beam search exactly as generate.py -> data_utils.py:188-242
+    drives it (every step extends `beam` live hypotheses; the loop always runs max_len steps), one synthetic dialogue at a time and
+    `batch_dialogues` side by side; greedy; and, as cpu_baseline, the FIRST `cpu_steps` steps of the same search on the CPU oracle
+    (a bounded sample: the whole 20-step search takes ~40 s per dialogue on the host).  hypothesis-tokens = decode() calls of the
+    reference's loop = 1 + (steps - 1) * beam per dialogue."""
+    from mtn_amd.decode import beam_search_decode, beam_search_decode_many, greedy_decode
+    from mtn_amd.synthetic import synthetic_batch
+    SOS, EOS, UNK, PAD = 2, 3, 0, 1
+    was_training = model.training
+    model.eval()
+    out = {}
+    try:
+        batches = [synthetic_batch(cfg["vocab"], 1, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev,
+                                   seed=100 + i, ragged=False) for i in range(dialogues)]
+        run = lambda b: beam_search_decode(model, b, max_len, SOS, UNK, EOS, PAD, beam=beam, nbest=beam, use_graph=use_graph)
+        run(batches[0])                                    # warm-up (allocator, first graph capture)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in batches:
+            run(b)
+        torch.cuda.synchronize()
+        t_beam = time.perf_counter() - t0
+        live = 1 + (max_len - 1) * beam
+        out["beam"] = {"hypothesis_tokens_per_s": round(dialogues * live / t_beam, 1), "dialogues_per_s": round(dialogues / t_beam, 2),
+                       "ms_per_step": round(1e3 * t_beam / dialogues / max_len, 3)}
+        greedy_decode(model, batches[0], max_len, SOS, PAD, use_graph=use_graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in batches:
+            greedy_decode(model, b, max_len, SOS, PAD, use_graph=use_graph)
+        torch.cuda.synchronize()
+        t_g = time.perf_counter() - t0
+        out["greedy"] = {"tokens_per_s": round(dialogues * (max_len - 1) / t_g, 1), "ms_per_step": round(1e3 * t_g / dialogues / (max_len - 1), 3)}
+        if batch_dialogues > 0:
+            D = batch_dialogues
+            big = synthetic_batch(cfg["vocab"], D, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=300, ragged=True)
+            many = lambda: beam_search_decode_many(model, big, max_len, SOS, UNK, EOS, PAD, beam=beam, nbest=beam, use_graph=use_graph)
+            many()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                many()
+            torch.cuda.synchronize()
+            t_many = (time.perf_counter() - t0) / 2
+            out["beam_batched"] = {"dialogues_side_by_side": D, "hypothesis_tokens_per_s": round(D * live / t_many, 1),
+                                   "dialogues_per_s": round(D / t_many, 2), "ms_per_step": round(1e3 * t_many / max_len, 3)}
+        out.update({"what": f"cfg5: beam-{beam} / greedy decode of the cfg2 model, max_len {max_len}, one dialogue at a time "
+                            f"({dialogues} dialogues) and {batch_dialogues} side by side; eval mode, same weights as the train step",
+                    "unit": "hypothesis-tokens/s", "beam_width": beam, "max_len": max_len, "hip_graph": use_graph})
+        if cpu:
+            live_cpu = 1 + (cpu_steps - 1) * beam
+            out["cpu_baseline"] = decode_cpu_baseline(model, cfg, cpu_steps, beam, live_cpu, SOS, UNK, EOS)
+            out["cpu_baseline"]["sample"] = f"first {cpu_steps} steps of the same beam-{beam} search ({live_cpu} decode() calls), " + out["cpu_baseline"]["sample"]
+    finally:
+        model.train(was_training)
+    return out
+
+
+def hbm_peak_measured(dev):
+    """GB/s of a plain 16-byte-per-lane streaming copy (1 GiB read + 1 GiB written: past the 256 MiB Infinity Cache) on this box:
+    the measured ceiling beside the 8 TB/s spec for the HBM-bound launches (include/mtn_hip.h mtn_measure_hbm_peak)."""
+    import ctypes as C
+    from mtn_amd import lib as L
+    n = 1 << 30
+    src = torch.empty(n, device=dev, dtype=torch.uint8)
+    dst = torch.empty(n, device=dev, dtype=torch.uint8)
+    src.zero_()
+    g = C.c_double(0.0)
+    L.check(L.load().mtn_measure_hbm_peak(src.data_ptr(), dst.data_ptr(), n, torch.cuda.current_stream().cuda_stream, C.byref(g)))
+    del src, dst
+    return round(g.value, 1)
+
+
 def gemm_census_roofline(step, peak_tflops):
     """Live roofline of the step's dominant kernel family, the grouped MFMA GEMMs.  One eager pass of the step's
     forward+backward is recorded by the library's launch census (include/mtn_hip.h: mtn_census_*), then EVERY recorded GEMM
@@ -194,6 +270,36 @@ def gemm_census_roofline(step, peak_tflops):
                         "achieved_TFLOPs": round(tot_fl / tot_us / 1e6, 1), "frac": round(tot_fl / tot_us / 1e6 / peak_tflops, 4)}
 
 
+def pmc_source():
+    """Which committed PMC summary the `traffic` figures come from: file name, its git blob id (sha1 of "blob <len>\\0" + bytes:
+    `git hash-object`), and the library source revision it was collected on when the summary records one — so that a stale
+    summary (kernels changed, PMC passes not re-run) is visible in the line instead of silently quoted."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    raw = open(files[-1], "rb").read()
+    blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()
+    try:
+        meta = json.loads(raw).get("collected_on")
+    except Exception:
+        meta = None
+    return {"file": os.path.relpath(files[-1], ROOT), "git_blob": blob, "collected_on": meta,
+            "csrc_sha16_now": csrc_sha16(), "stale": (meta or {}).get("csrc_sha16") not in (None, csrc_sha16())}
+
+
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources: identifies the build a profile belongs to."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mtn_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json, written by
     tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs with the gfx950 corrections of MI355X_MICROARCH.md)."""
@@ -221,6 +327,43 @@ def pmc_step_traffic():
         return None
 
 
+def dp_schedule_one_rank(args, cfg, model, batch, B, timed_window):
+    import socket
+    import torch.distributed as dist
+    from mtn_amd import dp
+    from mtn_amd.train_step import TrainStep
+    try:
+        created = False
+        if not dist.is_initialized():
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dp.init_distributed(force=True)
+            created = True
+        sync = dp.GradSync(lambda: model.flat_buffers()[2], force=True)
+        st = TrainStep(model, batch, cfg["vocab"], pad=1, warmup=4000, grad_sync=sync, use_graph=not args.no_graph)
+        for _ in range(3):
+            st()
+        dt, _, _ = timed_window(st, args.steps)
+        sh = st.sharded
+        calls = dict(sh.calls) if sh is not None else {}
+        out = {"ms_per_step": round(dt / args.steps * 1e3, 4), "samples_per_s": round(B * args.steps / dt, 1),
+               "rccl_ranks": dist.get_world_size(), "dist_backend": dist.get_backend(),
+               "schedule": ("layer-segmented backward (N+3 hipGraphs), " if st.overlap else "two-graph schedule, ") +
+                           ("reduce-scatter -> Adam on the shard -> all-gather per slice" if sh is not None else "all-reduce per slice + full Adam"),
+               "collectives_issued": calls, "slices_per_step": len(st._slices()),
+               "what": "the step of a data-parallel rank on this one GPU, every collective through a one-rank RCCL group "
+                       "(shard = the whole slice): schedule cost without peers; same batch as `value`"}
+        del st
+        if created:
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+        return out
+    except Exception as e:  # pragma: no cover
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -229,6 +372,11 @@ def main():
     from mtn_amd.synthetic import CONFIGS, flops_per_sample, synthetic_batch
     from mtn_amd.train_step import TrainStep
 
+    if args.no_record:
+        dp.ALLOW_EMULATION = True
+    elif os.environ.get("MTN_DP_EMULATE_WORLD", "1") not in ("", "0", "1"):
+        sys.exit("bench.py: MTN_DP_EMULATE_WORLD produces wrong parameters (timing probe): pass --no-record to run it; such a line "
+                 "is marked \"record\": false and must not be quoted")
     rank, world, local = dp.init_distributed()
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
@@ -302,8 +450,13 @@ def main():
                 secondary["batch64_one_gpu"] = {"samples_per_s": round(64 * args.steps / dt64, 1), "ms_per_step": round(dt64 / args.steps * 1e3, 4),
                                                 "what": "same model and step at batch 64 (BASELINE configs[2] per-GPU batch) on this one GPU"}
                 del st64, b64
-            elif world > 1 and rank == 0:
-                pass      # (filled below: every rank must take part in the barriers of timed_window)
+            if world == 1:
+                # the data-parallel schedule of an N-GPU job on this ONE rank, every collective through RCCL (a one-rank "nccl"
+                # group): layer-segmented backward, per-slice reduce-scatter -> Adam on the shard -> all-gather on side streams
+                # (dp.ShardedOptimizerSync).  What a rank of the scaling run computes besides waiting for its peers.
+                secondary["dp_schedule_one_rank"] = dp_schedule_one_rank(args, cfg, model, batch, B, timed_window)
+                # BASELINE configs[4]: decode on the same weights (never `value`)
+                secondary["decode"] = decode_measure(model, cfg, dev, use_graph=not args.no_graph, cpu=not args.no_cpu_baseline)
             if world > 1:
                 # the same per-GPU batch on ONE rank without any exchange (graph of forward+backward+optimiser epilogue): the
                 # figure a DP rank is compared with, measured in the same job; the other ranks idle at the barriers
@@ -359,6 +512,10 @@ def main():
                         "frac_of_measured_peak": (round(d["achieved_TFLOPs"] / step_info["mfma_peak_measured_TFLOPs"], 4)
                                                   if step_info.get("mfma_peak_measured_TFLOPs") and lp == torch.bfloat16 else None)}
 
+            try:
+                hbm_peak = hbm_peak_measured(dev)
+            except Exception:  # pragma: no cover
+                hbm_peak = None
             TABLE = "gemm_tt_dma128_table_kernel"
             if dom == TABLE:
                 # the parameter-gradient + optimiser launch: 28 B of parameter streams per weight behind every 2*K flops -> HBM-bound
@@ -367,7 +524,10 @@ def main():
                         "frac": round(d["achieved_GBps_algorithmic"] / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(dom),
                         "launches_per_step": d["launches_per_step"], "avg_us_per_launch": d["avg_us"],
                         "gflop_per_launch": d["gflop_per_launch"], "algorithmic_bytes_per_launch": int(d["algorithmic_MB_per_launch"] * 1e6),
-                        "achieved_TFLOPs": d["achieved_TFLOPs"]}
+                        "achieved_TFLOPs": d["achieved_TFLOPs"],
+                        "peak_measured": hbm_peak,
+                        "frac_of_measured_peak": round(d["achieved_GBps_algorithmic"] / hbm_peak, 4) if hbm_peak else None,
+                        "peak_measured_what": "GB/s of a 16-byte-per-lane streaming copy (1 GiB read + 1 GiB written) on this box, best of 10"}
                 second = max((n for n in table if n != TABLE), key=lambda nm: table[nm]["total_us_per_step"])
                 roof["next_kernel"] = mfma_roof(second)
             else:
@@ -377,11 +537,13 @@ def main():
                             "duration per launch, averaged over all of its launches in one step (library launch census, each "
                             "launch replayed in step order, one HIP-event pair each, 5 passes); traffic = HBM bytes per launch from the "
                             "committed rocprofv3 PMC passes")
+            roof["traffic_source"] = pmc_source()
             roof.update({"all_gemm_kernels": allg, "kernels": table, "step": step_info})
         except Exception as e:  # pragma: no cover
             roof = {"bound": "mfma", "achieved": round(step_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(step_tf / peak, 5),
                     "traffic": None, "error": str(e), "step": step_info}
         line = {"metric": "train-step samples/sec (d_model=512, 6L MTN)", "value": round(value, 2), "unit": "samples/s",
+                **({"record": False} if args.no_record else {}),
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"{args.workload}: d_model={cfg['d_model']} N={cfg['N']} h={cfg['h']} d_ff={cfg['d_ff']} |V|={cfg['vocab']} "

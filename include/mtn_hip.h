@@ -353,6 +353,9 @@ int mtn_ffn_param_grad_work(int dtype, const mtn_ffn_args* args, mtn_gemm_proble
  * saved buffers are those of the four-launch path.  mtn_fused_enable(0) turns that off for the process (A/B measurements and
  * the tests that compare the two paths); returns the previous setting (-1 = never set: environment MTN_FUSED=0 disables). */
 int mtn_fused_enable(int on);
+/* How many sublayer groups took which path since the library was loaded: out4 = {forward fused, forward per-stage, backward
+ * fused (groups with attention members), backward per-stage}.  The parity tests use it to assert that the fused kernels ran. */
+int mtn_fused_counters(long* out4);
 int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
 int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
 
@@ -492,6 +495,14 @@ const char* mtn_census_variant_name(int variant);
 /* Achievable dense bf16 MFMA rate of this box (register-only v_mfma_f32_16x16x32_bf16 issue, synchronises on its own
  * events): the measured denominator bench.py reports beside the 2.5 PFLOP/s spec figure.  scratch: >= 2048*256 floats. */
 int mtn_measure_mfma_peak(int iters, float* scratch, void* stream, double* tflops);
+/* Achievable HBM rate of this box: a 16-byte-per-lane streaming copy src -> dst of `bytes` bytes (both buffers >= bytes, well
+ * beyond the 256 MiB Infinity Cache; synchronises on its own events), (read + written bytes) / time in GB/s — the measured
+ * denominator bench.py reports beside the 8 TB/s spec for the HBM-bound parameter-gradient + optimiser launch. */
+int mtn_measure_hbm_peak(const void* src, void* dst, long bytes, void* stream, double* gbps);
+/* The library's development / test switches (MTN_GEMM_*, MTN_ATTN_*, MTN_LN_*, MTN_EMBED_DETERMINISTIC, ...) are read from the
+ * environment once per call site and cached: a process that changes one after the library has used it calls this to make the
+ * next launches re-read them.  Returns the new generation number. */
+int mtn_reload_env(void);
 
 #ifdef __cplusplus
 }

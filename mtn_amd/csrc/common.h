@@ -29,6 +29,14 @@ void mtn_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// ---------------------------------------------------------------- environment switches (host)
+// Development / test switches are read through a per-site cache instead of getenv() on every launch (a linear scan of the
+// environment, ~10 of them on the GEMM dispatch path: ~2 us per launch on the eager paths).  A process that changes such a
+// variable after its first use calls mtn_reload_env() (include/mtn_hip.h); the tests do.
+struct MtnEnvVar { const char* name; int gen; bool set; char val[56]; };
+const char* mtn_env_lookup(MtnEnvVar* v);      // nullptr when unset (elementwise.hip)
+#define MTN_ENV(NAME) ([]() -> const char* { static MtnEnvVar v_ = {NAME, -1, false, {0}}; return mtn_env_lookup(&v_); }())
+
 // ---------------------------------------------------------------- bf16 <-> f32
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved

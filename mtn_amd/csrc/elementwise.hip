@@ -1,6 +1,7 @@
 // elementwise.hip — HBM-bound helpers on the path: casts, dropout-backward, fused Adam/Noam
 // (train.py:190, data_utils.py:92-117).  16-byte vector accesses, grid-stride loops.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -14,6 +15,20 @@ void mtn_set_error(const char* fmt, ...) {
 }
 extern "C" const char* mtn_last_error(void) { return g_err; }
 extern "C" int mtn_version(void) { return 100; }
+
+// ---------------------------------------------------------------- environment switches (common.h: MTN_ENV)
+static int g_env_gen = 0;
+extern "C" int mtn_reload_env(void) { return __atomic_add_fetch(&g_env_gen, 1, __ATOMIC_RELAXED); }
+const char* mtn_env_lookup(MtnEnvVar* v) {
+    const int g = __atomic_load_n(&g_env_gen, __ATOMIC_RELAXED);
+    if (v->gen != g) {
+        const char* e = getenv(v->name);
+        v->set = e != nullptr;
+        if (e) { strncpy(v->val, e, sizeof(v->val) - 1); v->val[sizeof(v->val) - 1] = 0; }
+        v->gen = g;
+    }
+    return v->set ? v->val : nullptr;
+}
 
 static inline int grid_for(long n_vec) {
     long b = (n_vec + 255) / 256;
@@ -271,5 +286,41 @@ extern "C" int mtn_adam_step(int dtype, long n, float* p, const float* g, float*
     else
         hipLaunchKernelGGL((adam_kernel<float>), dim3(grid_for(n >> 2)), dim3(256), 0, s, n, p, g, m, v, (float*)p_lp, state, grad_scale, beta1, beta2, eps);
     MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}
+
+// ---------------------------------------------------------------- on-box HBM ceiling (measurement support, bench.py)
+// A 16-byte-per-lane streaming copy src -> dst of `bytes` bytes (caller's buffers, each >= bytes and well beyond the 256 MiB
+// Infinity Cache): what THIS box's HBM delivers to a kernel that does nothing but move bytes — the measured denominator
+// beside the 8 TB/s spec for the HBM-bound launches (parameter-gradient + optimiser table launch, adam_kernel).  Reports the
+// best of 10 repetitions as (bytes read + bytes written) / time.
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
+    typedef __attribute__((ext_vector_type(4))) unsigned nt4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        const nt4 v = __builtin_nontemporal_load((const nt4*)(src + i));
+        __builtin_nontemporal_store(v, (nt4*)(dst + i));
+    }
+}
+
+extern "C" int mtn_measure_hbm_peak(const void* src, void* dst, long bytes, void* stream, double* gbps) {
+    MTN_CHECK_ARG(src && dst && gbps && bytes >= (1L << 20) && bytes % 16 == 0, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { mtn_set_error("hipEventCreate failed"); return MTN_ERR_LAUNCH; }
+    const long n16 = bytes / 16;
+    double best = 0.0;
+    for (int rep = 0; rep < 10; ++rep) {
+        (void)hipEventRecord(e0, s);
+        hipLaunchKernelGGL(hbm_copy_kernel, dim3(256 * 8), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        const double g = 2.0 * (double)bytes / (ms * 1e-3) / 1e9;
+        if (g > best) best = g;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    MTN_CHECK_LAUNCH();
+    *gbps = best;
     return MTN_OK;
 }

@@ -3,7 +3,8 @@
 //     dq, dk, dv = attention backward of the head      (autograd of attention(), mtn.py:221-231)
 // instead of a grouped GEMM launch (dO for all heads, through HBM) followed by the attention-backward launch.  The gradient of
 // the input projections (dq|dk|dv -> d LayerNorm-out, a contraction over ALL heads) stays a grouped GEMM, as does everything
-// after it.  bf16, d_model = 512, d_k = 64, at most 32 query rows per sample (longer sequences keep the two-launch path).
+// after it.  bf16, d_model = 512, d_k = 64; a sample's query rows are taken in blocks of 32 (NQB = 1, 2 or 3 blocks: up to the 80
+// rows a workgroup holds — AVSD targets reach 54 tokens, queries 42; longer streams keep the two-launch path).
 //
 // Same construction as the forward kernel: a 512-thread workgroup = (member, block of whole samples, head) issues
 // everything it reads up front — dy rows (bf16, [row][512]) and the head's q, k, v, o rows (128 bytes each) by LDS-DMA, mask bytes,
@@ -58,7 +59,8 @@ struct FbGroup {
 static constexpr int FB_DSROW = 80;        // bytes per row of a tile image [32 keys][32 queries] bf16 (+ 16 pad)
 static constexpr int FB_TILE_IMG = 32 * FB_DSROW;
 static constexpr int FB_TEAM_SCRATCH = 4 * FB_TILE_IMG;   // a team's {P^T, dS^T} images, double-buffered over key tiles
-static constexpr int FB_SCRATCH = 2 * FB_TEAM_SCRATCH + 8 * 128;      // ... two teams, then D_q[32] of each wave: 21.0 KiB
+static constexpr int FB_DS_BYTES = 3 * 128;                // D_q of a wave's sample: up to 3 query blocks of 32
+static constexpr int FB_SCRATCH = 2 * FB_TEAM_SCRATCH + 8 * FB_DS_BYTES;      // ... two teams, then D_q[96] of each wave: 23.0 KiB
 
 struct FbLds { int dy, qi, oi, doi, ki, vi, mask, scratch, total; };
 __host__ __device__ inline FbLds fb_lds_map(int mt, int key_rows, int mask_bytes) {
@@ -128,7 +130,7 @@ __device__ __forceinline__ float fb_dot8(const uint4& x, const uint4& y) {
     return s;
 }
 
-template <int MT>
+template <int MT, int NQB>
 __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, const int rb, unsigned char* smem, const int stop, const int tl) {
     const int tid = threadIdx.x;
     FB_STAMP(0);
@@ -155,7 +157,7 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     // score tile in the first phase, head columns 16 w4 .. +15 of dq, dk, dv in the second
     const int team = wave >> 2, w4 = wave & 3, qt = w4 & 1, kt = w4 >> 1;
     unsigned char* tm_s = smem + L.scratch + team * FB_TEAM_SCRATCH;
-    float* Ds = (float*)(smem + L.scratch + 2 * FB_TEAM_SCRATCH + wave * 128);    // D_q of the wave's sample
+    float* Ds = (float*)(smem + L.scratch + 2 * FB_TEAM_SCRATCH + wave * FB_DS_BYTES);    // D_q of the wave's sample
 
     // ================================================================ everything this workgroup reads, issued now
     uint8_t mkb[FH_MASKB];
@@ -185,16 +187,18 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
         for (int s = 0; s < 8; ++s) wf[s] = *(const uint4*)(wrow + s * 32);
     }
     // softmax statistics {row max, 1 / row sum} of the team's first sample (queries 8lg + 4qt + r): in flight with everything else
-    float mxq[4], invq[4];
+    float mxq[NQB][4], invq[NQB][4];
     {
         const int si0 = team < nsamp ? team : 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
-            const float2 st = *(const float2*)(M.lse + 2 * ((size_t)((b0 + si0) * (FH_D / FH_DK) + slice) * a + qc));
-            mxq[r] = st.x;
-            invq[r] = st.y;
-        }
+        for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 32 * qb + 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
+                const float2 st = *(const float2*)(M.lse + 2 * ((size_t)((b0 + si0) * (FH_D / FH_DK) + slice) * a + qc));
+                mxq[qb][r] = st.x;
+                invq[qb][r] = st.y;
+            }
     }
     const DropState ds = drop_init(M.drop);
     FB_STAMP(1);
@@ -258,14 +262,16 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
         const int sic = live ? si : nsamp - 1;
         const int b = b0 + sic, qrow0 = sic * a, krow0 = sic * mk;
         const DropBase dbase = drop_base((uint64_t)(b * (FH_D / FH_DK) + slice) * (uint64_t)a * (uint64_t)mk);   // P-dropout index of (q, key) = base + q * mk + key
-        uint4 qf[2], dof[2];
-        float Dq[4];
-        f32x4_t dqt[2];                                            // dQ^T[head column 16 w4 + 4lg + r][query 16 qt' + l15]
-        dqt[0] = dqt[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        uint4 qf[NQB][2], dof[NQB][2];
+        float Dq[NQB][4];
+        f32x4_t dqt[NQB][2];                                       // dQ^T[head column 16 w4 + 4lg + r][query 32 qb + 16 q2 + l15]
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) dqt[qb][0] = dqt[qb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (live) {
             // D_q = sum_c dO[q][c] O[q][c]: lanes 2q, 2q+1 each take half a row (every wave of the team, for its own use)
-            {
-                const int q = lane >> 1, half = lane & 1, row = qrow0 + q;
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+                const int q = 32 * qb + (lane >> 1), half = lane & 1, row = qrow0 + q;
                 float sacc = 0.f;
                 if (q < a) {
 #pragma unroll
@@ -277,110 +283,126 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
             }
             // A fragments of Q and dO: accumulator row i of query tile qt <-> query 8(i/4) + 4qt + (i%4), so that the C values of the
             // two query tiles at one lane group are queries 8lg + 0..7 — the B-operand slot order of the contractions over the query
-            {
-                int q = 8 * (l15 >> 2) + 4 * qt + (l15 & 3);
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+                int q = 32 * qb + 8 * (l15 >> 2) + 4 * qt + (l15 & 3);
                 q = q < a ? q : a - 1;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    qf[ks] = fh_hfrag(qi_s, qrow0 + q, ks * 4 + lg);
-                    dof[ks] = fh_hfrag(doi_s, qrow0 + q, ks * 4 + lg);
+                    qf[qb][ks] = fh_hfrag(qi_s, qrow0 + q, ks * 4 + lg);
+                    dof[qb][ks] = fh_hfrag(doi_s, qrow0 + q, ks * 4 + lg);
                 }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
-                if (rd != 0) {                                     // (later rounds load their statistics here)
-                    const float2 st = *(const float2*)(M.lse + 2 * ((size_t)(b * (FH_D / FH_DK) + slice) * a + qc));
-                    mxq[r] = st.x;
-                    invq[r] = st.y;
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 32 * qb + 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
+                    if (rd != 0) {                                 // (later rounds load their statistics here)
+                        const float2 st = *(const float2*)(M.lse + 2 * ((size_t)(b * (FH_D / FH_DK) + slice) * a + qc));
+                        mxq[qb][r] = st.x;
+                        invq[qb][r] = st.y;
+                    }
+                    Dq[qb][r] = Ds[q];
                 }
-                Dq[r] = Ds[q];
-            }
         }
         if (rd == 0) FB_STAMP(5);
 
-        for (int j0 = 0; j0 < mk; j0 += 32, buf ^= 1) {
-            unsigned char* pt_s = tm_s + buf * (2 * FB_TILE_IMG);  // P^T (dropped out) [key][query]
-            unsigned char* dst_s = pt_s + FB_TILE_IMG;             // dS^T [key][query]
-            if (live) {
-                // ---- phase 1: this wave's 16 x 16 quadrant of S = Q K^T and dP = dO V^T, then P and dS
-                const int key = j0 + kt * 16 + l15, kc = key < mk ? key : mk - 1;
-                uint4 kf[2], vf[2];
+        for (int j0 = 0; j0 < mk; j0 += 32) {
+            // dV^T, dK^T of this key tile: summed over the sample's query blocks before they are stored
+            f32x4_t av[2], ak[2];
+            av[0] = av[1] = ak[0] = ak[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    kf[ks] = fh_hfrag(ki_s, krow0 + kc, ks * 4 + lg);
-                    vf[ks] = fh_hfrag(vi_s, krow0 + kc, ks * 4 + lg);
-                }
-                f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = sc;   // C layout: rows q = 8lg + 4qt + r, column key
+            for (int qb = 0; qb < NQB; ++qb, buf ^= 1) {
+                unsigned char* pt_s = tm_s + buf * (2 * FB_TILE_IMG);  // P^T (dropped out) [key][query of the block]
+                unsigned char* dst_s = pt_s + FB_TILE_IMG;             // dS^T [key][query of the block]
+                if (live) {
+                    // ---- phase 1: this wave's 16 x 16 quadrant of S = Q K^T and dP = dO V^T, then P and dS
+                    const int key = j0 + kt * 16 + l15, kc = key < mk ? key : mk - 1;
+                    uint4 kf[2], vf[2];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    mma16<bf16_t>(sc, qf[ks], kf[ks]);
-                    mma16<bf16_t>(dp, dof[ks], vf[ks]);
-                }
-                if (rd == 0 && j0 == 0) FB_STAMP(6);
-                // straight-line code (clamped indices and selects), so that the four elements' dependent chains overlap
-                float pd[4], dsv[4];
+                    for (int ks = 0; ks < 2; ++ks) {
+                        kf[ks] = fh_hfrag(ki_s, krow0 + kc, ks * 4 + lg);
+                        vf[ks] = fh_hfrag(vi_s, krow0 + kc, ks * 4 + lg);
+                    }
+                    f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = sc;   // C layout: rows q = 32qb + 8lg + 4qt + r, column key
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
-                    const bool valid = key < mk && q < a;
-                    const bool keep_score = mk_s[(sic * qa + (M.mask_sq ? qc : 0)) * mk + kc] != 0;
-                    const float sv = keep_score ? sc[r] * scale : -1e9f;
-                    const float p = __expf(sv - mxq[r]) * invq[r];
-                    const bool kp = drop_keep_at(ds, dbase, (uint32_t)(qc * mk + kc));     // dropout off: threshold 0, scale 1
-                    const float pdr = kp ? p * ds.scale : 0.f;
-                    const float dpd = kp ? dp[r] * ds.scale : 0.f;
-                    pd[r] = valid ? pdr : 0.f;
-                    dsv[r] = (valid && keep_score) ? p * (dpd - Dq[r]) : 0.f;
+                    for (int ks = 0; ks < 2; ++ks) {
+                        mma16<bf16_t>(sc, qf[qb][ks], kf[ks]);
+                        mma16<bf16_t>(dp, dof[qb][ks], vf[ks]);
+                    }
+                    if (rd == 0 && j0 == 0 && qb == 0) FB_STAMP(6);
+                    // straight-line code (clamped indices and selects), so that the four elements' dependent chains overlap
+                    float pd[4], dsv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = 32 * qb + 8 * lg + 4 * qt + r, qc = q < a ? q : a - 1;
+                        const bool valid = key < mk && q < a;
+                        const bool keep_score = mk_s[(sic * qa + (M.mask_sq ? qc : 0)) * mk + kc] != 0;
+                        const float sv = keep_score ? sc[r] * scale : -1e9f;
+                        const float p = __expf(sv - mxq[qb][r]) * invq[qb][r];
+                        const bool kp = drop_keep_at(ds, dbase, (uint32_t)(qc * mk + kc));     // dropout off: threshold 0, scale 1
+                        const float pdr = kp ? p * ds.scale : 0.f;
+                        const float dpd = kp ? dp[r] * ds.scale : 0.f;
+                        pd[r] = valid ? pdr : 0.f;
+                        dsv[r] = (valid && keep_score) ? p * (dpd - Dq[qb][r]) : 0.f;
+                    }
+                    const int off = (kt * 16 + l15) * FB_DSROW + (8 * lg + 4 * qt) * 2;      // the lane's four queries are consecutive
+                    *(uint2*)(pt_s + off) = make_uint2(fh_pack2(pd[0], pd[1]), fh_pack2(pd[2], pd[3]));
+                    *(uint2*)(dst_s + off) = make_uint2(fh_pack2(dsv[0], dsv[1]), fh_pack2(dsv[2], dsv[3]));
+                    if (rd == 0 && j0 == 0 && qb == 0) FB_STAMP(7);
                 }
-                const int off = (kt * 16 + l15) * FB_DSROW + (8 * lg + 4 * qt) * 2;      // the lane's four queries are consecutive
-                *(uint2*)(pt_s + off) = make_uint2(fh_pack2(pd[0], pd[1]), fh_pack2(pd[2], pd[3]));
-                *(uint2*)(dst_s + off) = make_uint2(fh_pack2(dsv[0], dsv[1]), fh_pack2(dsv[2], dsv[3]));
-                if (rd == 0 && j0 == 0) FB_STAMP(7);
+                __syncthreads();                                       // the tile's images are complete (the other buffer may still be read)
+                if (live) {
+                    // ---- phase 2: head columns 16 w4 .. +15.  dV^T += dO^T P, dK^T += Q^T dS (contraction over the block's 32 queries,
+                    // per key sub-tile), dQ^T += K^T dS^T (contraction over the tile's 32 keys); A operands by transposing reads of the
+                    // row-major images
+                    const uint4 dot_ = fb_tfrag(doi_s, qrow0 + 32 * qb, w4 * 16, l15, lg);
+                    const uint4 qt_ = fb_tfrag(qi_s, qrow0 + 32 * qb, w4 * 16, l15, lg);
+                    const uint4 kt_ = fb_tfrag(ki_s, krow0 + j0, w4 * 16, l15, lg);
+                    uint4 pf[2], sf[2], sfq[2];
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        pf[k2] = *(const uint4*)(pt_s + (k2 * 16 + l15) * FB_DSROW + lg * 16);      // keys 16 k2 + l15, queries 8lg .. +7
+                        sf[k2] = *(const uint4*)(dst_s + (k2 * 16 + l15) * FB_DSROW + lg * 16);
+                        sfq[k2] = fb_tfrag_img(dst_s, k2 * 16, l15, lg);                           // queries 16 k2 + l15, keys 8lg .. +7
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        mma16<bf16_t>(av[k2], dot_, pf[k2]);
+                        mma16<bf16_t>(ak[k2], qt_, sf[k2]);
+                        mma16<bf16_t>(dqt[qb][k2], kt_, sfq[k2]);
+                    }
+                    if (rd == 0 && j0 == 0 && qb == 0) FB_STAMP(8);
+                }
             }
-            __syncthreads();                                       // the tile's images are complete (the other buffer may still be read)
-            if (live) {
-                // ---- phase 2: head columns 16 w4 .. +15.  dV^T = dO^T P, dK^T = Q^T dS (contraction over the 32 queries, per key
-                // sub-tile), dQ^T += K^T dS^T (contraction over the tile's 32 keys); A operands by transposing reads of the row-major images
-                const uint4 dot_ = fb_tfrag(doi_s, qrow0, w4 * 16, l15, lg);
-                const uint4 qt_ = fb_tfrag(qi_s, qrow0, w4 * 16, l15, lg);
-                const uint4 kt_ = fb_tfrag(ki_s, krow0 + j0, w4 * 16, l15, lg);
-                uint4 pf[2], sf[2], sfq[2];
+            if (live && stop != 3) {
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
-                    pf[k2] = *(const uint4*)(pt_s + (k2 * 16 + l15) * FB_DSROW + lg * 16);      // keys 16 k2 + l15, queries 8lg .. +7
-                    sf[k2] = *(const uint4*)(dst_s + (k2 * 16 + l15) * FB_DSROW + lg * 16);
-                    sfq[k2] = fb_tfrag_img(dst_s, k2 * 16, l15, lg);                           // queries 16 k2 + l15, keys 8lg .. +7
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    f32x4_t av = f32x4_t{0.f, 0.f, 0.f, 0.f}, ak = av;
-                    mma16<bf16_t>(av, dot_, pf[k2]);
-                    mma16<bf16_t>(ak, qt_, sf[k2]);
-                    mma16<bf16_t>(dqt[k2], kt_, sfq[k2]);
                     const int key = j0 + k2 * 16 + l15;
-                    if (key < mk && stop != 3) {   // lane holds head columns 16 w4 + 4lg + r of key column `key`
+                    if (key < mk) {                    // lane holds head columns 16 w4 + 4lg + r of key column `key`
                         const size_t go = (krow_g0 + krow0 + key) * M.ldkv + slice * FH_DK + w4 * 16 + 4 * lg;
-                        *(uint2*)(M.dv + go) = make_uint2(fh_pack2(av[0], av[1]), fh_pack2(av[2], av[3]));
-                        *(uint2*)(M.dk + go) = make_uint2(fh_pack2(ak[0] * scale, ak[1] * scale), fh_pack2(ak[2] * scale, ak[3] * scale));
+                        *(uint2*)(M.dv + go) = make_uint2(fh_pack2(av[k2][0], av[k2][1]), fh_pack2(av[k2][2], av[k2][3]));
+                        *(uint2*)(M.dk + go) = make_uint2(fh_pack2(ak[k2][0] * scale, ak[k2][1] * scale), fh_pack2(ak[k2][2] * scale, ak[k2][3] * scale));
                     }
                 }
-                if (rd == 0 && j0 == 0) FB_STAMP(8);
             }
         }
         if (rd == 0) FB_STAMP(10);
         if (live) {
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                const int q = q2 * 16 + l15;
-                if (q < a && stop != 3) {
-                    bf16_t* dqg = M.dq + (size_t)(row0 + qrow0 + q) * M.ldq + slice * FH_DK + w4 * 16 + 4 * lg;
-                    *(uint2*)dqg = make_uint2(fh_pack2(dqt[q2][0] * scale, dqt[q2][1] * scale), fh_pack2(dqt[q2][2] * scale, dqt[q2][3] * scale));
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int q = 32 * qb + q2 * 16 + l15;
+                    if (q < a && stop != 3) {
+                        bf16_t* dqg = M.dq + (size_t)(row0 + qrow0 + q) * M.ldq + slice * FH_DK + w4 * 16 + 4 * lg;
+                        *(uint2*)dqg = make_uint2(fh_pack2(dqt[qb][q2][0] * scale, dqt[qb][q2][1] * scale), fh_pack2(dqt[qb][q2][2] * scale, dqt[qb][q2][3] * scale));
+                    }
                 }
-            }
         }
         if (rd == 0) FB_STAMP(11);
     }
@@ -396,9 +418,17 @@ __global__ __launch_bounds__(FH_THREADS) void fused_head_bwd_kernel(const FbGrou
     const int hpg = (FH_D / FH_DK) / M.hg;
     const int slice = (xcd % M.hg) * hpg + (j % hpg), rb = (j / hpg) * M.sg + (xcd / M.hg);
     if (rb * M.rows_per_wg >= M.rows) return;
-    if (M.mt <= 2) fb_body<2>(M, slice, rb, smem, G.stop, G.tl);
-    else if (M.mt == 3) fb_body<3>(M, slice, rb, smem, G.stop, G.tl);
-    else fb_body<5>(M, slice, rb, smem, G.stop, G.tl);
+    // query blocks of 32 per sample: 1 (a <= 32), 2 (a <= 64: at least 3 row tiles), 3 (a <= 80: 5 row tiles)
+    if (M.a <= 32) {
+        if (M.mt <= 2) fb_body<2, 1>(M, slice, rb, smem, G.stop, G.tl);
+        else if (M.mt == 3) fb_body<3, 1>(M, slice, rb, smem, G.stop, G.tl);
+        else fb_body<5, 1>(M, slice, rb, smem, G.stop, G.tl);
+    } else if (M.a <= 64) {
+        if (M.mt == 3) fb_body<3, 2>(M, slice, rb, smem, G.stop, G.tl);
+        else fb_body<5, 2>(M, slice, rb, smem, G.stop, G.tl);
+    } else {
+        fb_body<5, 3>(M, slice, rb, smem, G.stop, G.tl);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -420,7 +450,7 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
     size_t lds = 0;
     for (int i = 0; i < n_mha; ++i) {
         const mtn_mha_args& A = mha[i];
-        if (A.d != FH_D || A.h != FH_D / FH_DK || !A.w_o_t || A.a > 32 || A.a < 1) return false;
+        if (A.d != FH_D || A.h != FH_D / FH_DK || !A.w_o_t || A.a > 80 || A.a < 1) return false;
         const bool self = A.self_attn != 0;
         const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
         if (A.mask && A.mask_sb != 0 && A.mask_sb != (long)qa * m) return false;

@@ -1213,7 +1213,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         // 128x128 row-major tiles: measured 330-350 TFLOP/s on the memory K/V launches against 370-400 for the 64x64
         // register-staged kernel at 5 workgroups per CU (K = 512 is too short to amortise a 16-fragment epilogue at two
         // workgroups per CU) -> opt-in (MTN_GEMM_NTB_MIN_TILES=<tiles>), kept for larger contractions
-        if (!at && !bt && getenv("MTN_GEMM_NTB_MIN_TILES") != nullptr) {
+        if (!at && !bt && MTN_ENV("MTN_GEMM_NTB_MIN_TILES") != nullptr) {
             bool ok = true;
             int t128 = 0;
             for (int i = 0; i < grp.count; ++i) {
@@ -1221,7 +1221,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
                 ok = ok && !q.rowsum_out && q.K % 8 == 0 && (long)q.M * q.lda * 2 < (1L << 31) && (long)q.N * q.ldb * 2 < (1L << 31);
                 t128 += ((q.M + 127) / 128) * ((q.N + 127) / 128);
             }
-            const char* tmin = getenv("MTN_GEMM_NTB_MIN_TILES");
+            const char* tmin = MTN_ENV("MTN_GEMM_NTB_MIN_TILES");
             if (ok && t128 >= atoi(tmin)) {
                 static bool attr_set = false;
                 if (!attr_set) {
@@ -1242,7 +1242,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         // workgroup per CU in ceil(tiles/256) rounds of (64+64)*K bytes; 32x32 tiles spread 4x the workgroups of half the
         // size, two per CU (their DMA latencies overlap: x0.75, fitted on tools/gemm_bench.hip).  MTN_GEMM_TILE forces one.
         GemmGroup g2 = grp;
-        const char* force = getenv("MTN_GEMM_TILE");
+        const char* force = MTN_ENV("MTN_GEMM_TILE");
         const int f = force ? atoi(force) : 0;
         double b64 = 0, b32 = 0, wg32max = 0;
         int t64 = 0;
@@ -1260,8 +1260,8 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         if (c32 < wg32max) c32 = wg32max;
         // half-size stages (256 B of contraction per row) double the resident workgroups: taken when the launch would
         // otherwise need a second round (64x64: one workgroup per CU at 128 KiB; 32x32: two at 64 KiB)
-        const bool half_ok = getenv("MTN_GEMM_NO_HALF") == nullptr;
-        const bool half_force = getenv("MTN_GEMM_FORCE_HALF") != nullptr;      // tests
+        const bool half_ok = MTN_ENV("MTN_GEMM_NO_HALF") == nullptr;
+        const bool half_force = MTN_ENV("MTN_GEMM_FORCE_HALF") != nullptr;      // tests
         if (f == 64 || (!f && c64 <= c32)) {
             const int t = retile(g2, 64, 64);
             if (half_force || (half_ok && t > 256)) return launch_dma<T, 64, 64, 256>(g2, t, s);
@@ -1276,19 +1276,19 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
     else if (at && bt) {
         // measured on the train step: 2 x 128x128 workgroups per CU hide latency worse than 8 x 64x64 ones (7.51 vs 7.25 ms per
         // step) although they pull half the bytes — kept behind MTN_GEMM_TT128=1 for larger batches.
-        bool big = getenv("MTN_GEMM_TT128") != nullptr;
+        bool big = MTN_ENV("MTN_GEMM_TT128") != nullptr;
         for (int i = 0; i < grp.count; ++i) big = big && grp.p[i].M >= 128 && grp.p[i].N >= 128;
-        bool ttd = (sizeof(T) == 2) && getenv("MTN_GEMM_TT_REG") == nullptr;      // LDS-DMA + transposing LDS reads (bf16)
+        bool ttd = (sizeof(T) == 2) && MTN_ENV("MTN_GEMM_TT_REG") == nullptr;      // LDS-DMA + transposing LDS reads (bf16)
         for (int i = 0; i < grp.count; ++i)
             ttd = ttd && grp.p[i].M % 8 == 0 && grp.p[i].N % 8 == 0 && (long)grp.p[i].K * grp.p[i].lda * 2 < (1L << 31) &&
                   (long)grp.p[i].K * grp.p[i].ldb * 2 < (1L << 31);
-        bool ttb = ttd && getenv("MTN_GEMM_TT64") == nullptr;                    // 128x128 tiles when every problem fills them
+        bool ttb = ttd && MTN_ENV("MTN_GEMM_TT64") == nullptr;                    // 128x128 tiles when every problem fills them
         int t128 = 0;
         for (int i = 0; i < grp.count; ++i) {
             ttb = ttb && grp.p[i].M >= 128 && grp.p[i].N >= 128;
             t128 += ((grp.p[i].M + 127) / 128) * ((grp.p[i].N + 127) / 128);
         }
-        const char* tmin = getenv("MTN_GEMM_TTB_MIN_TILES");
+        const char* tmin = MTN_ENV("MTN_GEMM_TTB_MIN_TILES");
         ttb = ttb && (t128 >= (tmin ? atoi(tmin) : 192) || adam.any);          // the coalesced optimiser epilogue lives in the 128-tile kernel
         if (ttb) {
             if constexpr (sizeof(T) == 2) {
@@ -1301,7 +1301,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
                 const int tiles = retile(g2, 128, 128);
                 g_variant = V_TT_DMA128; g_variant_tiles = tiles;
                 AdamGroup a2 = adam;
-                a2.lds_epilogue = adam.any && getenv("MTN_ADAM_EPILOGUE_DIRECT") == nullptr;
+                a2.lds_epilogue = adam.any && MTN_ENV("MTN_ADAM_EPILOGUE_DIRECT") == nullptr;
                 for (int i = 0; i < grp.count; ++i) {
                     const AdamSlot& sl = adam.a[i];
                     if (!sl.p) continue;
@@ -1334,7 +1334,7 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     memset(&grp, 0, sizeof(grp));
     memset(&adam, 0, sizeof(adam));
     grp.count = count;
-    grp.plain_tile_order = getenv("MTN_GEMM_PLAIN_TILES") != nullptr;
+    grp.plain_tile_order = MTN_ENV("MTN_GEMM_PLAIN_TILES") != nullptr;
     int tiles = 0;
     const int align = (dtype == MTN_BF16) ? 8 : 4;
     for (int i = 0; i < count; ++i) {
@@ -1373,7 +1373,7 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     // LDS-DMA path: row-major operands below 2 GiB, no row-sum side output, and a grid that fits the chip in about two
     // rounds (128 KiB of LDS = one workgroup per CU): large grids are throughput-bound and do better on the
     // register-staged kernel at 5 workgroups per CU.
-    const char* dmax = getenv("MTN_GEMM_DMA_MAX_TILES");
+    const char* dmax = MTN_ENV("MTN_GEMM_DMA_MAX_TILES");
     bool dma_ok = !problems[0].rowsum_out && tiles <= (dmax ? atoi(dmax) : 640);
     const long esz = (dtype == MTN_BF16) ? 2 : 4;
     for (int i = 0; i < count; ++i) {
@@ -1462,7 +1462,7 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
     H->tilemap_off = sizeof(TTHeader) + (long)count * sizeof(TTProblem);
     TTProblem* Q = (TTProblem*)(sl->host + H->problems_off);
     uint32_t* map = (uint32_t*)(sl->host + H->tilemap_off);
-    bool lds_ok = getenv("MTN_ADAM_EPILOGUE_DIRECT") == nullptr;
+    bool lds_ok = MTN_ENV("MTN_ADAM_EPILOGUE_DIRECT") == nullptr;
     int first = 0;
     for (int i = 0; i < count; ++i) {
         const mtn_gemm_problem& p = problems[i];
@@ -1490,8 +1490,8 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
     // traffic per launch for 0.44 GB of operands).  Here every problem is given to ONE XCD: grid index i holds a tile of the
     // queue of XCD i % 8; problems are dealt to the queues longest-processing-time-first on an estimate of their cost
     // (tiles x (contraction rows + the epilogue's bytes in row equivalents)), which balances the queues to within one problem.
-    if (getenv("MTN_TT_TABLE_SPREAD") != nullptr) {
-        H->plain_tile_order = getenv("MTN_GEMM_PLAIN_TILES") != nullptr;
+    if (MTN_ENV("MTN_TT_TABLE_SPREAD") != nullptr) {
+        H->plain_tile_order = MTN_ENV("MTN_GEMM_PLAIN_TILES") != nullptr;
         int pos = 0;
         for (int i = 0; i < count; ++i)
             for (int k = 0; k < Q[i].tiles_m * Q[i].tiles_n; ++k) map[pos++] = ((uint32_t)i << 12) | (uint32_t)k;

@@ -35,6 +35,14 @@ static mtn_gemm_problem gemm_init(const void* A, int lda, const void* B, int ldb
     return p;
 }
 
+// how often a group took the fused launches (tests assert that the fused kernels really ran): {fwd fused, fwd per-stage, bwd fused, bwd per-stage}
+static long g_fused_counts[4] = {0, 0, 0, 0};
+extern "C" int mtn_fused_counters(long* out4) {
+    MTN_CHECK_ARG(out4, "null output");
+    for (int i = 0; i < 4; ++i) out4[i] = g_fused_counts[i];
+    return MTN_OK;
+}
+
 #define RUN(expr)                        \
     do {                                 \
         int rc__ = (expr);               \
@@ -102,6 +110,7 @@ extern "C" int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* 
     for (int i = 0; i < n_ffn; ++i) RUN(check_ffn(&ffn[i], false));
     // Fused first launch (csrc/fused.hip): stages 1-3 in one kernel per (sample block, head | w_1 column slice)
     const bool fused = fh_group_eligible(dtype, n_mha, mha, n_ffn, ffn) != 0;
+    ++g_fused_counts[fused ? 0 : 1];
     if (fused) RUN(fh_group_fwd_stage1(n_mha, mha, n_ffn, ffn, stream));
     // 1. LayerNorm(x) -> xn (compute dtype); row statistics saved for backward
     if (!fused) {
@@ -242,6 +251,7 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
         else { io[i].dk = w.dkv; io[i].dv = lp_off(w.dkv, d, dtype); io[i].ldq = d; io[i].ldkv = 2 * d; }
     }
     const bool fb = n_mha > 0 && fb_group_eligible(dtype, n_mha, mha, io) != 0;
+    if (n_mha > 0) ++g_fused_counts[fb ? 2 : 3];
     if (fb) RUN(fb_group_bwd_stage(n_mha, mha, io, stream));
     // 2. dO = dyl Wo ;  dh = (dyl W2) * relu'(h) * hidden-dropout mask (both recovered from the saved hidden: hid > 0)
     if (!fb || n_ffn > 0) {

@@ -251,6 +251,7 @@ class DecodeSession:
 
 
 _SESSIONS: dict = {}
+SELECT_MAX_K = 16        # csrc/select.hip SEL_MAX_K
 KV_CACHE_FROM = 32      # prefix K/V cache by default for searches longer than this (at the reference's max_len = 20 the full-prefix
                         # pass is launch-latency-bound and as fast; the cache makes a token cost O(l) instead of O(l^2) work beyond it)
 
@@ -332,7 +333,9 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
     if kv_cache is None:
         kv_cache = max_len > KV_CACHE_FROM
     k = beam + 2
-    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph, kv_cache, select=(k + 1, end_symbol))
+    # device-side candidate selection (csrc/select.hip) holds at most SELECT_MAX_K entries per row: wider beams keep torch.topk
+    sel = (k + 1, end_symbol) if k + 1 <= SELECT_MAX_K else None
+    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph, kv_cache, select=sel)
     beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
     for l in range(max_len):
         logps = sess.step_many([bm.prefixes() for bm in beams])

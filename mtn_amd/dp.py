@@ -19,12 +19,17 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: Optional[str] = None) -> tuple:
-    """(rank, world_size, local_rank) from the torchrun environment; initialises the default process group."""
+ALLOW_EMULATION = False      # set by `bench.py --no-record` only: lets MTN_DP_EMULATE_WORLD (wrong results, timing probe) through
+
+
+def init_distributed(backend: Optional[str] = None, force: Optional[bool] = None) -> tuple:
+    """(rank, world_size, local_rank) from the torchrun environment; initialises the default process group.
+    ``force`` (default: MTN_FORCE_DIST=1): create the group even for ONE rank, so that the RCCL path runs on a 1-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    force = os.environ.get("MTN_FORCE_DIST") == "1"        # exercise the RCCL path with a single rank (1-GPU boxes)
+    if force is None:
+        force = os.environ.get("MTN_FORCE_DIST") == "1"    # exercise the RCCL path with a single rank (1-GPU boxes)
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -56,12 +61,15 @@ class GradSync:
     """Bucketed sum all-reduce of a flat gradient buffer.  ``flat_grad_fn`` returns the buffer (so the object survives a
     re-flatten); works on CUDA (RCCL) and CPU (gloo) tensors alike — the CPU tests drive it with the oracle model."""
 
-    def __init__(self, flat_grad_fn, group=None, n_buckets: int = 4, compress_bf16: bool = False):
+    def __init__(self, flat_grad_fn, group=None, n_buckets: int = 4, compress_bf16: bool = False, force: Optional[bool] = None):
         self.flat_grad_fn = flat_grad_fn
         self.group = group
         self.n_buckets = max(1, n_buckets)
         self.compress = compress_bf16
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if force is None:
+            force = os.environ.get("MTN_FORCE_DIST") == "1"
+        self.force = bool(force) and dist.is_initialized()       # one rank: issue the collectives anyway (RCCL on a 1-GPU box)
 
     def buckets(self, n: int):
         per = -(-n // self.n_buckets)
@@ -81,7 +89,7 @@ class GradSync:
     def reduce_range(self, lo: int, hi: int):
         """Asynchronous sum all-reduce of flat_grad[lo:hi] (issued behind everything already queued on the current stream;
         later work on the current stream does NOT wait for it).  Returns a handle for wait()."""
-        if (self.world == 1 and os.environ.get("MTN_FORCE_DIST") != "1") or hi <= lo:
+        if (self.world == 1 and not self.force) or hi <= lo:
             return None
         chunk = self.flat_grad_fn()[lo:hi]
         if self.compress:
@@ -100,7 +108,7 @@ class GradSync:
                 chunk.copy_(c16)
 
     def __call__(self):
-        if self.world == 1 and os.environ.get("MTN_FORCE_DIST") != "1":
+        if self.world == 1 and not self.force:
             return
         g = self.flat_grad_fn()
         for s, e in self.buckets(g.numel()):
@@ -133,14 +141,21 @@ class ShardedOptimizerSync:
     Collectives: RCCL in-place reduce_scatter_tensor / all_gather_into_tensor; other backends (gloo on CUDA tensors in the
     single-GPU tests) take an all-reduce + per-shard broadcasts with the same results."""
 
-    def __init__(self, flat_fn, grad_fn, update, group=None):
+    def __init__(self, flat_fn, grad_fn, update, group=None, force: Optional[bool] = None):
         self.flat_fn, self.grad_fn, self.update, self.group = flat_fn, grad_fn, update, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.native = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        # A one-rank RCCL group (MTN_FORCE_DIST=1 on a 1-GPU box) takes the SAME collective chain as N ranks — in-place
+        # reduce_scatter_tensor / all_gather_into_tensor, side stream, finish() — with per = the whole slice and own = lo, so
+        # that the code an N-GPU job executes has run (and is tested bit for bit against the fused one-rank step) before it.
+        if force is None:
+            force = os.environ.get("MTN_FORCE_DIST") == "1"
+        self.collective = self.world > 1 or (dist.is_initialized() and bool(force))
         self.side = None
         self._works = []
         self.slices = set()             # every (lo, hi) this object has been asked to handle (for gather())
+        self.calls = {"reduce_scatter": 0, "all_reduce": 0, "all_gather": 0, "broadcast": 0}   # collectives issued (tests, bench line)
 
     def gather(self, buf: torch.Tensor):
         """Make a per-element optimiser buffer (Adam moments) complete on every rank: each rank only ever updates its shards.
@@ -168,20 +183,29 @@ class ShardedOptimizerSync:
         cuda = grad.is_cuda
         if cuda and self.side is None:
             self.side = torch.cuda.Stream()
-        if self.world == 1:
-            emu = int(os.environ.get("MTN_DP_EMULATE_WORLD", "1"))     # TIMING ONLY (1-GPU boxes): update 1/emu of the slice, as a
-            n = hi - lo                                                # rank of an emu-GPU job would (the result is wrong)
+        if not self.collective:
+            # one rank, no process group: the plain update.  MTN_DP_EMULATE_WORLD (update 1/emu of the slice, as a rank of an
+            # emu-GPU job would: the RESULT IS WRONG) is a timing probe and only honoured when the caller opted in explicitly
+            # (dp.ALLOW_EMULATION, set by `bench.py --no-record`); otherwise it is refused loudly.
+            emu = int(os.environ.get("MTN_DP_EMULATE_WORLD", "1"))
+            if emu > 1 and not ALLOW_EMULATION:
+                raise RuntimeError("MTN_DP_EMULATE_WORLD produces wrong parameters (timing probe only): run it through "
+                                   "`bench.py --no-record`, never in a recorded line or a training run")
+            n = hi - lo
             self.update(lo, n if emu <= 1 else max(4, (n // (emu * 4)) * 4))
             return
         works = []
         if per > 0:
             if self.native:
                 w = dist.reduce_scatter_tensor(grad[own:own + per], grad[lo:tail], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.calls["reduce_scatter"] += 1
             else:
                 w = dist.all_reduce(grad[lo:tail], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.calls["all_reduce"] += 1
             works.append(w)
         if tail < hi:
             works.append(dist.all_reduce(grad[tail:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.calls["all_reduce"] += 1
 
         def chain():
             for w in works:
@@ -193,9 +217,11 @@ class ShardedOptimizerSync:
             if per > 0:
                 if self.native:
                     self._works.append(dist.all_gather_into_tensor(flat[lo:tail], flat[own:own + per], group=self.group, async_op=True))
+                    self.calls["all_gather"] += 1
                 else:
                     for r in range(self.world):
                         self._works.append(dist.broadcast(flat[lo + r * per: lo + (r + 1) * per], src=r, group=self.group, async_op=True))
+                        self.calls["broadcast"] += 1
 
         if cuda:
             self.side.wait_stream(torch.cuda.current_stream())

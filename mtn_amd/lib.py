@@ -143,6 +143,8 @@ SYMBOLS = {
     "mtn_census_replay": (C.c_int, [C.c_int, C.c_int, _P]),
     "mtn_census_variant_name": (C.c_char_p, [C.c_int]),
     "mtn_measure_mfma_peak": (C.c_int, [C.c_int, _P, _P, C.POINTER(C.c_double)]),
+    "mtn_measure_hbm_peak": (C.c_int, [_P, _P, C.c_long, _P, C.POINTER(C.c_double)]),
+    "mtn_reload_env": (C.c_int, []),
     "mtn_last_error": (C.c_char_p, []),
     "mtn_version": (C.c_int, []),
     "mtn_gemm": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
@@ -155,6 +157,7 @@ SYMBOLS = {
     "mtn_attention_bwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(AttnArgs), _P]),
     "mtn_cast_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(CastDesc), _P]),
     "mtn_fused_enable": (C.c_int, [C.c_int]),
+    "mtn_fused_counters": (C.c_int, [C.POINTER(C.c_long)]),
     "mtn_sublayer_group_fwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_sublayer_group_bwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_layernorm_bwd_partial_floats": (C.c_long, [C.c_int, C.c_int]),
@@ -204,6 +207,19 @@ def load():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def fused_counters():
+    """(forward fused, forward per-stage, backward fused, backward per-stage) group counts since the library was loaded."""
+    out = (C.c_long * 4)()
+    check(load().mtn_fused_counters(out))
+    return tuple(int(v) for v in out)
+
+
+def reload_env():
+    """Make the library re-read its MTN_* environment switches (they are cached per call site): call after changing one."""
+    if _lib is not None:
+        _lib.mtn_reload_env()
 
 
 def check(rc: int):

@@ -273,9 +273,14 @@ def main(argv=None):
             means.append(mean)
             if rank == 0:
                 print("epoch %d mean train loss per token: %f" % (epoch + 1, mean))
-            if args.model and rank == 0:
-                torch.save(model.state_dict(), f"{args.model}_{epoch + 1}.pth.tar")
-                torch.save(the_opt.state_dict(), f"{args.model}_{epoch + 1}_opt.pth.tar")
+            if args.model:
+                # EVERY rank builds the optimiser state: with the sharded optimiser (dp.ShardedOptimizerSync) a rank holds the
+                # Adam moments of its shards only and state_dict() gathers them with collectives; rank 0 alone writes the files
+                opt_state = the_opt.state_dict()
+                if rank == 0:
+                    torch.save(model.state_dict(), f"{args.model}_{epoch + 1}.pth.tar")
+                    torch.save(opt_state, f"{args.model}_{epoch + 1}_opt.pth.tar")
+                del opt_state
             if valid is not None:
                 from .data_utils import LabelSmoothing as _LS
                 vloss = validate(valid[0], valid[1], model, _LS(args.vocab_size, 1, 0.1), args.auto_encoder_ft, args.loss_l)

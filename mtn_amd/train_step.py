@@ -47,10 +47,17 @@ class TrainStep:
         self.sharded = None
         if grad_sync is not None and os.environ.get("MTN_DP_SHARDED", "1") != "0" and hasattr(self.opt.optimizer, "step_range"):
             from .dp import ShardedOptimizerSync
+            if getattr(grad_sync, "compress", False):
+                raise ValueError("bf16 gradient compression applies to the all-reduce scheme only (MTN_DP_SHARDED=0): the sharded "
+                                 "optimiser reduce-scatters the fp32 gradient in place")
             adam = self.opt.optimizer
-            self.sharded = ShardedOptimizerSync(lambda: model.flat_buffers()[0], lambda: model.flat_buffers()[2], adam.step_range,
-                                                group=getattr(grad_sync, "group", None))
-            adam._sharded = self.sharded
+            group = getattr(grad_sync, "group", None)
+            sh = getattr(adam, "_sharded", None)          # ONE exchange object per optimiser: every TrainStep over it (one per
+            if sh is None or sh.group is not group:       # batch shape, BucketedTrainer) shares the shard ownership and the
+                sh = ShardedOptimizerSync(lambda: model.flat_buffers()[0], lambda: model.flat_buffers()[2], adam.step_range, group=group,
+                                          force=getattr(grad_sync, "force", None))
+                adam._sharded = sh                        # slice set that state_dict()'s gather walks
+            self.sharded = sh
         self._g_seg = None
         self._st = None
         self._fuse_opt = False if fuse_optimizer is False else None
@@ -187,14 +194,21 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.overlap:
+            err = None
             try:
                 self._capture_segmented(side)
-                return
             except Exception as e:      # never lose the run to the more elaborate schedule: fall back to the simple one
-                import logging
-                logging.getLogger("mtn_amd").warning("layer-segmented capture failed (%s); using the two-graph schedule", e)
-                self.overlap, self._g_seg, self._st = False, None, None
-                torch.cuda.synchronize()
+                err = e
+            # the decision is COLLECTIVE: a rank that fell back alone would issue a different sequence of collectives
+            failed = torch.tensor([1.0 if err is not None else 0.0], device=self.model._flat.device)
+            self.grad_sync.all_reduce_scalars(failed)
+            if float(failed.item()) == 0.0:
+                return
+            import logging
+            logging.getLogger("mtn_amd").warning("layer-segmented capture failed on %d rank(s) (%s); using the two-graph schedule",
+                                                 int(failed.item()), err)
+            self.overlap, self._g_seg, self._st = False, None, None
+            torch.cuda.synchronize()
         self._capture_simple()
 
     def _capture_segmented(self, side):
@@ -276,11 +290,20 @@ class TrainStep:
             self._g_opt.replay()
         return self._loss
 
+    def _slices(self):
+        """The (lo, hi) ranges of the flat buffers the exchange works in, last-finished-first: [top layer .. end], layers
+        N-2 .. 0, [glue + encoder norms].  BOTH schedules use them, so which rank owns (and keeps the Adam moments of) an element
+        never depends on the schedule a step ran under."""
+        m = self.model
+        m.prepare()
+        sl = m._layer_slices
+        total, N = m._flat_grad.numel(), len(sl)
+        return [(sl[N - 1][0], total)] + [sl[k] for k in range(N - 2, -1, -1)] + [(0, sl[0][0])]
+
     def _whole_buffer_sharded(self):
-        """The simple schedule (MTN_DP_OVERLAP=0) with the sharded optimiser: the flat gradient in a few large slices."""
+        """The simple schedule (MTN_DP_OVERLAP=0, or the fallback) with the sharded optimiser: same slices as the segmented one."""
         self.opt.begin_sharded_step()
-        n = self.model._flat_grad.numel()
-        for lo, hi in self.grad_sync.buckets(n):
+        for lo, hi in self._slices():
             self.sharded.reduce_update(lo, hi)
         self.sharded.finish()
 

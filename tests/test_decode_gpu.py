@@ -151,3 +151,56 @@ def test_kv_cache_decode_equals_full_prefix_decode_on_a_long_search(dev, dtype):
         assert torch.equal(g_full, g_cache)
     else:
         assert float((g_full == g_cache).float().mean()) > 0.5      # bf16 near-ties may fork the chain late
+
+
+@pytest.mark.parametrize("beam", [14, 16])
+def test_wide_beams_keep_working(dev, beam):
+    """Beams wider than the device-side selection holds (csrc/select.hip keeps 16 entries per row: beam + 3 <= 16) take the
+    torch.topk branch: same n-best lists as the oracle's search (data_utils.py:188-242 with beam > 13)."""
+    from mtn_amd.decode import beam_search_decode
+    c = fx.GOLDEN_CONFIGS["cfg1_query"]
+    raw = one_dialogue(c, seed=4)
+    m_or, _ = fx.oracle_from_config(c)
+    with torch.no_grad():
+        ref_n, ref_best = orc.beam_search(m_or, fx.oracle_batch(raw), 6, fx.SOS, fx.UNK, fx.EOS, beam=beam, nbest=5)
+    model = build_model(c, torch.float32, dev).eval()
+    got_n, got_best = beam_search_decode(model, dev_batch(raw, dev), 6, fx.SOS, fx.UNK, fx.EOS, fx.PAD, beam=beam, nbest=5)
+    assert [list(t) for t, _ in got_n] == [list(t) for t, _ in ref_n]
+    assert max(abs(a[1] - r[1]) for a, r in zip(got_n, ref_n)) < 1e-3 and abs(got_best - ref_best) < 1e-3
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_cfg5_full_depth_first_decode_steps_match_oracle(dev, dtype):
+    """BASELINE configs[4] at its real depth: the 6-layer d_model=512 / 8-head model (cfg2's widths, |V| = 3000, Q/H/C = 20/128/40,
+    32 + 32 frames), beam 4.  The log-probabilities of the first three decode steps (generate.py -> data_utils.py:202-208: full
+    decode of every live prefix, generator on the last position) against the CPU oracle, for the prefixes the oracle's own beam
+    search would hold at those steps.  fp32 mode 1e-3, bf16 mode 1e-2, relative to the row's largest |log p|."""
+    from mtn_amd.decode import DecodeSession
+    from mtn_amd.synthetic import CONFIGS
+    k = CONFIGS["cfg2"]
+    c = dict(vocab=k["vocab"], N=k["N"], d_model=k["d_model"], d_ff=k["d_ff"], h=k["h"], ft_sizes=list(k["ft_sizes"]), B=1, Q=k["Q"], H=k["H"],
+             C=k["C"], T=k["T"], frames=list(k["frames"]), diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query")
+    raw = one_dialogue(c, seed=5)
+    m_or, _ = fx.oracle_from_config(c)
+    ob = fx.oracle_batch(raw)
+    beam = 4
+    model = build_model(c, dtype, dev).eval()
+    sess = DecodeSession(model, dev_batch(raw, dev), max_len=20, width=beam, pad=fx.PAD)
+    tol = 1e-3 if dtype == torch.float32 else 1e-2
+    prefixes = [[fx.SOS]]
+    with torch.no_grad():
+        q, v, cp, hs, ae = m_or.encode(ob.query, ob.query_mask, ob.his, ob.his_mask, ob.cap, ob.cap_mask, ob.fts, ob.fts_mask)
+        for step in range(3):
+            got = sess.step(prefixes).float().cpu()
+            nxt = []
+            for i, p in enumerate(prefixes):
+                st = torch.tensor([p], dtype=ob.query.dtype)
+                x, _ = m_or.decode(v, hs, cp, q, ob.fts_mask, ob.his_mask, ob.cap_mask, ob.query_mask, st, orc.subsequent_mask(len(p)), ae)
+                want = m_or.generator(x[:, -1])[0]
+                err = float((got[i] - want).abs().max() / want.abs().max())
+                assert err < tol, (step, i, err)
+                top = [int(t) for t in torch.argsort(want, descending=True) if int(t) not in (fx.UNK, fx.EOS)][:beam]
+                nxt += [p + [t] for t in top]
+            # the next step's prefixes: the oracle's best `beam` extensions (by its own log-probabilities; scores are not needed here)
+            prefixes = nxt[:beam]

@@ -156,3 +156,39 @@ def test_eager_two_rank_dp_equals_single_rank_on_concatenated_batch(tmp_path):
     gref = model._flat_grad.cpu()
     err = float((r0["grad1"] - gref).abs().max() / gref.abs().max())
     assert err < 1e-5, err
+
+
+def _train_cli_worker(rank, world, port, out_dir):
+    """python -m mtn_amd.train (corpus mode, captured graphs per padded shape) under two ranks, with --model: the epoch-end
+    checkpoint gathers the sharded Adam moments with collectives on EVERY rank, rank 0 writes the files (train.py:215-217)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      MTN_DIST_BACKEND="gloo")
+    os.environ.pop("MTN_DP_SHARDED", None)
+    from mtn_amd import train
+    means = train.main(["--corpus-videos", "4", "--num-epochs", "2", "--batch-size", "8", "--nb-blocks", "1", "--d-model", "64", "--d-ff", "128",
+                        "--att-h", "2", "--vocab-size", "60", "--ft-sizes", "16", "8", "--warmup-steps", "10", "--report-interval", "1000",
+                        "--compute-dtype", "fp32", "--valid-videos", "2", "--model", os.path.join(out_dir, "ck")])
+    torch.save({"means": means}, os.path.join(out_dir, f"cli{rank}.pt"))
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_training_cli_checkpoints_without_deadlock(tmp_path):
+    """rank 0 alone used to call the optimiser's state_dict(), whose sharded-moment gather is a collective the
+    other ranks never joined.  Two ranks through the CLI with --model and validation: both epochs finish, the files exist, and the
+    saved first moments are complete (the halves owned by rank 1 are non-zero too)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.start_processes(_train_cli_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    for e in (1, 2):
+        assert (tmp_path / f"ck_{e}.pth.tar").exists() and (tmp_path / f"ck_{e}_opt.pth.tar").exists()
+    assert (tmp_path / "ck_best.pth.tar").exists()
+    opt = torch.load(tmp_path / "ck_2_opt.pth.tar")
+    assert int(opt["step"]) > 0
+    for name, m1 in opt["optimizer"]["exp_avg"].items():
+        if m1.dim() == 2 and "linears.1" not in name and m1.numel() >= 64:
+            flat = m1.reshape(-1)
+            n = flat.numel() // 4
+            assert all(float(flat[i * n:(i + 1) * n].abs().max()) > 0 for i in range(4)), name     # every quarter was updated by some rank
+    r0, r1 = torch.load(tmp_path / "cli0.pt"), torch.load(tmp_path / "cli1.pt")
+    assert r0["means"] == r1["means"] and len(r0["means"]) == 2

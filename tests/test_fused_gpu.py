@@ -153,3 +153,72 @@ def test_fused_random_shapes_equal_four_launch_path(dev, seed):
         cos = float(torch.dot(r, g) / (r.norm() * g.norm() + 1e-30))
         assert cos > 0.999, (c, k, cos)
         assert float((g - r).norm() / r.norm()) < 5e-2, (c, k, float((g - r).norm() / r.norm()))
+
+
+@pytest.mark.parametrize("T", [20, 31, 40, 54])
+def test_fused_layer_gradients_match_oracle_directly(dev, T):
+    """One DecoderLayer at d_model 512 / 8 heads with the fused launches ON, driven with free input tensors (target stream,
+    memories, auto-encoder streams as leaves) against the oracle's autograd of the same layer (mtn.py:183-218 on
+    oracle.multi_head_attention / feed_forward): every kind of member the fused kernels serve — self-attention (causal + pad mask),
+    cross-attention over memories whose K|V were projected ahead of the layer loop (history with an EMPTY row = fully masked,
+    caption, query, video frames with padded tails) and over an un-projected memory (the auto-encoder outputs) — dropout off.
+    dq/dk/dv-side gradients: x.grad, every memory's .grad, w_qkv.grad of every attention, at the bf16 bar of 2e-2 relative to the
+    tensor's largest entry (the fused backward kernel was only compared with the four-launch path before).
+    T = 40 / 54 are AVSD's longer targets: more than 32 query rows per sample."""
+    from mtn_amd import lib, ops
+    c = dict(vocab=80, N=1, d_model=512, d_ff=2048, h=8, ft_sizes=[64, 32], B=5, Q=13, H=37, C=29, T=T, frames=[17, 9],
+             diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query")
+    model = build_model(c, torch.bfloat16, dev).train()             # dropout 0: train mode only to keep the autograd path
+    raw = raw_batch(c)
+    b = dev_batch(raw, dev)
+    ob = fx.oracle_batch(raw)
+    model.prepare()
+    d = c["d_model"]
+    g = torch.Generator().manual_seed(5)
+    shapes = dict(x=(c["B"], T, d), cap=(c["B"], c["C"], d), his=(c["B"], c["H"], d), q=(c["B"], c["Q"], d),
+                  v0=(c["B"], c["frames"][0], d), v1=(c["B"], c["frames"][1], d), ae0=(c["B"], c["Q"], d), ae1=(c["B"], c["Q"], d))
+    host = {k: torch.randn(*s, generator=g) for k, s in shapes.items()}
+    gy = {k: torch.randn(*shapes[k], generator=g) for k in ("x", "ae0", "ae1")}
+    # ---- oracle
+    oracle, _ = fx.oracle_from_config(c, requires_grad=True)
+    ol = {k: t.clone().requires_grad_() for k, t in host.items()}
+    ox, oae = oracle.decoder_layer(0, ol["x"], ol["cap"], ob.cap_mask, ol["his"], ob.his_mask, ol["q"], ob.query_mask, ob.trg_mask,
+                                   [ol["v0"], ol["v1"]], ob.fts_mask, [ol["ae0"], ol["ae1"]])
+    ((ox * gy["x"]).sum() + (oae[0] * gy["ae0"]).sum() + (oae[1] * gy["ae1"]).sum()).backward()
+    # ---- HIP, fused on
+    prev = lib.load().mtn_fused_enable(1)
+    try:
+        dl = {k: t.to(dev).requires_grad_() for k, t in host.items()}
+        for k in ("cap", "his", "q", "v0", "v1"):
+            dl[k]._mtn_lp = ops.cast_to_lp(dl[k].detach(), torch.bfloat16)       # what the Encoder leaves on a memory
+        ops.prepare_masks(b.trg_mask, b.his_mask, b.cap_mask, b.query_mask, b.fts_mask)
+        model.zero_glue_grads()
+        c0 = lib.fused_counters()
+        model.hoist_memory_kv(dl["cap"], dl["his"], dl["q"], [dl["v0"], dl["v1"]])
+        try:
+            y, aes = model.decoder.layers[0](dl["x"], dl["cap"], b.cap_mask, dl["his"], b.his_mask, dl["q"], b.query_mask, b.trg_mask,
+                                             [dl["v0"], dl["v1"]], b.fts_mask, [dl["ae0"], dl["ae1"]], "query")
+        finally:
+            model.clear_memory_kv()
+        loss = (y * gy["x"].to(dev)).sum() + (aes[0] * gy["ae0"].to(dev)).sum() + (aes[1] * gy["ae1"].to(dev)).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        c1 = lib.fused_counters()
+    finally:
+        lib.load().mtn_fused_enable(1 if prev != 0 else 0)
+    assert c1[0] - c0[0] == 7 and c1[1] == c0[1], "a forward group left the fused kernel"
+    assert c1[2] - c0[2] == 6 and c1[3] == c0[3], "a backward group with attention members left the fused kernel"
+    assert relmax(y, ox) < 1e-2 and relmax(aes[0], oae[0]) < 1e-2 and relmax(aes[1], oae[1]) < 1e-2
+    for k in host:
+        assert relmax(dl[k].grad, ol[k].grad) < 2e-2, (k, relmax(dl[k].grad, ol[k].grad))
+    sd = dict(model.named_parameters())
+    pre = "decoder.layers.0."
+    names = ["self_attn", "his_attn", "cap_attn", "src_attn"] + [f"auto_encoder_{t}.{i}" for t in ("self_attn", "vid_attn", "attn") for i in range(2)]
+    for n in names:
+        for j in range(4):
+            for part in ("weight", "bias"):
+                if j == 1 and part == "bias":
+                    continue            # key bias: mathematically zero gradient (shifts every score of a row equally)
+                key = f"{pre}{n}.linears.{j}.{part}"
+                got, want = sd[key].grad, oracle.p[key].grad
+                assert relmax(got, want) < 2e-2, (key, relmax(got, want))

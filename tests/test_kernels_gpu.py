@@ -120,6 +120,7 @@ def test_embedding_backward_is_deterministic(dev, d, monkeypatch):
     from mtn_amd import lib as L
     lib = L.load()
     monkeypatch.setenv("MTN_EMBED_DETERMINISTIC", "1")
+    __import__("mtn_amd.lib", fromlist=["lib"]).reload_env()
     V = 300
     g = torch.Generator().manual_seed(11)
     shapes = [(6, 1400), (5, 1800), (3, 333)]               # 8400 + 9000 + 999 rows > one 16384-token chunk
@@ -348,6 +349,7 @@ def test_gemm_tt_128_tile_group(dev, dtype):
     import os
     from mtn_amd import lib as L, ops
     os.environ["MTN_GEMM_TT128"] = "1"
+    L.reload_env()
     g = torch.Generator().manual_seed(9)
     probs, checks = [], []
     for (M, N, K) in [(512, 512, 640), (1536, 512, 100), (200, 136, 333), (3000, 512, 64)]:
@@ -365,6 +367,7 @@ def test_gemm_tt_128_tile_group(dev, dtype):
         torch.cuda.synchronize()
     finally:
         del os.environ["MTN_GEMM_TT128"]
+        L.reload_env()
     for out, rs, ref, rsum, _keep in checks:
         assert relmax(out, ref) < 1e-4
         assert relmax(rs, rsum) < 1e-4
@@ -377,6 +380,7 @@ def test_gemm_tt_dma_128_tile_group(dev):
     from mtn_amd import lib as L, ops
     dtype = torch.bfloat16
     os.environ["MTN_GEMM_TTB_MIN_TILES"] = "1"
+    L.reload_env()
     g = torch.Generator().manual_seed(10)
     probs, checks = [], []
     for (M, N, K) in [(512, 512, 640), (1536, 512, 100), (200, 136, 333), (3000, 512, 64), (128, 2048, 4096)]:
@@ -400,6 +404,7 @@ def test_gemm_tt_dma_128_tile_group(dev):
         assert L.load().mtn_census_variant_name(info.variant).decode() == "gemm_tt_dma128_kernel"
     finally:
         del os.environ["MTN_GEMM_TTB_MIN_TILES"]
+        L.reload_env()
     for out, rs, ref, rsum, _keep in checks:
         assert relmax(out, ref) < 1e-4
         assert relmax(rs, rsum) < 1e-4
@@ -422,11 +427,13 @@ def test_gemm_dma_128_tile_row_major(dev, M, N, K):
     p = _gemm_problem(L, A, B, M, N, K, 0, 0, K, K)
     p.bias, p.relu, p.residual, p.ldr, p.out_f32, p.out_lp, p.ldc = bd.data_ptr(), 1, rd.data_ptr(), N, out.data_ptr(), out_lp.data_ptr(), N
     os.environ["MTN_GEMM_NTB_MIN_TILES"] = "1"
+    L.reload_env()
     try:
         ops.gemm(L.dtype_code(dtype), [p])
         torch.cuda.synchronize()
     finally:
         del os.environ["MTN_GEMM_NTB_MIN_TILES"]
+        L.reload_env()
     ref = torch.relu(lp_round(a, dtype).double() @ lp_round(b, dtype).double().t() + bias.double()) + res.double()
     assert relmax(out, ref) < 1e-4 and relmax(out_lp.float(), ref) < 1e-2
 

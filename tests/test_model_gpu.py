@@ -269,6 +269,7 @@ def test_dropout_training_step_runs_and_is_seed_deterministic(dev, monkeypatch):
     assert l1 != l3
     assert torch.isfinite(g1).all() and torch.isfinite(g3).all()
     monkeypatch.setenv("MTN_EMBED_DETERMINISTIC", "1")   # atomic-free table gradient: the whole step is bitwise reproducible
+    __import__("mtn_amd.lib", fromlist=["lib"]).reload_env()
     l4, g4 = run(1000)
     l5, g5 = run(1000)
     assert l4 == l5 == l1 and torch.equal(g4, g5)
@@ -488,6 +489,7 @@ def test_optimiser_epilogue_covers_every_model_variant(dev, name, monkeypatch):
     steps equal two separate-optimiser steps bit for bit."""
     from mtn_amd.train_step import TrainStep
     monkeypatch.setenv("MTN_EMBED_DETERMINISTIC", "1")
+    __import__("mtn_amd.lib", fromlist=["lib"]).reload_env()
     c = fx.GOLDEN_CONFIGS[name]
     b = dev_batch(raw_batch(c), dev)
     res = []
@@ -510,6 +512,7 @@ def test_optimiser_epilogue_equals_separate_adam(dev, dtype, use_graph, monkeypa
     several steps (with the atomic-free table gradient, so that nothing else differs between two runs)."""
     from mtn_amd.train_step import TrainStep
     monkeypatch.setenv("MTN_EMBED_DETERMINISTIC", "1")
+    __import__("mtn_amd.lib", fromlist=["lib"]).reload_env()
     c = fx.GOLDEN_CONFIGS["cfg1_query"]
     b = dev_batch(raw_batch(c), dev)
     res = []
@@ -518,6 +521,7 @@ def test_optimiser_epilogue_equals_separate_adam(dev, dtype, use_graph, monkeypa
             monkeypatch.delenv("MTN_NO_FUSED_ADAM", raising=False)
         else:
             monkeypatch.setenv("MTN_NO_FUSED_ADAM", "1")
+            __import__("mtn_amd.lib", fromlist=["lib"]).reload_env()
         m = build_model(c, dtype, dev, dropout=0.1, attn_dropout=0.1).train()
         for mod in m.modules():
             if isinstance(mod, torch.nn.Dropout):

@@ -15,6 +15,7 @@ for B, RAGGED in ((32, True), (32, False), (128, True), (128, False)):
         toks.append(t.to(dev).reshape(-1).contiguous()); dxs.append(torch.randn(B * Lq, d, generator=g).to(dev))
     for mode in ("atomic", "det"):
         os.environ["MTN_EMBED_DETERMINISTIC"] = "0" if mode == "atomic" else "1"
+        L.reload_env()
         dlut = torch.zeros(V, d, device=dev)
         descs = (L.EmbedBwdDesc * 4)()
         for E, t, x in zip(descs, toks, dxs):

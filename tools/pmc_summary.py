@@ -66,6 +66,19 @@ for name, v in res["kernels"].items():
     f = name.split(" wgs=")[0]
     fam[f][0] += v["launches_per_step"]; fam[f][1] += v["hbm_bytes_per_launch"] * v["launches_per_step"]
 res["families"] = {f: {"launches_per_step": n, "hbm_bytes_per_launch": round(b / n)} for f, (n, b) in sorted(fam.items(), key=lambda kv: -kv[1][1])}
+# what the passes were collected on: bench.py's roofline.traffic_source compares it with the sources it runs on
+import hashlib
+import subprocess
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(root, "mtn_amd", "csrc", "*"))):
+    h.update(os.path.basename(f).encode())
+    h.update(open(f, "rb").read())
+try:
+    head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:
+    head = os.environ.get("MTN_GIT_HEAD")          # (the GPU box has no .git: tools/prof_round.sh passes it in)
+res["collected_on"] = {"csrc_sha16": h.hexdigest()[:16], "git_head": head}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res["corrections"]), json.dumps(res["step"]))
 for f, v in list(res["families"].items())[:16]:
