@@ -503,6 +503,10 @@ int mtn_measure_hbm_peak(const void* src, void* dst, long bytes, void* stream, d
  * environment once per call site and cached: a process that changes one after the library has used it calls this to make the
  * next launches re-read them.  Returns the new generation number. */
 int mtn_reload_env(void);
+/* Measurement support: a stream restricted to `n_cus` compute units (hipExtStreamCreateWithCUMask, bits dealt round-robin to the
+ * 8 XCDs), for overlap experiments (tools/overlap_cu_mask_probe.py).  The caller destroys it with mtn_stream_destroy(). */
+int mtn_stream_create_cu_masked(int n_cus, int low_priority, void** stream_out);
+int mtn_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

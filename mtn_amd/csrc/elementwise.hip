@@ -324,3 +324,28 @@ extern "C" int mtn_measure_hbm_peak(const void* src, void* dst, long bytes, void
     *gbps = best;
     return MTN_OK;
 }
+
+// ---------------------------------------------------------------- CU-masked streams (measurement support)
+// A stream whose kernels may only run on the first `n_cus` compute units the runtime enumerates (hipExtStreamCreateWithCUMask;
+// the mask bits are dealt to the XCDs round-robin, so the allowed CUs are spread evenly over the 8 dies), optionally at low
+// priority: tools/overlap_cu_mask_probe.py uses it to measure whether an HBM-bound pass (parameter gradients + optimiser) can
+// hide under the latency-bound backward chain.  The caller owns the stream (mtn_stream_destroy).
+extern "C" int mtn_stream_create_cu_masked(int n_cus, int low_priority, void** stream_out) {
+    MTN_CHECK_ARG(stream_out && n_cus >= 1 && n_cus <= 256, "n_cus must be in [1, 256]");
+    uint32_t mask[8];
+    for (int w = 0; w < 8; ++w) {
+        const int lo = w * 32;
+        mask[w] = n_cus >= lo + 32 ? 0xffffffffu : (n_cus > lo ? ((1u << (n_cus - lo)) - 1u) : 0u);
+    }
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, 8, mask);
+    if (e != hipSuccess) { mtn_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
+    (void)low_priority;      // (the CU-mask constructor takes no priority: a masked stream runs at the default priority)
+    *stream_out = (void*)s;
+    return MTN_OK;
+}
+extern "C" int mtn_stream_destroy(void* stream) {
+    MTN_CHECK_ARG(stream, "null stream");
+    if (hipStreamDestroy((hipStream_t)stream) != hipSuccess) { mtn_set_error("hipStreamDestroy failed"); return MTN_ERR_LAUNCH; }
+    return MTN_OK;
+}

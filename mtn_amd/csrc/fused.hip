@@ -35,6 +35,10 @@ struct FhMember {
     int a, m, blk;     // attention: query rows per sample, memory rows per sample, samples per workgroup
     int mt;            // row tiles (16 rows) of this member's workgroups: 2, 3 or 5
     int hg, sg;        // XCD-aware workgroup map: the 8 XCDs form hg slice groups x sg row-block groups (hg * sg = 8)
+    int late_v;        // long memory projected ahead of the layer loop: the V image takes the place of the (dead) xn image, its DMA
+                       // is issued once the projections are done (K + V of 512 keys x 64 columns do not fit beside the x rows)
+    int nks;           // attention: key ranges per (sample, 16 query rows): > 1 = long memory and few samples per workgroup, every
+                       // wave takes a range of 64-key chunks and the partial {max, sum, O} meet through LDS
     int ncols;         // FFN: d_ff
     int ld_out;        // row stride of `out`
     float eps;
@@ -67,19 +71,30 @@ struct FhGroup {
 
 // LDS map (bytes), the same arithmetic on host and device
 struct FhLds { int gains, xn, xm, qi, ki, vi, mask, total; };
-__host__ __device__ inline FhLds fh_lds_map(int mt, bool raw, int key_rows, int pad_rows, int mask_bytes, int ffn_blocks = 0) {
+__host__ __device__ inline FhLds fh_lds_map(int mt, bool raw, int key_rows, int pad_rows, int mask_bytes, int ffn_blocks = 0, bool late_v = false) {
     FhLds L;
     L.gains = 0;                                            // a_2 | b_2 | biases of the workgroup's output columns
     L.xn = 4096 + 1024;                                     // also the exchange area of the two contraction halves (4*NP*mt KiB)
+    const int krows = ((key_rows + pad_rows + 7) & ~7);     // keys + finite padding up to the end of the last 64-key chunk
+    if (late_v) {                                           // V image over the xn image (dead after the projections), then Q, K, mask
+        L.vi = L.xn;
+        const int top = mt * 16 * FH_ROWB > krows * FH_HROWB ? mt * 16 * FH_ROWB : krows * FH_HROWB;
+        L.xm = L.xn + top;
+        L.qi = L.xm;
+        L.ki = L.qi + mt * 16 * FH_HROWB;
+        L.mask = L.ki + krows * FH_HROWB;
+        L.total = L.mask + ((mask_bytes + 15) & ~15);
+        return L;
+    }
     L.xm = L.xn + mt * 16 * FH_ROWB;
     L.qi = L.xm + (raw ? mt * 16 * FH_ROWB : 0);
     L.ki = L.qi + mt * 16 * (ffn_blocks ? ffn_blocks * FH_HROWB : FH_HROWB);     // Q image, or the feed-forward output tile [row][64 * NP]
-    const int krows = ((key_rows + pad_rows + 7) & ~7);     // keys + finite padding up to the end of the last 64-key chunk
     L.vi = L.ki + krows * FH_HROWB;
     L.mask = L.vi + krows * FH_HROWB;
     L.total = L.mask + ((mask_bytes + 15) & ~15);
     return L;
 }
+static constexpr int FH_PART_FLOATS = 18;                   // a wave's attention partial per lane: O^T (16) + running max + running sum
 // image rows behind the keys that a 64-key chunk of the last sample may touch
 __host__ __device__ inline int fh_pad_rows(int kind, int mk) { return kind == FH_CROSS_READY ? ((mk + 63) & ~63) - mk : 64; }
 
@@ -109,7 +124,8 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     const int key_rows = ffn ? 0 : ((kind == FH_SELF || raw) ? MT * 16 : nsamp * m);
     const int qa = M.mask_sq ? a : 1;
     const int mask_bytes = ffn ? 0 : nsamp * qa * m;   // the mask image always exists (all ones without a mask): no branch per score
-    const FhLds L = fh_lds_map(MT, raw, key_rows, fh_pad_rows(kind, mk), mask_bytes, ffn ? NP : 0);
+    const bool late_v = kind == FH_CROSS_READY && M.late_v != 0;
+    const FhLds L = fh_lds_map(MT, raw, key_rows, fh_pad_rows(kind, mk), mask_bytes, ffn ? NP : 0, late_v);
     unsigned char* xn_s = smem + L.xn;
     unsigned char* xm_s = smem + L.xm;
     unsigned char* qi_s = smem + L.qi;
@@ -146,7 +162,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             const unsigned vk = row < Kr ? (unsigned)row * (4 * FH_D) + (unsigned)((slot ^ (row & 7)) << 4) : 0x80000000u;
             const unsigned vv = row < Kr ? (unsigned)row * (4 * FH_D) + (unsigned)((slot ^ ((row >> 1) & 7)) << 4) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (fh_lds_void_t*)(ki_s + i * 1024), 16, vk, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (fh_lds_void_t*)(vi_s + i * 1024), 16, vv, 0, 0, 0);
+            if (!late_v) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (fh_lds_void_t*)(vi_s + i * 1024), 16, vv, 0, 0, 0);
         }
     }
     // (3) x rows: row group rg = wave + 8i holds rows 4rg .. 4rg+3, one per 16-lane row; lane l15 reads columns 64j + 4*l15
@@ -327,6 +343,21 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
                     acc[p][mt][0] += o[0]; acc[p][mt][1] += o[1]; acc[p][mt][2] += o[2]; acc[p][mt][3] += o[3];
                 }
     }
+    if (late_v) {
+        // the xn image and the exchange area inside it are dead once every wave has read its partner's tiles: the V head rows of
+        // the block's samples go there now (second memory generation of this workgroup: it lands under the epilogue and the
+        // Q-row stores, and is waited for just before the attention)
+        __syncthreads();
+        const int Kr = nsamp * m;
+        const bf16_t* vbase = M.kv + (size_t)rm0 * (2 * FH_D) + slice * FH_DK + FH_D;
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (Kr - 1) * (4 * FH_D) + FH_HROWB, 0x00020000);
+        const int ninst = ((Kr + fh_pad_rows(kind, mk) + 7) & ~7) >> 3;
+        for (int i = wave; i < ninst; i += 8) {
+            const int row = i * 8 + (lane >> 3), slot = lane & 7;
+            const unsigned vv = row < Kr ? (unsigned)row * (4 * FH_D) + (unsigned)((slot ^ ((row >> 1) & 7)) << 4) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (fh_lds_void_t*)(vi_s + i * 1024), 16, vv, 0, 0, 0);
+        }
+    }
     if (G.stop == 2) {
         float t_ = 0.f;
 #pragma unroll
@@ -402,12 +433,17 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     }
     if (G.stop == 3) return;
 
-    // ---- attention of this head, on chip.  Item = (sample, 16 query rows), one wave each.
+    // ---- attention of this head, on chip.  Item = (sample, 16 query rows[, key range]), one wave each.
     FH_STAMP(8);
+    if (late_v) {                                  // the V image's DMA (issued after the projections) has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     const float scale = 0.125f;                    // 1 / sqrt(64)
     const int nqt = (a + 15) >> 4;
-    for (int it = wave; it < nsamp * nqt; it += 8) {
-        const int si = it / nqt, qt = it - si * nqt;
+    // one item over the 64-key chunks [cbeg, cend): S^T = K Q^T, masked online softmax, O^T += V^T P^T.  Leaves the un-normalised
+    // O^T[head column 16nt + 4lg + r][query l15], the running max and the running sum of the range.
+    auto attend = [&](const int si, const int qt, const int cbeg, const int cend, f32x4_t (&ot)[4], float& mrun, float& lrun) {
         const int b = b0 + si;
         const DropBase dbase = drop_base((uint64_t)(b * (FH_D / FH_DK) + slice) * (uint64_t)a * (uint64_t)mk);   // P-dropout index of (q, key) = base + q * mk + key
         const int q = qt * 16 + l15, qc = q < a ? q : a - 1;
@@ -415,12 +451,11 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         uint4 qf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[ks] = fh_hfrag(qi_s, qrow, ks * 4 + lg);
-        f32x4_t ot[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) ot[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        float mrun = -INFINITY, lrun = 0.f;
+        mrun = -INFINITY; lrun = 0.f;
         const unsigned char* mrow = mk_s + (size_t)(si * qa + (M.mask_sq ? qc : 0)) * mk;
-        for (int c0 = 0; c0 < mk; c0 += 64) {
+        for (int c0 = cbeg; c0 < cend; c0 += 64) {
             // S^T tile kt, accumulator row i <-> key c0 + 32(kt/2) + 8(i/4) + 4(kt%2) + (i%4): a lane's values of tiles 2u, 2u+1
             // are keys c0 + 32u + 8lg + 0..7 — the B-operand slot order of the V^T P^T contraction
             const bool wide = mk - c0 > 32;                        // keys 32..63 of the chunk exist (uniform): short memories skip that half
@@ -482,7 +517,10 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
                 for (int nt = 0; nt < 4; ++nt) mma16<bf16_t>(ot[nt], vf[nt], pf);
             }
         }
-        // lane holds O^T[head column 16nt + 4lg + r][query l15]
+    };
+    // lane holds O^T[head column 16nt + 4lg + r][query l15]: normalise, store the head's output columns and {max, 1 / sum}
+    auto finish = [&](const int si, const int qt, const f32x4_t (&ot)[4], const float mrun, const float lrun) {
+        const int b = b0 + si, q = qt * 16 + l15;
         if (q < a) {
             const float inv = 1.0f / lrun;
             bf16_t* og = M.o + (size_t)(b * a + q) * FH_D + slice * FH_DK + 4 * lg;
@@ -494,6 +532,59 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
                 stp[0] = mrun;
                 stp[1] = inv;
             }
+        }
+    };
+    const int nks = M.nks;
+    if (nks <= 1) {
+        for (int it = wave; it < nsamp * nqt; it += 8) {
+            const int si = it / nqt, qt = it - si * nqt;
+            f32x4_t ot[4];
+            float mrun, lrun;
+            attend(si, qt, 0, mk, ot, mrun, lrun);
+            finish(si, qt, ot, mrun, lrun);
+        }
+    } else {
+        // Few (sample, query tile) pairs and a long memory: nks waves share a pair, each over its own range of 64-key chunks;
+        // the partial {O^T, max, sum} of a pair's waves meet in LDS (over the K image, dead by then) and the pair's first wave
+        // combines them:  m* = max m_k,  l* = sum l_k e^(m_k - m*),  O* = sum O_k e^(m_k - m*).
+        const int npairs = nsamp * nqt;                        // host: npairs * nks <= 8
+        const int pair = wave / nks, kr = wave - pair * nks;
+        const bool live = pair < npairs;
+        const int si = live ? pair / nqt : 0, qt = live ? pair - si * nqt : 0;
+        const int chunks = (mk + 63) >> 6, per = (chunks + nks - 1) / nks;
+        int cbeg = kr * per * 64, cend = (kr + 1) * per * 64;
+        cend = cend < mk ? cend : mk;
+        f32x4_t ot[4];
+        float mrun = -INFINITY, lrun = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) ot[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (live && cbeg < cend) attend(si, qt, cbeg, cend, ot, mrun, lrun);
+        __syncthreads();                                       // every wave is done with the K and V images
+        // slot of a non-first wave of a pair: pair * (nks - 1) + kr - 1  (at most 7 slots of FH_PART_FLOATS x 64 floats)
+        float* part = (float*)ki_s + (size_t)(pair * (nks - 1) + kr - 1) * (FH_PART_FLOATS * 64) + lane;
+        if (live && kr != 0) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[(nt * 4 + r) * 64] = ot[nt][r];
+            part[16 * 64] = mrun;
+            part[17 * 64] = lrun;
+        }
+        __syncthreads();
+        if (live && kr == 0) {
+            for (int k = 1; k < nks; ++k) {
+                const float* pk = (const float*)ki_s + (size_t)(pair * (nks - 1) + k - 1) * (FH_PART_FLOATS * 64) + lane;
+                const float mo = pk[16 * 64], lo = pk[17 * 64];
+                const float mn = fmaxf(mrun, mo);
+                const float wa = (mrun == -INFINITY) ? 0.f : __expf(mrun - mn), wb = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+                lrun = lrun * wa + lo * wb;
+                mrun = mn;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ot[nt][r] = ot[nt][r] * wa + pk[(nt * 4 + r) * 64] * wb;
+            }
+            finish(si, qt, ot, mrun, lrun);
         }
     }
     FH_STAMP(9);
@@ -555,12 +646,12 @@ static constexpr int FH_LDS_MAX = 160 * 1024;
 // row tiles a workgroup may have: {2, 3, 5} in the 1- and 3-block kernels, {2, 4} in the 4-block kernel
 static const int fh_mt_sets[2][3] = {{2, 3, 5}, {2, 4, 4}};
 
-struct FhPlan { int blk, mt, lds; };
-static int fh_member_lds(const mtn_mha_args& A, int blk, int mt) {
+struct FhPlan { int blk, mt, lds, late_v; };
+static int fh_member_lds(const mtn_mha_args& A, int blk, int mt, bool late_v = false) {
     const bool self = A.self_attn != 0, raw = !self && !A.kv_ready;
     const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
     const int kind = self ? FH_SELF : (raw ? FH_CROSS_RAW : FH_CROSS_READY);
-    return fh_lds_map(mt, raw, (self || raw) ? mt * 16 : blk * m, fh_pad_rows(kind, m), blk * qa * m).total;
+    return fh_lds_map(mt, raw, (self || raw) ? mt * 16 : blk * m, fh_pad_rows(kind, m), blk * qa * m, 0, late_v).total;
 }
 // Rows per workgroup for an attention member: whole samples, inside the row tiles (<= 80 rows) and the LDS; as few workgroups as
 // it takes to stay within the member's share of one round of the chip (these launches are bound by the bytes each CU pulls:
@@ -569,7 +660,7 @@ static FhPlan fh_plan_mha(const mtn_mha_args& A, int budget, int np) {
     const int* fh_mt_choices = fh_mt_sets[np == 4];
     const bool self = A.self_attn != 0, raw = !self && !A.kv_ready;
     const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
-    FhPlan best = {0, 0, 0};
+    FhPlan best = {0, 0, 0, 0};
     if (A.mask && A.mask_sb != 0 && A.mask_sb != (long)qa * m) return best;      // the block's mask bytes must be contiguous
     if (A.mask && A.mask_sq != 0 && A.mask_sq != m) return best;
     for (int blk = 1; blk <= A.B; ++blk) {
@@ -579,9 +670,13 @@ static FhPlan fh_plan_mha(const mtn_mha_args& A, int budget, int np) {
             if (fh_mt_choices[c] * 16 >= R && (!raw || fh_mt_choices[c] * 16 >= Rm)) { mt = fh_mt_choices[c]; break; }
         if (!mt) break;
         if (A.mask && blk * qa * m > FH_THREADS * FH_MASKB) break;
-        const int lds = fh_member_lds(A, blk, mt);
+        int lds = fh_member_lds(A, blk, mt), late = 0;
+        if (lds > FH_LDS_MAX && !self && !raw) {       // K + V images of a long projected memory: V over the (dead) xn image
+            lds = fh_member_lds(A, blk, mt, true);
+            late = 1;
+        }
         if (lds > FH_LDS_MAX) break;
-        best = FhPlan{blk, mt, lds};
+        best = FhPlan{blk, mt, lds, late};
         if (((A.B + blk - 1) / blk) * (FH_D / FH_DK) <= budget) break;
     }
     return best;
@@ -625,7 +720,20 @@ static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn
         if (pl.blk == 0) return false;
         FhMember& M = G.m[n];
         M.kind = a.self_attn ? FH_SELF : (a.kv_ready ? FH_CROSS_READY : FH_CROSS_RAW);
-        M.a = a.a; M.m = a.self_attn ? a.a : a.m; M.blk = pl.blk; M.mt = pl.mt;
+        M.a = a.a; M.m = a.self_attn ? a.a : a.m; M.blk = pl.blk; M.mt = pl.mt; M.late_v = pl.late_v;
+        {   // key ranges per (sample, 16 query rows): all 8 waves of a workgroup that holds few pairs and a long memory
+            static const bool ksplit = [] { const char* e = getenv("MTN_FH_KSPLIT"); return !(e && e[0] == '0'); }();
+            const int npairs = pl.blk * ((a.a + 15) / 16), chunks = (M.m + 63) / 64;
+            int nks = 1;
+            if (ksplit && npairs <= 4 && chunks >= 4 && !a.self_attn && a.kv_ready) {     // (long memories projected ahead of the layer loop)
+                nks = npairs == 1 ? 8 : (npairs == 2 ? 4 : 2);
+                while (nks > chunks) nks >>= 1;
+                // the partials of a pair's non-first waves (FH_PART_FLOATS x 64 floats each) meet over the K image
+                const int kimg = ((pl.blk * M.m + fh_pad_rows(FH_CROSS_READY, M.m) + 7) & ~7) * FH_HROWB;
+                if (npairs * (nks - 1) * FH_PART_FLOATS * 64 * 4 > kimg) nks = 1;
+            }
+            M.nks = nks;
+        }
         M.rows = a.B * a.a; M.rows_per_wg = pl.blk * a.a; M.nslice = FH_D / FH_DK;
         M.eps = a.ln_eps; M.x = a.x; M.ln_a = a.ln_a; M.ln_b = a.ln_b;
         M.w = (const bf16_t*)a.w_qkv; M.bias = a.b_qkv; M.mem = (const bf16_t*)a.mem;

@@ -3,8 +3,10 @@
 //     dq, dk, dv = attention backward of the head      (autograd of attention(), mtn.py:221-231)
 // instead of a grouped GEMM launch (dO for all heads, through HBM) followed by the attention-backward launch.  The gradient of
 // the input projections (dq|dk|dv -> d LayerNorm-out, a contraction over ALL heads) stays a grouped GEMM, as does everything
-// after it.  bf16, d_model = 512, d_k = 64; a sample's query rows are taken in blocks of 32 (NQB = 1, 2 or 3 blocks: up to the 80
-// rows a workgroup holds — AVSD targets reach 54 tokens, queries 42; longer streams keep the two-launch path).
+// after it.  bf16, d_model = 512, d_k = 64; a sample's query rows are taken in blocks of 32 (NQB = 1 or 2 blocks: up to 64 query
+// rows — AVSD targets reach 54 tokens, queries 42; longer streams keep the two-launch path).  A memory too long for the LDS
+// (BASELINE configs[3]: 512 history tokens, 256 frames) streams its K / V head rows through a two-slot ring of 128 keys while
+// both four-wave teams work on the workgroup's one sample.
 //
 // Same construction as the forward kernel: a 512-thread workgroup = (member, block of whole samples, head) issues
 // everything it reads up front — dy rows (bf16, [row][512]) and the head's q, k, v, o rows (128 bytes each) by LDS-DMA, mask bytes,
@@ -26,6 +28,8 @@ struct FbMember {
     int a, m, blk, mt;         // query rows / memory rows per sample, samples per workgroup, row tiles of the workgroup
     int hg, sg;                // XCD map (fused.hip)
     int self_attn;             // k, v rows are the query rows' own (packed qkv buffer)
+    int ring;                  // long memory (one sample per workgroup): K / V head rows stream through a two-slot ring of 128 keys,
+                               // both four-wave teams work on the sample (alternate key tiles), dQ partials met through LDS
     int ldq, ldkv;             // row strides (elements) of q / dq and of k, v / dk, dv
     const bf16_t* dyl;         // [rows, 512] gradient entering the dropped-out branch
     const bf16_t* wot;         // W_o^T [512, 512]
@@ -59,18 +63,19 @@ struct FbGroup {
 static constexpr int FB_DSROW = 80;        // bytes per row of a tile image [32 keys][32 queries] bf16 (+ 16 pad)
 static constexpr int FB_TILE_IMG = 32 * FB_DSROW;
 static constexpr int FB_TEAM_SCRATCH = 4 * FB_TILE_IMG;   // a team's {P^T, dS^T} images, double-buffered over key tiles
-static constexpr int FB_DS_BYTES = 3 * 128;                // D_q of a wave's sample: up to 3 query blocks of 32
-static constexpr int FB_SCRATCH = 2 * FB_TEAM_SCRATCH + 8 * FB_DS_BYTES;      // ... two teams, then D_q[96] of each wave: 23.0 KiB
+static constexpr int FB_DS_BYTES = 2 * 128;                // D_q of a wave's sample: up to 2 query blocks of 32
+static constexpr int FB_SCRATCH = 2 * FB_TEAM_SCRATCH + 8 * FB_DS_BYTES;      // ... two teams, then D_q[64] of each wave: 22.0 KiB
 
+static constexpr int FB_RING_KEYS = 128;   // keys per ring slot
 struct FbLds { int dy, qi, oi, doi, ki, vi, mask, scratch, total; };
-__host__ __device__ inline FbLds fb_lds_map(int mt, int key_rows, int mask_bytes) {
+__host__ __device__ inline FbLds fb_lds_map(int mt, int key_rows, int mask_bytes, bool ring = false) {
     FbLds L;
     L.dy = 0;                                              // also the exchange area of the two contraction halves (4 * mt KiB)
     L.qi = mt * 16 * FH_ROWB;
     L.oi = L.qi + mt * 16 * FH_HROWB;
     L.doi = L.oi + mt * 16 * FH_HROWB;
     L.ki = L.doi + mt * 16 * FH_HROWB;
-    const int krows = ((key_rows + 7) & ~7) + 32;          // + one key tile of finite padding
+    const int krows = ring ? 2 * FB_RING_KEYS : ((key_rows + 7) & ~7) + 32;          // two ring slots | all keys + one key tile of finite padding
     L.vi = L.ki + krows * FH_HROWB;
     L.mask = L.vi + krows * FH_HROWB;
     L.total = L.mask + ((mask_bytes + 15) & ~15);
@@ -130,7 +135,7 @@ __device__ __forceinline__ float fb_dot8(const uint4& x, const uint4& y) {
     return s;
 }
 
-template <int MT, int NQB>
+template <int MT, int NQB, bool RING>
 __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, const int rb, unsigned char* smem, const int stop, const int tl) {
     const int tid = threadIdx.x;
     FB_STAMP(0);
@@ -145,7 +150,7 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     const size_t krow_g0 = M.self_attn ? (size_t)row0 : (size_t)b0 * M.m;     // first key row of the block in k / v / dk / dv
     const int qa = M.mask_sq ? a : 1;
     const int mask_bytes = nsamp * qa * mk;                // the mask image always exists (all ones without a mask): no branch per score
-    const FbLds L = fb_lds_map(MT, M.self_attn ? MT * 16 : M.blk * M.m, M.blk * qa * mk);
+    const FbLds L = fb_lds_map(MT, M.self_attn ? MT * 16 : M.blk * M.m, M.blk * qa * mk, RING);
     unsigned char* dy_s = smem + L.dy;
     unsigned char* qi_s = smem + L.qi;
     unsigned char* oi_s = smem + L.oi;
@@ -177,8 +182,20 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     }
     fb_dma_head_rows(M.q + (size_t)row0 * M.ldq + slice * FH_DK, M.ldq, R, MT * 16, qi_s, wave, lane);
     fb_dma_head_rows(M.o + (size_t)row0 * FH_D + slice * FH_DK, FH_D, R, MT * 16, oi_s, wave, lane);
-    fb_dma_head_rows(M.k + krow_g0 * M.ldkv + slice * FH_DK, M.ldkv, Kr, ((Kr + 7) & ~7) + 32, ki_s, wave, lane);
-    fb_dma_head_rows(M.v + krow_g0 * M.ldkv + slice * FH_DK, M.ldkv, Kr, ((Kr + 7) & ~7) + 32, vi_s, wave, lane);
+    // K / V head rows of key block bk (FB_RING_KEYS keys) into ring slot bk & 1: 4 LDS-DMA instructions per wave
+    auto ring_dma = [&](const int bk) {
+        const int k0 = bk * FB_RING_KEYS, valid = Kr - k0 < FB_RING_KEYS ? Kr - k0 : FB_RING_KEYS;
+        const size_t g0 = (krow_g0 + k0) * M.ldkv + slice * FH_DK;
+        fb_dma_head_rows(M.k + g0, M.ldkv, valid, FB_RING_KEYS, ki_s + (bk & 1) * (FB_RING_KEYS * FH_HROWB), wave, lane);
+        fb_dma_head_rows(M.v + g0, M.ldkv, valid, FB_RING_KEYS, vi_s + (bk & 1) * (FB_RING_KEYS * FH_HROWB), wave, lane);
+    };
+    if constexpr (RING) {
+        ring_dma(0);
+        if (FB_RING_KEYS < Kr) ring_dma(1);
+    } else {
+        fb_dma_head_rows(M.k + krow_g0 * M.ldkv + slice * FH_DK, M.ldkv, Kr, ((Kr + 7) & ~7) + 32, ki_s, wave, lane);
+        fb_dma_head_rows(M.v + krow_g0 * M.ldkv + slice * FH_DK, M.ldkv, Kr, ((Kr + 7) & ~7) + 32, vi_s, wave, lane);
+    }
     // W_o^T rows slice*64 + 16wc .. +15, this wave's half of the contraction; coalesced: lane 4r + c reads (row r, chunk c)
     uint4 wf[8];
     {
@@ -189,7 +206,7 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     // softmax statistics {row max, 1 / row sum} of the team's first sample (queries 8lg + 4qt + r): in flight with everything else
     float mxq[NQB][4], invq[NQB][4];
     {
-        const int si0 = team < nsamp ? team : 0;
+        const int si0 = (!RING && team < nsamp) ? team : 0;
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
@@ -252,12 +269,13 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     FB_STAMP(4);
     if (stop == 2) return;
 
-    // ---- attention backward: two samples at a time, a team of four waves each; one workgroup barrier per key tile of 32
+    // ---- attention backward: two samples at a time, a team of four waves each; one workgroup barrier per key tile of 32.
+    //      RING: ONE sample, both teams on it — team t takes the key tiles 64 i + 32 t — and the keys stream through the ring
     const float scale = 0.125f;
-    const int nrounds = (nsamp + 1) >> 1;
+    const int nrounds = RING ? 1 : (nsamp + 1) >> 1;
     int buf = 0;
     for (int rd = 0; rd < nrounds; ++rd) {
-        const int si = 2 * rd + team;
+        const int si = RING ? 0 : 2 * rd + team;
         const bool live = si < nsamp;                              // team-uniform; an idle team only keeps the barriers
         const int sic = live ? si : nsamp - 1;
         const int b = b0 + sic, qrow0 = sic * a, krow0 = sic * mk;
@@ -309,7 +327,21 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
         }
         if (rd == 0) FB_STAMP(5);
 
-        for (int j0 = 0; j0 < mk; j0 += 32) {
+        const int niter = RING ? (mk + 63) >> 6 : (mk + 31) >> 5;
+        for (int it = 0; it < niter; ++it) {
+            const int j0 = RING ? 64 * it + 32 * team : 32 * it;   // first key of this team's tile
+            const bool tlive = live && j0 < mk;
+            int jimg = krow0 + j0;                                 // image row of key j0
+            if constexpr (RING) {
+                if ((it & 1) == 0) {
+                    // key block it / 2 has landed in its slot: the only younger vector-memory operations of this wave are the 4 LDS-DMA
+                    // instructions of the next block (loads return in order), if there is one
+                    if ((it / 2 + 1) * FB_RING_KEYS < mk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();          // (raw barriers in this loop: __syncthreads() would drain the refill DMA in flight)
+                }
+                jimg = ((j0 / FB_RING_KEYS) & 1) * FB_RING_KEYS + (j0 & (FB_RING_KEYS - 1));
+            }
             // dV^T, dK^T of this key tile: summed over the sample's query blocks before they are stored
             f32x4_t av[2], ak[2];
             av[0] = av[1] = ak[0] = ak[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -317,14 +349,14 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
             for (int qb = 0; qb < NQB; ++qb, buf ^= 1) {
                 unsigned char* pt_s = tm_s + buf * (2 * FB_TILE_IMG);  // P^T (dropped out) [key][query of the block]
                 unsigned char* dst_s = pt_s + FB_TILE_IMG;             // dS^T [key][query of the block]
-                if (live) {
+                if (tlive) {
                     // ---- phase 1: this wave's 16 x 16 quadrant of S = Q K^T and dP = dO V^T, then P and dS
                     const int key = j0 + kt * 16 + l15, kc = key < mk ? key : mk - 1;
                     uint4 kf[2], vf[2];
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        kf[ks] = fh_hfrag(ki_s, krow0 + kc, ks * 4 + lg);
-                        vf[ks] = fh_hfrag(vi_s, krow0 + kc, ks * 4 + lg);
+                        kf[ks] = fh_hfrag(ki_s, jimg + (kc - j0), ks * 4 + lg);
+                        vf[ks] = fh_hfrag(vi_s, jimg + (kc - j0), ks * 4 + lg);
                     }
                     f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = sc;   // C layout: rows q = 32qb + 8lg + 4qt + r, column key
 #pragma unroll
@@ -353,14 +385,17 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                     *(uint2*)(dst_s + off) = make_uint2(fh_pack2(dsv[0], dsv[1]), fh_pack2(dsv[2], dsv[3]));
                     if (rd == 0 && j0 == 0 && qb == 0) FB_STAMP(7);
                 }
-                __syncthreads();                                       // the tile's images are complete (the other buffer may still be read)
-                if (live) {
+                if constexpr (RING) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                } else __syncthreads();                                // the tile's images are complete (the other buffer may still be read)
+                if (tlive) {
                     // ---- phase 2: head columns 16 w4 .. +15.  dV^T += dO^T P, dK^T += Q^T dS (contraction over the block's 32 queries,
                     // per key sub-tile), dQ^T += K^T dS^T (contraction over the tile's 32 keys); A operands by transposing reads of the
                     // row-major images
                     const uint4 dot_ = fb_tfrag(doi_s, qrow0 + 32 * qb, w4 * 16, l15, lg);
                     const uint4 qt_ = fb_tfrag(qi_s, qrow0 + 32 * qb, w4 * 16, l15, lg);
-                    const uint4 kt_ = fb_tfrag(ki_s, krow0 + j0, w4 * 16, l15, lg);
+                    const uint4 kt_ = fb_tfrag(ki_s, jimg, w4 * 16, l15, lg);
                     uint4 pf[2], sf[2], sfq[2];
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2) {
@@ -379,7 +414,7 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                     if (rd == 0 && j0 == 0 && qb == 0) FB_STAMP(8);
                 }
             }
-            if (live && stop != 3) {
+            if (tlive && stop != 3) {
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
                     const int key = j0 + k2 * 16 + l15;
@@ -390,9 +425,37 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                     }
                 }
             }
+            if constexpr (RING) {
+                if ((it & 1) == 1) {                               // the slot of key block it / 2 is free once every wave is past it: refill it
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if ((it / 2 + 2) * FB_RING_KEYS < mk) ring_dma(it / 2 + 2);
+                }
+            }
         }
         if (rd == 0) FB_STAMP(10);
-        if (live) {
+        if constexpr (RING) {
+            // the two teams hold partial dQ^T sums over their key tiles: team 1 hands its over through LDS (the dy / tile-image area is dead)
+            __syncthreads();
+            float* dx = (float*)dy_s + (size_t)(w4 * 64 + lane) * (8 * NQB);
+            if (team == 1) {
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2) *(f32x4_t*)(dx + (qb * 2 + q2) * 4) = dqt[qb][q2];
+            }
+            __syncthreads();
+            if (team == 0) {
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2) {
+                        const f32x4_t o = *(const f32x4_t*)(dx + (qb * 2 + q2) * 4);
+                        dqt[qb][q2][0] += o[0]; dqt[qb][q2][1] += o[1]; dqt[qb][q2][2] += o[2]; dqt[qb][q2][3] += o[3];
+                    }
+            }
+        }
+        if (live && (!RING || team == 0)) {
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
@@ -408,6 +471,10 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     }
 }
 
+// WIDE = false: every member has at most 32 query rows per sample and keeps all its keys in LDS (the train step of BASELINE
+// configs[1..2]); WIDE = true: also the bodies for query blocks of 32 (a <= 80) and for long memories through the key ring.
+// Two kernels so that the common launch keeps its register allocation (the wide bodies need more live fragments).
+template <bool WIDE>
 __global__ __launch_bounds__(FH_THREADS) void fused_head_bwd_kernel(const FbGroup G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int g = 0;
@@ -418,17 +485,22 @@ __global__ __launch_bounds__(FH_THREADS) void fused_head_bwd_kernel(const FbGrou
     const int hpg = (FH_D / FH_DK) / M.hg;
     const int slice = (xcd % M.hg) * hpg + (j % hpg), rb = (j / hpg) * M.sg + (xcd / M.hg);
     if (rb * M.rows_per_wg >= M.rows) return;
-    // query blocks of 32 per sample: 1 (a <= 32), 2 (a <= 64: at least 3 row tiles), 3 (a <= 80: 5 row tiles)
-    if (M.a <= 32) {
-        if (M.mt <= 2) fb_body<2, 1>(M, slice, rb, smem, G.stop, G.tl);
-        else if (M.mt == 3) fb_body<3, 1>(M, slice, rb, smem, G.stop, G.tl);
-        else fb_body<5, 1>(M, slice, rb, smem, G.stop, G.tl);
-    } else if (M.a <= 64) {
-        if (M.mt == 3) fb_body<3, 2>(M, slice, rb, smem, G.stop, G.tl);
-        else fb_body<5, 2>(M, slice, rb, smem, G.stop, G.tl);
-    } else {
-        fb_body<5, 3>(M, slice, rb, smem, G.stop, G.tl);
+    if constexpr (WIDE) {
+        if (M.ring) {                                           // one sample per workgroup, a <= 64 (host)
+            if (M.a <= 32) fb_body<2, 1, true>(M, slice, rb, smem, G.stop, G.tl);
+            else if (M.mt == 3) fb_body<3, 2, true>(M, slice, rb, smem, G.stop, G.tl);
+            else fb_body<5, 2, true>(M, slice, rb, smem, G.stop, G.tl);
+            return;
+        }
+        if (M.a > 32) {                                         // query blocks of 32: 2 (at least 3 row tiles)
+            if (M.mt == 3) fb_body<3, 2, false>(M, slice, rb, smem, G.stop, G.tl);
+            else fb_body<5, 2, false>(M, slice, rb, smem, G.stop, G.tl);
+            return;
+        }
     }
+    if (M.mt <= 2) fb_body<2, 1, false>(M, slice, rb, smem, G.stop, G.tl);
+    else if (M.mt == 3) fb_body<3, 1, false>(M, slice, rb, smem, G.stop, G.tl);
+    else fb_body<5, 1, false>(M, slice, rb, smem, G.stop, G.tl);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -438,7 +510,7 @@ static constexpr int FB_LDS_MAX = 160 * 1024;
 // workspace pointers of one member (sublayer.hip carves them)
 struct FbIo { const void* dyl; void *dq, *dk, *dv; int ldq, ldkv; };
 
-struct FbLaunch { FbGroup G; int wgs; size_t lds; };
+struct FbLaunch { FbGroup G; int wgs; size_t lds; bool wide; };
 static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch& P) {
     if (n_mha < 1 || n_mha > FB_MAX_MEMBERS) return false;
     FbGroup& G = P.G;
@@ -448,28 +520,35 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
     const int mts[3] = {2, 3, 5};
     int wgs = 0;
     size_t lds = 0;
+    P.wide = false;
     for (int i = 0; i < n_mha; ++i) {
         const mtn_mha_args& A = mha[i];
-        if (A.d != FH_D || A.h != FH_D / FH_DK || !A.w_o_t || A.a > 80 || A.a < 1) return false;
+        if (A.d != FH_D || A.h != FH_D / FH_DK || !A.w_o_t || A.a > 64 || A.a < 1) return false;
         const bool self = A.self_attn != 0;
         const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
         if (A.mask && A.mask_sb != 0 && A.mask_sb != (long)qa * m) return false;
         if (A.mask && A.mask_sq != 0 && A.mask_sq != m) return false;
-        int blk = 0, mt = 0, l = 0;
+        int blk = 0, mt = 0, l = 0, ring = 0;
         for (int b = 1; b <= A.B; ++b) {
             int t = 0;
             for (int c = 0; c < 3; ++c)
                 if (mts[c] * 16 >= b * A.a) { t = mts[c]; break; }
             if (!t) break;
             if (A.mask && b * qa * m > FH_THREADS * FH_MASKB) break;
-            const int need = fb_lds_map(t, self ? t * 16 : b * m, b * qa * m).total;
+            int need = fb_lds_map(t, self ? t * 16 : b * m, b * qa * m).total;
+            if (need > FB_LDS_MAX && b == 1 && !self && A.a <= 64) {       // a long memory: its keys stream through the ring, one sample per workgroup
+                need = fb_lds_map(t, m, qa * m, true).total;
+                if (need <= FB_LDS_MAX) { blk = 1; mt = t; l = need; ring = 1; }
+                break;
+            }
             if (need > FB_LDS_MAX) break;
             blk = b; mt = t; l = need;
             if (((A.B + b - 1) / b) * (FH_D / FH_DK) <= budget) break;
         }
         if (!blk) return false;
         FbMember& M = G.m[i];
-        M.rows = A.B * A.a; M.rows_per_wg = blk * A.a; M.a = A.a; M.m = m; M.blk = blk; M.mt = mt; M.self_attn = self;
+        M.rows = A.B * A.a; M.rows_per_wg = blk * A.a; M.a = A.a; M.m = m; M.blk = blk; M.mt = mt; M.self_attn = self; M.ring = ring;
+        P.wide = P.wide || ring || A.a > 32;
         M.dyl = (const bf16_t*)io[i].dyl; M.wot = (const bf16_t*)A.w_o_t;
         M.q = (const bf16_t*)A.qkv; M.ldq = self ? 3 * FH_D : FH_D;
         M.k = self ? (const bf16_t*)A.qkv + FH_D : (const bf16_t*)A.kv;
@@ -510,7 +589,8 @@ int fb_group_bwd_stage(int n_mha, const mtn_mha_args* mha, const FbIo* io, void*
     MTN_CHECK_ARG(fb_plan(n_mha, mha, io, P), "group outside the fused backward kernel's tiling");
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)fused_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_MAX) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)fused_head_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute((const void*)fused_head_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS_MAX) != hipSuccess) {
             mtn_set_error("fused_head_bwd_kernel: cannot raise the dynamic LDS limit");
             return MTN_ERR_LAUNCH;
         }
@@ -529,7 +609,8 @@ int fb_group_bwd_stage(int n_mha, const mtn_mha_args* mha, const FbIo* io, void*
         }
     }
 #endif
-    hipLaunchKernelGGL(fused_head_bwd_kernel, dim3(P.wgs), dim3(FH_THREADS), P.lds, (hipStream_t)stream, P.G);
+    if (P.wide) hipLaunchKernelGGL(fused_head_bwd_kernel<true>, dim3(P.wgs), dim3(FH_THREADS), P.lds, (hipStream_t)stream, P.G);
+    else hipLaunchKernelGGL(fused_head_bwd_kernel<false>, dim3(P.wgs), dim3(FH_THREADS), P.lds, (hipStream_t)stream, P.G);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }

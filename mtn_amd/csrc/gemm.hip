@@ -15,6 +15,8 @@
 struct GemmGroup {
     int count;
     int plain_tile_order;      // ablation (MTN_GEMM_PLAIN_TILES=1): row-major tile order, no XCD-aware mapping
+    // 2-D XCD map of the LDS-DMA kernels (xcd_tile2d): problem g's tiles form rg x (8 / rg) blocks, one per XCD; 0 = band map
+    unsigned char xcd_rg[MTN_GEMM_MAX_GROUP];
     int tile_start[MTN_GEMM_MAX_GROUP + 1];
     mtn_gemm_problem p[MTN_GEMM_MAX_GROUP];
 };
@@ -87,6 +89,35 @@ __device__ __forceinline__ void xcd_tile(const GemmGroup& grp, int g, int t, int
     (void)g;
     if (row_band) { tm = idx / tiles_n; tn = idx - tm * tiles_n; }
     else { tn = idx / tiles_m; tm = idx - tn * tiles_m; }
+}
+
+// 2-D variant for the latency-bound LDS-DMA launches (a few hundred tiles per problem).  The band map above gives an XCD a
+// contiguous run of T/8 tiles in row-major order, i.e. 1-3 row panels and ALL column panels: every XCD pulls the whole B
+// operand (the weight).  Here the 8 XCDs form rg row groups x cg = 8/rg column groups and XCD (i, j) takes the tiles of row band
+// i and column band j, so that a problem moves cg x A + rg x B bytes through the fabric instead of ~2 x A + 8 x B (the map that
+// took the fused kernel's launches from 67 to 25 MB, csrc/fused.hip).  Needs tile counts divisible by the grouping (chosen on the
+// host, GemmGroup::xcd_rg) and the problem's first workgroup on XCD 0; otherwise the band map stays.
+__device__ __forceinline__ void xcd_tile2d(int rg, int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int cg = 8 / rg;
+    const int c = t & 7, r = t >> 3;                         // XCD (by dispatch order), rank of the tile inside it
+    const int bm = tiles_m / rg, bn = tiles_n / cg;          // the XCD's block of tiles
+    const int ri = c / cg, ci = c - ri * cg;
+    const int lm = r / bn, ln = r - lm * bn;
+    tm = ri * bm + lm;
+    tn = ci * bn + ln;
+}
+// host: the grouping with the least fabric traffic, cg x (M x K) + rg x (N x K); 0 when the problem does not qualify
+static int pick_xcd_rg(int first_tile, int tiles_m, int tiles_n, long M, long N) {
+    if ((first_tile & 7) != 0 || ((tiles_m * tiles_n) & 7) != 0) return 0;
+    int best = 0;
+    double cost = 1e300;
+    for (int rg = 1; rg <= 8; rg *= 2) {
+        const int cg = 8 / rg;
+        if (tiles_m % rg != 0 || tiles_n % cg != 0) continue;
+        const double c = (double)cg * M + (double)rg * N;
+        if (c < cost) { cost = c; best = rg; }
+    }
+    return best;
 }
 
 static constexpr int TILE = 64;
@@ -549,7 +580,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     const int t = (int)blockIdx.x - grp.tile_start[g];
     const int tiles_m = (M + BM - 1) / BM;
     int tm_, tn_;
-    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
+    if (grp.xcd_rg[g]) xcd_tile2d(grp.xcd_rg[g], t, tiles_m, tiles_n, tm_, tn_);
+    else xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
     const int row0 = tm_ * BM, col0 = tn_ * BN;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1194,11 +1226,14 @@ static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
 }
 
 // tile_start[] for a given tile shape; returns the total
-static int retile(GemmGroup& grp, int bm, int bn) {
+static int retile(GemmGroup& grp, int bm, int bn, bool xcd2d = false) {
     int tiles = 0;
+    const bool on = xcd2d && !grp.plain_tile_order && !(MTN_ENV("MTN_GEMM_XCD2D") && MTN_ENV("MTN_GEMM_XCD2D")[0] == '0');
     for (int i = 0; i < grp.count; ++i) {
         grp.tile_start[i] = tiles;
-        tiles += ((grp.p[i].M + bm - 1) / bm) * ((grp.p[i].N + bn - 1) / bn);
+        const int tm = (grp.p[i].M + bm - 1) / bm, tn = (grp.p[i].N + bn - 1) / bn;
+        grp.xcd_rg[i] = on ? (unsigned char)pick_xcd_rg(tiles, tm, tn, grp.p[i].M, grp.p[i].N) : 0;
+        tiles += tm * tn;
     }
     for (int i = grp.count; i <= MTN_GEMM_MAX_GROUP; ++i) grp.tile_start[i] = tiles;
     return tiles;
@@ -1263,12 +1298,12 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         const bool half_ok = MTN_ENV("MTN_GEMM_NO_HALF") == nullptr;
         const bool half_force = MTN_ENV("MTN_GEMM_FORCE_HALF") != nullptr;      // tests
         if (f == 64 || (!f && c64 <= c32)) {
-            const int t = retile(g2, 64, 64);
+            const int t = retile(g2, 64, 64, true);
             if (half_force || (half_ok && t > 256)) return launch_dma<T, 64, 64, 256>(g2, t, s);
             return launch_dma<T, 64, 64, 512>(g2, t, s);
         }
-        if (f == 3264) return launch_dma<T, 32, 64, 512>(g2, retile(g2, 32, 64), s);
-        const int t = retile(g2, 32, 32);
+        if (f == 3264) return launch_dma<T, 32, 64, 512>(g2, retile(g2, 32, 64, true), s);
+        const int t = retile(g2, 32, 32, true);
         if (half_force || (half_ok && t > 1024)) return launch_dma<T, 32, 32, 256>(g2, t, s);   // (measured in the step: 640 tiles 10.7 vs 10.1 us, 1280 tiles 12.7 vs 13.8 us)
         return launch_dma<T, 32, 32, 512>(g2, t, s);
     } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp, NoAdam{});

@@ -17,6 +17,7 @@
 // csrc/fused.hip
 int fh_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn);
 int fh_group_fwd_stage1(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
+int fh_is_enabled();
 // csrc/fused_bwd.hip
 struct FbIo { const void* dyl; void *dq, *dk, *dv; int ldq, ldkv; };
 int fb_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, const FbIo* io);
@@ -109,7 +110,33 @@ extern "C" int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* 
     for (int i = 0; i < n_mha; ++i) RUN(check_mha(&mha[i], false));
     for (int i = 0; i < n_ffn; ++i) RUN(check_ffn(&ffn[i], false));
     // Fused first launch (csrc/fused.hip): stages 1-3 in one kernel per (sample block, head | w_1 column slice)
-    const bool fused = fh_group_eligible(dtype, n_mha, mha, n_ffn, ffn) != 0;
+    bool fused = fh_group_eligible(dtype, n_mha, mha, n_ffn, ffn) != 0;
+    mtn_mha_args pre[MTN_SUBLAYER_MAX_GROUP];
+    if (!fused && n_mha > 0 && dtype == MTN_BF16 && fh_is_enabled()) {
+        // A member that attends an un-projected memory (x attends an auto-encoder output, mtn.py:215) keeps that memory's rows in LDS
+        // beside its own: with long query sequences (AVSD targets of 40-54 tokens) that does not fit.  Project K | V of those
+        // memories with one grouped GEMM first and hand them to the fused kernel as memories projected ahead (kv_ready): three
+        // launches for the group instead of five.
+        bool any = false;
+        for (int i = 0; i < n_mha; ++i) {
+            pre[i] = mha[i];
+            if (!mha[i].self_attn && !mha[i].kv_ready) { pre[i].kv_ready = 1; any = true; }
+        }
+        if (any && fh_group_eligible(dtype, n_mha, pre, n_ffn, ffn) != 0) {
+            mtn_gemm_problem p[MTN_SUBLAYER_MAX_GROUP];
+            int n = 0;
+            for (int i = 0; i < n_mha; ++i) {
+                const mtn_mha_args* a = &mha[i];
+                if (a->self_attn || a->kv_ready) continue;
+                const int d = a->d;
+                p[n] = gemm_init(a->mem, d, lp_off(a->w_qkv, (long)d * d, dtype), d, a->B * a->m, 2 * d, d, 0, 0);
+                p[n].bias = a->b_qkv + d; p[n].out_lp = a->kv; p[n].ldc = 2 * d; ++n;
+            }
+            RUN(mtn_gemm(dtype, n, p, stream));
+            mha = pre;
+            fused = true;
+        }
+    }
     ++g_fused_counts[fused ? 0 : 1];
     if (fused) RUN(fh_group_fwd_stage1(n_mha, mha, n_ffn, ffn, stream));
     // 1. LayerNorm(x) -> xn (compute dtype); row statistics saved for backward

@@ -145,6 +145,8 @@ SYMBOLS = {
     "mtn_measure_mfma_peak": (C.c_int, [C.c_int, _P, _P, C.POINTER(C.c_double)]),
     "mtn_measure_hbm_peak": (C.c_int, [_P, _P, C.c_long, _P, C.POINTER(C.c_double)]),
     "mtn_reload_env": (C.c_int, []),
+    "mtn_stream_create_cu_masked": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mtn_stream_destroy": (C.c_int, [_P]),
     "mtn_last_error": (C.c_char_p, []),
     "mtn_version": (C.c_int, []),
     "mtn_gemm": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),

@@ -18,6 +18,13 @@ import torch
 
 from .data_utils import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
 
+# Stream capture checks "potentially unsafe" runtime calls; in the default (global) mode a call from ANY thread invalidates the
+# capture — and ProcessGroupNCCL's watchdog thread polls its work events (hipEventQuery) for a while after every collective, so a
+# step captured right after an exchange (a new batch shape in BucketedTrainer, the fallback schedule, a second TrainStep) died
+# with hipErrorStreamCaptureInvalidated (seen on hardware: tools/dp_rccl_probe.py, round 3).  Only this thread's calls matter here:
+# the kernels come from this thread and from autograd's device thread, both onto the capturing stream.
+CAPTURE_MODE = os.environ.get("MTN_CAPTURE_MODE", "thread_local")
+
 
 class TrainStep:
     def __init__(self, model, batch, vocab: int, pad: int = 1, warmup: int = 4000, factor: float = 1.0, lam: float = 1.0,
@@ -221,13 +228,13 @@ class TrainStep:
         self._g_seg, pool = [], None
         for fn, rng in segs:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=CAPTURE_MODE):
                 fn()
             pool = g.pool()
             self._g_seg.append((g.replay, rng))
         self._loss = self._loss_t
         self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt, pool=pool):
+        with torch.cuda.graph(self._g_opt, pool=pool, capture_error_mode=CAPTURE_MODE):
             if self.sharded is not None:
                 self.opt.optimizer.refresh_copies()          # the updates ran shard by shard between the segment graphs
             else:
@@ -237,17 +244,17 @@ class TrainStep:
     def _capture_simple(self):
         self._g_fb = torch.cuda.CUDAGraph()
         if self.grad_sync is None:
-            with torch.cuda.graph(self._g_fb):
+            with torch.cuda.graph(self._g_fb, capture_error_mode=CAPTURE_MODE):
                 if self._fused():
                     self._loss = self._step_fused()
                 else:
                     self._loss = self._fwd_bwd()
                     self._optim()
         else:
-            with torch.cuda.graph(self._g_fb):
+            with torch.cuda.graph(self._g_fb, capture_error_mode=CAPTURE_MODE):
                 self._loss = self._fwd_bwd()
             self._g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
+            with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool(), capture_error_mode=CAPTURE_MODE):
                 if self.sharded is not None:
                     self.opt.optimizer.refresh_copies()
                 else:
