@@ -372,6 +372,8 @@ def main():
     from mtn_amd.synthetic import CONFIGS, flops_per_sample, synthetic_batch
     from mtn_amd.train_step import TrainStep
 
+    if args.bf16_grad_allreduce:
+        os.environ["MTN_DP_SHARDED"] = "0"     # bf16 compression exists for the all-reduce scheme only (the sharded optimiser reduce-scatters fp32 in place)
     if args.no_record:
         dp.ALLOW_EMULATION = True
     elif os.environ.get("MTN_DP_EMULATE_WORLD", "1") not in ("", "0", "1"):

@@ -296,10 +296,17 @@ extern "C" int mtn_adam_step(int dtype, long n, float* p, const float* g, float*
 // best of 10 repetitions as (bytes read + bytes written) / time.
 __global__ __launch_bounds__(256) void hbm_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
     typedef __attribute__((ext_vector_type(4))) unsigned nt4;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
-        const nt4 v = __builtin_nontemporal_load((const nt4*)(src + i));
-        __builtin_nontemporal_store(v, (nt4*)(dst + i));
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {        // four independent 16-byte loads in flight per thread
+        const nt4 a = __builtin_nontemporal_load((const nt4*)(src + i)), b = __builtin_nontemporal_load((const nt4*)(src + i + stride));
+        const nt4 c = __builtin_nontemporal_load((const nt4*)(src + i + 2 * stride)), d = __builtin_nontemporal_load((const nt4*)(src + i + 3 * stride));
+        __builtin_nontemporal_store(a, (nt4*)(dst + i));
+        __builtin_nontemporal_store(b, (nt4*)(dst + i + stride));
+        __builtin_nontemporal_store(c, (nt4*)(dst + i + 2 * stride));
+        __builtin_nontemporal_store(d, (nt4*)(dst + i + 3 * stride));
     }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load((const nt4*)(src + i)), (nt4*)(dst + i));
 }
 
 extern "C" int mtn_measure_hbm_peak(const void* src, void* dst, long bytes, void* stream, double* gbps) {

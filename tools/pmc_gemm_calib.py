@@ -18,6 +18,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the cases must run on gemm_dma_kernel (the kernel whose traffic is in question), whatever their tile count
+os.environ["MTN_GEMM_DMA_MAX_TILES"] = "100000000"
+os.environ["MTN_GEMM_K512_MIN_TILES"] = "0"
+os.environ["MTN_GEMM_NO_HALF"] = "1"
 
 # name -> (M, N, K, residual fp32?, out fp32?)       A [M,K] bf16 is read once; B [N,K] is tiny; C [M,N]
 CASES = {
@@ -25,6 +29,7 @@ CASES = {
     "dma_A_resid_f32out": (1 << 20, 64, 512, True, True),
     "dma_A_k2048_bf16out": (1 << 18, 64, 2048, False, False),
     "dma32_A_only_bf16out": (1 << 20, 32, 512, False, False),
+    "dma_A_and_B_square": (8192, 8192, 512, False, False),      # 128 x 128 tiles of 64 x 64: every panel shared by 128 workgroups
 }
 
 
