@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--windows", type=int, default=4, help="extra timed windows of --steps steps after the one `value` comes from")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (batch-64 figure, one-rank RCCL "
                     "schedule and decode figures at N=1, exchange-free single-rank figure at N>1)")
+    ap.add_argument("--dp-one-rank-probe", action="store_true", help=argparse.SUPPRESS)     # child process of the N = 1 secondary measurement
     ap.add_argument("--no-record", action="store_true", help="development probe: allows MTN_DP_EMULATE_WORLD (a rank updates 1/N of "
                     "every slice as in an N-GPU job — WRONG parameters, timing only); the line is then marked \"record\": false")
     args = ap.parse_args()
@@ -327,45 +328,88 @@ def pmc_step_traffic():
         return None
 
 
-def dp_schedule_one_rank(args, cfg, model, batch, B, timed_window):
+def dp_schedule_one_rank(args):
+    """The data-parallel schedule of an N-GPU job on ONE rank with every collective through RCCL, measured in a FRESH process
+    (`bench.py --dp-one-rank-probe`): the process group is created first, the model and its flat buffers afterwards — the order
+    of a real multi-rank job (main() below).  (Creating the one-rank group late, inside this process, next to the graphs and
+    buffers of the main measurement, made every collective ~0.7 ms slower: 14.8 instead of 5.1 ms per step, r03 profiles.)"""
     import socket
-    import torch.distributed as dist
-    from mtn_amd import dp
-    from mtn_amd.train_step import TrainStep
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MTN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp-one-rank-probe", "--steps", str(args.steps), "--workload", args.workload,
+           "--dtype", args.dtype, "--dropout", str(args.dropout)] + (["--no-graph"] if args.no_graph else []) + \
+          (["--batch-per-gpu", str(args.batch_per_gpu)] if args.batch_per_gpu else [])
     try:
-        created = False
-        if not dist.is_initialized():
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dp.init_distributed(force=True)
-            created = True
-        sync = dp.GradSync(lambda: model.flat_buffers()[2], force=True)
-        st = TrainStep(model, batch, cfg["vocab"], pad=1, warmup=4000, grad_sync=sync, use_graph=not args.no_graph)
-        for _ in range(3):
-            st()
-        dt, _, _ = timed_window(st, args.steps)
-        sh = st.sharded
-        calls = dict(sh.calls) if sh is not None else {}
-        out = {"ms_per_step": round(dt / args.steps * 1e3, 4), "samples_per_s": round(B * args.steps / dt, 1),
-               "rccl_ranks": dist.get_world_size(), "dist_backend": dist.get_backend(),
-               "schedule": ("layer-segmented backward (N+3 hipGraphs), " if st.overlap else "two-graph schedule, ") +
-                           ("reduce-scatter -> Adam on the shard -> all-gather per slice" if sh is not None else "all-reduce per slice + full Adam"),
-               "collectives_issued": calls, "slices_per_step": len(st._slices()),
-               "what": "the step of a data-parallel rank on this one GPU, every collective through a one-rank RCCL group "
-                       "(shard = the whole slice): schedule cost without peers; same batch as `value`"}
-        del st
-        if created:
-            torch.cuda.synchronize()
-            dist.destroy_process_group()
-        return out
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": (out.stderr or out.stdout)[-400:]}
     except Exception as e:  # pragma: no cover
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def dp_one_rank_probe(args):
+    """Child of dp_schedule_one_rank(): prints one JSON object."""
+    import torch.distributed as dist
+    from mtn_amd import dp, lib, make_model
+    from mtn_amd.synthetic import CONFIGS, synthetic_batch
+    from mtn_amd.train_step import TrainStep
+    dp.init_distributed(force=True)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    lib.load()
+    cfg = dict(CONFIGS[args.workload])
+    B = args.batch_per_gpu or cfg["B"]
+    lp = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = make_model(cfg["vocab"], cfg["vocab"], N=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"], dropout=args.dropout,
+                       ft_sizes=cfg["ft_sizes"], diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query", compute_dtype=lp,
+                       attn_dropout=0.1 if args.dropout > 0 else 0.0).to(dev).train()
+    model.prepare()
+    sync = dp.GradSync(lambda: model.flat_buffers()[2], force=True)
+    sync.broadcast_(model._flat)
+    batch = synthetic_batch(cfg["vocab"], B, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=1, ragged=False)
+
+    def timed(st):
+        for _ in range(3):
+            st()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps * 1e3
+
+    st = TrainStep(model, batch, cfg["vocab"], pad=1, warmup=4000, grad_sync=sync, use_graph=not args.no_graph)
+    ms = timed(st)
+    sh = st.sharded
+    out = {"ms_per_step": round(ms, 4), "samples_per_s": round(B / ms * 1e3, 1), "rccl_ranks": dist.get_world_size(), "dist_backend": dist.get_backend(),
+           "schedule": ("layer-segmented backward (N+3 hipGraphs), " if st.overlap else "two-graph schedule, ") +
+                       ("reduce-scatter -> Adam on the shard -> all-gather per slice" if sh is not None else "all-reduce per slice + full Adam"),
+           "collectives_issued": dict(sh.calls) if sh is not None else {}, "slices_per_step": len(st._slices()), "batch_per_gpu": B,
+           "what": "the step of a data-parallel rank on this one GPU in a fresh process, every collective through a one-rank RCCL group "
+                   "(shard = the whole slice): the schedule's cost without peers (segmentation, the separate optimiser pass, RCCL "
+                   "calls); same batch as `value`"}
+    if sh is not None:                       # the same schedule with the collectives skipped: what the RCCL calls themselves cost
+        st2 = TrainStep(model, batch, cfg["vocab"], pad=1, warmup=4000, grad_sync=sync, use_graph=not args.no_graph)
+        st2.sharded.collective = False
+        out["ms_per_step_collectives_skipped"] = round(timed(st2), 4)
+        st2.sharded.collective = True
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.dp_one_rank_probe:
+        return dp_one_rank_probe(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     from mtn_amd import dp, lib, make_model
@@ -456,7 +500,7 @@ def main():
                 # the data-parallel schedule of an N-GPU job on this ONE rank, every collective through RCCL (a one-rank "nccl"
                 # group): layer-segmented backward, per-slice reduce-scatter -> Adam on the shard -> all-gather on side streams
                 # (dp.ShardedOptimizerSync).  What a rank of the scaling run computes besides waiting for its peers.
-                secondary["dp_schedule_one_rank"] = dp_schedule_one_rank(args, cfg, model, batch, B, timed_window)
+                secondary["dp_schedule_one_rank"] = dp_schedule_one_rank(args)
                 # BASELINE configs[4]: decode on the same weights (never `value`)
                 secondary["decode"] = decode_measure(model, cfg, dev, use_graph=not args.no_graph, cpu=not args.no_cpu_baseline)
             if world > 1:
@@ -529,7 +573,7 @@ def main():
                         "achieved_TFLOPs": d["achieved_TFLOPs"],
                         "peak_measured": hbm_peak,
                         "frac_of_measured_peak": round(d["achieved_GBps_algorithmic"] / hbm_peak, 4) if hbm_peak else None,
-                        "peak_measured_what": "GB/s of a 16-byte-per-lane streaming copy (1 GiB read + 1 GiB written) on this box, best of 10"}
+                        "peak_measured_what": "GB/s of a 16-byte-per-lane streaming copy (1 GiB read + 1 GiB written) on this box: best over non-temporal / plain accesses, 1 / 4 loads in flight per thread, 8-32 workgroups per CU"}
                 second = max((n for n in table if n != TABLE), key=lambda nm: table[nm]["total_us_per_step"])
                 roof["next_kernel"] = mfma_roof(second)
             else:

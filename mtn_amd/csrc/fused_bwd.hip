@@ -546,6 +546,12 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
             if (((A.B + b - 1) / b) * (FH_D / FH_DK) <= budget) break;
         }
         if (!blk) return false;
+        static const int ring_min = [] { const char* e = getenv("MTN_FB_RING_MIN"); return e ? atoi(e) : 192; }();
+        if (blk == 1 && !ring && !self && m >= ring_min && A.a <= 64) {
+            // one sample per workgroup anyway (two would not fit): take the ring form, where BOTH four-wave teams work on the sample
+            const int need = fb_lds_map(mt, m, qa * m, true).total;
+            if (need <= FB_LDS_MAX) { ring = 1; l = need; }
+        }
         FbMember& M = G.m[i];
         M.rows = A.B * A.a; M.rows_per_wg = blk * A.a; M.a = A.a; M.m = m; M.blk = blk; M.mt = mt; M.self_attn = self; M.ring = ring;
         P.wide = P.wide || ring || A.a > 32;
