@@ -215,8 +215,14 @@ typedef struct {
     const void* d_o;
     void *dq, *dk_out, *dv_out;
     /* backward, set by the library (callers leave them 0): one launch covers query rows q0 .. q0+qn-1 of every sequence;
-       sequences longer than 32 rows are walked in several passes, kv_accum != 0 = add dk/dv to the earlier passes' sums */
+       sequences longer than 32 rows are walked in several passes, kv_accum != 0 = add dk/dv to the earlier passes' sums,
+       kv_last != 0 = this pass writes the final dk/dv */
     int q0, qn, kv_accum;
+    /* backward, optional (caller): fp32 workspace of 2 * B * m * h * dk floats.  With it a multi-pass backward keeps the dK / dV
+       sums of the passes in fp32 ([B*m][h*dk] for dK, then the same for dV) and rounds to the output type once, in the last
+       pass; without it the passes accumulate in the (low-precision) output buffers. */
+    float* kv_acc;
+    int kv_last;
 } mtn_attn_args;
 #define MTN_ATTN_MAX_GROUP 4
 /* Grouped forms: up to MTN_ATTN_MAX_GROUP independent attention problems (different shapes allowed) per launch. */

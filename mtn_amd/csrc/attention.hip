@@ -570,13 +570,28 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_mfma_kernel(const AttnGro
                     T* pk = dkg + (size_t)key * A.ldkv + dt * 16 + 4 * lg;
                     float4 ov = make_float4(av[0], av[1], av[2], av[3]);
                     float4 ok_ = make_float4(ak[0] * scale, ak[1] * scale, ak[2] * scale, ak[3] * scale);
-                    if (A.kv_accum) {                       // a later query-block pass: add to the earlier passes' sums
-                        const float4 pv0 = load4<T>(pv), pk0 = load4<T>(pk);
-                        ov.x += pv0.x; ov.y += pv0.y; ov.z += pv0.z; ov.w += pv0.w;
-                        ok_.x += pk0.x; ok_.y += pk0.y; ok_.z += pk0.z; ok_.w += pk0.w;
+                    if (A.kv_acc && !(A.kv_last && !A.kv_accum)) {
+                        // several query-block passes with an fp32 workspace: the sums of the passes stay in fp32 and are rounded
+                        // to the output type once, by the last pass
+                        const size_t HD = (size_t)A.h * DK;
+                        float* wk = A.kv_acc + ((size_t)b * m + key) * HD + hh * DK + dt * 16 + 4 * lg;
+                        float* wv = wk + (size_t)A.B * m * HD;
+                        if (A.kv_accum) {
+                            const float4 pv0 = *(const float4*)wv, pk0 = *(const float4*)wk;
+                            ov.x += pv0.x; ov.y += pv0.y; ov.z += pv0.z; ov.w += pv0.w;
+                            ok_.x += pk0.x; ok_.y += pk0.y; ok_.z += pk0.z; ok_.w += pk0.w;
+                        }
+                        if (A.kv_last) { store4<T>(pv, ov); store4<T>(pk, ok_); }
+                        else { *(float4*)wv = ov; *(float4*)wk = ok_; }
+                    } else {
+                        if (A.kv_accum) {                   // a later query-block pass: add to the earlier passes' sums
+                            const float4 pv0 = load4<T>(pv), pk0 = load4<T>(pk);
+                            ov.x += pv0.x; ov.y += pv0.y; ov.z += pv0.z; ov.w += pv0.w;
+                            ok_.x += pk0.x; ok_.y += pk0.y; ok_.z += pk0.z; ok_.w += pk0.w;
+                        }
+                        store4<T>(pv, ov);
+                        store4<T>(pk, ok_);
                     }
-                    store4<T>(pv, ov);
-                    store4<T>(pk, ok_);
                 }
             }
         }
@@ -775,6 +790,7 @@ extern "C" int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args
                     mtn_attn_args& t = P.a[P.count++];
                     t = args[i];
                     t.q0 = q0; t.qn = args[i].a - q0 < BQ ? args[i].a - q0 : BQ; t.kv_accum = q0 > 0;
+                    t.kv_last = q0 + BQ >= args[i].a;
                     const int kt = (t.m + BK - 1) / BK;
                     nw = kt > nw ? kt : nw;
                     wgs += t.B * t.h;

@@ -218,9 +218,10 @@ extern "C" long mtn_mha_bwd_ws_lp_elems(int B, int a, int m, int d, int self_att
     return 2 * rows * d + (self_attn ? 3 * rows * d : rows * d + 2 * rows_m * d);
 }
 extern "C" long mtn_mha_bwd_ws_f32_floats(int B, int a, int m, int d) {
-    (void)m;
     long rows = (long)B * a;
-    return rows * d + mtn_layernorm_bwd_partial_floats((int)rows, d);
+    // + the fp32 dK / dV sums of a multi-pass attention backward (more than 32 query rows on the per-stage path)
+    const long kvacc = a > 32 ? 2L * B * (m > a ? m : a) * d : 0;
+    return rows * d + mtn_layernorm_bwd_partial_floats((int)rows, d) + kvacc;
 }
 extern "C" long mtn_ffn_bwd_ws_f32_floats(int rows, int d, int d_ff) {
     (void)d_ff;
@@ -228,7 +229,7 @@ extern "C" long mtn_ffn_bwd_ws_f32_floats(int rows, int d, int d_ff) {
 }
 
 // Workspace carving (same for the backward kernels and for the deferred parameter-gradient problems).
-struct MhaWs { void *dyl, *dO, *dqkv, *dkv; float *dxn, *ln_partial; };
+struct MhaWs { void *dyl, *dO, *dqkv, *dkv; float *dxn, *ln_partial, *kv_acc; };
 static MhaWs mha_ws(const mtn_mha_args* a, int dtype) {
     const long rows = (long)a->B * a->a, d = a->d;
     MhaWs w;
@@ -238,6 +239,7 @@ static MhaWs mha_ws(const mtn_mha_args* a, int dtype) {
     w.dkv = lp_off(w.dqkv, rows * d, dtype);
     w.dxn = a->ws_f32;                                  // [rows,d]
     w.ln_partial = a->ws_f32 + rows * d;
+    w.kv_acc = a->a > 32 ? w.ln_partial + mtn_layernorm_bwd_partial_floats((int)rows, (int)d) : nullptr;   // [2][rows_m, d] fp32
     return w;
 }
 struct FfnWs { void *dyl, *dh; float *dxn, *ln_partial; };
@@ -310,6 +312,7 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
             const MhaWs w = mha_ws(a, dtype);
             attn_args_of(a, dtype, &t[i]);
             t[i].d_o = w.dO;
+            t[i].kv_acc = w.kv_acc;
             if (a->self_attn) { t[i].dq = w.dqkv; t[i].dk_out = lp_off(w.dqkv, a->d, dtype); t[i].dv_out = lp_off(w.dqkv, 2 * a->d, dtype); }
             else { t[i].dq = w.dqkv; t[i].dk_out = w.dkv; t[i].dv_out = lp_off(w.dkv, a->d, dtype); }
         }

@@ -43,7 +43,7 @@ class AttnArgs(C.Structure):
                 ("mask", C.c_void_p), ("mask_sb", C.c_long), ("mask_sq", C.c_long), ("drop", Dropout),
                 ("o", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p),
                 ("d_o", C.c_void_p), ("dq", C.c_void_p), ("dk_out", C.c_void_p), ("dv_out", C.c_void_p),
-                ("q0", C.c_int), ("qn", C.c_int), ("kv_accum", C.c_int)]
+                ("q0", C.c_int), ("qn", C.c_int), ("kv_accum", C.c_int), ("kv_acc", C.c_void_p), ("kv_last", C.c_int)]
 
 
 class MhaArgs(C.Structure):

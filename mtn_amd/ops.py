@@ -1175,6 +1175,10 @@ def attention_bwd(q, k, v, o, lse, d_o, mask, heads: int, p_drop: float = 0.0, s
     args.drop = _drop(p_drop, salt, seed)
     args.o, args.ldo, args.lse = o.data_ptr(), d, lse.data_ptr()
     args.d_o, args.dq, args.dk_out, args.dv_out = d_o.contiguous().data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    kv_acc = None
+    if a > 32 and q.dtype != torch.float32:      # several query-block passes: their dK / dV sums stay in fp32 until the last one
+        kv_acc = torch.empty(2, B * m, d, device=q.device, dtype=torch.float32)
+        args.kv_acc = kv_acc.data_ptr()
     L.check(L.load().mtn_attention_bwd(L.dtype_code(q.dtype), C.byref(args), L.stream_ptr()))
     return dq, dk, dv
 

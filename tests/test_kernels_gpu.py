@@ -276,11 +276,12 @@ def _attn_ref(q, k, v, mask, h):
 @pytest.mark.parametrize("B,h,a,m,dk,kind", [
     (2, 4, 20, 20, 32, "causal"), (3, 8, 20, 128, 64, "pad"), (2, 2, 7, 37, 16, "pad"), (1, 4, 20, 300, 64, "pad"),
     (2, 4, 33, 70, 64, "none"), (2, 8, 54, 54, 64, "causal"), (2, 8, 20, 520, 64, "pad"), (1, 4, 20, 1000, 64, "pad"),
-    (2, 8, 100, 100, 64, "causal"), (1, 4, 238, 45, 64, "pad"), (2, 2, 70, 33, 32, "none")])
+    (2, 8, 100, 100, 64, "causal"), (1, 4, 238, 45, 64, "pad"), (2, 2, 70, 33, 32, "none"), (2, 4, 256, 256, 64, "causal")])
 def test_attention_fwd_bwd(dev, dtype, B, h, a, m, dk, kind):
     """Causal / key-padding / absent masks, a fully masked row (uniform attention, zero score-gradient), key counts that
     are not multiples of the 64/32-key tiles, multi-tile online softmax, and query counts beyond 64 rows (the backward walks
-    the queries in passes of 32 and accumulates dK / dV: captions as the auto-encoder stream reach 238 tokens)."""
+    the queries in passes of 32 and accumulates dK / dV — in an fp32 workspace, rounded to bf16 once by the last pass: captions as
+    the auto-encoder stream reach 238 tokens; a = 256 is eight passes)."""
     from mtn_amd import ops
     d = h * dk
     g = torch.Generator().manual_seed(B * 100 + a + m)
