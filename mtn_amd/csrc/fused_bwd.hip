@@ -523,7 +523,8 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
     P.wide = false;
     for (int i = 0; i < n_mha; ++i) {
         const mtn_mha_args& A = mha[i];
-        if (A.d != FH_D || A.h != FH_D / FH_DK || !A.w_o_t || A.a > 64 || A.a < 1) return false;
+        static const int max_a = [] { const char* e = getenv("MTN_FB_MAX_A"); return e ? atoi(e) : 64; }();       // (A/B: 32 = round 2's limit)
+        if (A.d != FH_D || A.h != FH_D / FH_DK || !A.w_o_t || A.a > max_a || A.a < 1) return false;
         const bool self = A.self_attn != 0;
         const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
         if (A.mask && A.mask_sb != 0 && A.mask_sb != (long)qa * m) return false;
