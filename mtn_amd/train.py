@@ -73,6 +73,8 @@ def parse(argv=None):
                         "schema, <prefix>_opt.pth.tar = optimiser moments + schedule state)")
     p.add_argument("--eager", action="store_true", help="corpus mode: one eager step per batch instead of captured graphs per padded shape")
     p.add_argument("--bucket", default=8, type=int, help="corpus mode: batch lengths are rounded up to multiples of this")
+    p.add_argument("--corpus-max-answer", default=18, type=int, help="synthetic corpus: longest answer (AVSD's reach 52 tokens)")
+    p.add_argument("--corpus-max-question", default=20, type=int, help="synthetic corpus: longest question (AVSD's reach 42 tokens)")
     p.add_argument("--corpus-videos", default=0, type=int,
                    help="> 0: train on a synthetic ragged CORPUS of that many videos (10 turns each) through the reference's "
                         "epoch loop — batch planning, device-side batch assembly, one eager step per batch — instead of "
@@ -80,7 +82,7 @@ def parse(argv=None):
     return p.parse_args(argv)
 
 
-def synthetic_corpus(n_videos, vocab, ft_sizes, seed, turns=10):
+def synthetic_corpus(n_videos, vocab, ft_sizes, seed, turns=10, max_answer=18, max_question=20):
     """A ragged corpus in the layout data_handler.load returns (dialogs + per-video feature arrays), lengths in the ranges
     of the AVSD data: questions/answers 3-20 tokens, captions 10-40, 20-40 frames per video."""
     import numpy as np
@@ -91,7 +93,7 @@ def synthetic_corpus(n_videos, vocab, ft_sizes, seed, turns=10):
     for v in vids:
         cap, hist = tok(10, 40), np.zeros(0, np.int64)
         for _ in range(turns):
-            q, a = tok(3, 20), tok(3, 18)
+            q, a = tok(3, max_question), tok(3, max_answer)
             ans = np.concatenate([[2], a, [3]]).astype(np.int64)                     # <sos> ... <eos>
             dialogs.append([v, qa, hist.copy() if len(hist) else np.array([1], np.int64), q, ans[:-1], ans[1:], cap])
             hist = np.concatenate([hist, q, a])
@@ -236,7 +238,8 @@ def main(argv=None):
         from .data_utils import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
         synthetic = train_data is None
         max_len = 256 if synthetic else args.max_length         # (run.sh passes 256, the parser's default is the reference's 20)
-        data = synthetic_corpus(args.corpus_videos, args.vocab_size, args.ft_sizes, args.rand_seed) if synthetic else train_data
+        data = (synthetic_corpus(args.corpus_videos, args.vocab_size, args.ft_sizes, args.rand_seed, max_answer=args.corpus_max_answer,
+                                 max_question=args.corpus_max_question) if synthetic else train_data)
         indices, n_samples = make_batch_indices(data, batchsize=args.batch_size, max_length=max_len, separate_caption=True)  # train.py:126
         indices = indices[:len(indices) // world * world][rank::world]   # data parallel: equal shares of the planned batches (every
                                                                          # rank must issue the same number of gradient exchanges)
