@@ -557,6 +557,49 @@ __device__ __forceinline__ void dma_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsi
     }
 }
 
+// B operand stored CONTRACTION-MAJOR ([K][N] row-major: a weight matrix W[out k][in n] used as dX = dY W — no transposed copy of
+// W has to exist): the [k][BN columns] tile lands in LDS as it is (rows of BN * 2 bytes) and the MFMA fragments come out of the
+// transposing LDS read ds_read_b64_tr_b16 (semantics: gemm_tt_dma_kernel above).  16-byte slots are XOR-swizzled so that the 8
+// rows one LDS cycle of the read touches (k0..k0+3 of two lane groups, 8 rows apart) sit in 8 different 32-byte bank groups:
+// 128-byte rows (BN = 64): even / odd rows own the two halves of the bank sweep, the slot PAIR moves with bits 1 and 3 of k;
+// 64-byte rows (BN = 32): four consecutive rows own a quarter each, bit 3 of k selects the 32-byte half.
+template <int BN> __device__ __forceinline__ int kn_swz(int krow) {
+    if constexpr (BN == 64) return ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);
+    else return ((krow >> 3) & 1) << 1;
+}
+template <int BN, int ROWB>
+__device__ __forceinline__ void dma_issue_tile_kn(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_tile, int ld_bytes, int N, int K,
+                                                  int col0, int k0, int wave, int lane) {
+    constexpr int RP = BN * 2;                                   // bytes per tile row
+    constexpr int CPR = RP / 16;                                 // 16-byte chunks per row (8 or 4)
+    constexpr int RPI = 1024 / RP;                               // k rows per wave-instruction (8 or 16)
+#pragma unroll
+    for (int j = 0; j < BN * ROWB / 4096; ++j) {
+        const int krow = (j * 4 + wave) * RPI + lane / CPR;
+        const int c = (lane % CPR) ^ kn_swz<BN>(krow);           // source chunk that lands in slot (lane % CPR)
+        const int gk = k0 + krow, gn = col0 + c * 8;
+        unsigned voff = (gk < K && gn < N) ? (unsigned)gk * (unsigned)ld_bytes + (unsigned)gn * 2u : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + j * 4096 + wave * 1024), 16, voff, 0, 0, 0);
+    }
+}
+// fragment for column tile n_off (multiple of 16 inside the tile) and contraction step ks (32 rows) of a [k][BN] image
+template <int BN>
+__device__ __forceinline__ uint4 kn_frag(const unsigned char* img, int n_off, int ks, int l15, int lg) {
+    uint4 f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int krow = ks * 32 + 8 * lg + 4 * r + (l15 >> 2);
+        const int col = n_off + 4 * (l15 & 3);
+        const int slot = (col >> 3) ^ kn_swz<BN>(krow);
+        const unsigned addr = (unsigned)(size_t)(img + krow * (BN * 2) + slot * 16 + (col & 7) * 2);
+        unsigned long long v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        if (r == 0) { f.x = (unsigned)v; f.y = (unsigned)(v >> 32); }
+        else { f.z = (unsigned)v; f.w = (unsigned)(v >> 32); }
+    }
+    return f;
+}
+
 // Tile BM x BN (64x64, 32x64 or 32x32), 4 waves as 2x2, each wave (BM/32) x (BN/32) MFMA 16x16 tiles.  The smaller tiles
 // exist because these launches are bound by how fast ONE CU can pull its operand panels (~27 GB/s per CU measured, LDS-DMA
 // and register staging alike): a [640 x 512] output is 80 workgroups of 128 KiB at 64x64 but 320 workgroups of 64 KiB at
@@ -564,7 +607,7 @@ __device__ __forceinline__ void dma_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsi
 // ROWB = bytes of contraction per row per stage: 512 (whole K <= 512-byte contractions in flight at once: best latency for
 // launches of one round) or 256 (half the LDS: twice the resident workgroups, for launches that would otherwise need a
 // second round).
-template <typename T, int BM, int BN, int DMA_ROWB>
+template <typename T, int BM, int BN, int DMA_ROWB, bool BTR = false>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     constexpr int BK = DMA_ROWB / (int)sizeof(T);            // 256 / 128 bf16, 128 / 64 fp32
     constexpr int TM = BM / 32, TN = BN / 32;                // MFMA tiles per wave
@@ -588,7 +631,13 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
     const int lda_b = P.lda * (int)sizeof(T), ldb_b = P.ldb * (int)sizeof(T);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (M - 1) * lda_b + K * (int)sizeof(T), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (N - 1) * ldb_b + K * (int)sizeof(T), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = BTR ? __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (K - 1) * ldb_b + N * (int)sizeof(T), 0x00020000)
+                                          : __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (N - 1) * ldb_b + K * (int)sizeof(T), 0x00020000);
+    // the B tile of a stage: row-major [BN rows][DMA_ROWB bytes of k], or (BTR: B stored [K][N]) [BK k-rows][BN columns]
+    auto issue_b = [&](unsigned char* dst, int k0) {
+        if constexpr (BTR) dma_issue_tile_kn<BN, DMA_ROWB>(rB, dst, ldb_b, N, K, col0, k0, wave, lane);
+        else dma_issue_tile<T, BN, DMA_ROWB>(rB, dst, ldb_b, N, K, col0, k0, wave, lane);
+    };
 
     f32x4_t acc[TM][TN];
 #pragma unroll
@@ -604,10 +653,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
 #ifndef MTN_DBG_NO_LOAD
     // prologue: up to two stages in flight (NDMA LDS-DMA instructions per wave per stage, always)
     dma_issue_tile<T, BM, DMA_ROWB>(rA, smem, lda_b, M, K, row0, 0, wave, lane);
-    dma_issue_tile<T, BN, DMA_ROWB>(rB, smem + A_BYTES, ldb_b, N, K, col0, 0, wave, lane);
+    issue_b(smem + A_BYTES, 0);
     if (nstages > 1) {
         dma_issue_tile<T, BM, DMA_ROWB>(rA, smem + STAGE_BYTES, lda_b, M, K, row0, BK, wave, lane);
-        dma_issue_tile<T, BN, DMA_ROWB>(rB, smem + STAGE_BYTES + A_BYTES, ldb_b, N, K, col0, BK, wave, lane);
+        issue_b(smem + STAGE_BYTES + A_BYTES, BK);
     }
 #endif
     const DropState ds = drop_init(P.drop);        // scalar seed load + key hashing ride under the operand DMA
@@ -629,6 +678,43 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
 #ifdef MTN_DBG_NO_COMPUTE
         ksteps = 0;
 #endif
+        if constexpr (BTR) {
+            // The transposing reads are inline asm (no builtin): the compiler neither counts nor overlaps them, so the loop is
+            // software-pipelined by hand — the fragments of step ks+1 are in flight while the MFMAs of step ks issue (ping-pong
+            // registers, one explicit lgkmcnt(0) per step).  Without it every step exposed one LDS round trip: +1-2 us per launch.
+            uint4 a0[TM], b0[TN], a1[TM], b1[TN];
+            auto load = [&](int ks, uint4* a, uint4* b) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int ra = wr * (BM / 2) + i * 16 + l15;
+                    const unsigned addr = (unsigned)(size_t)(sA + ra * DMA_ROWB + (((ks * 4 + lg) ^ (ra & 15)) << 4));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(addr));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = kn_frag<BN>(sB, wc * (BN / 2) + j * 16, ks, l15, lg);
+            };
+            auto mfmas = [&](const uint4* a, const uint4* b) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], b[j], a[i]);
+            };
+            if (ksteps > 0) load(0, a0, b0);
+            for (int ks = 0; ks < ksteps; ks += 2) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < ksteps) load(ks + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(a0, b0);
+                if (ks + 1 < ksteps) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks + 2 < ksteps) load(ks + 2, a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(a1, b1);
+                }
+            }
+        } else {
 #pragma unroll 2
         for (int ks = 0; ks < ksteps; ++ks) {
             uint4 a[TM], b[TN];
@@ -647,13 +733,14 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator: see epilogue
         }
+        }
 #ifndef MTN_DBG_NO_LOAD
         if (s + 2 < nstages) {           // refill this buffer with stage s+2 once every wave is done reading it
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             unsigned char* dst = smem + (s & 1) * STAGE_BYTES;
             dma_issue_tile<T, BM, DMA_ROWB>(rA, dst, lda_b, M, K, row0, (s + 2) * BK, wave, lane);
-            dma_issue_tile<T, BN, DMA_ROWB>(rB, dst + A_BYTES, ldb_b, N, K, col0, (s + 2) * BK, wave, lane);
+            issue_b(dst + A_BYTES, (s + 2) * BK);
         }
 #endif
     }
@@ -1086,6 +1173,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_dma128_table_kernel(const TTHe
     else { tn_ = idx / Q.tiles_m; tm_ = idx - tn_ * Q.tiles_m; }
     AdamCoef coef;
     if (hdr->any) coef = adam_coef(hdr->state, hdr->grad_scale, hdr->beta1, hdr->beta2, hdr->eps);
+#ifdef MTN_TT_ABLATION
+    // measurement build (tools/tt_ablation.sh): bit 1 = no contraction (the optimiser epilogue alone, zero gradients), bit 2 = no epilogue
+    if (hdr->plain_tile_order & 2) P.K = 0;
+    if (hdr->plain_tile_order & 4) { S.p = nullptr; P.out_f32 = nullptr; }
+    if (hdr->plain_tile_order & 8) S.lpT = nullptr;              // no transposed compute-dtype copy
+    if (hdr->plain_tile_order & 16) S.lp = nullptr;              // no compute-dtype copy
+#endif
     tt128_tile(P, S, hdr->lds_epilogue != 0, coef, tm_ * 128, tn_ * 128, smem);
 }
 
@@ -1209,20 +1303,29 @@ static const char* const g_variant_name[V_COUNT] = {
     "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
     "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages", "gemm_tt_dma128_table_kernel", "gemm_k512_kernel"};
 
-template <typename T, int BM, int BN, int ROWB>
+template <typename T, int BM, int BN, int ROWB, bool BTR = false>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
     g_variant = (BM == 64) ? (ROWB == 512 ? V_DMA64 : V_DMA64H) : (BN == 64 ? V_DMA3264 : (ROWB == 512 ? V_DMA32 : V_DMA32H));
     g_variant_tiles = tiles;
     constexpr int LDS = 2 * (BM + BN) * ROWB;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set && LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN, ROWB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN, ROWB, BTR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { mtn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB>), dim3(tiles), dim3(256), LDS, s, grp);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR>), dim3(tiles), dim3(256), LDS, s, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
+}
+
+// row-major B, or (btr: bf16 only) B stored [K][N]
+template <typename T, int BM, int BN, int ROWB>
+static int launch_dma_any(const GemmGroup& grp, int tiles, bool btr, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        if (btr) return launch_dma<T, BM, BN, ROWB, true>(grp, tiles, s);
+    }
+    return launch_dma<T, BM, BN, ROWB, false>(grp, tiles, s);
 }
 
 // tile_start[] for a given tile shape; returns the total
@@ -1272,7 +1375,12 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
             }
         }
     }
-    if (!at && !bt && dma_ok) {
+    // B stored contraction-major ([K][N], b_trans = 1: dX = dY W with W as the forward pass keeps it): same kernel, the B tile is
+    // brought as [k][columns] and its fragments come out of the transposing LDS read — bf16 only, N and ldb multiples of 8
+    bool btr_ok = bt && sizeof(T) == 2 && MTN_ENV("MTN_GEMM_NT_REG") == nullptr;
+    for (int i = 0; i < grp.count && btr_ok; ++i)
+        btr_ok = grp.p[i].N % 8 == 0 && grp.p[i].ldb % 8 == 0 && (long)grp.p[i].K * grp.p[i].ldb * 2 < (1L << 31);
+    if (!at && dma_ok && (!bt || btr_ok)) {
         // Tile choice by the bytes ONE CU has to pull (the bound of these launches, ~27 GB/s per CU): 64x64 tiles run one
         // workgroup per CU in ceil(tiles/256) rounds of (64+64)*K bytes; 32x32 tiles spread 4x the workgroups of half the
         // size, two per CU (their DMA latencies overlap: x0.75, fitted on tools/gemm_bench.hip).  MTN_GEMM_TILE forces one.
@@ -1299,13 +1407,13 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         const bool half_force = MTN_ENV("MTN_GEMM_FORCE_HALF") != nullptr;      // tests
         if (f == 64 || (!f && c64 <= c32)) {
             const int t = retile(g2, 64, 64, true);
-            if (half_force || (half_ok && t > 256)) return launch_dma<T, 64, 64, 256>(g2, t, s);
-            return launch_dma<T, 64, 64, 512>(g2, t, s);
+            if (half_force || (half_ok && t > 256)) return launch_dma_any<T, 64, 64, 256>(g2, t, bt, s);
+            return launch_dma_any<T, 64, 64, 512>(g2, t, bt, s);
         }
-        if (f == 3264) return launch_dma<T, 32, 64, 512>(g2, retile(g2, 32, 64, true), s);
+        if (f == 3264 && !bt) return launch_dma<T, 32, 64, 512>(g2, retile(g2, 32, 64, true), s);
         const int t = retile(g2, 32, 32, true);
-        if (half_force || (half_ok && t > 1024)) return launch_dma<T, 32, 32, 256>(g2, t, s);   // (measured in the step: 640 tiles 10.7 vs 10.1 us, 1280 tiles 12.7 vs 13.8 us)
-        return launch_dma<T, 32, 32, 512>(g2, t, s);
+        if (half_force || (half_ok && t > 1024)) return launch_dma_any<T, 32, 32, 256>(g2, t, bt, s);   // (measured in the step: 640 tiles 10.7 vs 10.1 us, 1280 tiles 12.7 vs 13.8 us)
+        return launch_dma_any<T, 32, 32, 512>(g2, t, bt, s);
     } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp, NoAdam{});
     else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp, NoAdam{});
     else if (at && bt) {
@@ -1409,7 +1517,9 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     // rounds (128 KiB of LDS = one workgroup per CU): large grids are throughput-bound and do better on the
     // register-staged kernel at 5 workgroups per CU.
     const char* dmax = MTN_ENV("MTN_GEMM_DMA_MAX_TILES");
-    bool dma_ok = !problems[0].rowsum_out && tiles <= (dmax ? atoi(dmax) : 640);
+    // (b_trans = 1: the register-staged <N,T> fallback is 1.5x slower than <N,N> — 33.7 vs 21.7 us on the memories' dX launch,
+    //  the LDS-DMA kernel with half stages 24.2: tools/nt_gemm_probe.py — so the LDS-DMA kernel keeps those too)
+    bool dma_ok = !problems[0].rowsum_out && tiles <= (dmax ? atoi(dmax) : (problems[0].b_trans && !problems[0].a_trans ? 4096 : 640));
     const long esz = (dtype == MTN_BF16) ? 2 : 4;
     for (int i = 0; i < count; ++i) {
         const mtn_gemm_problem& p = problems[i];
@@ -1532,6 +1642,9 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
             for (int k = 0; k < Q[i].tiles_m * Q[i].tiles_n; ++k) map[pos++] = ((uint32_t)i << 12) | (uint32_t)k;
     } else {
         H->plain_tile_order = 1;                                          // inside a problem: plain order, one L2 sees them all
+#ifdef MTN_TT_ABLATION
+        if (const char* e = MTN_ENV("MTN_TT_ABLATE")) H->plain_tile_order |= atoi(e) & 30;
+#endif
         std::vector<int> order(count);
         std::vector<double> cost(count);
         for (int i = 0; i < count; ++i) {

@@ -501,6 +501,10 @@ class Generator(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------ top level
+# which transposed weight copies (besides W_o^T) the flat layout keeps: see EncoderDecoder._flatten
+KEEP_WT_DEFAULT = ""
+
+
 class EncoderDecoder(nn.Module):
     def __init__(self, query_encoder, his_encoder, cap_encoder, vid_encoder, decoder, query_embed, his_embed, cap_embed,
                  tgt_embed, generator, diff_encoder=False, auto_encoder_embed=None, auto_encoder_ft=None,
@@ -600,7 +604,14 @@ class EncoderDecoder(nn.Module):
         self._flat_lp = torch.empty(total, device=dev, dtype=lp) if lp != torch.float32 else flat
         self._flat_version = -1
         self._flat_lpT = torch.zeros(total, device=dev, dtype=lp) if dev.type == "cuda" else None
-        tdescs = []          # (offset, rows, cols) of every 2-D path weight that gets a transposed copy
+        # (offset, rows, cols) of every 2-D path weight that gets a transposed copy.  Only W_o does (the fused head backward
+        # reads W_o^T rows, csrc/fused_bwd.hip): every other dX = dY W runs on the LDS-DMA GEMM with W as it lies (b_trans = 1:
+        # [k][n] tiles + transposing LDS reads, csrc/gemm.hip), so the optimiser epilogue writes no transposed copy for them —
+        # those scattered 128-byte runs were 16 % of the launch for 7 % of its bytes (profiles/r03_tt_ablation.txt).
+        # MTN_KEEP_WT=qkv,w1,w2,gen (or "all") keeps the named ones (A/B).
+        keep_env = os.environ.get("MTN_KEEP_WT", KEEP_WT_DEFAULT)
+        keep = {"qkv", "w1", "w2", "gen"} if keep_env in ("all", "1") else {k for k in keep_env.split(",") if k}
+        tdescs = []
         fusable = []         # ... of those, the weights whose gradient is ONE deferred GEMM (optimiser epilogue)
         optional = set()     # ... offsets of fusable weights that may legitimately get no deferred GEMM in a step
         if dev.type == "cuda":
@@ -628,9 +639,11 @@ class EncoderDecoder(nn.Module):
                                 grads=dict(w_qkv=gw, b_qkv=gb, w_o=gwo, b_o=gbo))
                 if self._flat_lpT is not None:
                     oq, oo = path_off[id(m.linears[0].weight)], path_off[id(m.linears[3].weight)]
-                    m._fused["w_qkv_lpT"] = self._flat_lpT[oq:oq + 3 * d * d].view(d, 3 * d)
                     m._fused["w_o_lpT"] = self._flat_lpT[oo:oo + d * d].view(d, d)
-                    tdescs += [(oq, 3 * d, d), (oo, d, d)]
+                    tdescs += [(oo, d, d)]
+                    if "qkv" in keep:
+                        m._fused["w_qkv_lpT"] = self._flat_lpT[oq:oq + 3 * d * d].view(d, 3 * d)
+                        tdescs += [(oq, 3 * d, d)]
                     fusable += [(oq, 3 * d, d), (oo, d, d)]
             elif isinstance(m, PositionwiseFeedForward) and id(m.w_1.weight) in path_off:
                 w1, w1l, g1 = views(m.w_1.weight); b1, _, gb1 = views(m.w_1.bias)
@@ -640,9 +653,12 @@ class EncoderDecoder(nn.Module):
                 if self._flat_lpT is not None:
                     o1, o2 = path_off[id(m.w_1.weight)], path_off[id(m.w_2.weight)]
                     ffd, dm = m.w_1.weight.shape
-                    m._fused["w1_lpT"] = self._flat_lpT[o1:o1 + ffd * dm].view(dm, ffd)
-                    m._fused["w2_lpT"] = self._flat_lpT[o2:o2 + ffd * dm].view(ffd, dm)
-                    tdescs += [(o1, ffd, dm), (o2, dm, ffd)]
+                    if "w1" in keep:
+                        m._fused["w1_lpT"] = self._flat_lpT[o1:o1 + ffd * dm].view(dm, ffd)
+                        tdescs += [(o1, ffd, dm)]
+                    if "w2" in keep:
+                        m._fused["w2_lpT"] = self._flat_lpT[o2:o2 + ffd * dm].view(ffd, dm)
+                        tdescs += [(o2, dm, ffd)]
                     fusable += [(o1, ffd, dm), (o2, dm, ffd)]
             elif isinstance(m, Generator):
                 o_w, o_b = path_off[id(m.proj.weight)], path_off[id(m.proj.bias)]
@@ -650,9 +666,10 @@ class EncoderDecoder(nn.Module):
                 m._fused = dict(w_lp=self._flat_lp[o_w:o_w + nw].view(m.proj.weight.shape), bias=flat[o_b:o_b + nb],
                                 grad_w=grad[o_w:o_w + nw].view(m.proj.weight.shape), grad_b=grad[o_b:o_b + nb], lp_dtype=lp, w_lpT=None)
                 vocab, dm = m.proj.weight.shape
-                if self._flat_lpT is not None and vocab % 8 == 0 and not any(t[0] == o_w for t in tdescs):
-                    m._fused["w_lpT"] = self._flat_lpT[o_w:o_w + nw].view(dm, vocab)     # dX of the loss head on the LDS-DMA path
-                    tdescs.append((o_w, vocab, dm))
+                if self._flat_lpT is not None and vocab % 8 == 0 and not any(t[0] == o_w for t in fusable):
+                    if "gen" in keep:
+                        m._fused["w_lpT"] = self._flat_lpT[o_w:o_w + nw].view(dm, vocab)
+                        tdescs.append((o_w, vocab, dm))
                     fusable.append((o_w, vocab, dm))
                     optional.add(o_w)            # its dW reaches the queue only through the fused loss head
                 m._fused["queue"] = self._queue

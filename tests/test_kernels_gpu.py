@@ -559,3 +559,54 @@ def test_gemm_k512_many_large_problems(dev):
     for out, ref, N in refs:
         assert relmax(out[:, :N].float(), ref) < 1e-2
         assert bool((out[:, N:].float() == 7.0).all())             # nothing written past the problem's columns
+
+
+@pytest.mark.parametrize("force", ["", "MTN_GEMM_TILE=64", "MTN_GEMM_TILE=32", "MTN_GEMM_TILE=64,MTN_GEMM_FORCE_HALF=1", "MTN_GEMM_TILE=32,MTN_GEMM_FORCE_HALF=1"])
+def test_gemm_contraction_major_b_on_lds_dma(dev, force):
+    """dX = dY W with W as the forward pass keeps it (b_trans = 1: B stored [K][N]) on gemm_dma_kernel's [k][n]-tile variant
+    (transposing LDS reads): every tile / stage size, ragged M, N (multiples of 8) and K (tails inside a stage and across
+    stages), grouped, with the gate + residual + both-outputs epilogue the FFN backward uses.  The census must show the
+    LDS-DMA kernel, not the register-staged fallback."""
+    import ctypes as C
+    import os
+    from mtn_amd import lib as L, ops
+    dtype = torch.bfloat16
+    env = dict(kv.split("=") for kv in force.split(",") if kv)
+    os.environ.update(env)
+    L.reload_env()
+    lib = L.load()
+    g = torch.Generator().manual_seed(21)
+    probs, checks = [], []
+    for (M, N, K) in [(640, 512, 2048), (640, 2048, 512), (104, 72, 136), (1000, 1536, 512), (33, 8, 40), (96, 520, 304)]:
+        a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * torch.linspace(0.5, 1.5, N).unsqueeze(1)
+        res, gate = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+        A, B = a.to(dev, dtype), b.t().contiguous().to(dev, dtype)            # B: [K][N]
+        Res, Gate = res.to(dev), gate.to(dev, dtype)
+        of = torch.full((M, N), float("nan"), device=dev)
+        ol = torch.empty(M, N, device=dev, dtype=dtype)
+        p = _gemm_problem(L, A, B, M, N, K, 0, 1, K, N)
+        p.gate, p.gate_scale, p.residual, p.ldr, p.out_f32, p.out_lp, p.ldc = Gate.data_ptr(), 1.25, Res.data_ptr(), N, of.data_ptr(), ol.data_ptr(), N
+        probs.append(p)
+        v = lp_round(a, dtype).double() @ lp_round(b, dtype).double().t()
+        v = torch.where(lp_round(gate, dtype).double() > 0, v * 1.25, torch.zeros_like(v)) + res.double()
+        checks.append((of, ol, v, K, (A, B, Res, Gate)))
+    try:
+        lib.mtn_census_begin()
+        for p in probs[:2]:
+            ops.gemm(L.MTN_BF16, [p])                # the two FFN-backward shapes of the train step, one launch each
+        ops.gemm(L.MTN_BF16, probs[2:])              # the ragged ones grouped
+        torch.cuda.synchronize()
+        n = lib.mtn_census_end()
+        names = []
+        for i in range(n):
+            info = L.CensusLaunch()
+            L.check(lib.mtn_census_info(i, C.byref(info)))
+            names.append(lib.mtn_census_variant_name(info.variant).decode())
+    finally:
+        for k in env:
+            del os.environ[k]
+        L.reload_env()
+    assert n == 3 and all("dma" in nm.lower() for nm in names), names
+    for of, ol, v, K, _keep in checks:
+        assert relmax(of, v) < 1e-5 * math.sqrt(K)
+        assert relmax(ol.float(), v) < 1e-2
