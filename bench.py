@@ -529,7 +529,9 @@ def main():
                      "achieved_TFLOPs": round(step_tf, 2), "frac": round(step_tf / peak, 5),
                      "gflop_per_sample": gflop, "gflop_per_sample_closed_form": round(gflop_formula, 3),
                      "hip_event_ms_per_step": round(ev_ms, 4),
-                     "optimiser_bytes_per_step": (28 if step._fused() else 38) * sum(p.numel() for p in model.parameters())}
+                     # fused: p, m, v read + written, the bf16 copy written (the transposed copy only for the W_o matrices);
+                     # separate pass: + the gradient written and read back, + every transposed copy read and written
+                     "optimiser_bytes_per_step": (26 if step._fused() else 38) * sum(p.numel() for p in model.parameters())}
         hbm = pmc_step_traffic()
         if hbm is not None and world == 1 and args.workload == "cfg2" and B == 32:
             # whole-step HBM-side traffic from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, gfx950 corrections) / measured step time
@@ -564,7 +566,7 @@ def main():
                 hbm_peak = None
             TABLE = "gemm_tt_dma128_table_kernel"
             if dom == TABLE:
-                # the parameter-gradient + optimiser launch: 28 B of parameter streams per weight behind every 2*K flops -> HBM-bound
+                # the parameter-gradient + optimiser launch: 26-28 B of parameter streams per weight behind every 2*K flops -> HBM-bound
                 d = table[dom]
                 roof = {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps_algorithmic"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(d["achieved_GBps_algorithmic"] / PEAK_HBM_GBS, 4), "traffic": pmc_traffic(dom),
@@ -579,7 +581,7 @@ def main():
             else:
                 roof = mfma_roof(dom)
             roof["what"] = ("dominant kernel of the step (largest summed duration): algorithmic bytes (operands once + per weight the "
-                            "optimiser epilogue's 28 B: p, m, v read and written, two bf16 copies written) or FLOPs per launch / HIP-event "
+                            "optimiser epilogue's 26 B: p, m, v read and written, the bf16 copy written; + 2 B for the W_o matrices' transposed copy) or FLOPs per launch / HIP-event "
                             "duration per launch, averaged over all of its launches in one step (library launch census, each "
                             "launch replayed in step order, one HIP-event pair each, 5 passes); traffic = HBM bytes per launch from the "
                             "committed rocprofv3 PMC passes")

@@ -980,22 +980,34 @@ __device__ __forceinline__ void tt128_tile(const mtn_gemm_problem& P, const Adam
         __builtin_amdgcn_s_barrier();
         const unsigned char* sA = smem + (s & 1) * 2 * TTB_TILE_BYTES;
         const unsigned char* sB = sA + TTB_TILE_BYTES;
+        // Both contraction steps of the stage are read up front (2 x 16 transposing reads; they are inline asm, the compiler does
+        // not overlap them with anything): the MFMAs of step 0 issue once at most 15 reads are outstanding (LDS returns in
+        // order: all 16 of step 0 have landed), those of step 1 hide under them.
+        static_assert(TTB_KS / 32 == 2, "two contraction steps per stage");
+        uint4 a[2][4], b[2][4];
 #pragma unroll
-        for (int ks = 0; ks < TTB_KS / 32; ++ks) {
-            uint4 a[4], b[4];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = ttb_frag(sA, wr * 64 + i * 16, ks, l15, lg);
-                b[i] = ttb_frag(sB, wc * 64 + i * 16, ks, l15, lg);
+                a[ks][i] = ttb_frag(sA, wr * 64 + i * 16, ks, l15, lg);
+                b[ks][i] = ttb_frag(sB, wc * 64 + i * 16, ks, l15, lg);
             }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#ifdef MTN_TTB_NOPIPE
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+            if (ks == 0) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator (vector epilogue)
-                if (do_rowsum && wc == 0) mma16<T>(rs[i], ones, a[i]);
+                for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], b[ks][j], a[ks][i]);     // transposed accumulator (vector epilogue)
+                if (do_rowsum && wc == 0) mma16<T>(rs[i], ones, a[ks][i]);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (s + 2 < nstages) {
             __builtin_amdgcn_s_barrier();
@@ -1077,10 +1089,10 @@ __device__ __forceinline__ void tt128_tile(const mtn_gemm_problem& P, const Adam
                     if (q & 1) pk[k][q >> 1] |= bits << 16; else pk[k][q >> 1] = bits;
                 }
             }
+            if (S.lpT) {                                            // (tile-uniform: only W_o keeps a transposed copy)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *(uint4*)(st + (c4 + k) * 72 + rb * 8) = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
-            __syncthreads();
-            if (S.lpT) {
+                for (int k = 0; k < 4; ++k) *(uint4*)(st + (c4 + k) * 72 + rb * 8) = make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]);
+                __syncthreads();
                 const int r8 = (tid & 7) * 8;                       // 8 consecutive rows = 16 bytes of one column of the tile
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
@@ -1398,7 +1410,9 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
             b32 += n32 * 64.0 * kb;
             if (64.0 * kb > wg32max) wg32max = 64.0 * kb;
         }
-        const double c64 = (double)((t64 + 255) / 256) * (b64 / t64);
+        double c64 = (double)((t64 + 255) / 256) * (b64 / t64);
+        // 257..512 tiles of 64x64 run in ONE round on half-size stages (two workgroups per CU, like the 32x32 tiles: x0.75)
+        if (t64 > 256 && t64 <= 512 && MTN_ENV("MTN_GEMM_NO_HALF") == nullptr && MTN_ENV("MTN_GEMM_C64H") != nullptr) c64 = 0.75 * b64 / 256.0;
         double c32 = 0.75 * b32 / 256.0;
         if (c32 < wg32max) c32 = wg32max;
         // half-size stages (256 B of contraction per row) double the resident workgroups: taken when the launch would
@@ -1410,7 +1424,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
             if (half_force || (half_ok && t > 256)) return launch_dma_any<T, 64, 64, 256>(g2, t, bt, s);
             return launch_dma_any<T, 64, 64, 512>(g2, t, bt, s);
         }
-        if (f == 3264 && !bt) return launch_dma<T, 32, 64, 512>(g2, retile(g2, 32, 64, true), s);
+        if (f == 3264) return launch_dma_any<T, 32, 64, 512>(g2, retile(g2, 32, 64, true), bt, s);
         const int t = retile(g2, 32, 32, true);
         if (half_force || (half_ok && t > 1024)) return launch_dma_any<T, 32, 32, 256>(g2, t, bt, s);   // (measured in the step: 640 tiles 10.7 vs 10.1 us, 1280 tiles 12.7 vs 13.8 us)
         return launch_dma_any<T, 32, 32, 512>(g2, t, bt, s);

@@ -1,0 +1,11 @@
+# Builds tools/libmtn_hip_<name>.so = the library with extra compile flags on csrc/gemm.hip (the other objects are taken from
+# mtn_amd/build): same-box A/B of a compile-time choice through MTN_HIP_LIB.
+#   bash tools/build_variant.sh nopipe -DMTN_TTB_NOPIPE && MTN_HIP_LIB=tools/libmtn_hip_nopipe.so python bench.py ...
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+python -m mtn_amd.build > /dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c mtn_amd/csrc/gemm.hip -o /tmp/gemm_$name.o 2>/dev/null
+objs=$(ls mtn_amd/build/*.o | grep -v "/gemm.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/libmtn_hip_$name.so /tmp/gemm_$name.o $objs
+ls -la tools/libmtn_hip_$name.so
