@@ -1412,7 +1412,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         }
         double c64 = (double)((t64 + 255) / 256) * (b64 / t64);
         // 257..512 tiles of 64x64 run in ONE round on half-size stages (two workgroups per CU, like the 32x32 tiles: x0.75)
-        if (t64 > 256 && t64 <= 512 && MTN_ENV("MTN_GEMM_NO_HALF") == nullptr && MTN_ENV("MTN_GEMM_C64H") != nullptr) c64 = 0.75 * b64 / 256.0;
+        if (t64 > 256 && t64 <= 512 && MTN_ENV("MTN_GEMM_NO_HALF") == nullptr && !(MTN_ENV("MTN_GEMM_C64H") && MTN_ENV("MTN_GEMM_C64H")[0] == '0')) c64 = 0.75 * b64 / 256.0;   // +0.3 % cfg2, +0.5 % at 64 samples (profiles/r03_o_c64h_ab.txt)
         double c32 = 0.75 * b32 / 256.0;
         if (c32 < wg32max) c32 = wg32max;
         // half-size stages (256 B of contraction per row) double the resident workgroups: taken when the launch would
