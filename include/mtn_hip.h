@@ -255,8 +255,8 @@ typedef struct {
     const float* b_qkv;
     const void* w_o; /* lowp [d,d] */
     const float* b_o;
-    const void* w_qkv_t; /* lowp [d,3d] = w_qkv^T, optional (backward: NULL -> slower transposing GEMM path) */
-    const void* w_o_t;   /* lowp [d,d]  = w_o^T,  optional */
+    const void* w_qkv_t; /* lowp [d,3d] = w_qkv^T, optional (backward: NULL -> dX = dY W reads w_qkv as it lies, b_trans = 1 on the LDS-DMA GEMM: what the training step does since round 3) */
+    const void* w_o_t;   /* lowp [d,d]  = w_o^T,  optional; REQUIRED for the fused head backward (it reads w_o^T rows), NULL -> staged path */
     float* y;    /* [B,a,d] */
     void* xn;    /* lowp [B*a,d]  saved */
     float* mean; /* [B*a]         saved */
@@ -313,8 +313,8 @@ typedef struct {
     const float* b1;
     const void* w2; /* lowp [d,d_ff] */
     const float* b2;
-    const void* w1_t; /* lowp [d,d_ff] = w1^T, optional (backward) */
-    const void* w2_t; /* lowp [d_ff,d] = w2^T, optional (backward) */
+    const void* w1_t; /* lowp [d,d_ff] = w1^T, optional (backward; NULL -> w1 as it lies, b_trans = 1) */
+    const void* w2_t; /* lowp [d_ff,d] = w2^T, optional (backward; NULL -> w2 as it lies, b_trans = 1) */
     float* y;    /* [rows,d] */
     void* xn;    /* lowp [rows,d]    saved */
     float* mean; /* saved */

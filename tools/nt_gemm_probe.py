@@ -63,7 +63,7 @@ def main():
 
     for label, shapes in CASES:
         print(label)
-        for env in ({}, {"MTN_GEMM_TILE": "64"}, {"MTN_GEMM_TILE": "32"}, {"MTN_GEMM_TILE": "3264"}, {"MTN_GEMM_DMA_MAX_TILES": "4096"}):
+        for env in ({}, {"MTN_GEMM_TILE": "64"}, {"MTN_GEMM_TILE": "32"}, {"MTN_GEMM_TILE": "3264"}, {"MTN_GEMM_DMA_MAX_TILES": "4096"}, {"MTN_GEMM_NTB_MIN_TILES": "1"}):
             os.environ.update(env)
             L.reload_env()
             row = []
