@@ -63,6 +63,14 @@ template <> struct LP<bf16_t> {
 // One 16-byte fragment pair -> 16x16 accumulator.  A fragment lane l holds row (l&15), contraction slots
 // (l>>4)*EPV .. +EPV-1 of the KSTEP-wide step; B likewise for column (l&15).  The slot->k map is the same
 // permutation on both operands, so any k-order inside the 16 bytes is fine.
+// 16 bytes of MFMA operand read by inline asm (ds_read_b128 / ds_read_b64_tr_b16): a native vector so that it can be an asm "+v"
+// operand, and the pass that ties its consumers to the wait behind the read (MTN_LANDED)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ uint4 as_uint4(const u32x4_t& v) { return make_uint4(v.x, v.y, v.z, v.w); }
+// The compiler believes an asm read's result is there when the asm statement ends; anything it derives from it could be computed
+// before the s_waitcnt that really delivers it.  Passing the register through an empty asm right after the wait makes every
+// consumer depend on a statement that cannot move above the wait.
+#define MTN_LANDED(v) asm volatile("" : "+v"(v))
 template <typename T> __device__ __forceinline__ void mma16(f32x4_t& acc, const uint4& a, const uint4& b);
 template <> __device__ __forceinline__ void mma16<bf16_t>(f32x4_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&b, acc, 0, 0, 0);

@@ -678,12 +678,16 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
 #ifdef MTN_DBG_NO_COMPUTE
         ksteps = 0;
 #endif
-        if constexpr (BTR) {
-            // The transposing reads are inline asm (no builtin): the compiler neither counts nor overlaps them, so the loop is
-            // software-pipelined by hand — the fragments of step ks+1 are in flight while the MFMAs of step ks issue (ping-pong
-            // registers, one explicit lgkmcnt(0) per step).  Without it every step exposed one LDS round trip: +1-2 us per launch.
-            uint4 a0[TM], b0[TN], a1[TM], b1[TN];
-            auto load = [&](int ks, uint4* a, uint4* b) {
+        {
+            // Every fragment read is INLINE ASM, for two reasons.  (1) The compiler puts s_waitcnt vmcnt(0) in front of any LDS read
+            // it can see while LDS-DMA instructions are outstanding (it cannot tell the stage being read from the one being filled):
+            // with plain loads here the refill of stage s+2 was drained before stage s+1 — landed long ago — could be touched, one
+            // exposed DMA latency per stage beyond the second (round 3: found on the persistent K = 512 kernel, csrc/gemm_k512.hip).
+            // (2) The transposing read of the BTR form has no builtin.  The compiler neither counts nor overlaps asm reads, so the
+            // loop is software-pipelined by hand: the fragments of step ks+1 are in flight while the MFMAs of step ks issue
+            // (ping-pong registers, one explicit lgkmcnt(0) per step).
+            u32x4_t a0[TM], b0[TN], a1[TM], b1[TN];
+            auto load = [&](int ks, u32x4_t* a, u32x4_t* b) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int ra = wr * (BM / 2) + i * 16 + l15;
@@ -691,48 +695,46 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
                     asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(addr));
                 }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = kn_frag<BN>(sB, wc * (BN / 2) + j * 16, ks, l15, lg);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (BTR) {
+                        const uint4 f = kn_frag<BN>(sB, wc * (BN / 2) + j * 16, ks, l15, lg);
+                        b[j] = u32x4_t{f.x, f.y, f.z, f.w};
+                    } else {
+                        const int rb = wc * (BN / 2) + j * 16 + l15;
+                        const unsigned addr = (unsigned)(size_t)(sB + rb * DMA_ROWB + (((ks * 4 + lg) ^ (rb & 15)) << 4));
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(addr));
+                    }
+                }
             };
-            auto mfmas = [&](const uint4* a, const uint4* b) {
+            auto mfmas = [&](const u32x4_t* a, const u32x4_t* b) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], b[j], a[i]);
+                    for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], as_uint4(b[j]), as_uint4(a[i]));     // transposed accumulator: see epilogue
+            };
+            auto landed = [&](u32x4_t* a, u32x4_t* b) {                // (MTN_LANDED: common.h)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < TM; ++i) MTN_LANDED(a[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) MTN_LANDED(b[j]);
+                __builtin_amdgcn_sched_barrier(0);
             };
             if (ksteps > 0) load(0, a0, b0);
             for (int ks = 0; ks < ksteps; ks += 2) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
+                landed(a0, b0);
                 if (ks + 1 < ksteps) load(ks + 1, a1, b1);
                 __builtin_amdgcn_sched_barrier(0);
                 mfmas(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (ks + 1 < ksteps) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
+                    landed(a1, b1);
                     if (ks + 2 < ksteps) load(ks + 2, a0, b0);
                     __builtin_amdgcn_sched_barrier(0);
                     mfmas(a1, b1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        } else {
-#pragma unroll 2
-        for (int ks = 0; ks < ksteps; ++ks) {
-            uint4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int ra = wr * (BM / 2) + i * 16 + l15;
-                a[i] = *(const uint4*)(sA + ra * DMA_ROWB + (((ks * 4 + lg) ^ (ra & 15)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int rb = wc * (BN / 2) + j * 16 + l15;
-                b[j] = *(const uint4*)(sB + rb * DMA_ROWB + (((ks * 4 + lg) ^ (rb & 15)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator: see epilogue
-        }
         }
 #ifndef MTN_DBG_NO_LOAD
         if (s + 2 < nstages) {           // refill this buffer with stage s+2 once every wave is done reading it

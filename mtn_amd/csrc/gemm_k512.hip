@@ -94,6 +94,235 @@ __global__ __launch_bounds__(GK_THREADS) void gemm_k512_kernel(const GkGroup G) 
     }
 }
 
+// ====================================================================================================================
+// Persistent form (round 3).  The kernel above runs one workgroup per CU through load-everything -> wait -> compute -> store:
+// the CU's MFMAs idle while its 256 KiB arrive and its memory path idles while they run (6.9 rounds x 11 us for 1 768 tiles).
+// Here 256 workgroups stay resident (one per CU) and each walks a list of UNITS = 64 rows x 128 columns of one problem:
+//   * the W tile [128][512] is loaded ONCE per (problem, column tile) and stays in registers across the unit's row tiles;
+//   * the x tile [64][512] arrives by LDS-DMA into one of two 64 KiB images, TWO units ahead of the MFMAs (counted vmcnt: the
+//     8 instructions of the newest image may still fly), so the loads of unit i+1 run under the MFMAs, staging and stores of unit i;
+//   * the output tile leaves through a separate staging area as whole 256-byte row segments.
+// Unit -> workgroup map: XCD x (= blockIdx % 8: workgroups are dealt to the XCDs round-robin) owns the row tiles tm = x (mod 8)
+// of every problem, for ALL column tiles — its L2 sees an eighth of the x rows, once — and inside an XCD workgroup j of 32 takes
+// units u = j, j + 32, ... of the (row tile, column tile) list with the column tile fastest: with 8 (or 4, 2, 16) column tiles a
+// workgroup keeps ONE column tile, and the 8 workgroups that share a row tile walk their lists side by side.
+// ====================================================================================================================
+static constexpr int GP_ROWS = 64;
+static constexpr int GP_IMG = GP_ROWS * FH_ROWB;           // 64 KiB
+static constexpr int GP_STG = 2 * GP_IMG;                  // staging area behind the two images
+static constexpr int GP_LDS = GP_STG + GP_ROWS * GK_CPITCH;   // 148 480 B
+static constexpr int GP_GRID = 256;
+
+struct GpUnit { int p, tn, tm; };                          // p < 0: none
+
+__device__ __forceinline__ GpUnit gp_first_from(const GkGroup& G, int p, int u, int xcd, int j) {
+    // first unit at or after (problem p, list position u) of this workgroup; u < 0: start of problem p
+    for (; p < G.count; ++p, u = -1) {
+        const GkProblem& P = G.p[p];
+        const int ntn = (P.N + 127) >> 7, tm64 = (P.M + GP_ROWS - 1) / GP_ROWS;
+        const int nr = tm64 > xcd ? (tm64 - xcd + 7) >> 3 : 0;
+        if (u < 0) u = (j + 5 * p) & 31;                   // rotate the workgroups per problem: short lists do not always feed the same ones
+        if (u < nr * ntn) return GpUnit{p, u % ntn, xcd + 8 * (u / ntn)};
+    }
+    return GpUnit{-1, 0, 0};
+}
+
+__global__ __launch_bounds__(GK_THREADS, 2) void gemm_k512p_kernel(const GkGroup G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+
+    auto unit_u = [&](const GpUnit& c) {                   // list position of a unit (inverse of gp_first_from's map)
+        const int ntn = (G.p[c.p].N + 127) >> 7;
+        return ((c.tm - xcd) >> 3) * ntn + c.tn;
+    };
+    auto next_of = [&](const GpUnit& c) { return gp_first_from(G, c.p, unit_u(c) + 32, xcd, j); };
+    // Roles: waves 0-3 bring the x images (16 LDS-DMA instructions each per image), waves 4-7 store the output tiles.  vmcnt is
+    // per wave and counts loads and stores alike, which complete out of order with each other: a wave that did both could not
+    // let the newest image fly without first draining its stores (measured: 6-7 us per unit instead of 1.3).
+    const bool loader = wave < 4;
+    auto issue_x = [&](const GpUnit& c, unsigned char* img) {
+        if (!loader || c.p < 0) return;
+#ifdef GP_ABLATE_NO_DMA
+        if (c.tm >= 0) return;
+#endif
+        const GkProblem& P = G.p[c.p];
+        const int row0 = c.tm * GP_ROWS;
+        const int R = (P.M - row0) < GP_ROWS ? (P.M - row0) : GP_ROWS;
+        const unsigned ldab = (unsigned)P.lda * 2u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)row0 * P.lda), 0, (R - 1) * ldab + FH_ROWB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < GP_ROWS / 4; ++i) {
+            const int r = wave + 4 * i;
+            const unsigned vo = r < R ? (unsigned)r * ldab + (unsigned)((lane ^ (r & 15)) << 4) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (fh_lds_void_t*)(img + r * FH_ROWB), 16, vo, 0, 0, 0);
+        }
+    };
+    uint4 wf[16];
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto issue_w = [&](const GpUnit& c) {                  // coalesced: lane 4r + c reads (row r, 16-byte chunk c); operand order by ds_bpermute
+        const GkProblem& P = G.p[c.p];
+        int n = c.tn * 128 + 16 * wave + (lane >> 2);
+        n = n < P.N ? n : P.N - 1;
+        const bf16_t* wrow = P.B + (size_t)n * P.ldb + (lane & 3) * 8;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wf[s] = *(const uint4*)(wrow + s * 32);
+        const int colq = c.tn * 128 + 16 * wave + 4 * lg;
+        bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.bias && colq < P.N) bq = *(const float4*)(P.bias + colq);
+    };
+
+    // W fragments into operand order as soon as they land — inside the block that loaded them, so that no pending register load
+    // crosses the loop's back edge: the compiler would otherwise wait vmcnt(0) in front of every unit's first MFMA (it cannot know
+    // how many image instructions follow the W loads on every path) and the x prefetch would never overlap anything.
+    auto load_w = [&](const GpUnit& c) {
+        issue_w(c);
+        const int src = (4 * l15 + lg) * 4;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            wf[s].x = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[s].x);
+            wf[s].y = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[s].y);
+            wf[s].z = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[s].z);
+            wf[s].w = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[s].w);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+#ifdef GP_STAMPS
+    // timing build: shader-clock stamps of workgroup GP_STAMPS's lane 0 of wave 0 and wave 4, written behind problem 0's output
+    long long* dbg_ = (long long*)(G.p[0].out + (size_t)G.p[0].M * G.p[0].ldc) + (wave >= 4 ? 512 : 0);
+    int dbg_n_ = 0;
+#define GP_STAMP() do { if ((int)blockIdx.x == GP_STAMPS && (tid == 0 || tid == 256) && dbg_n_ < 500) dbg_[dbg_n_++] = (long long)wall_clock64(); } while (0)
+#else
+#define GP_STAMP() do { } while (0)
+#endif
+    GpUnit cur = gp_first_from(G, 0, -1, xcd, j);
+    if (cur.p < 0) return;
+    GpUnit nxt = next_of(cur);
+    GP_STAMP();
+    issue_x(cur, smem);
+    if (nxt.p >= 0) issue_x(nxt, smem + GP_IMG);
+    load_w(cur);                                                       // (waits for the two images too: once per workgroup)
+    GP_STAMP();
+    for (int i = 0;; ++i) {
+        // image i (and a W tile issued before the newest image) has landed once at most the newest image's 16 instructions fly:
+        // loads return in order among loads (the loader waves issue nothing else)
+        if (loader) {
+            if (nxt.p >= 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        GP_STAMP();                                                    // [5i+2] image wait over
+        __builtin_amdgcn_s_barrier();
+        GP_STAMP();                                                    // [5i+3] barrier A passed
+        const unsigned char* img = smem + (i & 1) * GP_IMG;
+        f32x4_t acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#ifndef GP_ABLATE_NO_MFMA
+#ifdef GP_ABLATE_MFMA_X2
+        for (int rep_ = 0; rep_ < 2; ++rep_)
+#endif
+        {   // x fragments of step s+1 in flight under the MFMAs of step s (two register sets).  The reads are INLINE ASM on purpose:
+            // the compiler puts s_waitcnt vmcnt(0) in front of any LDS read it can see while LDS-DMA instructions are outstanding
+            // (it cannot tell the image being read from the one being filled) — which would drain the prefetched image before every
+            // unit.  Ordering is by hand: the counted vmcnt + barrier above, one lgkmcnt(0) per step here.
+            u32x4_t xa[4], xb[4];
+            const unsigned ibase = (unsigned)(size_t)img;
+            auto xload = [&](u32x4_t* x, int s) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int row = mt * 16 + l15;
+                    const unsigned addr = ibase + row * FH_ROWB + (((s * 4 + lg) ^ (row & 15)) << 4);
+#ifdef GP_ABLATE_NO_LDS
+                    x[mt] = u32x4_t{addr, addr + 1, addr + 2, addr + 3};
+#else
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(x[mt]) : "v"(addr));
+#endif
+                }
+            };
+            auto landed = [&](u32x4_t* x) {                            // (MTN_LANDED: common.h)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) MTN_LANDED(x[mt]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            xload(xa, 0);
+#pragma unroll
+            for (int s = 0; s < 16; s += 2) {
+                landed(xa);
+                xload(xb, s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) mma16<bf16_t>(acc[mt], wf[s], as_uint4(xa[mt]));
+                __builtin_amdgcn_sched_barrier(0);                     // (the MFMAs are not memory operations: without this fence the scheduler
+                landed(xb);                                            //  moves the wait in front of them and nothing overlaps)
+                if (s + 2 < 16) xload(xa, s + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) mma16<bf16_t>(acc[mt], wf[s + 1], as_uint4(xb[mt]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#endif
+        GP_STAMP();                                                    // [5i+4] MFMAs issued
+        // C[16 mt + l15][16 wave + 4 lg + k] -> staging rows (the storing waves took the previous tile out of it before this unit's first barrier)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int r = mt * 16 + l15;
+            *(uint2*)(smem + GP_STG + r * GK_CPITCH + (16 * wave + 4 * lg) * 2) =
+                make_uint2(fh_pack2(acc[mt][0] + bq.x, acc[mt][1] + bq.y), fh_pack2(acc[mt][2] + bq.z, acc[mt][3] + bq.w));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GP_STAMP();                                                    // [5i+5] staged
+        __builtin_amdgcn_s_barrier();                                  // staging complete; every wave is done with image i
+        GP_STAMP();                                                    // [5i+6] barrier B passed
+        const GpUnit nn = nxt.p >= 0 ? next_of(nxt) : GpUnit{-1, 0, 0};
+        const bool new_w = nxt.p >= 0 && (nxt.p != cur.p || nxt.tn != cur.tn);
+        if (new_w) load_w(nxt);                                        // (every wave is done with the old fragments; waits for image i+1 as well)
+#ifndef GP_STORES_AFTER_DMA
+        // the tile's stores go into the CU's memory pipeline BEFORE the next image's 64 LDS-DMA instructions: behind them they sat
+        // until the image had landed (the storing waves took 4-5 us per unit, timeline in profiles/r03_k512_persistent.txt)
+        if (loader) { __builtin_amdgcn_s_barrier(); issue_x(nn.p >= 0 ? nn : GpUnit{-1, 0, 0}, smem + (i & 1) * GP_IMG); }
+#else
+        if (nn.p >= 0) issue_x(nn, smem + (i & 1) * GP_IMG);          // two units ahead, into the image just consumed
+#endif
+        if (!loader) {                                                 // whole 256-byte row segments: 16 lanes per row, 16 rows per pass
+            const GkProblem& P = G.p[cur.p];
+            const int row0 = cur.tm * GP_ROWS, col0 = cur.tn * 128;
+            const int R = (P.M - row0) < GP_ROWS ? (P.M - row0) : GP_ROWS;
+            const int t4 = tid - 256;
+            u32x4_t o[4];
+            // (inline asm for the same reason as the fragment reads: a visible LDS read would be given s_waitcnt vmcnt(0) — here that
+            //  is this wave's previous stores, one full store latency per read)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const unsigned addr = (unsigned)(size_t)(smem + GP_STG + (ps * 16 + (t4 >> 4)) * GK_CPITCH + (t4 & 15) * 16);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(o[ps]) : "v"(addr));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is in registers: it has left the staging area before this wave reaches the next barrier
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) MTN_LANDED(o[ps]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int r = ps * 16 + (t4 >> 4), c8 = t4 & 15;
+                const int col = col0 + c8 * 8;
+#ifdef GP_ABLATE_NO_STORE
+                if (r < R && col < P.N && o[ps].x == 0x12345678u)
+#else
+                if (r < R && col < P.N)
+#endif
+                    *(uint4*)(P.out + (size_t)(row0 + r) * P.ldc + col) = as_uint4(o[ps]);
+            }
+#ifndef GP_STORES_AFTER_DMA
+            __builtin_amdgcn_s_barrier();
+#endif
+        }
+        if (nxt.p < 0) break;
+        cur = nxt; nxt = nn;
+    }
+}
+
 // -> 1 when the launch was taken (every problem: bf16, row-major x row-major, K = 512, plain bias epilogue into out_lp), 0 when the
 // caller should use the general kernels, < 0 on a launch error
 int gemm_k512_try(int count, const mtn_gemm_problem* p, int min_tiles, hipStream_t s, int* tiles_out) {
@@ -121,7 +350,20 @@ int gemm_k512_try(int count, const mtn_gemm_problem* p, int min_tiles, hipStream
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)gemm_k512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GK_LDS) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void*)gemm_k512p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS) != hipSuccess) return 0;
         attr = true;
+    }
+    // Persistent form: measured per launch in the step, same box (profiles/r03_u_k512_persistent_ab.txt): 69.4 vs 69.0 us at 14 units
+    // per workgroup (cfg2, batch 32), 104 vs 123 us at 28 (batch 64) — the resident workgroups pay ~5 us of start-up per W tile and
+    // their x images land in 4-5 us however few are in flight, so it wins only when the lists are long.  MTN_K512_PERSIST=1 / 0 forces.
+    long units = 0;
+    for (int i = 0; i < count; ++i) units += (long)((p[i].M + GP_ROWS - 1) / GP_ROWS) * ((p[i].N + 127) / 128);
+    const char* pe = MTN_ENV("MTN_K512_PERSIST");
+    if (pe ? pe[0] != '0' : units >= 20L * GP_GRID) {
+        hipLaunchKernelGGL(gemm_k512p_kernel, dim3(GP_GRID), dim3(GK_THREADS), GP_LDS, s, G);
+        if (hipGetLastError() != hipSuccess) return -1;
+        if (tiles_out) *tiles_out = GP_GRID;
+        return 1;
     }
     hipLaunchKernelGGL(gemm_k512_kernel, dim3(tiles), dim3(GK_THREADS), GK_LDS, s, G);
     if (hipGetLastError() != hipSuccess) return -1;

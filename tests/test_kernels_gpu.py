@@ -529,15 +529,23 @@ def test_topk_rows_matches_sort(dev, rows, V, k, ld_pad):
     assert torch.equal(out[:, 2 * k].double(), ref[:, min(3, V - 1)])
 
 
-def test_gemm_k512_many_large_problems(dev):
+@pytest.mark.parametrize("persistent", [True, False])
+def test_gemm_k512_many_large_problems(dev, persistent):
     """csrc/gemm_k512.hip (taken for launches of >= 512 output tiles of 128 x 128 with K = 512, plain bias epilogue into a bf16
     output — the memories' K|V projections): several problems in one launch, row counts that are not multiples of the tile, a
-    narrow N, row strides larger than the row, against fp32 matmul of the same bf16 operands (one bf16 rounding of the result)."""
+    narrow N, row strides larger than the row, against fp32 matmul of the same bf16 operands (one bf16 rounding of the result).
+    Both forms: the persistent one (256 resident workgroups walking 64-row units, x tiles two units ahead; N = 520 and 264 make a
+    workgroup change its column tile between units, M = 10 leaves most XCDs without a unit of that problem) and the tile-per-
+    workgroup one (MTN_K512_PERSIST=0)."""
     import ctypes as C
+    import os
     from mtn_amd import lib as L
     lib = L.load()
+    os.environ["MTN_K512_PERSIST"] = "1" if persistent else "0"
+    L.reload_env()
     g = torch.Generator(device="cpu").manual_seed(5)
-    shapes = [(4096, 1024, 512, 1024), (1000, 1024, 512, 1024), (640, 520, 640, 528), (4096, 1024, 512, 1024), (4096, 1024, 512, 1024), (1280, 1024, 512, 1024)]
+    shapes = [(4096, 1024, 512, 1024), (1000, 1024, 512, 1024), (640, 520, 640, 528), (4096, 1024, 512, 1024), (4096, 1024, 512, 1024), (1280, 1024, 512, 1024),
+              (10, 1024, 512, 1024), (777, 264, 520, 272), (4090, 512, 512, 512), (65, 8, 512, 16)]
     probs = (L.GemmProblem * len(shapes))()
     keep, refs = [], []
     for i, (M, N, lda, ldc) in enumerate(shapes):
@@ -550,12 +558,17 @@ def test_gemm_k512_many_large_problems(dev):
         p.bias, p.gate_scale, p.out_lp, p.ldc = b.data_ptr(), 1.0, out.data_ptr(), ldc
         keep += [a, w, b]
         refs.append((out, a[:, :512].float() @ w.float().t() + b, N))
-    lib.mtn_census_begin()
-    L.check(lib.mtn_gemm(L.MTN_BF16, len(shapes), probs, L.stream_ptr()))
-    torch.cuda.synchronize()
-    assert lib.mtn_census_end() == 1
+    try:
+        lib.mtn_census_begin()
+        L.check(lib.mtn_gemm(L.MTN_BF16, len(shapes), probs, L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert lib.mtn_census_end() == 1
+    finally:
+        os.environ.pop("MTN_K512_PERSIST", None)
+        L.reload_env()
     info = L.CensusLaunch(); lib.mtn_census_info(0, C.byref(info))
     assert lib.mtn_census_variant_name(info.variant).decode() == "gemm_k512_kernel"
+    assert info.workgroups == (256 if persistent else sum(((M + 127) // 128) * ((N + 127) // 128) for M, N, _, _ in shapes))
     for out, ref, N in refs:
         assert relmax(out[:, :N].float(), ref) < 1e-2
         assert bool((out[:, N:].float() == 7.0).all())             # nothing written past the problem's columns

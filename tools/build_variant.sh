@@ -1,11 +1,13 @@
-# Builds tools/libmtn_hip_<name>.so = the library with extra compile flags on csrc/gemm.hip (the other objects are taken from
-# mtn_amd/build): same-box A/B of a compile-time choice through MTN_HIP_LIB.
+# Builds tools/libmtn_hip_<name>.so = the library with extra compile flags on ONE source (SRC=gemm by default; the other objects
+# are taken from mtn_amd/build): same-box A/B of a compile-time choice through MTN_HIP_LIB.
 #   bash tools/build_variant.sh nopipe -DMTN_TTB_NOPIPE && MTN_HIP_LIB=tools/libmtn_hip_nopipe.so python bench.py ...
+#   SRC=gemm_k512 bash tools/build_variant.sh k_nomfma -DGP_ABLATE_NO_MFMA
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 python -m mtn_amd.build > /dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c mtn_amd/csrc/gemm.hip -o /tmp/gemm_$name.o 2>/dev/null
-objs=$(ls mtn_amd/build/*.o | grep -v "/gemm.o")
+SRC=${SRC:-gemm}
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c mtn_amd/csrc/$SRC.hip -o /tmp/gemm_$name.o 2>/dev/null
+objs=$(ls mtn_amd/build/*.o | grep -v "/$SRC.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/libmtn_hip_$name.so /tmp/gemm_$name.o $objs
 ls -la tools/libmtn_hip_$name.so
