@@ -1302,6 +1302,151 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(const GemmGroup grp
 
 // ---------------------------------------------------------------- launch census (measurement support, bench.py)
 // While recording, every mtn_gemm call keeps a copy of its problem list; mtn_census_replay re-issues a recorded launch so
+// ====================================================================================================================
+// 128 x 128 output tiles, 512 threads, FOUR stages of 64 contraction elements in LDS (round 3).  For launches of one round of big
+// tiles with a long contraction — the memory-gradient GEMM dmem = dkv Wkv ([8 064 x 512 x 1 024]: 252 tiles) was 1 008 tiles of
+// 64 x 64 on half stages, 31 us: every CU pulled 1 MiB where 512 KiB do.  A row-major [128 rows][64 k]; B either row-major
+// [128 n][64 k] or (BTR) as the weight lies, [64 k][128 n] (256-byte rows, the table kernel's loader and transposing fragment
+// reads).  8 waves = 2 row halves x 4 column quarters, wave tile 64 x 32 (4 x 2 MFMA tiles).  Stage s+3 is issued while stage s
+// is computed: three stages (96 KiB) in flight per workgroup, counted vmcnt, ONE barrier per stage; every fragment read is
+// inline asm (see gemm_dma_kernel: a visible LDS read would drain the stages in flight).
+// ====================================================================================================================
+static constexpr int G8_BK = 64;
+static constexpr int G8_OP_BYTES = 128 * 128;              // one operand's stage: 128 rows x 128 B, or 64 k-rows x 256 B
+static constexpr int G8_STAGE = 2 * G8_OP_BYTES;           // 32 KiB
+static constexpr int G8_NST = 4;
+static constexpr int G8_LDS = G8_NST * G8_STAGE;           // 128 KiB
+
+template <bool BTR>
+__global__ __launch_bounds__(512, 2) void gemm_dma128x_kernel(const GemmGroup grp) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    int g = 0;
+    while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
+    const mtn_gemm_problem& P = grp.p[g];
+    const int M = P.M, N = P.N, K = P.K;
+    const int tiles_n = (N + 127) / 128, tiles_m = (M + 127) / 128;
+    const int t = (int)blockIdx.x - grp.tile_start[g];
+    int tm_, tn_;
+    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
+    const int row0 = tm_ * 128, col0 = tn_ * 128;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3, lg = lane >> 4, l15 = lane & 15;
+    const int lda_b = P.lda * 2, ldb_b = P.ldb * 2;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (M - 1) * lda_b + K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = BTR ? __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (K - 1) * ldb_b + N * 2, 0x00020000)
+                                          : __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (N - 1) * ldb_b + K * 2, 0x00020000);
+    // 4 LDS-DMA instructions per wave per stage, always: 2 for A (8 rows of 128 B each), 2 for B
+    auto issue_rows = [&](__amdgpu_buffer_rsrc_t rs, unsigned char* dst, int ld_bytes, int R, int r0, int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int inst = j * 8 + wave;
+            const int row = inst * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);                    // source chunk that lands in slot (lane & 7)
+            const int gk = k0 + c * 8;
+            int grow = r0 + row;
+            grow = grow < R ? grow : R - 1;                          // rows past the end only feed outputs that are never stored
+            unsigned voff = (gk < K) ? (unsigned)grow * (unsigned)ld_bytes + (unsigned)gk * 2u : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + inst * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+    auto issue_kn = [&](unsigned char* dst, int k0) {               // B as it lies: [64 k][128 n], 4 k-rows of 256 B per instruction
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int inst = j * 8 + wave;
+            const int krow = inst * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ ttb_swz(krow);
+            const int gk = k0 + krow, gn = col0 + c * 8;
+            unsigned voff = (gk < K && gn < N) ? (unsigned)gk * (unsigned)ldb_b + (unsigned)gn * 2u : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(dst + inst * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+    auto issue = [&](int st) {
+        unsigned char* dst = smem + (st & (G8_NST - 1)) * G8_STAGE;
+        issue_rows(rA, dst, lda_b, M, row0, st * G8_BK);
+        if constexpr (BTR) issue_kn(dst + G8_OP_BYTES, st * G8_BK);
+        else issue_rows(rB, dst + G8_OP_BYTES, ldb_b, N, col0, st * G8_BK);
+    };
+
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nstages = (K + G8_BK - 1) / G8_BK;
+    for (int st = 0; st < 3 && st < nstages; ++st) issue(st);
+    const DropState ds = drop_init(P.drop);
+    for (int s = 0; s < nstages; ++s) {
+        const int ahead = nstages - 1 - s;                           // stages issued behind this one: min(ahead, 2) may still fly
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // stage s is in LDS for every wave; every wave is done with stage s-1
+        if (s + 3 < nstages) issue(s + 3);                           // ... whose buffer takes stage s+3
+        const unsigned char* sA = smem + (s & (G8_NST - 1)) * G8_STAGE;
+        const unsigned char* sB = sA + G8_OP_BYTES;
+        u32x4_t a0[4], b0[2], a1[4], b1[2];
+        auto load = [&](int ks, u32x4_t* a, u32x4_t* b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wr * 64 + i * 16 + l15;
+                const unsigned addr = (unsigned)(size_t)(sA + ra * 128 + (((ks * 4 + lg) ^ (ra & 7)) << 4));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(addr));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (BTR) {
+                    const uint4 f = ttb_frag(sB, wc * 32 + j * 16, ks, l15, lg);
+                    b[j] = u32x4_t{f.x, f.y, f.z, f.w};
+                } else {
+                    const int rb = wc * 32 + j * 16 + l15;
+                    const unsigned addr = (unsigned)(size_t)(sB + rb * 128 + (((ks * 4 + lg) ^ (rb & 7)) << 4));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(addr));
+                }
+            }
+        };
+        auto landed = [&](u32x4_t* a, u32x4_t* b) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) MTN_LANDED(a[i]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) MTN_LANDED(b[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mfmas = [&](const u32x4_t* a, const u32x4_t* b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma16<T>(acc[i][j], as_uint4(b[j]), as_uint4(a[i]));     // transposed accumulator (vector epilogue)
+        };
+        load(0, a0, b0);
+        landed(a0, b0);
+        load(1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        landed(a1, b1);
+        mfmas(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + wr * 64 + i * 16 + l15;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wc * 32 + j * 16 + lg * 4;
+            if (col >= N) continue;
+            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+        }
+    }
+}
+
+
 // that the caller can time each of the step's GEMM launches with HIP events on the launch stream.
 #include <algorithm>
 #include <vector>
@@ -1311,11 +1456,11 @@ static std::vector<CensusEntry> g_census;
 static std::vector<CensusTable> g_census_tables;
 static bool g_census_on = false;
 static int g_variant = 0, g_variant_tiles = 0;     // set by launch_gemm: which kernel the dispatch picked
-enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_DMA128, V_DMA64H, V_DMA32H, V_TT_TABLE, V_K512, V_COUNT };
+enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_DMA128, V_DMA64H, V_DMA32H, V_TT_TABLE, V_K512, V_DMA128X, V_COUNT };
 static const char* const g_variant_name[V_COUNT] = {
     "gemm_kernel<N,N> 64x64 reg-staged", "gemm_kernel<N,T>", "gemm_kernel<T,N>", "gemm_kernel<T,T> 64x64 reg-staged",
     "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
-    "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages", "gemm_tt_dma128_table_kernel", "gemm_k512_kernel"};
+    "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages", "gemm_tt_dma128_table_kernel", "gemm_k512_kernel", "gemm_dma128x_kernel (128x128, four stages)"};
 
 template <typename T, int BM, int BN, int ROWB, bool BTR = false>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
@@ -1384,6 +1529,38 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
                 const int tiles = retile(g2, 128, 128);
                 g_variant = V_DMA128; g_variant_tiles = tiles;
                 hipLaunchKernelGGL(gemm_dma128_kernel, dim3(tiles), block, NTB_LDS, s, g2);
+                MTN_CHECK_LAUNCH();
+                return MTN_OK;
+            }
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        // one round (or a few) of 128 x 128 tiles with four stages in flight: launches with >= 192 such tiles and a contraction of
+        // >= 768 (at K = 512 the register-staged 64 x 64 kernel is as fast: 18.4 vs 19.0 us on the generator logits), either B layout:
+        // the memory-gradient GEMM 23.6 -> 17.3 us per launch, step +0.9 % (profiles/r03_w_gemm128x_ab.txt)
+        const char* xmin = MTN_ENV("MTN_GEMM_128X_MIN_TILES");
+        const int x_min = xmin ? atoi(xmin) : 192;
+        if (!at && x_min > 0) {
+            bool ok = true;
+            int t128 = 0;
+            for (int i = 0; i < grp.count; ++i) {
+                const mtn_gemm_problem& q = grp.p[i];
+                ok = ok && !q.rowsum_out && q.K % 8 == 0 && q.K >= (xmin ? 256 : 768) && q.N % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 &&
+                     (long)q.M * q.lda * 2 < (1L << 31) && (long)(bt ? q.K : q.N) * q.ldb * 2 < (1L << 31);
+                t128 += ((q.M + 127) / 128) * ((q.N + 127) / 128);
+            }
+            if (ok && t128 >= x_min) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+                    attr_set = true;
+                }
+                GemmGroup g2 = grp;
+                const int tiles = retile(g2, 128, 128);
+                g_variant = V_DMA128X; g_variant_tiles = tiles;
+                if (bt) hipLaunchKernelGGL(gemm_dma128x_kernel<true>, dim3(tiles), dim3(512), G8_LDS, s, g2);
+                else hipLaunchKernelGGL(gemm_dma128x_kernel<false>, dim3(tiles), dim3(512), G8_LDS, s, g2);
                 MTN_CHECK_LAUNCH();
                 return MTN_OK;
             }

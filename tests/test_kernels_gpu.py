@@ -623,3 +623,47 @@ def test_gemm_contraction_major_b_on_lds_dma(dev, force):
     for of, ol, v, K, _keep in checks:
         assert relmax(of, v) < 1e-5 * math.sqrt(K)
         assert relmax(ol.float(), v) < 1e-2
+
+
+@pytest.mark.parametrize("bt", [0, 1])
+def test_gemm_128x128_four_stage_kernel(dev, bt):
+    """gemm_dma128x_kernel (launches of >= 192 tiles of 128 x 128: the memory-gradient GEMM of the step): both B layouts (row-major,
+    and the weight as it lies = b_trans 1), ragged M / N / K (K tails inside a stage, fewer stages than the pipeline is deep),
+    grouped, with the residual-accumulate + both-outputs epilogue of the memory gradient."""
+    import ctypes as C
+    import os
+    from mtn_amd import lib as L, ops
+    dtype = torch.bfloat16
+    os.environ["MTN_GEMM_128X_MIN_TILES"] = "1"
+    L.reload_env()
+    lib = L.load()
+    g = torch.Generator().manual_seed(31 + bt)
+    probs, checks = [], []
+    for (M, N, K) in [(8064, 512, 1024), (1000, 1536, 520), (200, 136, 264), (130, 8, 256), (257, 384, 3000)]:
+        a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * torch.linspace(0.5, 1.5, N).unsqueeze(1)
+        res = torch.randn(M, N, generator=g)
+        A = a.to(dev, dtype)
+        B = (b.t().contiguous() if bt else b).to(dev, dtype)
+        Res = res.to(dev)
+        of = torch.full((M, N), float("nan"), device=dev)
+        ol = torch.empty(M, N, device=dev, dtype=dtype)
+        p = _gemm_problem(L, A, B, M, N, K, 0, bt, K, N if bt else K)
+        p.residual, p.ldr, p.out_f32, p.out_lp, p.ldc = Res.data_ptr(), N, of.data_ptr(), ol.data_ptr(), N
+        probs.append(p)
+        v = lp_round(a, dtype).double() @ lp_round(b, dtype).double().t() + res.double()
+        checks.append((of, ol, v, K, (A, B, Res)))
+    try:
+        lib.mtn_census_begin()
+        ops.gemm(L.MTN_BF16, probs)
+        torch.cuda.synchronize()
+        n = lib.mtn_census_end()
+        info = L.CensusLaunch()
+        L.check(lib.mtn_census_info(0, C.byref(info)))
+        name = lib.mtn_census_variant_name(info.variant).decode()
+    finally:
+        del os.environ["MTN_GEMM_128X_MIN_TILES"]
+        L.reload_env()
+    assert n == 1 and name.startswith("gemm_dma128x_kernel"), name
+    for of, ol, v, K, _keep in checks:
+        assert relmax(of, v) < 1e-5 * math.sqrt(K)
+        assert relmax(ol.float(), v) < 1e-2

@@ -20,6 +20,8 @@ CASES = [
     ("dxn = dh W1                 [640 x 512 x 2048]", [(640, 512, 2048)]),
     ("dmem = dkv Wkv              [8064 x 512 x 1024]", [(8064, 512, 1024)]),
     ("dmem, 3 members             [2688 x 512 x 1024] x3", [(2688, 512, 1024)] * 3),
+    ("dmem at 64 samples          [16128 x 512 x 1024]", [(16128, 512, 1024)]),
+    ("generator logits            [1920 x 3000 x 512]", [(1920, 3000, 512)]),
 ]
 
 
@@ -63,7 +65,7 @@ def main():
 
     for label, shapes in CASES:
         print(label)
-        for env in ({}, {"MTN_GEMM_TILE": "64"}, {"MTN_GEMM_TILE": "32"}, {"MTN_GEMM_TILE": "3264"}, {"MTN_GEMM_DMA_MAX_TILES": "4096"}, {"MTN_GEMM_NTB_MIN_TILES": "1"}):
+        for env in ({}, {"MTN_GEMM_TILE": "64"}, {"MTN_GEMM_TILE": "32"}, {"MTN_GEMM_TILE": "3264"}, {"MTN_GEMM_128X_MIN_TILES": "0"}, {"MTN_GEMM_128X_MIN_TILES": "1"}):
             os.environ.update(env)
             L.reload_env()
             row = []
