@@ -607,7 +607,9 @@ __device__ __forceinline__ uint4 kn_frag(const unsigned char* img, int n_off, in
 // ROWB = bytes of contraction per row per stage: 512 (whole K <= 512-byte contractions in flight at once: best latency for
 // launches of one round) or 256 (half the LDS: twice the resident workgroups, for launches that would otherwise need a
 // second round).
-template <typename T, int BM, int BN, int DMA_ROWB, bool BTR = false>
+// NBUF = 4 (round 3, long contractions in one round of workgroups): a ring of four half-size stages, stage s+3 issued while stage s
+// is computed — three stages in flight instead of "refill after compute", one barrier per stage instead of two.
+template <typename T, int BM, int BN, int DMA_ROWB, bool BTR = false, int NBUF = 2>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     constexpr int BK = DMA_ROWB / (int)sizeof(T);            // 256 / 128 bf16, 128 / 64 fp32
     constexpr int TM = BM / 32, TN = BN / 32;                // MFMA tiles per wave
@@ -650,28 +652,40 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     if (P.out_lp) { ((T*)P.out_lp)[(size_t)(row0 + (tid >> 2)) * P.ldc + col0 + (tid & 3)] = 0; }
     return;
 #endif
+    auto issue_stage = [&](int st) {
+        unsigned char* dst = smem + (st & (NBUF - 1)) * STAGE_BYTES;
+        dma_issue_tile<T, BM, DMA_ROWB>(rA, dst, lda_b, M, K, row0, st * BK, wave, lane);
+        issue_b(dst + A_BYTES, st * BK);
+    };
 #ifndef MTN_DBG_NO_LOAD
-    // prologue: up to two stages in flight (NDMA LDS-DMA instructions per wave per stage, always)
-    dma_issue_tile<T, BM, DMA_ROWB>(rA, smem, lda_b, M, K, row0, 0, wave, lane);
-    issue_b(smem + A_BYTES, 0);
-    if (nstages > 1) {
-        dma_issue_tile<T, BM, DMA_ROWB>(rA, smem + STAGE_BYTES, lda_b, M, K, row0, BK, wave, lane);
-        issue_b(smem + STAGE_BYTES + A_BYTES, BK);
-    }
+    // prologue: NBUF = 2: up to two stages in flight; NBUF = 4: up to three (NDMA LDS-DMA instructions per wave per stage, always)
+    for (int st = 0; st < (NBUF == 2 ? 2 : NBUF - 1) && st < nstages; ++st) issue_stage(st);
 #endif
     const DropState ds = drop_init(P.drop);        // scalar seed load + key hashing ride under the operand DMA
     for (int s = 0; s < nstages; ++s) {
-        // stage s landed, stage s+1 (if any) still flying: vmcnt(NDMA) / vmcnt(0)
-        if (s + 1 < nstages) {
+        // stage s landed; the stages behind it may still fly (NBUF = 2: one, NBUF = 4: two): counted vmcnt
+        const int ahead = nstages - 1 - s;
+        static_assert(NDMA == 16 || NDMA == 12 || NDMA == 8 || NDMA == 6 || NDMA == 4 || NDMA == 2, "unexpected stage size");
+        if (NBUF > 2 && ahead >= 2) {
+            static_assert(NBUF == 2 || 2 * NDMA <= 16, "vmcnt immediates end at 63, keep the pipeline's count small");
+            if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if (ahead >= 1) {
             if constexpr (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if constexpr (NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            static_assert(NDMA == 16 || NDMA == 12 || NDMA == 8 || NDMA == 6 || NDMA == 4, "unexpected stage size");
+            else if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const unsigned char* sA = smem + (s & 1) * STAGE_BYTES;
+#ifndef MTN_DBG_NO_LOAD
+        if constexpr (NBUF > 2) {                  // every wave is done with stage s-1: its buffer takes stage s + NBUF - 1
+            if (s + NBUF - 1 < nstages) issue_stage(s + NBUF - 1);
+        }
+#endif
+        const unsigned char* sA = smem + (s & (NBUF - 1)) * STAGE_BYTES;
         const unsigned char* sB = sA + A_BYTES;
         const int kleft = K - s * BK;
         int ksteps = kleft >= BK ? DMA_ROWB / 64 : (kleft * (int)sizeof(T) + 63) / 64;   // 64-byte contraction steps holding data
@@ -737,12 +751,12 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
             }
         }
 #ifndef MTN_DBG_NO_LOAD
-        if (s + 2 < nstages) {           // refill this buffer with stage s+2 once every wave is done reading it
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            unsigned char* dst = smem + (s & 1) * STAGE_BYTES;
-            dma_issue_tile<T, BM, DMA_ROWB>(rA, dst, lda_b, M, K, row0, (s + 2) * BK, wave, lane);
-            issue_b(dst + A_BYTES, (s + 2) * BK);
+        if constexpr (NBUF == 2) {
+            if (s + 2 < nstages) {       // refill this buffer with stage s+2 once every wave is done reading it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue_stage(s + 2);
+            }
         }
 #endif
     }
@@ -1462,29 +1476,29 @@ static const char* const g_variant_name[V_COUNT] = {
     "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
     "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages", "gemm_tt_dma128_table_kernel", "gemm_k512_kernel", "gemm_dma128x_kernel (128x128, four stages)"};
 
-template <typename T, int BM, int BN, int ROWB, bool BTR = false>
+template <typename T, int BM, int BN, int ROWB, bool BTR = false, int NBUF = 2>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
     g_variant = (BM == 64) ? (ROWB == 512 ? V_DMA64 : V_DMA64H) : (BN == 64 ? V_DMA3264 : (ROWB == 512 ? V_DMA32 : V_DMA32H));
     g_variant_tiles = tiles;
-    constexpr int LDS = 2 * (BM + BN) * ROWB;
+    constexpr int LDS = NBUF * (BM + BN) * ROWB;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set && LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN, ROWB, BTR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { mtn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR>), dim3(tiles), dim3(256), LDS, s, grp);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF>), dim3(tiles), dim3(256), LDS, s, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
 
 // row-major B, or (btr: bf16 only) B stored [K][N]
-template <typename T, int BM, int BN, int ROWB>
+template <typename T, int BM, int BN, int ROWB, int NBUF = 2>
 static int launch_dma_any(const GemmGroup& grp, int tiles, bool btr, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        if (btr) return launch_dma<T, BM, BN, ROWB, true>(grp, tiles, s);
+        if (btr) return launch_dma<T, BM, BN, ROWB, true, NBUF>(grp, tiles, s);
     }
-    return launch_dma<T, BM, BN, ROWB, false>(grp, tiles, s);
+    return launch_dma<T, BM, BN, ROWB, false, NBUF>(grp, tiles, s);
 }
 
 // tile_start[] for a given tile shape; returns the total
@@ -1598,13 +1612,21 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         // otherwise need a second round (64x64: one workgroup per CU at 128 KiB; 32x32: two at 64 KiB)
         const bool half_ok = MTN_ENV("MTN_GEMM_NO_HALF") == nullptr;
         const bool half_force = MTN_ENV("MTN_GEMM_FORCE_HALF") != nullptr;      // tests
+        // long contractions in ONE round of workgroups on the ring of four half-size stages: opt-in (MTN_GEMM_DEEP=1) — measured
+        // -0.8 % on the cfg2 step, +-0 at batch 64 (profiles/r03_x_deep_ring_ab.txt): twice the barriers for stages half the size
+        // cost more than the third stage in flight brings at these sizes
+        int kmax = 0;
+        for (int i = 0; i < grp.count; ++i) kmax = grp.p[i].K > kmax ? grp.p[i].K : kmax;
+        const bool deep = sizeof(T) == 2 && kmax * (int)sizeof(T) > 1024 && MTN_ENV("MTN_GEMM_DEEP") && MTN_ENV("MTN_GEMM_DEEP")[0] == '1';
         if (f == 64 || (!f && c64 <= c32)) {
             const int t = retile(g2, 64, 64, true);
+            if (deep && t <= 256 && !half_force) return launch_dma_any<T, 64, 64, 256, 4>(g2, t, bt, s);
             if (half_force || (half_ok && t > 256)) return launch_dma_any<T, 64, 64, 256>(g2, t, bt, s);
             return launch_dma_any<T, 64, 64, 512>(g2, t, bt, s);
         }
         if (f == 3264) return launch_dma_any<T, 32, 64, 512>(g2, retile(g2, 32, 64, true), bt, s);
         const int t = retile(g2, 32, 32, true);
+        if (deep && t <= 512 && !half_force) return launch_dma_any<T, 32, 32, 256, 4>(g2, t, bt, s);
         if (half_force || (half_ok && t > 1024)) return launch_dma_any<T, 32, 32, 256>(g2, t, bt, s);   // (measured in the step: 640 tiles 10.7 vs 10.1 us, 1280 tiles 12.7 vs 13.8 us)
         return launch_dma_any<T, 32, 32, 512>(g2, t, bt, s);
     } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp, NoAdam{});

@@ -574,7 +574,8 @@ def test_gemm_k512_many_large_problems(dev, persistent):
         assert bool((out[:, N:].float() == 7.0).all())             # nothing written past the problem's columns
 
 
-@pytest.mark.parametrize("force", ["", "MTN_GEMM_TILE=64", "MTN_GEMM_TILE=32", "MTN_GEMM_TILE=64,MTN_GEMM_FORCE_HALF=1", "MTN_GEMM_TILE=32,MTN_GEMM_FORCE_HALF=1"])
+@pytest.mark.parametrize("force", ["", "MTN_GEMM_TILE=64", "MTN_GEMM_TILE=32", "MTN_GEMM_TILE=64,MTN_GEMM_FORCE_HALF=1", "MTN_GEMM_TILE=32,MTN_GEMM_FORCE_HALF=1",
+                                   "MTN_GEMM_TILE=64,MTN_GEMM_DEEP=1", "MTN_GEMM_TILE=32,MTN_GEMM_DEEP=1"])
 def test_gemm_contraction_major_b_on_lds_dma(dev, force):
     """dX = dY W with W as the forward pass keeps it (b_trans = 1: B stored [K][N]) on gemm_dma_kernel's [k][n]-tile variant
     (transposing LDS reads): every tile / stage size, ragged M, N (multiples of 8) and K (tails inside a stage and across
