@@ -176,6 +176,11 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         for (int j = 0; j < 8; ++j)
             xv[i][j] = ok ? *(const float4*)(xg + (size_t)r * FH_D + 64 * j + 4 * l15) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    FH_STAMP(14);                                  // x rows issued (masks and the LDS-DMA images before them)
+#ifdef FH_PROBE_X_LANDED
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FH_STAMP(15);                                  // timing experiment only: x rows (and everything before them) landed, nothing else asked for yet
+#endif
     // (4) LayerNorm gains: threads 0..127 a_2, 128..255 b_2 (one float4 each) -> LDS
     float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 256) gv = *(const float4*)((tid < 128 ? M.ln_a : M.ln_b - FH_D) + tid * 4);

@@ -114,6 +114,14 @@ int main(int argc, char** argv) {
                 if (q[12] >= q[0] && q[13] >= q[12]) { v12 += (q[12] - q[0]) * 0.01; v13 += (q[13] - q[0]) * 0.01; v1 += (q[1] - q[0]) * 0.01; ++nn; }
             }
             if (nn) printf("    mean since workgroup entry: member found %.2f us, loads issued %.2f us, dropout key %.2f us\n", v12 / nn, v13 / nn, v1 / nn);
+            double v14 = 0, v15 = 0; int n14 = 0, n15 = 0;
+            for (int w = 0; w < P.wgs; ++w) {
+                const unsigned long long* q = &h[(size_t)w * 16];
+                if (q[14] >= q[0] && q[14] > 0) { v14 += (q[14] - q[0]) * 0.01; ++n14; }
+                if (q[15] >= q[0] && q[15] > 0) { v15 += (q[15] - q[0]) * 0.01; ++n15; }
+            }
+            if (n14) printf("    mean since workgroup entry: x rows issued %.2f us%s\n", v14 / n14, n15 ? "" : "");
+            if (n15) printf("    (experiment: wait for the x rows before asking for anything else) x rows landed %.2f us\n", v15 / n15);
         }
         {   // shader clock: cycles between the first and the last stamp of a workgroup that ran to the end / wall time between them
             double mhz = 0; int nn = 0;
