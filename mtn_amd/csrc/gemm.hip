@@ -1556,14 +1556,15 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         const int x_min = xmin ? atoi(xmin) : 192;
         if (!at && x_min > 0) {
             bool ok = true;
-            int t128 = 0;
+            int t128 = 0, kmax = 0;
             for (int i = 0; i < grp.count; ++i) {
                 const mtn_gemm_problem& q = grp.p[i];
-                ok = ok && !q.rowsum_out && q.K % 8 == 0 && q.K >= (xmin ? 256 : 768) && q.N % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 &&
+                ok = ok && !q.rowsum_out && q.K % 8 == 0 && q.K >= 256 && q.N % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 &&
                      (long)q.M * q.lda * 2 < (1L << 31) && (long)(bt ? q.K : q.N) * q.ldb * 2 < (1L << 31);
                 t128 += ((q.M + 127) / 128) * ((q.N + 127) / 128);
+                kmax = q.K > kmax ? q.K : kmax;
             }
-            if (ok && t128 >= x_min) {
+            if (ok && t128 >= x_min && (xmin || kmax >= 768)) {            // (the memory gradient shares its launch with the K = 512 dX of the same group)
                 static bool attr_set = false;
                 if (!attr_set) {
                     (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
