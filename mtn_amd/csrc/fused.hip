@@ -146,23 +146,23 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     // (2) LDS-DMA: rows of an un-projected memory (x attends an auto-encoder stream, mtn.py:215), or this head's K and V
     //     rows of a memory projected ahead of the layer loop.  Rows past the end arrive as zeros (buffer bound).
     if (raw) {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(M.mem + (size_t)rm0 * FH_D), 0, Rm * FH_ROWB, 0x00020000);
+        const fh_rsrc_t rsrc = fh_make_rsrc(M.mem + (size_t)rm0 * FH_D, (unsigned)(Rm * FH_ROWB));
         for (int r = wave; r < MT * 16; r += 8) {     // one wave-instruction = one 1 KiB row; slot `lane` receives chunk lane ^ (r & 15)
             const unsigned voff = r < Rm ? (unsigned)r * FH_ROWB + (unsigned)((lane ^ (r & 15)) << 4) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (fh_lds_void_t*)(xm_s + r * FH_ROWB), 16, voff, 0, 0, 0);
+            fh_dma16(rsrc, (unsigned)(size_t)(xm_s + r * FH_ROWB), voff);
         }
     } else if (kind == FH_CROSS_READY) {
         const int Kr = nsamp * m;
         const bf16_t* kbase = M.kv + (size_t)rm0 * (2 * FH_D) + slice * FH_DK;
-        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (Kr - 1) * (4 * FH_D) + FH_HROWB, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + FH_D), 0, (Kr - 1) * (4 * FH_D) + FH_HROWB, 0x00020000);
+        const fh_rsrc_t rk = fh_make_rsrc(kbase, (unsigned)((Kr - 1) * (4 * FH_D) + FH_HROWB));
+        const fh_rsrc_t rv = fh_make_rsrc(kbase + FH_D, (unsigned)((Kr - 1) * (4 * FH_D) + FH_HROWB));
         const int ninst = ((Kr + fh_pad_rows(kind, mk) + 7) & ~7) >> 3;        // 8 head rows (128 B each) per wave-instruction
         for (int i = wave; i < ninst; i += 8) {
             const int row = i * 8 + (lane >> 3), slot = lane & 7;
             const unsigned vk = row < Kr ? (unsigned)row * (4 * FH_D) + (unsigned)((slot ^ (row & 7)) << 4) : 0x80000000u;
             const unsigned vv = row < Kr ? (unsigned)row * (4 * FH_D) + (unsigned)((slot ^ ((row >> 1) & 7)) << 4) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (fh_lds_void_t*)(ki_s + i * 1024), 16, vk, 0, 0, 0);
-            if (!late_v) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (fh_lds_void_t*)(vi_s + i * 1024), 16, vv, 0, 0, 0);
+            fh_dma16(rk, (unsigned)(size_t)(ki_s + i * 1024), vk);
+            if (!late_v) fh_dma16(rv, (unsigned)(size_t)(vi_s + i * 1024), vv);
         }
     }
     // (3) x rows: row group rg = wave + 8i holds rows 4rg .. 4rg+3, one per 16-lane row; lane l15 reads columns 64j + 4*l15
@@ -355,12 +355,12 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         __syncthreads();
         const int Kr = nsamp * m;
         const bf16_t* vbase = M.kv + (size_t)rm0 * (2 * FH_D) + slice * FH_DK + FH_D;
-        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (Kr - 1) * (4 * FH_D) + FH_HROWB, 0x00020000);
+        const fh_rsrc_t rv = fh_make_rsrc(vbase, (unsigned)((Kr - 1) * (4 * FH_D) + FH_HROWB));
         const int ninst = ((Kr + fh_pad_rows(kind, mk) + 7) & ~7) >> 3;
         for (int i = wave; i < ninst; i += 8) {
             const int row = i * 8 + (lane >> 3), slot = lane & 7;
             const unsigned vv = row < Kr ? (unsigned)row * (4 * FH_D) + (unsigned)((slot ^ ((row >> 1) & 7)) << 4) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (fh_lds_void_t*)(vi_s + i * 1024), 16, vv, 0, 0, 0);
+            fh_dma16(rv, (unsigned)(size_t)(vi_s + i * 1024), vv);
         }
     }
     if (G.stop == 2) {

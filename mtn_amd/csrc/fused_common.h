@@ -16,6 +16,27 @@ enum { FH_SELF = 0, FH_CROSS_READY = 1, FH_CROSS_RAW = 2, FH_FFN = 3 };
 
 
 typedef __attribute__((address_space(3))) void fh_lds_void_t;
+
+// LDS-DMA issued by INLINE ASM (round 3).  With the builtin the compiler knows that LDS-DMA is outstanding and puts
+// s_waitcnt vmcnt(0) in front of every LDS read it can see afterwards (it cannot tell the image being filled from the bytes being
+// read) — in the fused forward kernel that drained the weight fragments before the LayerNorm could read its gains from LDS.  Issued
+// by asm the compiler does not see it: every reader of a DMA'd image sits behind an explicit s_waitcnt vmcnt + barrier in the
+// source (and the compiler's own counted waits for register loads only get more conservative: loads return in order).
+// Buffer resource words: base[31:0], base[47:32] (stride 0), num_records (bytes), flags 0x00020000 — as make_buffer_rsrc builds them.
+typedef __attribute__((ext_vector_type(4))) int fh_rsrc_t;
+__device__ __forceinline__ fh_rsrc_t fh_make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)(size_t)base;
+    fh_rsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+// 64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024) (lds_addr wave-uniform); voff = byte offset per lane, >= num_records reads zeros
+__device__ __forceinline__ void fh_dma16(fh_rsrc_t rsrc, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
 typedef __attribute__((ext_vector_type(2))) __bf16 fh_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float fh_f32x2;
 
