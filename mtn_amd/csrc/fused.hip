@@ -133,7 +133,35 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     unsigned char* vi_s = smem + L.vi;
     unsigned char* mk_s = smem + L.mask;
 
-    // ================================================================ everything this workgroup reads, issued now
+    // ================================================================ everything this workgroup reads
+    // Order of issue (round 3): the small things the LayerNorm needs from LDS first (gains, biases, masks), then the x rows, then
+    // the LDS-DMA images, then the weight fragments.  The x rows have landed at 3.5 us, but a wave is busy issuing its weight loads
+    // until 7.5 us and only then normalises (3.4 us: profiles/r03_fh_xrows_timeline.txt).  Tried: waves 4-7 normalise first and ask
+    // for their weights afterwards (FH_SPLIT_ORDER) — no gain (profiles/r03_fh_order.txt): a wave gets one 1 KiB load through every
+    // ~180 ns whatever the other waves do (about a dozen loads in flight per wave), so the memory phase is bounded by the EIGHT waves'
+    // memory-level parallelism, not by the CU's pipe, and every wave still does "its loads, then its rows" one after the other.
+    // (4) LayerNorm gains: threads 0..127 a_2, 128..255 b_2 (one float4 each) -> LDS
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 256) gv = *(const float4*)((tid < 128 ? M.ln_a : M.ln_b - FH_D) + tid * 4);
+    // weight blocks: block p covers output columns ncol[p] .. +63 of the Linear; this wave: columns 16*wc .. +15, contraction
+    // steps 8*kh .. +7
+    int ncol[NP];
+    bool act[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (ffn) { ncol[p] = slice * (64 * NP) + p * 64; act[p] = ncol[p] + 16 * wc < M.ncols; }
+        else { ncol[p] = p * FH_D + slice * FH_DK; act[p] = (p == 0) || (p < 3 && kind != FH_CROSS_READY); }
+    }
+    // biases of the workgroup's 64 * NP output columns -> LDS (behind the gains)
+    float bias_v = 0.f;
+    if (tid < 64 * NP) {
+        const int p_ = tid >> 6;
+        bool on = false;
+        int nc = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) if (p == p_) { on = act[p] || (ffn && ncol[p] + (tid & 63) < M.ncols); nc = ncol[p]; }
+        if (on) bias_v = M.bias[nc + (tid & 63)];
+    }
     // (1) mask bytes of the block's samples
     uint8_t mkb[FH_MASKB];
     const uint8_t* mask_g = M.mask ? M.mask + (size_t)b0 * M.mask_sb : nullptr;   // contiguous: mask_sb is 0 or qa * m
@@ -143,8 +171,20 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         mkb[i] = 1;
         if (M.mask && idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * m)];
     }
-    // (2) LDS-DMA: rows of an un-projected memory (x attends an auto-encoder stream, mtn.py:215), or this head's K and V
-    //     rows of a memory projected ahead of the layer loop.  Rows past the end arrive as zeros (buffer bound).
+    // (3) x rows: row group rg = wave + 8i holds rows 4rg .. 4rg+3, one per 16-lane row; lane l15 reads columns 64j + 4*l15
+    const float* __restrict__ xg = M.x + (size_t)row0 * FH_D;
+    float4 xv[NG][8];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int r = 4 * (wave + 8 * i) + lg;
+        const bool ok = r < R;                     // (groups past the tile range have r >= MT*16 >= R)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            xv[i][j] = ok ? *(const float4*)(xg + (size_t)r * FH_D + 64 * j + 4 * l15) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    FH_STAMP(14);                                  // x rows issued
+    // (2) LDS-DMA (inline asm: fused_common.h): rows of an un-projected memory (x attends an auto-encoder stream, mtn.py:215), or
+    //     this head's K and V rows of a memory projected ahead of the layer loop.  Rows past the end arrive as zeros (buffer bound).
     if (raw) {
         const fh_rsrc_t rsrc = fh_make_rsrc(M.mem + (size_t)rm0 * FH_D, (unsigned)(Rm * FH_ROWB));
         for (int r = wave; r < MT * 16; r += 8) {     // one wave-instruction = one 1 KiB row; slot `lane` receives chunk lane ^ (r & 15)
@@ -165,66 +205,30 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             if (!late_v) fh_dma16(rv, (unsigned)(size_t)(vi_s + i * 1024), vv);
         }
     }
-    // (3) x rows: row group rg = wave + 8i holds rows 4rg .. 4rg+3, one per 16-lane row; lane l15 reads columns 64j + 4*l15
-    const float* __restrict__ xg = M.x + (size_t)row0 * FH_D;
-    float4 xv[NG][8];
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-        const int r = 4 * (wave + 8 * i) + lg;
-        const bool ok = r < R;                     // (groups past the tile range have r >= MT*16 >= R)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            xv[i][j] = ok ? *(const float4*)(xg + (size_t)r * FH_D + 64 * j + 4 * l15) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    FH_STAMP(14);                                  // x rows issued (masks and the LDS-DMA images before them)
-#ifdef FH_PROBE_X_LANDED
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FH_STAMP(15);                                  // timing experiment only: x rows (and everything before them) landed, nothing else asked for yet
-#endif
-    // (4) LayerNorm gains: threads 0..127 a_2, 128..255 b_2 (one float4 each) -> LDS
-    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 256) gv = *(const float4*)((tid < 128 ? M.ln_a : M.ln_b - FH_D) + tid * 4);
-    // (5) weight fragments: block p covers output columns ncol[p] .. +63 of the Linear; this wave: columns 16*wc .. +15,
-    //     contraction steps 8*kh .. +7
-    int ncol[NP];
-    bool act[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        if (ffn) { ncol[p] = slice * (64 * NP) + p * 64; act[p] = ncol[p] + 16 * wc < M.ncols; }
-        else { ncol[p] = p * FH_D + slice * FH_DK; act[p] = (p == 0) || (p < 3 && kind != FH_CROSS_READY); }
-    }
-    // The MFMA A-operand layout (lane 16c + r <-> row r, 16-byte chunk c of the 64-byte step) would make every quad of
-    // adjacent lanes touch four different weight rows: the texture addresser then takes 64 cycles per wave-instruction instead
-    // of 16.  So the loads are issued COALESCED — lane 4r + c reads (row r, chunk c): a quad = 64 contiguous bytes — and the
+    // (5) weight fragments.  The MFMA A-operand layout (lane 16c + r <-> row r, 16-byte chunk c of the 64-byte step) would make every
+    // quad of adjacent lanes touch four different weight rows: the texture addresser then takes 64 cycles per wave-instruction
+    // instead of 16.  So the loads are issued COALESCED — lane 4r + c reads (row r, chunk c): a quad = 64 contiguous bytes — and the
     // fragments are put in operand order on chip, once they have landed (4 ds_bpermute per fragment).
     uint4 wf[NP][8];
+    auto issue_weights = [&]() {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        if (act[p]) {
-            const bf16_t* wrow = M.w + (size_t)(ncol[p] + 16 * wc + (lane >> 2)) * FH_D + kh * 256 + (lane & 3) * 8;
+        for (int p = 0; p < NP; ++p) {
+            if (act[p]) {
+                const bf16_t* wrow = M.w + (size_t)(ncol[p] + 16 * wc + (lane >> 2)) * FH_D + kh * 256 + (lane & 3) * 8;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
-        } else {                                    // inactive block (q-only member in a 3-block launch, attention member in a 4-block one)
+                for (int s = 0; s < 8; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
+            } else {                                    // inactive block (q-only member in a 3-block launch, attention member in a 4-block one)
 #pragma unroll
-            for (int s = 0; s < 8; ++s) wf[p][s] = make_uint4(0, 0, 0, 0);
+                for (int s = 0; s < 8; ++s) wf[p][s] = make_uint4(0, 0, 0, 0);
+            }
         }
-    }
-    // biases of the workgroup's 64 * NP output columns -> LDS (behind the gains)
-    float bias_v = 0.f;
-    if (tid < 64 * NP) {
-        const int p_ = tid >> 6;
-        bool on = false;
-        int nc = 0;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) if (p == p_) { on = act[p] || (ffn && ncol[p] + (tid & 63) < M.ncols); nc = ncol[p]; }
-        if (on) bias_v = M.bias[nc + (tid & 63)];
-    }
-    FH_STAMP(13);                                  // all loads issued
-    const DropState ds = drop_init(M.drop);
-    FH_STAMP(1);                                   // ... and the dropout key derived (one more scalar round trip)
-
-    // ================================================================ on chip from here
-    // masks and gains -> LDS
+    };
+#ifdef FH_SPLIT_ORDER
+    const bool w_first = wave < 4;                 // (experiment: waves 4-7 normalise first; wave w and w + 4 share a SIMD)
+#else
+    const bool w_first = true;
+#endif
+    // masks, gains and biases -> LDS (they were asked for first: the x rows, the images and the weights may still fly)
 #pragma unroll
     for (int i = 0; i < FH_MASKB; ++i) {
         const int idx = tid + FH_THREADS * i;
@@ -232,9 +236,15 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     }
     if (tid < 256) *(float4*)(smem + L.gains + tid * 16) = gv;
     if (tid < 64 * NP) *(float*)(smem + L.gains + 4096 + tid * 4) = bias_v;
-    FH_STAMP(2);                                   // masks, x rows (issued before the gains) and gains have landed
-    __syncthreads();
+    FH_STAMP(2);                                   // masks, gains and biases have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // (raw: __syncthreads would wait for every load in flight)
     FH_STAMP(3);
+    if (w_first) issue_weights();
+    __builtin_amdgcn_sched_barrier(0);
+    FH_STAMP(13);                                  // first half of the waves: all loads issued
+    const DropState ds = drop_init(M.drop);
+    FH_STAMP(1);                                   // ... and the dropout key derived (one more scalar round trip)
 
     // ---- LayerNorm (mtn.py:111-114): 16 lanes per row, 32 elements per lane; row -> bf16 -> LDS image
     const bool save = slice == 0;
@@ -268,6 +278,9 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             if (save && r < R) *(uint2*)(M.xn + (size_t)(row0 + r) * FH_D + 64 * j + 4 * l15) = u;
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!w_first) issue_weights();
+    __builtin_amdgcn_sched_barrier(0);
     // zero padding behind the key images (a key chunk may run past the last key: its V rows must be finite)
     if (!ffn && kind != FH_CROSS_READY) {
         for (int i = tid; i < 64 * FH_HROWB / 16; i += FH_THREADS) {

@@ -35,6 +35,7 @@ __device__ __forceinline__ fh_rsrc_t fh_make_rsrc(const void* base, unsigned byt
 }
 // 64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024) (lds_addr wave-uniform); voff = byte offset per lane, >= num_records reads zeros
 __device__ __forceinline__ void fh_dma16(fh_rsrc_t rsrc, unsigned lds_addr, unsigned voff) {
+    lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);        // an "s" operand is not made uniform for us
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
 typedef __attribute__((ext_vector_type(2))) __bf16 fh_bf16x2;
