@@ -539,21 +539,21 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 // one operand tile of ROWS rows x ROWB bytes (512 or 256): ROWS*ROWB/4096 LDS-DMA instructions per wave, each 1 KiB
 // (2 rows of 512 B or 4 rows of 256 B); 16-byte slots XOR-swizzled with (row & 15) inside the row
-template <typename T, int ROWS, int ROWB>
+template <typename T, int ROWS, int ROWB, int NW = 4>
 __device__ __forceinline__ void dma_issue_tile(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_tile, int ld_bytes, int R,
                                                int K, int row0, int k0, int wave, int lane) {
     constexpr int EPV = LP<T>::EPV;
     constexpr int CPR = ROWB / 16;                               // 16-byte chunks per row (32 or 16)
     constexpr int RPI = 1024 / ROWB;                             // rows per wave-instruction (2 or 4)
 #pragma unroll
-    for (int j = 0; j < ROWS * ROWB / 4096; ++j) {
-        const int row = (j * 4 + wave) * RPI + lane / CPR;       // tile row written by this lane
+    for (int j = 0; j < ROWS * ROWB / (1024 * NW); ++j) {
+        const int row = (j * NW + wave) * RPI + lane / CPR;      // tile row written by this lane
         const int c = (lane % CPR) ^ (row & 15);                 // source chunk that lands in slot (lane % CPR)
         const int gk = k0 + c * EPV;
         int grow = row0 + row;
         grow = grow < R ? grow : R - 1;                          // rows past the end only feed outputs that are never stored
         unsigned voff = (gk < K) ? (unsigned)grow * (unsigned)ld_bytes + (unsigned)gk * (unsigned)sizeof(T) : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + j * 4096 + wave * 1024), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + (j * NW + wave) * 1024), 16, voff, 0, 0, 0);
     }
 }
 
@@ -567,19 +567,19 @@ template <int BN> __device__ __forceinline__ int kn_swz(int krow) {
     if constexpr (BN == 64) return ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);
     else return ((krow >> 3) & 1) << 1;
 }
-template <int BN, int ROWB>
+template <int BN, int ROWB, int NW = 4>
 __device__ __forceinline__ void dma_issue_tile_kn(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_tile, int ld_bytes, int N, int K,
                                                   int col0, int k0, int wave, int lane) {
     constexpr int RP = BN * 2;                                   // bytes per tile row
     constexpr int CPR = RP / 16;                                 // 16-byte chunks per row (8 or 4)
     constexpr int RPI = 1024 / RP;                               // k rows per wave-instruction (8 or 16)
 #pragma unroll
-    for (int j = 0; j < BN * ROWB / 4096; ++j) {
-        const int krow = (j * 4 + wave) * RPI + lane / CPR;
+    for (int j = 0; j < BN * ROWB / (1024 * NW); ++j) {
+        const int krow = (j * NW + wave) * RPI + lane / CPR;
         const int c = (lane % CPR) ^ kn_swz<BN>(krow);           // source chunk that lands in slot (lane % CPR)
         const int gk = k0 + krow, gn = col0 + c * 8;
         unsigned voff = (gk < K && gn < N) ? (unsigned)gk * (unsigned)ld_bytes + (unsigned)gn * 2u : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + j * 4096 + wave * 1024), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(lds_tile + (j * NW + wave) * 1024), 16, voff, 0, 0, 0);
     }
 }
 // fragment for column tile n_off (multiple of 16 inside the tile) and contraction step ks (32 rows) of a [k][BN] image
@@ -609,12 +609,17 @@ __device__ __forceinline__ uint4 kn_frag(const unsigned char* img, int n_off, in
 // second round).
 // NBUF = 4 (round 3, long contractions in one round of workgroups): a ring of four half-size stages, stage s+3 issued while stage s
 // is computed — three stages in flight instead of "refill after compute", one barrier per stage instead of two.
-template <typename T, int BM, int BN, int DMA_ROWB, bool BTR = false, int NBUF = 2>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
+// NW = 8 (round 3: the 64 x 64 tile on full stages, ONE workgroup per CU): eight waves instead of four.  A wave gets one 1 KiB
+// load through every ~180 ns however many it has queued (profiles/r03_fh_order.txt), so a CU's fill rate is its resident waves x
+// ~5.6 GB/s: four waves pulled 22-26 GB/s where the two-workgroups-per-CU variants (eight waves) reach twice that.  Waves as 2 row
+// halves x 4 column quarters (wave tile 32 x 16).
+template <typename T, int BM, int BN, int DMA_ROWB, bool BTR = false, int NBUF = 2, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp) {
     constexpr int BK = DMA_ROWB / (int)sizeof(T);            // 256 / 128 bf16, 128 / 64 fp32
-    constexpr int TM = BM / 32, TN = BN / 32;                // MFMA tiles per wave
+    constexpr int WC = NW / 2;                               // waves across the columns (2 or 4); two across the rows
+    constexpr int TM = BM / 32, TN = BN / (16 * WC);         // MFMA tiles per wave
     constexpr int A_BYTES = BM * DMA_ROWB, B_BYTES = BN * DMA_ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int NDMA = (BM + BN) * DMA_ROWB / 4096;        // LDS-DMA instructions per wave per stage
+    constexpr int NDMA = (BM + BN) * DMA_ROWB / (1024 * NW); // LDS-DMA instructions per wave per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     int g = 0;
@@ -630,15 +635,15 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
     const int row0 = tm_ * BM, col0 = tn_ * BN;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1, lg = lane >> 4, l15 = lane & 15;
+    const int wr = wave / WC, wc = wave % WC, lg = lane >> 4, l15 = lane & 15;
     const int lda_b = P.lda * (int)sizeof(T), ldb_b = P.ldb * (int)sizeof(T);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (M - 1) * lda_b + K * (int)sizeof(T), 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = BTR ? __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (K - 1) * ldb_b + N * (int)sizeof(T), 0x00020000)
                                           : __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (N - 1) * ldb_b + K * (int)sizeof(T), 0x00020000);
     // the B tile of a stage: row-major [BN rows][DMA_ROWB bytes of k], or (BTR: B stored [K][N]) [BK k-rows][BN columns]
     auto issue_b = [&](unsigned char* dst, int k0) {
-        if constexpr (BTR) dma_issue_tile_kn<BN, DMA_ROWB>(rB, dst, ldb_b, N, K, col0, k0, wave, lane);
-        else dma_issue_tile<T, BN, DMA_ROWB>(rB, dst, ldb_b, N, K, col0, k0, wave, lane);
+        if constexpr (BTR) dma_issue_tile_kn<BN, DMA_ROWB, NW>(rB, dst, ldb_b, N, K, col0, k0, wave, lane);
+        else dma_issue_tile<T, BN, DMA_ROWB, NW>(rB, dst, ldb_b, N, K, col0, k0, wave, lane);
     };
 
     f32x4_t acc[TM][TN];
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
 #endif
     auto issue_stage = [&](int st) {
         unsigned char* dst = smem + (st & (NBUF - 1)) * STAGE_BYTES;
-        dma_issue_tile<T, BM, DMA_ROWB>(rA, dst, lda_b, M, K, row0, st * BK, wave, lane);
+        dma_issue_tile<T, BM, DMA_ROWB, NW>(rA, dst, lda_b, M, K, row0, st * BK, wave, lane);
         issue_b(dst + A_BYTES, st * BK);
     };
 #ifndef MTN_DBG_NO_LOAD
@@ -711,10 +716,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if constexpr (BTR) {
-                        const uint4 f = kn_frag<BN>(sB, wc * (BN / 2) + j * 16, ks, l15, lg);
+                        const uint4 f = kn_frag<BN>(sB, wc * (BN / WC) + j * 16, ks, l15, lg);
                         b[j] = u32x4_t{f.x, f.y, f.z, f.w};
                     } else {
-                        const int rb = wc * (BN / 2) + j * 16 + l15;
+                        const int rb = wc * (BN / WC) + j * 16 + l15;
                         const unsigned addr = (unsigned)(size_t)(sB + rb * DMA_ROWB + (((ks * 4 + lg) ^ (rb & 15)) << 4));
                         asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(addr));
                     }
@@ -771,7 +776,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmGroup grp) {
         if (row >= M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = col0 + wc * (BN / 2) + j * 16 + lg * 4;
+            const int col = col0 + wc * (BN / WC) + j * 16 + lg * 4;
             if (col >= N) continue;
             epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
         }
@@ -1476,29 +1481,29 @@ static const char* const g_variant_name[V_COUNT] = {
     "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
     "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages", "gemm_tt_dma128_table_kernel", "gemm_k512_kernel", "gemm_dma128x_kernel (128x128, four stages)"};
 
-template <typename T, int BM, int BN, int ROWB, bool BTR = false, int NBUF = 2>
+template <typename T, int BM, int BN, int ROWB, bool BTR = false, int NBUF = 2, int NW = 4>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
     g_variant = (BM == 64) ? (ROWB == 512 ? V_DMA64 : V_DMA64H) : (BN == 64 ? V_DMA3264 : (ROWB == 512 ? V_DMA32 : V_DMA32H));
     g_variant_tiles = tiles;
     constexpr int LDS = NBUF * (BM + BN) * ROWB;
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set && LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { mtn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF>), dim3(tiles), dim3(256), LDS, s, grp);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF, NW>), dim3(tiles), dim3(64 * NW), LDS, s, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
 
 // row-major B, or (btr: bf16 only) B stored [K][N]
-template <typename T, int BM, int BN, int ROWB, int NBUF = 2>
+template <typename T, int BM, int BN, int ROWB, int NBUF = 2, int NW = 4>
 static int launch_dma_any(const GemmGroup& grp, int tiles, bool btr, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        if (btr) return launch_dma<T, BM, BN, ROWB, true, NBUF>(grp, tiles, s);
+        if (btr) return launch_dma<T, BM, BN, ROWB, true, NBUF, NW>(grp, tiles, s);
     }
-    return launch_dma<T, BM, BN, ROWB, false, NBUF>(grp, tiles, s);
+    return launch_dma<T, BM, BN, ROWB, false, NBUF, NW>(grp, tiles, s);
 }
 
 // tile_start[] for a given tile shape; returns the total
@@ -1622,7 +1627,11 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         if (f == 64 || (!f && c64 <= c32)) {
             const int t = retile(g2, 64, 64, true);
             if (deep && t <= 256 && !half_force) return launch_dma_any<T, 64, 64, 256, 4>(g2, t, bt, s);
-            if (half_force || (half_ok && t > 256)) return launch_dma_any<T, 64, 64, 256>(g2, t, bt, s);
+            if (half_force || (half_ok && t > 256)) {
+                if (MTN_ENV("MTN_GEMM_NW4") == nullptr && MTN_ENV("MTN_GEMM_NW4H") == nullptr) return launch_dma_any<T, 64, 64, 256, 2, 8>(g2, t, bt, s);
+                return launch_dma_any<T, 64, 64, 256>(g2, t, bt, s);
+            }
+            if (MTN_ENV("MTN_GEMM_NW4") == nullptr) return launch_dma_any<T, 64, 64, 512, 2, 8>(g2, t, bt, s);     // eight waves: see the kernel
             return launch_dma_any<T, 64, 64, 512>(g2, t, bt, s);
         }
         if (f == 3264) return launch_dma_any<T, 32, 64, 512>(g2, retile(g2, 32, 64, true), bt, s);
