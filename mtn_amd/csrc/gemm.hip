@@ -1618,6 +1618,11 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         // otherwise need a second round (64x64: one workgroup per CU at 128 KiB; 32x32: two at 64 KiB)
         const bool half_ok = MTN_ENV("MTN_GEMM_NO_HALF") == nullptr;
         const bool half_force = MTN_ENV("MTN_GEMM_FORCE_HALF") != nullptr;      // tests
+        {   // eight waves pull a 64 x 64 workgroup's bytes faster than four did when the 0.75 above was fitted: the 64 x 64 cost is
+            // weighted 0.8 (sweep in profiles/r03_ac_c64_scale_sweep.txt: cfg2 +0.3 %, batch 64 +2.1 % against 1.0; 0.5 loses)
+            const char* sc = MTN_ENV("MTN_GEMM_C64_SCALE");
+            c64 *= sc ? atof(sc) : 0.8;
+        }
         // long contractions in ONE round of workgroups on the ring of four half-size stages: opt-in (MTN_GEMM_DEEP=1) — measured
         // -0.8 % on the cfg2 step, +-0 at batch 64 (profiles/r03_x_deep_ring_ab.txt): twice the barriers for stages half the size
         // cost more than the third stage in flight brings at these sizes
