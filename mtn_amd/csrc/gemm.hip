@@ -1336,8 +1336,12 @@ static constexpr int G8_STAGE = 2 * G8_OP_BYTES;           // 32 KiB
 static constexpr int G8_NST = 4;
 static constexpr int G8_LDS = G8_NST * G8_STAGE;           // 128 KiB
 
-template <bool BTR>
-__global__ __launch_bounds__(512, 2) void gemm_dma128x_kernel(const GemmGroup grp) {
+// NW = 16 waves (1 024 threads, wave tile 32 x 32) pull the stages faster than 8 (a CU's fill rate grows with its resident waves).
+template <bool BTR, int NW = 16>
+__global__ __launch_bounds__(64 * NW) void gemm_dma128x_kernel(const GemmGroup grp) {
+    constexpr int WR = NW / 4;                                     // waves down the rows (2 or 4); four across the columns
+    constexpr int TM = 128 / (16 * WR);                            // MFMA tiles per wave down the rows (4 or 2)
+    constexpr int IPW = 16 / NW;                                   // LDS-DMA instructions per wave per operand per stage (2 or 1)
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -1357,11 +1361,11 @@ __global__ __launch_bounds__(512, 2) void gemm_dma128x_kernel(const GemmGroup gr
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (M - 1) * lda_b + K * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = BTR ? __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (K - 1) * ldb_b + N * 2, 0x00020000)
                                           : __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (N - 1) * ldb_b + K * 2, 0x00020000);
-    // 4 LDS-DMA instructions per wave per stage, always: 2 for A (8 rows of 128 B each), 2 for B
+    // 2 * IPW LDS-DMA instructions per wave per stage, always: IPW for A (8 rows of 128 B each), IPW for B
     auto issue_rows = [&](__amdgpu_buffer_rsrc_t rs, unsigned char* dst, int ld_bytes, int R, int r0, int k0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int inst = j * 8 + wave;
+        for (int j = 0; j < IPW; ++j) {
+            const int inst = j * NW + wave;
             const int row = inst * 8 + (lane >> 3);
             const int c = (lane & 7) ^ (row & 7);                    // source chunk that lands in slot (lane & 7)
             const int gk = k0 + c * 8;
@@ -1373,8 +1377,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dma128x_kernel(const GemmGroup gr
     };
     auto issue_kn = [&](unsigned char* dst, int k0) {               // B as it lies: [64 k][128 n], 4 k-rows of 256 B per instruction
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int inst = j * 8 + wave;
+        for (int j = 0; j < IPW; ++j) {
+            const int inst = j * NW + wave;
             const int krow = inst * 4 + (lane >> 4);
             const int c = (lane & 15) ^ ttb_swz(krow);
             const int gk = k0 + krow, gn = col0 + c * 8;
@@ -1389,9 +1393,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dma128x_kernel(const GemmGroup gr
         else issue_rows(rB, dst + G8_OP_BYTES, ldb_b, N, col0, st * G8_BK);
     };
 
-    f32x4_t acc[4][2];
+    f32x4_t acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -1400,18 +1404,18 @@ __global__ __launch_bounds__(512, 2) void gemm_dma128x_kernel(const GemmGroup gr
     const DropState ds = drop_init(P.drop);
     for (int s = 0; s < nstages; ++s) {
         const int ahead = nstages - 1 - s;                           // stages issued behind this one: min(ahead, 2) may still fly
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (ahead >= 2) { if constexpr (IPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else if (ahead == 1) { if constexpr (IPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                // stage s is in LDS for every wave; every wave is done with stage s-1
         if (s + 3 < nstages) issue(s + 3);                           // ... whose buffer takes stage s+3
         const unsigned char* sA = smem + (s & (G8_NST - 1)) * G8_STAGE;
         const unsigned char* sB = sA + G8_OP_BYTES;
-        u32x4_t a0[4], b0[2], a1[4], b1[2];
+        u32x4_t a0[TM], b0[2], a1[TM], b1[2];
         auto load = [&](int ks, u32x4_t* a, u32x4_t* b) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ra = wr * 64 + i * 16 + l15;
+            for (int i = 0; i < TM; ++i) {
+                const int ra = wr * (16 * TM) + i * 16 + l15;
                 const unsigned addr = (unsigned)(size_t)(sA + ra * 128 + (((ks * 4 + lg) ^ (ra & 7)) << 4));
                 asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(addr));
             }
@@ -1430,14 +1434,14 @@ __global__ __launch_bounds__(512, 2) void gemm_dma128x_kernel(const GemmGroup gr
         auto landed = [&](u32x4_t* a, u32x4_t* b) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 4; ++i) MTN_LANDED(a[i]);
+            for (int i = 0; i < TM; ++i) MTN_LANDED(a[i]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) MTN_LANDED(b[j]);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto mfmas = [&](const u32x4_t* a, const u32x4_t* b) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mma16<T>(acc[i][j], as_uint4(b[j]), as_uint4(a[i]));     // transposed accumulator (vector epilogue)
         };
@@ -1453,8 +1457,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dma128x_kernel(const GemmGroup gr
     }
     const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + wr * 64 + i * 16 + l15;
+    for (int i = 0; i < TM; ++i) {
+        const int row = row0 + wr * (16 * TM) + i * 16 + l15;
         if (row >= M) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1572,15 +1576,22 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
             if (ok && t128 >= x_min && (xmin || kmax >= 768)) {            // (the memory gradient shares its launch with the K = 512 dX of the same group)
                 static bool attr_set = false;
                 if (!attr_set) {
-                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
                     attr_set = true;
                 }
                 GemmGroup g2 = grp;
                 const int tiles = retile(g2, 128, 128);
                 g_variant = V_DMA128X; g_variant_tiles = tiles;
-                if (bt) hipLaunchKernelGGL(gemm_dma128x_kernel<true>, dim3(tiles), dim3(512), G8_LDS, s, g2);
-                else hipLaunchKernelGGL(gemm_dma128x_kernel<false>, dim3(tiles), dim3(512), G8_LDS, s, g2);
+                if (MTN_ENV("MTN_GEMM_128X_NW8") != nullptr) {
+                    if (bt) hipLaunchKernelGGL((gemm_dma128x_kernel<true, 8>), dim3(tiles), dim3(512), G8_LDS, s, g2);
+                    else hipLaunchKernelGGL((gemm_dma128x_kernel<false, 8>), dim3(tiles), dim3(512), G8_LDS, s, g2);
+                } else {
+                    if (bt) hipLaunchKernelGGL((gemm_dma128x_kernel<true, 16>), dim3(tiles), dim3(1024), G8_LDS, s, g2);
+                    else hipLaunchKernelGGL((gemm_dma128x_kernel<false, 16>), dim3(tiles), dim3(1024), G8_LDS, s, g2);
+                }
                 MTN_CHECK_LAUNCH();
                 return MTN_OK;
             }
