@@ -317,9 +317,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp) {
 
 // The same kernel for d <= 256*MAXV with ALL global loads of the wave's two rows issued before any arithmetic (the generic
 // kernel above walks the rows one after the other: two dependent memory round trips on the critical path of backward).
-template <int MAXV>
-__global__ __launch_bounds__(256) void ln_bwd_small_kernel(const LnBwdGroup grp) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4 waves][2][d]
+// NWV = 8 (round 3): eight waves of ONE row each instead of four of two — a wave gets one load through every ~100-180 ns however many
+// it has queued, so the 14 loads of a two-row wave were 1.4-2.5 us of issue on a 6.6 us launch.
+template <int MAXV, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV) void ln_bwd_small_kernel(const LnBwdGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [NWV waves][2][d]
     int gi = 0;
     while (gi + 1 < grp.count && (int)blockIdx.x >= grp.block_start[gi + 1]) ++gi;
     const mtn_ln_bwd_desc& D = grp.d[gi];
@@ -327,8 +329,8 @@ __global__ __launch_bounds__(256) void ln_bwd_small_kernel(const LnBwdGroup grp)
     const float eps = D.eps;
     const int blk = (int)blockIdx.x - grp.block_start[gi];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = blk * LN_BWD_ROWS_PER_BLOCK + wave * LN_BWD_ROWS_PER_WAVE;
-    constexpr int R = LN_BWD_ROWS_PER_WAVE;
+    constexpr int R = LN_BWD_ROWS_PER_BLOCK / NWV;
+    const int r0 = blk * LN_BWD_ROWS_PER_BLOCK + wave * R;
     float4 xv[R][MAXV], gv[R][MAXV], dv[R][MAXV], av[MAXV];
     float mu[R], rs[R];
 #pragma unroll
@@ -438,10 +440,16 @@ __global__ __launch_bounds__(256) void ln_bwd_small_kernel(const LnBwdGroup grp)
     }
     __syncthreads();
     float* pp = D.partial + (size_t)blk * 2 * d;
-    for (int c = threadIdx.x * 4; c < 2 * d; c += 1024) {
+    for (int c = threadIdx.x * 4; c < 2 * d; c += 256 * NWV) {
         float4 a = *(const float4*)(sm + c), b = *(const float4*)(sm + 2 * d + c);
         float4 e = *(const float4*)(sm + 4 * d + c), f = *(const float4*)(sm + 6 * d + c);
-        *(float4*)(pp + c) = make_float4((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y), (a.z + b.z) + (e.z + f.z), (a.w + b.w) + (e.w + f.w));
+        float4 t = make_float4((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y), (a.z + b.z) + (e.z + f.z), (a.w + b.w) + (e.w + f.w));
+        if constexpr (NWV == 8) {
+            a = *(const float4*)(sm + 8 * d + c); b = *(const float4*)(sm + 10 * d + c);
+            e = *(const float4*)(sm + 12 * d + c); f = *(const float4*)(sm + 14 * d + c);
+            t.x += (a.x + b.x) + (e.x + f.x); t.y += (a.y + b.y) + (e.y + f.y); t.z += (a.z + b.z) + (e.z + f.z); t.w += (a.w + b.w) + (e.w + f.w);
+        }
+        *(float4*)(pp + c) = t;
     }
 }
 
@@ -524,7 +532,10 @@ extern "C" int mtn_layernorm_bwd_group(int count, const mtn_ln_bwd_desc* descs, 
     }
     for (int i = count; i <= MTN_LN_MAX_GROUP; ++i) grp.block_start[i] = blocks;
     const size_t lds = any_partial ? sizeof(float) * 8 * (size_t)dmax : 0;
-    if (dmax <= 512 && MTN_ENV("MTN_LN_BWD_GENERIC") == nullptr) hipLaunchKernelGGL(ln_bwd_small_kernel<2>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, grp);
+    if (dmax <= 512 && MTN_ENV("MTN_LN_BWD_GENERIC") == nullptr) {
+        if (MTN_ENV("MTN_LN_BWD_4W") != nullptr) hipLaunchKernelGGL((ln_bwd_small_kernel<2, 4>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, grp);
+        else hipLaunchKernelGGL((ln_bwd_small_kernel<2, 8>), dim3(blocks), dim3(512), 2 * lds, (hipStream_t)stream, grp);
+    }
     else hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
