@@ -472,6 +472,11 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const LnFinalizeG
         const float* p = D.partial + c;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int i = q;
+        for (; i + 112 < D.nparts; i += 128) {                   // eight independent loads per round (long streams: 512 partial rows)
+            const float a0 = p[(size_t)(i + 0) * 2 * d], a1 = p[(size_t)(i + 16) * 2 * d], a2 = p[(size_t)(i + 32) * 2 * d], a3 = p[(size_t)(i + 48) * 2 * d];
+            const float a4 = p[(size_t)(i + 64) * 2 * d], a5 = p[(size_t)(i + 80) * 2 * d], a6 = p[(size_t)(i + 96) * 2 * d], a7 = p[(size_t)(i + 112) * 2 * d];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3; s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+        }
         for (; i + 48 < D.nparts; i += 64) {
             s0 += p[(size_t)(i + 0) * 2 * d]; s1 += p[(size_t)(i + 16) * 2 * d];
             s2 += p[(size_t)(i + 32) * 2 * d]; s3 += p[(size_t)(i + 48) * 2 * d];
