@@ -1,0 +1,12 @@
+set -x
+R=$GRAFT_REPO_ROOT
+cd $R
+O=gpurun_out/r03_ak_tt_nt.txt
+rm -f $O
+one() {  # $1 = env assignment, $2.. = bench flags
+  v=$1; shift
+  echo "== $v  $*" >> $O
+  env $v timeout -k 5 200 python bench.py --no-cpu-baseline --no-secondary --no-record --windows 1 --steps 30 "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; k=r['kernels'].get('gemm_tt_dma128_table_kernel', {}); print('samples/s', d['value'], 'step ms', d['ms_per_step'], '| table launch us', k.get('avg_us'))" >> $O 2>&1
+}
+for v in "X=1" "MTN_HIP_LIB=$R/tools/libmtn_hip_ttnt.so" "X=1" "MTN_HIP_LIB=$R/tools/libmtn_hip_ttnt.so"; do one $v; done
+cat $O
