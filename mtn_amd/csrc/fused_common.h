@@ -34,10 +34,15 @@ __device__ __forceinline__ fh_rsrc_t fh_make_rsrc(const void* base, unsigned byt
     return r;
 }
 // 64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024) (lds_addr wave-uniform); voff = byte offset per lane, >= num_records reads zeros
+// (m0 is on the clobber list so that the compiler re-materialises it if it ever holds something there; clang warns that it does not
+//  PRESERVE reserved registers across an asm statement, which is exactly the contract wanted here)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void fh_dma16(fh_rsrc_t rsrc, unsigned lds_addr, unsigned voff) {
     lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);        // an "s" operand is not made uniform for us
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 typedef __attribute__((ext_vector_type(2))) __bf16 fh_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float fh_f32x2;
 
