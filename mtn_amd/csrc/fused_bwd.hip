@@ -85,12 +85,14 @@ __host__ __device__ inline FbLds fb_lds_map(int mt, int key_rows, int mask_bytes
 
 // 128-byte head rows [nrows_valid of nrows_total] -> LDS image by LDS-DMA; rows past the end arrive as zeros
 __device__ __forceinline__ void fb_dma_head_rows(const bf16_t* base, int ld_elems, int valid, int total, unsigned char* img, int wave, int lane) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (valid - 1) * ld_elems * 2 + FH_HROWB, 0x00020000);
+    // (inline-asm LDS-DMA, fused_common.h: with the builtin the compiler drains every DMA in flight in front of the LDS reads it can
+    //  see — the ring's refill never overlapped the tiles computed from the other slot)
+    const fh_rsrc_t rs = fh_make_rsrc(base, (unsigned)((valid - 1) * ld_elems * 2 + FH_HROWB));
     const int ninst = (total + 7) >> 3;
     for (int i = wave; i < ninst; i += 8) {
         const int row = i * 8 + (lane >> 3), slot = lane & 7;
         const unsigned vo = row < valid ? (unsigned)row * (unsigned)(ld_elems * 2) + (unsigned)((slot ^ (row & 7)) << 4) : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (fh_lds_void_t*)(img + i * 1024), 16, vo, 0, 0, 0);
+        fh_dma16(rs, (unsigned)(size_t)(img + i * 1024), vo);
     }
 }
 // A-operand fragment of X^T from a row-major [row][64] image swizzled with row & 7: head columns n_off + (lane & 15),
@@ -174,10 +176,10 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
         if (M.mask && idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * mk)];
     }
     {   // dy rows [R][512] (rows past R: zeros), 16-byte slots swizzled with row & 15
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(M.dyl + (size_t)row0 * FH_D), 0, R * FH_ROWB, 0x00020000);
+        const fh_rsrc_t rs = fh_make_rsrc(M.dyl + (size_t)row0 * FH_D, (unsigned)(R * FH_ROWB));
         for (int r = wave; r < MT * 16; r += 8) {
             const unsigned vo = r < R ? (unsigned)r * FH_ROWB + (unsigned)((lane ^ (r & 15)) << 4) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (fh_lds_void_t*)(dy_s + r * FH_ROWB), 16, vo, 0, 0, 0);
+            fh_dma16(rs, (unsigned)(size_t)(dy_s + r * FH_ROWB), vo);
         }
     }
     fb_dma_head_rows(M.q + (size_t)row0 * M.ldq + slice * FH_DK, M.ldq, R, MT * 16, qi_s, wave, lane);
