@@ -35,6 +35,9 @@ extern "C" {
 
 /* Library / error reporting. */
 const char* mtn_last_error(void);
+/* 100: rounds 1-3.  110 (round 4): mtn_gemm_problem gained `ln`, mtn_mha_args / mtn_ffn_args gained `ln_fold` (callers must zero
+ * the structs or set them), mtn_attn_args gained kv_acc / kv_last in round 3, and mtn_mha_bwd_ws_f32_floats() /
+ * mtn_ffn_bwd_ws_f32_floats() return larger workspaces (multi-pass dK / dV sums; LayerNorm row-sum partials). */
 int mtn_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -82,6 +85,36 @@ typedef struct {
     float beta1, beta2, eps;
 } mtn_adam_fuse;
 
+/* LayerNorm backward by linearity (round 4; bf16, row-major A, B as the weight lies: dX = dY W).
+ * A sublayer computes q = W LN(x) + b with LN(x) = a2 (x - mean) rstd + b2 (mtn.py:111-114, 127).  The two row sums LayerNorm
+ * backward needs from g = dq W —  s1 = sum_c a2_c g_c  and  s2 = sum_c a2_c (x_c - mean) g_c  — are linear in dq:
+ *     s1 = sum_k dq_k u_k,                 u_k = sum_c W_kc a2_c
+ *     s2 = 1/rstd sum_k dq_k (q_k - c_k),  c_k = b_k + sum_c W_kc b2_c        (q = the SAVED projection output)
+ * so the kernels that PRODUCE dq emit them as per-row partial sums (one pair per row and column block, plain stores, no
+ * cross-workgroup synchronisation) and the GEMM g = dq W finishes LayerNorm backward in its epilogue:
+ *     dx = rstd a2 g - rstd s1/d - s2 rstd^2/(std (d-1)) (x - mean) + dres
+ * instead of writing g for a separate LayerNorm-backward launch.  u | c ("fold vectors", float [2K]) come from mtn_ln_fold().
+ *   mode MTN_LN_EMIT    (the GEMM that produces dq itself: dh = (dy W2) gated, FFN sublayers; N % 64 == 0, 64-column tiles):
+ *       part[row][N/64][2] += {sum v u, sum v (gate * gate_inv_scale - c)} over each 64-column block of the row; v = the stored value
+ *   mode MTN_LN_CONSUME (g = dq W, N = d_model <= 512):  out_f32 / out_lp of the problem are ignored (may be NULL);
+ *       part[row][np][2] are summed in index order; dx, dx_lp (through dx_lp_drop, as mtn_ln_bwd_desc) are written;
+ *       colpart [ceil(M/8)][2N] receives the da2 | db2 partial rows of mtn_layernorm_bwd (same layout: finalize unchanged). */
+#define MTN_LN_EMIT 1
+#define MTN_LN_CONSUME 2
+typedef struct mtn_ln_epilogue_s {
+    int mode;
+    const float* fold;     /* EMIT: u[N] then c[N] */
+    float gate_inv_scale;  /* EMIT: 1 / (the gate's dropout scale) */
+    float* part;           /* EMIT: written; CONSUME: read */
+    int np;                /* CONSUME: partial pairs per row */
+    const float *x, *a2, *mean, *rstd, *dres; /* CONSUME: the fields of mtn_ln_bwd_desc; x, mean, rstd saved by forward, dres optional */
+    float eps;
+    float* dx;
+    void* dx_lp;           /* optional, compute dtype */
+    mtn_dropout dx_lp_drop;
+    float* colpart;        /* optional */
+} mtn_ln_epilogue;
+
 typedef struct {
     const void* A;
     const void* B;
@@ -102,6 +135,7 @@ typedef struct {
                                    (an accumulated gradient leaving also as the masked compute-dtype operand of its consumer) */
     float* rowsum_out;
     const mtn_adam_fuse* adam; /* HOST pointer, read during the call only; NULL = plain GEMM */
+    const struct mtn_ln_epilogue_s* ln; /* HOST pointer, read during the call only; NULL = none (LayerNorm-backward epilogue, above) */
 } mtn_gemm_problem;
 
 #define MTN_GEMM_MAX_GROUP 16
@@ -174,6 +208,17 @@ int mtn_layernorm_fwd_group(int dtype, int count, const mtn_ln_fwd_desc* descs /
 int mtn_layernorm_bwd_group(int count, const mtn_ln_bwd_desc* descs /* host array */, void* stream);
 int mtn_layernorm_fwd(int dtype, int rows, int d, float eps, const float* x, const float* a2, const float* b2,
                       float* y_f32, void* y_lp, float* mean, float* rstd, void* stream);
+/* Fold vectors of the Linears that follow a LayerNorm (see mtn_ln_epilogue): for each descriptor, with W [K, d] in the compute
+ * dtype (bf16), out[k] = sum_c W[k][c] a2[c] and out[K + k] = bias[k] + sum_c W[k][c] b2[c].  One launch for the whole model:
+ * `descs_device` is a DEVICE array of `count` descriptors, `block_desc` a DEVICE int32 array giving the descriptor of each
+ * 32-row block (block_start = the descriptor's first block), total_blocks = sum ceil(K / 32).  d % 8 == 0, d <= 2048. */
+typedef struct {
+    const void* w;
+    const float *bias, *a2, *b2;
+    float* out;
+    int K, block_start;
+} mtn_ln_fold_desc;
+int mtn_ln_fold(int dtype, const mtn_ln_fold_desc* descs_device, const int* block_desc, int total_blocks, int d, void* stream);
 long mtn_layernorm_bwd_partial_floats(int rows, int d);
 int mtn_layernorm_bwd_nparts(int rows);
 /* da2/db2 == NULL: only dx is produced now and `partial` is left for a later grouped mtn_layernorm_bwd_finalize()
@@ -292,6 +337,10 @@ typedef struct {
        [B*m, d] — written by the dmem GEMM's epilogue instead of a cast launch */
     void* dmem_lp;
     mtn_dropout dmem_lp_drop;
+    /* optional: fold vectors of w_qkv behind this sublayer's LayerNorm (mtn_ln_fold: float [2K], K = 3d self / d cross: only the
+       q block sees LN(x)).  With them (bf16, fused head backward) LayerNorm backward rides in the dLN-out GEMM's epilogue
+       (mtn_ln_epilogue) and the group's LayerNorm-backward launch disappears; NULL = the separate launch. */
+    const float* ln_fold;
 } mtn_mha_args;
 int mtn_mha_sublayer_fwd(int dtype, const mtn_mha_args* args, void* stream);
 int mtn_mha_sublayer_bwd(int dtype, const mtn_mha_args* args, void* stream);
@@ -338,6 +387,7 @@ typedef struct {
     /* forward, optional: compute-dtype copy of y [rows,d], written by the same epilogue — for an output that a later sublayer
        attends as un-projected memory (an auto-encoder stream, mtn.py:215), which otherwise costs a cast launch */
     void* y_lp;
+    const float* ln_fold; /* optional: fold vectors of w1 (float [2 d_ff]), as mtn_mha_args.ln_fold */
 } mtn_ffn_args;
 int mtn_ffn_sublayer_fwd(int dtype, const mtn_ffn_args* args, void* stream);
 int mtn_ffn_sublayer_bwd(int dtype, const mtn_ffn_args* args, void* stream);
@@ -362,6 +412,9 @@ int mtn_fused_enable(int on);
 /* How many sublayer groups took which path since the library was loaded: out4 = {forward fused, forward per-stage, backward
  * fused (groups with attention members), backward per-stage}.  The parity tests use it to assert that the fused kernels ran. */
 int mtn_fused_counters(long* out4);
+/* Backward groups (since the library was loaded) whose LayerNorm backward rode in the epilogue of the dLN-out GEMM (mtn_ln_epilogue)
+ * instead of its own launch: the tests use it to assert which path ran. */
+long mtn_ln_epilogue_groups(void);
 int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
 int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
 

@@ -14,7 +14,7 @@ void mtn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* mtn_last_error(void) { return g_err; }
-extern "C" int mtn_version(void) { return 100; }
+extern "C" int mtn_version(void) { return 110; }
 
 // ---------------------------------------------------------------- environment switches (common.h: MTN_ENV)
 static int g_env_gen = 0;

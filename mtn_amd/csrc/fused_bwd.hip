@@ -44,6 +44,13 @@ struct FbMember {
     bf16_t* dq;
     bf16_t* dk;
     bf16_t* dv;
+    // LayerNorm backward by linearity (mtn_ln_epilogue, include/mtn_hip.h): with the fold vectors u | c of w_qkv (lnf: u[lnK] then
+    // c[lnK]; lnK = 1536 self / 512 cross) the workgroup also writes, per query row, the head's share of the two row sums the
+    // dLN-out GEMM's epilogue needs: ln_part[row][head] = {sum dq u, sum dq (q - c)} over the head's 64 columns (+ the dk, dv
+    // terms of a self-attention, whose key rows are the query rows).  NULL = off.
+    const float* lnf;
+    float* ln_part;
+    int lnK;
 };
 #ifdef FB_TIMELINE
 // development build (tools/fb_timeline.py): 16 wall-clock stamps (100 MHz) per workgroup of the launch selected with MTN_FB_TL_LAUNCH
@@ -65,6 +72,9 @@ static constexpr int FB_TILE_IMG = 32 * FB_DSROW;
 static constexpr int FB_TEAM_SCRATCH = 4 * FB_TILE_IMG;   // a team's {P^T, dS^T} images, double-buffered over key tiles
 static constexpr int FB_DS_BYTES = 2 * 128;                // D_q of a wave's sample: up to 2 query blocks of 32
 static constexpr int FB_SCRATCH = 2 * FB_TEAM_SCRATCH + 8 * FB_DS_BYTES;      // ... two teams, then D_q[64] of each wave: 22.0 KiB
+// behind them (the dy image is >= 32 KiB): the head's fold vectors [q | k | v][u | c][64] (1.5 KiB) and the row-sum slots
+// [row][wave of the team][2] (32 B per row, <= 2.5 KiB) of the LayerNorm-by-linearity side output
+static constexpr int FB_FOLD_FLOATS = 3 * 2 * 64;
 
 static constexpr int FB_RING_KEYS = 128;   // keys per ring slot
 struct FbLds { int dy, qi, oi, doi, ki, vi, mask, scratch, total; };
@@ -219,6 +229,12 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                 invq[qb][r] = st.y;
             }
     }
+    const bool lnon = M.lnf != nullptr;
+    float fold_v = 0.f;
+    if (lnon && tid < (M.self_attn ? FB_FOLD_FLOATS : 2 * 64))      // thread -> (part q|k|v, u|c, head column)
+        fold_v = M.lnf[((tid >> 6) & 1) * M.lnK + (tid >> 7) * FH_D + slice * FH_DK + (tid & 63)];
+    float* fold_s = (float*)(smem + L.scratch + FB_SCRATCH);
+    float* rs_s = fold_s + FB_FOLD_FLOATS;
     const DropState ds = drop_init(M.drop);
     FB_STAMP(1);
 
@@ -270,6 +286,42 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     __syncthreads();                                            // dO image complete; the exchange area (in the dy image) is dead too
     FB_STAMP(4);
     if (stop == 2) return;
+    // the lane's fold-vector values: parts q | k | v, head columns 16 w4 + 4 lg .. +3 (registers for the whole attention stage)
+    float4 fu[3], fc[3];
+    fu[0] = fu[1] = fu[2] = fc[0] = fc[1] = fc[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lnon) {
+        if (tid < FB_FOLD_FLOATS) fold_s[tid] = fold_v;
+        for (int i = tid; i < MT * 16 * 8; i += FH_THREADS) rs_s[i] = 0.f;
+        __syncthreads();
+        const int colh = 16 * w4 + 4 * lg;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            if (part > 0 && !M.self_attn) break;
+            fu[part] = *(const float4*)(fold_s + part * 128 + colh);
+            fc[part] = *(const float4*)(fold_s + part * 128 + 64 + colh);
+        }
+    }
+    // the lane's share of the two LayerNorm row sums for gradient values val[0..3] (head columns 16 w4 + 4 lg .. +3) of the row whose
+    // saved projection output sits in row `irow` of `img` (q, k or v image; part 0 / 1 / 2 of the fold vectors).  fp32 values: the
+    // GEMM reads them rounded to bf16, a difference of rounding noise in two sums over 512-1536 terms
+    auto ln_dot = [&](const float (&val)[4], const unsigned char* img, const int irow, const int part, float& p1, float& p2) {
+        const int colh = 16 * w4 + 4 * lg;
+        const float4 u4 = fu[part], c4 = fc[part];
+        const uint2 sv = *(const uint2*)(img + irow * FH_HROWB + (((colh >> 3) ^ (irow & 7)) << 4) + (colh & 7) * 2);
+        const float s0 = __uint_as_float(sv.x << 16), s1 = __uint_as_float(sv.x & 0xffff0000u), s2 = __uint_as_float(sv.y << 16), s3 = __uint_as_float(sv.y & 0xffff0000u);
+        p1 += (val[0] * u4.x + val[1] * u4.y) + (val[2] * u4.z + val[3] * u4.w);
+        p2 += (val[0] * (s0 - c4.x) + val[1] * (s1 - c4.y)) + (val[2] * (s2 - c4.z) + val[3] * (s3 - c4.w));
+    };
+    // ... summed over the four lane groups; lane group 0 adds it to this wave's slot of block row `brow` (nobody else touches it)
+    auto ln_add = [&](float p1, float p2, const int brow, const bool ok) {
+        p1 = fh_cross_sum(p1);
+        p2 = fh_cross_sum(p2);
+        if (ok && lg == 0) {
+            float2* slot = (float2*)rs_s + brow * 4 + w4;
+            const float2 o = *slot;
+            *slot = make_float2(o.x + p1, o.y + p2);
+        }
+    };
 
     // ---- attention backward: two samples at a time, a team of four waves each; one workgroup barrier per key tile of 32.
     //      RING: ONE sample, both teams on it — team t takes the key tiles 64 i + 32 t — and the keys stream through the ring
@@ -426,6 +478,19 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                         *(uint2*)(M.dk + go) = make_uint2(fh_pack2(ak[k2][0] * scale, ak[k2][1] * scale), fh_pack2(ak[k2][2] * scale, ak[k2][3] * scale));
                     }
                 }
+                if (lnon && M.self_attn) {             // a self-attention's key rows are its query rows: dk, dv feed the same LayerNorm
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        if (j0 + k2 * 16 >= mk) break;                 // (uniform) no key in this half of the tile
+                        const int key = j0 + k2 * 16 + l15, kc = key < mk ? key : mk - 1;
+                        const float dkv[4] = {ak[k2][0] * scale, ak[k2][1] * scale, ak[k2][2] * scale, ak[k2][3] * scale};
+                        const float dvv[4] = {av[k2][0], av[k2][1], av[k2][2], av[k2][3]};
+                        float p1 = 0.f, p2 = 0.f;
+                        ln_dot(dkv, ki_s, jimg + (kc - j0), 1, p1, p2);
+                        ln_dot(dvv, vi_s, jimg + (kc - j0), 2, p1, p2);
+                        ln_add(p1, p2, krow0 + kc, key < mk);
+                    }
+                }
             }
             if constexpr (RING) {
                 if ((it & 1) == 1) {                               // the slot of key block it / 2 is free once every wave is past it: refill it
@@ -467,9 +532,24 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                         bf16_t* dqg = M.dq + (size_t)(row0 + qrow0 + q) * M.ldq + slice * FH_DK + w4 * 16 + 4 * lg;
                         *(uint2*)dqg = make_uint2(fh_pack2(dqt[qb][q2][0] * scale, dqt[qb][q2][1] * scale), fh_pack2(dqt[qb][q2][2] * scale, dqt[qb][q2][3] * scale));
                     }
+                    if (lnon && 32 * qb + q2 * 16 < a) {           // (wave-uniform: the tile holds at least one query)
+                        const int qc = q < a ? q : a - 1;
+                        const float dqv[4] = {dqt[qb][q2][0] * scale, dqt[qb][q2][1] * scale, dqt[qb][q2][2] * scale, dqt[qb][q2][3] * scale};
+                        float p1 = 0.f, p2 = 0.f;
+                        ln_dot(dqv, qi_s, qrow0 + qc, 0, p1, p2);
+                        ln_add(p1, p2, qrow0 + qc, q < a);
+                    }
                 }
         }
         if (rd == 0) FB_STAMP(11);
+    }
+    if (lnon) {                                                 // the four waves' slots of every row -> this head's pair of the row
+        __syncthreads();
+        if (tid < R) {
+            const float2* sl = (const float2*)rs_s + tid * 4;
+            const float2 a0 = sl[0], a1 = sl[1], a2 = sl[2], a3 = sl[3];
+            ((float2*)M.ln_part)[(size_t)(row0 + tid) * (FH_D / FH_DK) + slice] = make_float2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
+        }
     }
 }
 
@@ -510,7 +590,7 @@ int fh_is_enabled();                                            // fused.hip
 static constexpr int FB_LDS_MAX = 160 * 1024;
 
 // workspace pointers of one member (sublayer.hip carves them)
-struct FbIo { const void* dyl; void *dq, *dk, *dv; int ldq, ldkv; };
+struct FbIo { const void* dyl; void *dq, *dk, *dv; int ldq, ldkv; const float* lnf; float* ln_part; };
 
 struct FbLaunch { FbGroup G; int wgs; size_t lds; bool wide; };
 static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch& P) {
@@ -566,6 +646,7 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
         M.o = (const bf16_t*)A.o; M.lse = A.lse;
         M.mask = A.mask; M.mask_sb = A.mask_sb; M.mask_sq = A.mask_sq; M.drop = A.drop_attn;
         M.dq = (bf16_t*)io[i].dq; M.dk = (bf16_t*)io[i].dk; M.dv = (bf16_t*)io[i].dv;
+        M.lnf = io[i].ln_part ? io[i].lnf : nullptr; M.ln_part = io[i].ln_part; M.lnK = self ? 3 * FH_D : FH_D;
         if (io[i].ldq != M.ldq || io[i].ldkv != M.ldkv) return false;
         const int nrb = (A.B + blk - 1) / blk;
         // XCD map: least bytes through the fabric, 8 x (row bytes / sg + weight bytes / hg)

@@ -50,27 +50,7 @@ __device__ __forceinline__ uint32_t fh_pack2(float a, float b) {        // v_cvt
     const fh_bf16x2 r = __builtin_convertvector(fh_f32x2{a, b}, fh_bf16x2);
     return *(const uint32_t*)&r;
 }
-// sum over the 16 lanes of a DPP row (every lane gets the total)
-__device__ __forceinline__ float fh_row16_sum(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
-    return v;
-}
-// combine across the four 16-lane rows of the wave (lanes with equal lane & 15)
-__device__ __forceinline__ float fh_cross_max(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float fh_cross_sum(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
+// (fh_row16_sum, fh_cross_max, fh_cross_sum: common.h)
 
 __device__ __forceinline__ uint4 fh_xfrag(const unsigned char* img, int row, int chunk) {          // [row][512] image
     return *(const uint4*)(img + row * FH_ROWB + ((chunk ^ (row & 15)) << 4));

@@ -9,6 +9,7 @@
 // LDS, so the MFMA fragment reads are always 16-byte, contraction-contiguous.
 // LDS rows are padded to 144 bytes: the 16 rows of a fragment read land on 16 distinct 16-byte slots.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -196,7 +197,7 @@ template <typename T, bool TR> struct Stage {
 // Epilogue for 4 consecutive output columns of one row: v += bias; relu; dropout; gate; v += residual; store fp32 / lowp.
 template <typename T, bool ADAM = false>
 __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropState& ds, bool vec, int row, int col, int N, const f32x4_t& acc,
-                                          const AdamSlot* adam = nullptr, const AdamCoef* coef = nullptr) {
+                                          const AdamSlot* adam = nullptr, const AdamCoef* coef = nullptr, float* v_out = nullptr, float* gate_out = nullptr) {
     float v[4] = {acc[0], acc[1], acc[2], acc[3]};
     const size_t o = (size_t)row * P.ldc + col;
     const int nv = (col + 4 <= N) ? 4 : N - col;
@@ -227,6 +228,7 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
                 const float g0 = __uint_as_float(u.x << 16), g1 = __uint_as_float(u.x & 0xffff0000u), g2 = __uint_as_float(u.y << 16), g3 = __uint_as_float(u.y & 0xffff0000u);
                 v[0] = g0 > 0.f ? v[0] * P.gate_scale : 0.f; v[1] = g1 > 0.f ? v[1] * P.gate_scale : 0.f;
                 v[2] = g2 > 0.f ? v[2] * P.gate_scale : 0.f; v[3] = g3 > 0.f ? v[3] * P.gate_scale : 0.f;
+                if (gate_out) { gate_out[0] = g0; gate_out[1] = g1; gate_out[2] = g2; gate_out[3] = g3; }
             } else {
                 float4 gq = *(const float4*)gp;
                 v[0] = gq.x > 0.f ? v[0] * P.gate_scale : 0.f; v[1] = gq.y > 0.f ? v[1] * P.gate_scale : 0.f;
@@ -243,6 +245,7 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
         if (vec) *(float4*)(P.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
         else for (int r = 0; r < nv; ++r) P.out_f32[o + r] = v[r];
     }
+    if (v_out) { v_out[0] = v[0]; v_out[1] = v[1]; v_out[2] = v[2]; v_out[3] = v[3]; }
     if (P.out_lp) {
         T* op = (T*)P.out_lp + o;
         if (ds.on && P.lp_drop_after_residual) {          // the stored f32 value stays whole; only this copy goes through the dropout
@@ -257,6 +260,186 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
                 *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
             }
         } else for (int r = 0; r < nv; ++r) op[r] = LP<T>::from_f32(v[r]);
+    }
+}
+
+
+// ---------------------------------------------------------------- LayerNorm-backward epilogue (mtn_ln_epilogue, include/mtn_hip.h)
+// Round 4.  A sublayer's backward ended with   [producer of dq] -> GEMM g = dq W -> LayerNorm-backward launch (5.8-6.7 us, 43 per step).
+// LayerNorm backward needs two sums over the whole row of g — which no 64-column tile of the GEMM has — but both are LINEAR in dq:
+//     s1 = sum_c a2_c g_c = dq . u,  u = W a2          s2 = sum_c a2_c (x_c - mean) g_c = (1 / rstd) dq . (q - c),  c = b + W b2
+// (q = the saved projection output: q - c = rstd W (a2 (x - mean))).  So the kernel that produces dq writes the partial dot
+// products of its own columns ({dq . u, dq . (q - c)} per row and column block: plain stores, no cross-workgroup traffic inside a
+// launch), and this epilogue adds them up, applies LayerNorm backward to the accumulators and writes dx (+ the masked compute-dtype
+// copy the next sublayer's backward reads, + the da2 | db2 partial rows): the LayerNorm-backward launch is gone.
+static constexpr int LNE_MAX_SLOTS = 8;
+static constexpr int LNE_LDS_EXTRA = 4096;      // LDS behind a kernel's operand stages: row sums of a tile (consume: 8 B per row; emit: 8 B per row and wave column)
+struct LnEpiSlot {
+    int mode, np;
+    const float* fold;
+    float* part;
+    const float *x, *a2, *mean, *rstd, *dres;
+    float* dx;
+    void* dx_lp;
+    float* colpart;
+    mtn_dropout dx_lp_drop;
+    float gate_inv_scale, eps;
+};
+struct LnEpiGroup {
+    unsigned char slot_of[MTN_GEMM_MAX_GROUP];   // 0 = plain problem, k + 1 = s[k]
+    LnEpiSlot s[LNE_MAX_SLOTS];
+};
+struct NoLn {};
+template <bool ON> struct LnArg { typedef NoLn type; };
+template <> struct LnArg<true> { typedef LnEpiGroup type; };
+
+// Accumulator geometry shared by the LDS-DMA kernels: for row tile i < RT and column tile j < CT a lane holds output row
+// row_base + 16 i + l15 and columns col_base + 16 j + 4 lg .. +3.  The workgroup tile has BMT rows from tile_row0 and 8 * BMT threads.
+// `lds`: >= 2 * BMT floats of scratch; the caller guarantees nothing else is read from it any more once every wave is here.
+template <int RT, int CT>
+struct LnConsumeLoads {               // everything the consume epilogue reads from memory, as issued (see ln_consume_issue)
+    float mu[RT], rs[RT];
+    float4 xv[RT][CT], dv[RT][CT], av[CT];
+    float p1, p2;
+};
+// Issue the epilogue's loads: the row statistics, x, the residual-branch gradient, the gains, and this thread's share of the tile's
+// row-sum partials (row tid / 8, entries tid % 8, + 8, ...).  The kernels call this right behind their first operand stages: the
+// round trip then hides under the contraction instead of following it.
+template <int RT, int CT>
+__device__ __forceinline__ void ln_consume_issue(const LnEpiSlot& E, LnConsumeLoads<RT, CT>& Q, const int M, const int N, const int tile_row0,
+                                                 const int row_base, const int col_base, const int l15, const int lg, const int tid) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int row = row_base + 16 * i + l15, rc = row < M ? row : M - 1;
+        Q.mu[i] = E.mean[rc]; Q.rs[i] = E.rstd[rc];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int col = col_base + 16 * j + 4 * lg;
+            Q.xv[i][j] = Q.dv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col_base + 16 * j < N) {
+                Q.xv[i][j] = *(const float4*)(E.x + (size_t)rc * N + col);
+                if (E.dres) Q.dv[i][j] = *(const float4*)(E.dres + (size_t)rc * N + col);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        Q.av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col_base + 16 * j < N) Q.av[j] = *(const float4*)(E.a2 + col_base + 16 * j + 4 * lg);
+    }
+    Q.p1 = Q.p2 = 0.f;
+    const int pr = tile_row0 + (tid >> 3);
+#ifdef LNE_ABL_NO_PART
+    if (false) {
+#else
+    if (pr < M) {
+#endif
+        const float2* pp = (const float2*)E.part + (size_t)pr * E.np;
+        for (int k = tid & 7; k < E.np; k += 8) { const float2 t = pp[k]; Q.p1 += t.x; Q.p2 += t.y; }
+    }
+}
+// The tile's row sums -> lds[2 * row], lds[2 * row + 1] (a region of their own behind the operand stages).  Called by every thread once
+// its loads have landed and BEFORE a workgroup barrier that precedes the epilogue — the kernels use the barrier of their last stage,
+// so the epilogue itself needs none.
+template <int RT, int CT>
+__device__ __forceinline__ void ln_consume_publish(const LnConsumeLoads<RT, CT>& Q, const int tid, float* lds) {
+    const float p1 = fh_row8_sum(Q.p1);                    // the row's eight threads are eight consecutive lanes: fixed summation order
+    const float p2 = fh_row8_sum(Q.p2);
+    if ((tid & 7) == 0) *(float2*)(lds + 2 * (tid >> 3)) = make_float2(p1, p2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <int RT, int CT, int BMT>
+__device__ __forceinline__ void ln_consume_epilogue(const LnEpiSlot& E, LnConsumeLoads<RT, CT>& Q, const f32x4_t (&acc)[RT][CT], const int M, const int N,
+                                                    const int tile_row0, const int row_base, const int col_base, const int l15, const int lg, const int tid, float* lds) {
+    const DropState nds = drop_init(E.dx_lp_drop);
+#ifdef LNE_ABL_NO_PART
+    const float p1 = Q.p1, p2 = Q.p2;
+#endif
+    const float inv_d = 1.0f / (float)N;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int row = row_base + 16 * i + l15, lr = row - tile_row0;
+        const bool live = row < M;
+#ifdef LNE_ABL_NO_PART
+        const float S1 = p1 + lr, P2 = p2;
+#else
+        const float S1 = lds[2 * lr], P2 = lds[2 * lr + 1];
+#endif
+        const float r = Q.rs[i];
+        const float std_u = fmaxf(1.0f / r - E.eps, 1e-30f);
+        const float c1 = r * S1 * inv_d;
+        const float c2 = P2 * r / (std_u * (float)(N - 1));            // s2 = P2 / rstd
+        const int pb = ((row_base + 16 * i) >> 3) + (l15 >> 3);      // da2 | db2 partial row: 8 rows each, as mtn_layernorm_bwd
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            if (col_base + 16 * j >= N) continue;
+            const int col = col_base + 16 * j + 4 * lg;
+            const float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            const float a[4] = {Q.av[j].x, Q.av[j].y, Q.av[j].z, Q.av[j].w};
+            const float x4[4] = {Q.xv[i][j].x, Q.xv[i][j].y, Q.xv[i][j].z, Q.xv[i][j].w};
+            const float d4[4] = {Q.dv[i][j].x, Q.dv[i][j].y, Q.dv[i][j].z, Q.dv[i][j].w};
+            float o[4], ga[4], gb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float e = x4[k] - Q.mu[i];
+                o[k] = r * (g[k] * a[k]) - c1 - c2 * e + d4[k];
+                ga[k] = live ? g[k] * e * r : 0.f;
+                gb[k] = live ? g[k] : 0.f;
+            }
+            if (live) {
+                const size_t eo = (size_t)row * N + col;
+                *(float4*)(E.dx + eo) = make_float4(o[0], o[1], o[2], o[3]);
+#ifdef LNE_ABL_NO_LP
+                if (false) {
+#else
+                if (E.dx_lp) {
+#endif
+                    if (nds.on) {
+                        const DropBase db = drop_base((uint64_t)eo);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = drop_keep_at(nds, db, k) ? o[k] * nds.scale : 0.f;
+                    }
+                    store_lp4<bf16_t>((bf16_t*)E.dx_lp + eo, make_float4(o[0], o[1], o[2], o[3]));
+                }
+            }
+#ifdef LNE_ABL_NO_COLPART
+            if (false) {
+#else
+            if (E.colpart) {
+#endif
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ga[k] = fh_row8_sum(ga[k]); gb[k] = fh_row8_sum(gb[k]); }
+                if ((l15 & 7) == 0 && pb * 8 < M) {
+                    float* cp = E.colpart + (size_t)pb * 2 * N + col;
+                    *(float4*)cp = make_float4(ga[0], ga[1], ga[2], ga[3]);
+                    *(float4*)(cp + N) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+                }
+            }
+        }
+    }
+}
+// MTN_LN_EMIT: the row-sum partials of a GEMM that produces dq itself.  p1[i], p2[i]: this lane's sums over its own columns of
+// row tile i; summed over the lane groups, then over the WCN waves that share the tile's rows (through LDS, in wave order), and
+// stored as pair `blk` (the tile's 64-column block) of the row.
+template <int RT, int BMT, int WCN>
+__device__ __forceinline__ void ln_emit_partials(const LnEpiSlot& E, float (&p1)[RT], float (&p2)[RT], const int M, const int nblk, const int blk,
+                                                 const int tile_row0, const int row_base, const int wc, const int l15, const int lg, const int tid, float* lds) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) { p1[i] = fh_cross_sum(p1[i]); p2[i] = fh_cross_sum(p2[i]); }
+    if (lg == 0) {                                         // (lds: a region of its own behind the operand stages)
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int lr = row_base - tile_row0 + 16 * i + l15;
+            lds[(lr * WCN + wc) * 2] = p1[i];
+            lds[(lr * WCN + wc) * 2 + 1] = p2[i];
+        }
+    }
+    __syncthreads();
+    if (tid < BMT && tile_row0 + tid < M) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WCN; ++w) { s1 += lds[(tid * WCN + w) * 2]; s2 += lds[(tid * WCN + w) * 2 + 1]; }
+        ((float2*)E.part)[(size_t)(tile_row0 + tid) * nblk + blk] = make_float2(s1, s2);
     }
 }
 
@@ -613,8 +796,8 @@ __device__ __forceinline__ uint4 kn_frag(const unsigned char* img, int n_off, in
 // load through every ~180 ns however many it has queued (profiles/r03_fh_order.txt), so a CU's fill rate is its resident waves x
 // ~5.6 GB/s: four waves pulled 22-26 GB/s where the two-workgroups-per-CU variants (eight waves) reach twice that.  Waves as 2 row
 // halves x 4 column quarters (wave tile 32 x 16).
-template <typename T, int BM, int BN, int DMA_ROWB, bool BTR = false, int NBUF = 2, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp) {
+template <typename T, int BM, int BN, int DMA_ROWB, bool BTR = false, int NBUF = 2, int NW = 4, bool LNE = false>
+__global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, const typename LnArg<LNE>::type lne) {
     constexpr int BK = DMA_ROWB / (int)sizeof(T);            // 256 / 128 bf16, 128 / 64 fp32
     constexpr int WC = NW / 2;                               // waves across the columns (2 or 4); two across the rows
     constexpr int TM = BM / 32, TN = BN / (16 * WC);         // MFMA tiles per wave
@@ -666,6 +849,29 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp) 
     // prologue: NBUF = 2: up to two stages in flight; NBUF = 4: up to three (NDMA LDS-DMA instructions per wave per stage, always)
     for (int st = 0; st < (NBUF == 2 ? 2 : NBUF - 1) && st < nstages; ++st) issue_stage(st);
 #endif
+    // LayerNorm epilogue (LNE): its loads go out right behind the first stages, so that their round trip hides under the contraction.
+    // The counted waits below stay as they are: with these loads in the queue a wait for stage s also waits for the loads issued
+    // before the stages behind s — at most a few instructions' worth of over-waiting in the first two iterations, exact afterwards.
+    typename std::conditional<LNE, LnConsumeLoads<TM, TN>, NoLn>::type lnq;
+    float4 emit_u[TN], emit_c[TN];
+    int lne_mode = 0;
+    if constexpr (LNE) {
+        const int sl = lne.slot_of[g];
+        if (sl != 0) {
+            const LnEpiSlot& E = lne.s[sl - 1];
+            lne_mode = E.mode;
+            if (E.mode == MTN_LN_CONSUME) ln_consume_issue<TM, TN>(E, lnq, M, N, row0, row0 + wr * (BM / 2), col0 + wc * (BN / WC), l15, lg, tid);
+            else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = col0 + wc * (BN / WC) + j * 16 + lg * 4;
+                    const int cc = col < N ? col : 0;
+                    emit_u[j] = *(const float4*)(E.fold + cc);
+                    emit_c[j] = *(const float4*)(E.fold + N + cc);
+                }
+            }
+        }
+    }
     const DropState ds = drop_init(P.drop);        // scalar seed load + key hashing ride under the operand DMA
     for (int s = 0; s < nstages; ++s) {
         // stage s landed; the stages behind it may still fly (NBUF = 2: one, NBUF = 4: two): counted vmcnt
@@ -683,7 +889,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp) 
             else if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (LNE) {                   // last stage: everything has landed, the epilogue's loads included — its row sums
+                if (lne_mode == MTN_LN_CONSUME) ln_consume_publish<TM, TN>(lnq, tid, (float*)(smem + NBUF * STAGE_BYTES));     // ride on this barrier
+            }
+        }
         __builtin_amdgcn_s_barrier();
 #ifndef MTN_DBG_NO_LOAD
         if constexpr (NBUF > 2) {                  // every wave is done with stage s-1: its buffer takes stage s + NBUF - 1
@@ -770,6 +981,42 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp) 
     //      output row m = l15, FOUR CONSECUTIVE output columns n = 4*lg + r of each 16x16 tile: bias, residual, gate and
     //      both outputs move as 8/16-byte vectors (4x fewer memory instructions than the row-per-register layout).
     const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+    if constexpr (LNE) {
+        static_assert(64 * NW == 8 * BM, "the LayerNorm epilogue deals a tile's rows to groups of eight threads");
+        const int sl = lne.slot_of[g];
+        if (sl != 0) {
+            const LnEpiSlot& E = lne.s[sl - 1];
+            if (lne_mode == MTN_LN_CONSUME) {
+                ln_consume_epilogue<TM, TN, BM>(E, lnq, acc, M, N, row0, row0 + wr * (BM / 2), col0 + wc * (BN / WC), l15, lg, tid, (float*)(smem + NBUF * STAGE_BYTES));
+                return;
+            }
+            // MTN_LN_EMIT: the ordinary epilogue, and the two dot products of the stored values on the way
+            float p1[TM], p2[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                p1[i] = p2[i] = 0.f;
+                const int row = row0 + wr * (BM / 2) + i * 16 + l15;
+                if (row >= M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = col0 + wc * (BN / WC) + j * 16 + lg * 4;
+                    if (col >= N) continue;
+                    float v[4], gt[4] = {0.f, 0.f, 0.f, 0.f};
+                    epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], nullptr, nullptr, v, gt);
+                    const float4 u4 = emit_u[j], c4 = emit_c[j];
+                    const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float vq = LP<T>::to_f32(LP<T>::from_f32(v[k]));     // the value the consumer GEMM will read
+                        p1[i] += vq * uu[k];
+                        p2[i] += vq * (gt[k] * E.gate_inv_scale - cc[k]);
+                    }
+                }
+            }
+            ln_emit_partials<TM, BM, WC>(E, p1, p2, M, N / 64, col0 / 64, row0, row0 + wr * (BM / 2), wc, l15, lg, tid, (float*)(smem + NBUF * STAGE_BYTES));
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = row0 + wr * (BM / 2) + i * 16 + l15;
@@ -1337,8 +1584,8 @@ static constexpr int G8_NST = 4;
 static constexpr int G8_LDS = G8_NST * G8_STAGE;           // 128 KiB
 
 // NW = 16 waves (1 024 threads, wave tile 32 x 32) pull the stages faster than 8 (a CU's fill rate grows with its resident waves).
-template <bool BTR, int NW = 16>
-__global__ __launch_bounds__(64 * NW) void gemm_dma128x_kernel(const GemmGroup grp) {
+template <bool BTR, int NW = 16, bool LNE = false>
+__global__ __launch_bounds__(64 * NW) void gemm_dma128x_kernel(const GemmGroup grp, const typename LnArg<LNE>::type lne) {
     constexpr int WR = NW / 4;                                     // waves down the rows (2 or 4); four across the columns
     constexpr int TM = 128 / (16 * WR);                            // MFMA tiles per wave down the rows (4 or 2)
     constexpr int IPW = 16 / NW;                                   // LDS-DMA instructions per wave per operand per stage (2 or 1)
@@ -1401,12 +1648,23 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma128x_kernel(const GemmGroup g
 
     const int nstages = (K + G8_BK - 1) / G8_BK;
     for (int st = 0; st < 3 && st < nstages; ++st) issue(st);
+    // LayerNorm-backward epilogue of the problems that carry one (MTN_LN_CONSUME; see gemm_dma_kernel): loads behind the first stages
+    typename std::conditional<LNE, LnConsumeLoads<TM, 2>, NoLn>::type lnq;
+    int lne_slot = 0;
+    if constexpr (LNE) {
+        static_assert(64 * NW == 8 * 128, "the LayerNorm epilogue deals a tile's rows to groups of eight threads");
+        lne_slot = lne.slot_of[g];
+        if (lne_slot != 0) ln_consume_issue<TM, 2>(lne.s[lne_slot - 1], lnq, M, N, row0, row0 + wr * (16 * TM), col0 + wc * 32, l15, lg, tid);
+    }
     const DropState ds = drop_init(P.drop);
     for (int s = 0; s < nstages; ++s) {
         const int ahead = nstages - 1 - s;                           // stages issued behind this one: min(ahead, 2) may still fly
         if (ahead >= 2) { if constexpr (IPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else if (ahead == 1) { if constexpr (IPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (LNE) { if (lne_slot != 0) ln_consume_publish<TM, 2>(lnq, tid, (float*)(smem + G8_LDS)); }       // (see gemm_dma_kernel)
+        }
         __builtin_amdgcn_s_barrier();                                // stage s is in LDS for every wave; every wave is done with stage s-1
         if (s + 3 < nstages) issue(s + 3);                           // ... whose buffer takes stage s+3
         const unsigned char* sA = smem + (s & (G8_NST - 1)) * G8_STAGE;
@@ -1456,6 +1714,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma128x_kernel(const GemmGroup g
         __builtin_amdgcn_sched_barrier(0);
     }
     const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+    if constexpr (LNE) {
+        if (lne_slot != 0) {
+            ln_consume_epilogue<TM, 2, 128>(lne.s[lne_slot - 1], lnq, acc, M, N, row0, row0 + wr * (16 * TM), col0 + wc * 32, l15, lg, tid, (float*)(smem + G8_LDS));
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = row0 + wr * (16 * TM) + i * 16 + l15;
@@ -1473,7 +1737,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma128x_kernel(const GemmGroup g
 // that the caller can time each of the step's GEMM launches with HIP events on the launch stream.
 #include <algorithm>
 #include <vector>
-struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GEMM_MAX_GROUP]; mtn_adam_fuse adam[MTN_GEMM_MAX_GROUP]; int table; };
+struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GEMM_MAX_GROUP]; mtn_adam_fuse adam[MTN_GEMM_MAX_GROUP]; mtn_ln_epilogue ln[MTN_GEMM_MAX_GROUP]; int table; };
 struct CensusTable { std::vector<mtn_gemm_problem> p; std::vector<mtn_adam_fuse> adam; };     // a table-form launch (any number of problems)
 static std::vector<CensusEntry> g_census;
 static std::vector<CensusTable> g_census_tables;
@@ -1485,29 +1749,41 @@ static const char* const g_variant_name[V_COUNT] = {
     "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
     "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages", "gemm_tt_dma128_table_kernel", "gemm_k512_kernel", "gemm_dma128x_kernel (128x128, four stages)"};
 
-template <typename T, int BM, int BN, int ROWB, bool BTR = false, int NBUF = 2, int NW = 4>
-static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s) {
+template <typename T, int BM, int BN, int ROWB, bool BTR = false, int NBUF = 2, int NW = 4, bool LNE = false>
+static int launch_dma_impl(const GemmGroup& grp, const typename LnArg<LNE>::type& lne, int tiles, hipStream_t s) {
     g_variant = (BM == 64) ? (ROWB == 512 ? V_DMA64 : V_DMA64H) : (BN == 64 ? V_DMA3264 : (ROWB == 512 ? V_DMA32 : V_DMA32H));
     g_variant_tiles = tiles;
-    constexpr int LDS = NBUF * (BM + BN) * ROWB;
+    constexpr int LDS = NBUF * (BM + BN) * ROWB + (LNE ? LNE_LDS_EXTRA : 0);       // (+ the LayerNorm epilogue's row-sum scratch)
     static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set && LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF, NW, LNE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { mtn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF, NW>), dim3(tiles), dim3(64 * NW), LDS, s, grp);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF, NW, LNE>), dim3(tiles), dim3(64 * NW), LDS, s, grp, lne);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
+}
+// `lne` (launches with a LayerNorm-backward epilogue, mtn_ln_epilogue): only the shapes the backward dX GEMMs take are instantiated
+// with it — bf16, B as the weight lies, a tile whose rows are dealt to groups of eight threads
+template <typename T, int BM, int BN, int ROWB, bool BTR = false, int NBUF = 2, int NW = 4>
+static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s, const LnEpiGroup* lne = nullptr) {
+    if (lne) {
+        if constexpr (sizeof(T) == 2 && BTR && NBUF == 2 && 64 * NW == 8 * BM && BM == BN)
+            return launch_dma_impl<T, BM, BN, ROWB, BTR, NBUF, NW, true>(grp, *lne, tiles, s);
+        mtn_set_error("mtn_gemm: no LayerNorm-epilogue form of this kernel (tile %d x %d, stage %d B, %d waves)", BM, BN, ROWB, NW);
+        return MTN_ERR_ARG;
+    }
+    return launch_dma_impl<T, BM, BN, ROWB, BTR, NBUF, NW, false>(grp, NoLn{}, tiles, s);
 }
 
 // row-major B, or (btr: bf16 only) B stored [K][N]
 template <typename T, int BM, int BN, int ROWB, int NBUF = 2, int NW = 4>
-static int launch_dma_any(const GemmGroup& grp, int tiles, bool btr, hipStream_t s) {
+static int launch_dma_any(const GemmGroup& grp, int tiles, bool btr, hipStream_t s, const LnEpiGroup* lne = nullptr) {
     if constexpr (sizeof(T) == 2) {
-        if (btr) return launch_dma<T, BM, BN, ROWB, true, NBUF, NW>(grp, tiles, s);
+        if (btr) return launch_dma<T, BM, BN, ROWB, true, NBUF, NW>(grp, tiles, s, lne);
     }
-    return launch_dma<T, BM, BN, ROWB, false, NBUF, NW>(grp, tiles, s);
+    return launch_dma<T, BM, BN, ROWB, false, NBUF, NW>(grp, tiles, s, lne);
 }
 
 // tile_start[] for a given tile shape; returns the total
@@ -1525,7 +1801,8 @@ static int retile(GemmGroup& grp, int bm, int bn, bool xcd2d = false) {
 }
 
 template <typename T>
-static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_tiles, bool at, bool bt, bool dma_ok, hipStream_t s) {
+static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_tiles, bool at, bool bt, bool dma_ok, hipStream_t s,
+                       const LnEpiGroup* lne = nullptr, bool lne_emit = false) {
     dim3 grid(total_tiles), block(256);
     g_variant_tiles = total_tiles;
     g_variant = at ? (bt ? V_REG_TT : V_REG_TN) : (bt ? V_REG_NT : V_REG_NN);
@@ -1533,7 +1810,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         // 128x128 row-major tiles: measured 330-350 TFLOP/s on the memory K/V launches against 370-400 for the 64x64
         // register-staged kernel at 5 workgroups per CU (K = 512 is too short to amortise a 16-fragment epilogue at two
         // workgroups per CU) -> opt-in (MTN_GEMM_NTB_MIN_TILES=<tiles>), kept for larger contractions
-        if (!at && !bt && MTN_ENV("MTN_GEMM_NTB_MIN_TILES") != nullptr) {
+        if (!at && !bt && !lne && MTN_ENV("MTN_GEMM_NTB_MIN_TILES") != nullptr) {
             bool ok = true;
             int t128 = 0;
             for (int i = 0; i < grp.count; ++i) {
@@ -1563,7 +1840,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         // the memory-gradient GEMM 23.6 -> 17.3 us per launch, step +0.9 % (profiles/r03_w_gemm128x_ab.txt)
         const char* xmin = MTN_ENV("MTN_GEMM_128X_MIN_TILES");
         const int x_min = xmin ? atoi(xmin) : 192;
-        if (!at && x_min > 0) {
+        if (!at && x_min > 0 && !lne_emit && (!lne || bt)) {
             bool ok = true;
             int t128 = 0, kmax = 0;
             for (int i = 0; i < grp.count; ++i) {
@@ -1580,17 +1857,19 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
                     (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
                     (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
                     (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS + LNE_LDS_EXTRA);
                     attr_set = true;
                 }
                 GemmGroup g2 = grp;
                 const int tiles = retile(g2, 128, 128);
                 g_variant = V_DMA128X; g_variant_tiles = tiles;
-                if (MTN_ENV("MTN_GEMM_128X_NW8") != nullptr) {
-                    if (bt) hipLaunchKernelGGL((gemm_dma128x_kernel<true, 8>), dim3(tiles), dim3(512), G8_LDS, s, g2);
-                    else hipLaunchKernelGGL((gemm_dma128x_kernel<false, 8>), dim3(tiles), dim3(512), G8_LDS, s, g2);
+                if (lne) hipLaunchKernelGGL((gemm_dma128x_kernel<true, 16, true>), dim3(tiles), dim3(1024), G8_LDS + LNE_LDS_EXTRA, s, g2, *lne);
+                else if (MTN_ENV("MTN_GEMM_128X_NW8") != nullptr) {
+                    if (bt) hipLaunchKernelGGL((gemm_dma128x_kernel<true, 8>), dim3(tiles), dim3(512), G8_LDS, s, g2, NoLn{});
+                    else hipLaunchKernelGGL((gemm_dma128x_kernel<false, 8>), dim3(tiles), dim3(512), G8_LDS, s, g2, NoLn{});
                 } else {
-                    if (bt) hipLaunchKernelGGL((gemm_dma128x_kernel<true, 16>), dim3(tiles), dim3(1024), G8_LDS, s, g2);
-                    else hipLaunchKernelGGL((gemm_dma128x_kernel<false, 16>), dim3(tiles), dim3(1024), G8_LDS, s, g2);
+                    if (bt) hipLaunchKernelGGL((gemm_dma128x_kernel<true, 16>), dim3(tiles), dim3(1024), G8_LDS, s, g2, NoLn{});
+                    else hipLaunchKernelGGL((gemm_dma128x_kernel<false, 16>), dim3(tiles), dim3(1024), G8_LDS, s, g2, NoLn{});
                 }
                 MTN_CHECK_LAUNCH();
                 return MTN_OK;
@@ -1602,13 +1881,19 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
     bool btr_ok = bt && sizeof(T) == 2 && MTN_ENV("MTN_GEMM_NT_REG") == nullptr;
     for (int i = 0; i < grp.count && btr_ok; ++i)
         btr_ok = grp.p[i].N % 8 == 0 && grp.p[i].ldb % 8 == 0 && (long)grp.p[i].K * grp.p[i].ldb * 2 < (1L << 31);
+    if (lne && !(!at && dma_ok && btr_ok)) {
+        mtn_set_error("mtn_gemm: a LayerNorm epilogue needs the LDS-DMA kernel (bf16, a_trans = 0, b_trans = 1, aligned operands, <= 4096 tiles)");
+        return MTN_ERR_ARG;
+    }
     if (!at && dma_ok && (!bt || btr_ok)) {
         // Tile choice by the bytes ONE CU has to pull (the bound of these launches, ~27 GB/s per CU): 64x64 tiles run one
         // workgroup per CU in ceil(tiles/256) rounds of (64+64)*K bytes; 32x32 tiles spread 4x the workgroups of half the
         // size, two per CU (their DMA latencies overlap: x0.75, fitted on tools/gemm_bench.hip).  MTN_GEMM_TILE forces one.
         GemmGroup g2 = grp;
         const char* force = MTN_ENV("MTN_GEMM_TILE");
-        const int f = force ? atoi(force) : 0;
+        int f = force ? atoi(force) : 0;
+        if (lne_emit) f = 64;                          // the emitted row-sum partials are per 64-column block
+        if (lne && f == 3264) f = 0;
         double b64 = 0, b32 = 0, wg32max = 0;
         int t64 = 0;
         for (int i = 0; i < grp.count; ++i) {
@@ -1642,19 +1927,19 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         const bool deep = sizeof(T) == 2 && kmax * (int)sizeof(T) > 1024 && MTN_ENV("MTN_GEMM_DEEP") && MTN_ENV("MTN_GEMM_DEEP")[0] == '1';
         if (f == 64 || (!f && c64 <= c32)) {
             const int t = retile(g2, 64, 64, true);
-            if (deep && t <= 256 && !half_force) return launch_dma_any<T, 64, 64, 256, 4>(g2, t, bt, s);
+            if (deep && t <= 256 && !half_force && !lne) return launch_dma_any<T, 64, 64, 256, 4>(g2, t, bt, s);
             if (half_force || (half_ok && t > 256)) {
-                if (MTN_ENV("MTN_GEMM_NW4") == nullptr && MTN_ENV("MTN_GEMM_NW4H") == nullptr) return launch_dma_any<T, 64, 64, 256, 2, 8>(g2, t, bt, s);
+                if (lne || (MTN_ENV("MTN_GEMM_NW4") == nullptr && MTN_ENV("MTN_GEMM_NW4H") == nullptr)) return launch_dma_any<T, 64, 64, 256, 2, 8>(g2, t, bt, s, lne);
                 return launch_dma_any<T, 64, 64, 256>(g2, t, bt, s);
             }
-            if (MTN_ENV("MTN_GEMM_NW4") == nullptr) return launch_dma_any<T, 64, 64, 512, 2, 8>(g2, t, bt, s);     // eight waves: see the kernel
+            if (lne || MTN_ENV("MTN_GEMM_NW4") == nullptr) return launch_dma_any<T, 64, 64, 512, 2, 8>(g2, t, bt, s, lne);     // eight waves: see the kernel
             return launch_dma_any<T, 64, 64, 512>(g2, t, bt, s);
         }
         if (f == 3264) return launch_dma_any<T, 32, 64, 512>(g2, retile(g2, 32, 64, true), bt, s);
         const int t = retile(g2, 32, 32, true);
-        if (deep && t <= 512 && !half_force) return launch_dma_any<T, 32, 32, 256, 4>(g2, t, bt, s);
-        if (half_force || (half_ok && t > 1024)) return launch_dma_any<T, 32, 32, 256>(g2, t, bt, s);   // (measured in the step: 640 tiles 10.7 vs 10.1 us, 1280 tiles 12.7 vs 13.8 us)
-        return launch_dma_any<T, 32, 32, 512>(g2, t, bt, s);
+        if (deep && t <= 512 && !half_force && !lne) return launch_dma_any<T, 32, 32, 256, 4>(g2, t, bt, s);
+        if (half_force || (half_ok && t > 1024)) return launch_dma_any<T, 32, 32, 256>(g2, t, bt, s, lne);   // (measured in the step: 640 tiles 10.7 vs 10.1 us, 1280 tiles 12.7 vs 13.8 us)
+        return launch_dma_any<T, 32, 32, 512>(g2, t, bt, s, lne);
     } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp, NoAdam{});
     else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp, NoAdam{});
     else if (at && bt) {
@@ -1715,15 +2000,19 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     MTN_CHECK_ARG(count >= 1 && count <= MTN_GEMM_MAX_GROUP && problems, "bad problem count");
     GemmGroup grp;
     AdamGroup adam;
+    LnEpiGroup lne;
     memset(&grp, 0, sizeof(grp));
     memset(&adam, 0, sizeof(adam));
+    memset(&lne, 0, sizeof(lne));
+    int n_lne = 0;
+    bool lne_emit = false;
     grp.count = count;
     grp.plain_tile_order = MTN_ENV("MTN_GEMM_PLAIN_TILES") != nullptr;
     int tiles = 0;
     const int align = (dtype == MTN_BF16) ? 8 : 4;
     for (int i = 0; i < count; ++i) {
         const mtn_gemm_problem& p = problems[i];
-        MTN_CHECK_ARG(p.A && p.B && (p.out_f32 || p.out_lp), "null operand/output");
+        MTN_CHECK_ARG(p.A && p.B && (p.out_f32 || p.out_lp || (p.ln && p.ln->mode == MTN_LN_CONSUME)), "null operand/output");
         MTN_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty problem");
         MTN_CHECK_ARG(p.a_trans == problems[0].a_trans && p.b_trans == problems[0].b_trans, "mixed layouts in one group");
         MTN_CHECK_ARG(p.lda % align == 0 && p.ldb % align == 0, "lda/ldb must be multiples of 16 bytes");
@@ -1736,6 +2025,28 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
         tiles += ((p.M + TILE - 1) / TILE) * ((p.N + TILE - 1) / TILE);
         grp.p[i] = p;
         grp.p[i].adam = nullptr;                  // host pointer: never dereferenced on the device
+        grp.p[i].ln = nullptr;
+        if (p.ln && p.ln->mode != 0) {
+            const mtn_ln_epilogue& e = *p.ln;
+            MTN_CHECK_ARG(dtype == MTN_BF16 && !p.a_trans && p.b_trans && !p.adam, "LayerNorm epilogue: bf16 dX = dY W problems only");
+            MTN_CHECK_ARG(n_lne < LNE_MAX_SLOTS, "LayerNorm epilogue: too many problems with one in this launch");
+            MTN_CHECK_ARG(e.part, "LayerNorm epilogue: null row-sum partial buffer");
+            LnEpiSlot& sl = lne.s[n_lne];
+            sl.mode = e.mode; sl.np = e.np; sl.fold = e.fold; sl.part = e.part;
+            sl.x = e.x; sl.a2 = e.a2; sl.mean = e.mean; sl.rstd = e.rstd; sl.dres = e.dres; sl.dx = e.dx; sl.dx_lp = e.dx_lp;
+            sl.colpart = e.colpart; sl.dx_lp_drop = e.dx_lp_drop; sl.gate_inv_scale = e.gate_inv_scale; sl.eps = e.eps;
+            if (e.mode == MTN_LN_EMIT) {
+                MTN_CHECK_ARG(e.fold && p.N % 64 == 0 && p.out_lp && (((uintptr_t)e.fold) & 15) == 0, "LayerNorm epilogue (emit): fold vectors, N % 64 == 0, a compute-dtype output");
+                lne_emit = true;
+            } else {
+                MTN_CHECK_ARG(e.mode == MTN_LN_CONSUME, "LayerNorm epilogue: bad mode");
+                MTN_CHECK_ARG(e.x && e.a2 && e.mean && e.rstd && e.dx && e.np >= 1, "LayerNorm epilogue (consume): null input");
+                MTN_CHECK_ARG(p.N % 16 == 0 && !p.bias && !p.relu && !p.gate && !p.residual && p.drop.p == 0.f, "LayerNorm epilogue (consume): plain g = dY W with N % 16 == 0");
+                MTN_CHECK_ARG(((((uintptr_t)e.x) | ((uintptr_t)e.a2) | ((uintptr_t)e.dx) | ((uintptr_t)e.dres) | ((uintptr_t)e.colpart) | ((uintptr_t)e.part)) & 15) == 0 &&
+                              (((uintptr_t)e.dx_lp) & 7) == 0, "LayerNorm epilogue (consume): misaligned buffer");
+            }
+            lne.slot_of[i] = (unsigned char)(++n_lne);
+        }
         if (p.adam) {
             const mtn_adam_fuse& f = *p.adam;
             MTN_CHECK_ARG(p.a_trans && p.b_trans, "the optimiser epilogue rides on parameter-gradient GEMMs (a_trans = b_trans = 1) only");
@@ -1769,11 +2080,11 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     // many large problems with the short contraction K = 512 (the memories' K|V projections for all layers): csrc/gemm_k512.hip
     int rc = 1, k512_tiles = 0;
     static const int k512_min = [] { const char* e = getenv("MTN_GEMM_K512_MIN_TILES"); return e ? atoi(e) : 512; }();
-    const int took = (dtype == MTN_BF16 && k512_min > 0) ? gemm_k512_try(count, problems, k512_min, s, &k512_tiles) : 0;
+    const int took = (dtype == MTN_BF16 && k512_min > 0 && !n_lne) ? gemm_k512_try(count, problems, k512_min, s, &k512_tiles) : 0;
     if (took < 0) { mtn_set_error("gemm_k512_kernel: launch failed"); return MTN_ERR_LAUNCH; }
     if (took == 1) { g_variant = V_K512; g_variant_tiles = k512_tiles; rc = MTN_OK; }
     else
-        rc = (dtype == MTN_BF16) ? launch_gemm<bf16_t>(grp, adam, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s)
+        rc = (dtype == MTN_BF16) ? launch_gemm<bf16_t>(grp, adam, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s, n_lne ? &lne : nullptr, lne_emit)
                                  : launch_gemm<float>(grp, adam, tiles, problems[0].a_trans, problems[0].b_trans, dma_ok, s);
     if (g_census_on && rc == MTN_OK) {
         CensusEntry e;
@@ -1782,6 +2093,7 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
         for (int i = 0; i < count; ++i) {
             e.p[i] = problems[i];
             if (problems[i].adam) e.adam[i] = *problems[i].adam;       // the caller's descriptor dies with the call
+            if (problems[i].ln) e.ln[i] = *problems[i].ln;
         }
         g_census.push_back(e);
     }
@@ -1982,6 +2294,9 @@ extern "C" int mtn_census_info(int i, mtn_census_launch* out) {
     for (int k = 0; k < e.count; ++k) {
         const mtn_gemm_problem& p = e.p[k];
         out->flops += 2.0 * p.M * p.N * p.K;
+        if (p.ln && e.ln[k].mode == MTN_LN_CONSUME)
+            out->bytes += ((double)p.M + p.N) * p.K * esz + (double)p.M * p.N * (8.0 + (e.ln[k].dres ? 4.0 : 0.0) + (e.ln[k].dx_lp ? esz : 0.0));
+        else
         out->bytes += ((double)p.M + p.N) * p.K * esz + (double)p.M * p.N * ((p.out_f32 ? 4.0 : 0.0) + (p.out_lp ? esz : 0.0)) +
                       (p.residual ? (double)p.M * p.N * 4.0 : 0.0);
         if (k < 4) { out->M[k] = p.M; out->N[k] = p.N; out->K[k] = p.K; }
@@ -2005,7 +2320,10 @@ extern "C" int mtn_census_replay(int i, int reps, void* stream) {
         return rc;
     }
     for (int k = 0; k < e.count; ++k)
+    {
         if (e.p[k].adam) e.p[k].adam = &e.adam[k];      // replays re-apply the optimiser epilogue (same cost; parameters drift by <= lr per replay)
+        if (e.p[k].ln) e.p[k].ln = &e.ln[k];            // ... and the LayerNorm epilogue (idempotent: it only reads the partials)
+    }
     int rc = MTN_OK;
     for (int r = 0; r < reps && rc == MTN_OK; ++r) rc = mtn_gemm(e.dtype, e.count, e.p, stream);
     g_census_on = was;

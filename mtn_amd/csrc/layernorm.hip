@@ -559,6 +559,67 @@ extern "C" int mtn_layernorm_bwd(int rows, int d, float eps, const float* x, con
     return MTN_OK;
 }
 
+// ------------------------------------------------------------------------------------------ fold vectors (mtn_ln_fold)
+// u[k] = sum_c W[k][c] a2[c],  c[k] = bias[k] + sum_c W[k][c] b2[c]  for every Linear W [K, d] that follows a LayerNorm (a2, b2):
+// what lets LayerNorm backward ride in the epilogue of g = dq W (mtn_ln_epilogue, include/mtn_hip.h).  Weights change every step,
+// so this runs once per step: one launch for the whole model (~88 MB of bf16 weights at BASELINE configs[1]), a wave per row,
+// 32 rows per 256-thread workgroup, the row as ONE 16-byte load per lane per 512 columns.
+template <int NJ>      // 512-column chunks of a row a lane may hold (1: d <= 512)
+__global__ __launch_bounds__(256) void ln_fold_kernel(const mtn_ln_fold_desc* __restrict__ descs, const int* __restrict__ block_desc, const int d) {
+    const mtn_ln_fold_desc D = descs[block_desc[blockIdx.x]];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = ((int)blockIdx.x - D.block_start) * 32 + wave * 8;
+    const bf16_t* w = (const bf16_t*)D.w;
+    uint4 wv[8][NJ];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = k0 + r < D.K ? k0 + r : D.K - 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = (lane + 64 * j) * 8;
+            wv[r][j] = c < d ? *(const uint4*)(w + (size_t)k * d + c) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    float su[8], sc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) su[r] = sc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c >= d) break;
+        const float4 a0 = *(const float4*)(D.a2 + c), a1 = *(const float4*)(D.a2 + c + 4);
+        const float4 b0 = *(const float4*)(D.b2 + c), b1 = *(const float4*)(D.b2 + c + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t q[4] = {wv[r][j].x, wv[r][j].y, wv[r][j].z, wv[r][j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(q[e] << 16), hi = __uint_as_float(q[e] & 0xffff0000u);
+                su[r] += lo * av[2 * e] + hi * av[2 * e + 1];
+                sc[r] += lo * bv[2 * e] + hi * bv[2 * e + 1];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float u = fh_cross_sum(fh_row16_sum(su[r])), c = fh_cross_sum(fh_row16_sum(sc[r]));      // (DPP + lane swaps: no LDS traffic)
+        if (lane == 0 && k0 + r < D.K) {
+            D.out[k0 + r] = u;
+            D.out[D.K + k0 + r] = c + (D.bias ? D.bias[k0 + r] : 0.f);
+        }
+    }
+}
+extern "C" int mtn_ln_fold(int dtype, const mtn_ln_fold_desc* descs_device, const int* block_desc, int total_blocks, int d, void* stream) {
+    MTN_CHECK_ARG(dtype == MTN_BF16, "fold vectors exist for the bf16 path only");
+    MTN_CHECK_ARG(descs_device && block_desc && total_blocks > 0, "null descriptor table");
+    MTN_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 2048, "d must be a multiple of 8, at most 2048");
+    if (d <= 512) hipLaunchKernelGGL(ln_fold_kernel<1>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_device, block_desc, d);
+    else hipLaunchKernelGGL(ln_fold_kernel<4>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_device, block_desc, d);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}
+
 // ------------------------------------------------------------------------------------------ embedding backward
 struct EmbedBwdGroup {
     int count;

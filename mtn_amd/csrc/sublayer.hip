@@ -19,9 +19,11 @@ int fh_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, 
 int fh_group_fwd_stage1(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
 int fh_is_enabled();
 // csrc/fused_bwd.hip
-struct FbIo { const void* dyl; void *dq, *dk, *dv; int ldq, ldkv; };
+struct FbIo { const void* dyl; void *dq, *dk, *dv; int ldq, ldkv; const float* lnf; float* ln_part; };
 int fb_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, const FbIo* io);
 int fb_group_bwd_stage(int n_mha, const mtn_mha_args* mha, const FbIo* io, void* stream);
+
+static constexpr int LN_PART_HEADS = 8;     // heads of the fused head backward (d = 512, d_k = 64): pairs per row of its LayerNorm row-sum partials
 
 static inline const char* lp_off(const void* p, long elems, int dtype) {
     return (const char*)p + elems * (dtype == MTN_BF16 ? 2 : 4);
@@ -38,6 +40,8 @@ static mtn_gemm_problem gemm_init(const void* A, int lda, const void* B, int ldb
 
 // how often a group took the fused launches (tests assert that the fused kernels really ran): {fwd fused, fwd per-stage, bwd fused, bwd per-stage}
 static long g_fused_counts[4] = {0, 0, 0, 0};
+static long g_ln_epi_groups = 0;               // backward groups whose LayerNorm backward rode in the stage-4 GEMM's epilogue
+extern "C" long mtn_ln_epilogue_groups(void) { return g_ln_epi_groups; }
 extern "C" int mtn_fused_counters(long* out4) {
     MTN_CHECK_ARG(out4, "null output");
     for (int i = 0; i < 4; ++i) out4[i] = g_fused_counts[i];
@@ -221,15 +225,16 @@ extern "C" long mtn_mha_bwd_ws_f32_floats(int B, int a, int m, int d) {
     long rows = (long)B * a;
     // + the fp32 dK / dV sums of a multi-pass attention backward (more than 32 query rows on the per-stage path)
     const long kvacc = a > 32 ? 2L * B * (m > a ? m : a) * d : 0;
-    return rows * d + mtn_layernorm_bwd_partial_floats((int)rows, d) + kvacc;
+    // + the LayerNorm row-sum partials of the fused head backward (mtn_ln_epilogue): {s1, s2} per row and head
+    return rows * d + mtn_layernorm_bwd_partial_floats((int)rows, d) + kvacc + rows * 2 * LN_PART_HEADS;
 }
 extern "C" long mtn_ffn_bwd_ws_f32_floats(int rows, int d, int d_ff) {
-    (void)d_ff;
-    return (long)rows * d + mtn_layernorm_bwd_partial_floats(rows, d);
+    // ... and of the dh GEMM: {s1, s2} per row and 64-column block of the hidden layer
+    return (long)rows * d + mtn_layernorm_bwd_partial_floats(rows, d) + (long)rows * 2 * ((d_ff + 63) / 64);
 }
 
 // Workspace carving (same for the backward kernels and for the deferred parameter-gradient problems).
-struct MhaWs { void *dyl, *dO, *dqkv, *dkv; float *dxn, *ln_partial, *kv_acc; };
+struct MhaWs { void *dyl, *dO, *dqkv, *dkv; float *dxn, *ln_partial, *kv_acc, *ln_part; };
 static MhaWs mha_ws(const mtn_mha_args* a, int dtype) {
     const long rows = (long)a->B * a->a, d = a->d;
     MhaWs w;
@@ -240,15 +245,18 @@ static MhaWs mha_ws(const mtn_mha_args* a, int dtype) {
     w.dxn = a->ws_f32;                                  // [rows,d]
     w.ln_partial = a->ws_f32 + rows * d;
     w.kv_acc = a->a > 32 ? w.ln_partial + mtn_layernorm_bwd_partial_floats((int)rows, (int)d) : nullptr;   // [2][rows_m, d] fp32
+    const long rows_kv = (long)a->B * (a->m > a->a ? a->m : a->a);
+    w.ln_part = w.ln_partial + mtn_layernorm_bwd_partial_floats((int)rows, (int)d) + (a->a > 32 ? 2L * rows_kv * d : 0);   // [rows][heads][2]
     return w;
 }
-struct FfnWs { void *dyl, *dh; float *dxn, *ln_partial; };
+struct FfnWs { void *dyl, *dh; float *dxn, *ln_partial, *ln_part; };
 static FfnWs ffn_ws(const mtn_ffn_args* a, int dtype) {
     FfnWs w;
     w.dyl = a->dyl_ready ? (void*)a->dyl_ready : a->ws_lp;          // [rows,d]
     w.dh = lp_off(a->ws_lp, (long)a->rows * a->d, dtype);           // [rows,d_ff]
     w.dxn = a->ws_f32;
     w.ln_partial = a->ws_f32 + (long)a->rows * a->d;
+    w.ln_part = w.ln_partial + mtn_layernorm_bwd_partial_floats(a->rows, a->d);      // [rows][d_ff / 64][2]
     return w;
 }
 
@@ -268,6 +276,11 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
             if (!ffn[i].dyl_ready) c[n++] = mtn_cast_desc{(long)ffn[i].rows * ffn[i].d, ffn[i].dy, ffn_ws(&ffn[i], dtype).dyl, ffn[i].drop_out};
         if (n) RUN(mtn_cast_group(dtype, n, c, stream));
     }
+    // LayerNorm backward in the epilogue of the stage-4 GEMM (mtn_ln_epilogue): every member brings the fold vectors of the Linear
+    // behind its LayerNorm, and the kernels that produce dq | dh can emit the row-sum partials (the fused head backward; the dh GEMM)
+    bool lnepi = dtype == MTN_BF16 && !(MTN_ENV("MTN_LN_EPI") && MTN_ENV("MTN_LN_EPI")[0] == '0');
+    for (int i = 0; i < n_mha; ++i) lnepi = lnepi && mha[i].ln_fold && mha[i].d == 512 && mha[i].h == LN_PART_HEADS;
+    for (int i = 0; i < n_ffn; ++i) lnepi = lnepi && ffn[i].ln_fold && ffn[i].d_ff % 64 == 0 && ffn[i].d % 16 == 0 && ffn[i].d <= 512;
     // Fused stage 2 + 3 of the attention members (csrc/fused_bwd.hip): dO of a head and the head's attention backward in one
     // kernel per (sample block, head); dO never goes to HBM
     FbIo io[MTN_SUBLAYER_MAX_GROUP];
@@ -276,13 +289,20 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
         const MhaWs w = mha_ws(a, dtype);
         const int d = a->d;
         io[i].dyl = w.dyl; io[i].dq = w.dqkv;
+        io[i].lnf = a->ln_fold; io[i].ln_part = (lnepi && a->ln_fold) ? w.ln_part : nullptr;
         if (a->self_attn) { io[i].dk = lp_off(w.dqkv, d, dtype); io[i].dv = lp_off(w.dqkv, 2 * d, dtype); io[i].ldq = io[i].ldkv = 3 * d; }
         else { io[i].dk = w.dkv; io[i].dv = lp_off(w.dkv, d, dtype); io[i].ldq = d; io[i].ldkv = 2 * d; }
     }
     const bool fb = n_mha > 0 && fb_group_eligible(dtype, n_mha, mha, io) != 0;
+    if (n_mha > 0 && !fb) {                       // the per-stage attention backward emits no partials: the group keeps its LayerNorm launch
+        lnepi = false;
+        for (int i = 0; i < n_mha; ++i) io[i].ln_part = nullptr;
+    }
+    if (lnepi) ++g_ln_epi_groups;
     if (n_mha > 0) ++g_fused_counts[fb ? 2 : 3];
     if (fb) RUN(fb_group_bwd_stage(n_mha, mha, io, stream));
     // 2. dO = dyl Wo ;  dh = (dyl W2) * relu'(h) * hidden-dropout mask (both recovered from the saved hidden: hid > 0)
+    mtn_ln_epilogue lne[2 * MTN_SUBLAYER_MAX_GROUP];
     if (!fb || n_ffn > 0) {
         mtn_gemm_problem p[2 * MTN_SUBLAYER_MAX_GROUP];
         int n = 0;
@@ -300,7 +320,14 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
             p[n] = a->w2_t ? gemm_init(w.dyl, d, a->w2_t, d, a->rows, ff, d, 0, 0) : gemm_init(w.dyl, d, a->w2, ff, a->rows, ff, d, 0, 1);
             p[n].gate = a->hid;
             p[n].gate_scale = (a->drop_hidden.p > 0.f && a->drop_hidden.seed) ? 1.0f / (1.0f - a->drop_hidden.p) : 1.0f;
-            p[n].out_lp = w.dh; p[n].ldc = ff; ++n;
+            p[n].out_lp = w.dh; p[n].ldc = ff;
+            if (lnepi) {                          // dh . u and dh . (pre-activation - c) per row and 64-column block, on the way out
+                mtn_ln_epilogue& e = lne[n];
+                memset(&e, 0, sizeof(e));
+                e.mode = MTN_LN_EMIT; e.fold = a->ln_fold; e.gate_inv_scale = 1.0f / p[n].gate_scale; e.part = w.ln_part;
+                p[n].ln = &e;
+            }
+            ++n;
         }
         RUN(run_gemms(dtype, n, p, stream));
     }
@@ -322,20 +349,34 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
     //    Wq^T, columns d..3d-1 are Wkv^T (row stride 3d)
     {
         mtn_gemm_problem p[3 * MTN_SUBLAYER_MAX_GROUP];
-        int n = 0;
+        mtn_ln_epilogue lc[2 * MTN_SUBLAYER_MAX_GROUP];
+        int n = 0, nlc = 0;
+        // LayerNorm backward of a member in the epilogue of its g = dq W problem (what stage 5 does otherwise)
+        auto consume = [&](mtn_gemm_problem& q, const float* x, const float* a2, const float* mean, const float* rstd, float eps, const float* dy, float* dx,
+                           void* next_dyl, const mtn_dropout& next_drop, float* part, int np, float* colpart) {
+            mtn_ln_epilogue& e = lc[nlc++];
+            memset(&e, 0, sizeof(e));
+            e.mode = MTN_LN_CONSUME; e.part = part; e.np = np; e.x = x; e.a2 = a2; e.mean = mean; e.rstd = rstd; e.dres = dy; e.eps = eps;
+            e.dx = dx; e.dx_lp = next_dyl; e.dx_lp_drop = next_drop; e.colpart = colpart;
+            q.ln = &e; q.out_f32 = nullptr;
+        };
         for (int i = 0; i < n_mha; ++i) {
             const mtn_mha_args* a = &mha[i];
             const MhaWs w = mha_ws(a, dtype);
             const int d = a->d, rows = a->B * a->a, rows_m = a->B * a->m;
             if (a->self_attn) {
-                p[n] = a->w_qkv_t ? gemm_init(w.dqkv, 3 * d, a->w_qkv_t, 3 * d, rows, d, 3 * d, 0, 0) : gemm_init(w.dqkv, 3 * d, a->w_qkv, d, rows, d, 3 * d, 0, 1);
-                p[n].out_f32 = w.dxn; p[n].ldc = d; ++n;
+                p[n] = (a->w_qkv_t && !lnepi) ? gemm_init(w.dqkv, 3 * d, a->w_qkv_t, 3 * d, rows, d, 3 * d, 0, 0) : gemm_init(w.dqkv, 3 * d, a->w_qkv, d, rows, d, 3 * d, 0, 1);
+                p[n].out_f32 = w.dxn; p[n].ldc = d;
+                if (lnepi) consume(p[n], a->x, a->ln_a, a->mean, a->rstd, a->ln_eps, a->dy, a->dx, a->next_dyl, a->next_drop, w.ln_part, LN_PART_HEADS, w.ln_partial);
+                ++n;
             } else {
-                p[n] = a->w_qkv_t ? gemm_init(w.dqkv, d, a->w_qkv_t, 3 * d, rows, d, d, 0, 0) : gemm_init(w.dqkv, d, a->w_qkv, d, rows, d, d, 0, 1);
-                p[n].out_f32 = w.dxn; p[n].ldc = d; ++n;
+                p[n] = (a->w_qkv_t && !lnepi) ? gemm_init(w.dqkv, d, a->w_qkv_t, 3 * d, rows, d, d, 0, 0) : gemm_init(w.dqkv, d, a->w_qkv, d, rows, d, d, 0, 1);
+                p[n].out_f32 = w.dxn; p[n].ldc = d;
+                if (lnepi) consume(p[n], a->x, a->ln_a, a->mean, a->rstd, a->ln_eps, a->dy, a->dx, a->next_dyl, a->next_drop, w.ln_part, LN_PART_HEADS, w.ln_partial);
+                ++n;
                 if (a->dmem) {
-                    p[n] = a->w_qkv_t ? gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv_t, d, dtype), 3 * d, rows_m, d, 2 * d, 0, 0)
-                                      : gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv, (long)d * d, dtype), d, rows_m, d, 2 * d, 0, 1);
+                    p[n] = (a->w_qkv_t && !lnepi) ? gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv_t, d, dtype), 3 * d, rows_m, d, 2 * d, 0, 0)
+                                                  : gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv, (long)d * d, dtype), d, rows_m, d, 2 * d, 0, 1);
                     if (a->dmem_accumulate) { p[n].residual = a->dmem; p[n].ldr = d; }
                     if (a->dmem_lp) { p[n].out_lp = a->dmem_lp; p[n].drop = a->dmem_lp_drop; p[n].lp_drop_after_residual = 1; }
                     p[n].out_f32 = a->dmem; p[n].ldc = d; ++n;
@@ -346,13 +387,15 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
             const mtn_ffn_args* a = &ffn[i];
             const FfnWs w = ffn_ws(a, dtype);
             const int d = a->d, ff = a->d_ff;
-            p[n] = a->w1_t ? gemm_init(w.dh, ff, a->w1_t, ff, a->rows, d, ff, 0, 0) : gemm_init(w.dh, ff, a->w1, d, a->rows, d, ff, 0, 1);
-            p[n].out_f32 = w.dxn; p[n].ldc = d; ++n;
+            p[n] = (a->w1_t && !lnepi) ? gemm_init(w.dh, ff, a->w1_t, ff, a->rows, d, ff, 0, 0) : gemm_init(w.dh, ff, a->w1, d, a->rows, d, ff, 0, 1);
+            p[n].out_f32 = w.dxn; p[n].ldc = d;
+            if (lnepi) consume(p[n], a->x, a->ln_a, a->mean, a->rstd, a->ln_eps, a->dy, a->dx, a->next_dyl, a->next_drop, w.ln_part, ff / 64, w.ln_partial);
+            ++n;
         }
-        RUN(run_gemms(dtype, n, p, stream));
+        RUN(run_gemms(dtype, n, p, stream));      // (lnepi: every problem has b_trans = 1 -> one launch, memory gradients included)
     }
     // 5. LayerNorm backward fused with the residual-branch gradient (critical path: dx only)
-    {
+    if (!lnepi) {
         mtn_ln_bwd_desc L[2 * MTN_SUBLAYER_MAX_GROUP];
         int n = 0;
         for (int i = 0; i < n_mha; ++i) {

@@ -104,6 +104,7 @@ class FusedAdam:
 
     def _buffers(self):
         flat, flat_lp, grad = self.model.flat_buffers()
+        self.model._ln_fold_stale = True          # every caller is about to change weights: the LayerNorm fold vectors go stale
         if self.m.data_ptr() == 0 or self.m.numel() != flat.numel() or self.m.device != flat.device:
             raise L.MtnHipError("model was re-flattened after the optimiser was built")
         return flat, flat_lp, grad, (None if flat_lp is flat else flat_lp.data_ptr())

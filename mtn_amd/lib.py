@@ -26,6 +26,17 @@ class AdamFuse(C.Structure):
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
 
 
+class LnEpilogue(C.Structure):
+    _fields_ = [("mode", C.c_int), ("fold", C.c_void_p), ("gate_inv_scale", C.c_float), ("part", C.c_void_p), ("np", C.c_int),
+                ("x", C.c_void_p), ("a2", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("dres", C.c_void_p),
+                ("eps", C.c_float), ("dx", C.c_void_p), ("dx_lp", C.c_void_p), ("dx_lp_drop", Dropout), ("colpart", C.c_void_p)]
+
+
+class LnFoldDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("a2", C.c_void_p), ("b2", C.c_void_p), ("out", C.c_void_p),
+                ("K", C.c_int), ("block_start", C.c_int)]
+
+
 class GemmProblem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("lda", C.c_int), ("ldb", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_trans", C.c_int), ("b_trans", C.c_int),
@@ -34,7 +45,7 @@ class GemmProblem(C.Structure):
                 ("residual", C.c_void_p), ("ldr", C.c_int),
                 ("out_f32", C.c_void_p), ("out_lp", C.c_void_p), ("ldc", C.c_int), ("lp_drop_after_residual", C.c_int),
                 ("rowsum_out", C.c_void_p),
-                ("adam", C.POINTER(AdamFuse))]
+                ("adam", C.POINTER(AdamFuse)), ("ln", C.POINTER(LnEpilogue))]
 
 
 class AttnArgs(C.Structure):
@@ -59,7 +70,7 @@ class MhaArgs(C.Structure):
                 ("d_w_qkv", C.c_void_p), ("d_b_qkv", C.c_void_p), ("d_w_o", C.c_void_p), ("d_b_o", C.c_void_p),
                 ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int),
                 ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout), ("kv_ready", C.c_int),
-                ("dmem_lp", C.c_void_p), ("dmem_lp_drop", Dropout)]
+                ("dmem_lp", C.c_void_p), ("dmem_lp_drop", Dropout), ("ln_fold", C.c_void_p)]
 
 
 class FfnArgs(C.Structure):
@@ -73,7 +84,8 @@ class FfnArgs(C.Structure):
                 ("d_ln_a", C.c_void_p), ("d_ln_b", C.c_void_p), ("d_w1", C.c_void_p), ("d_b1", C.c_void_p),
                 ("d_w2", C.c_void_p), ("d_b2", C.c_void_p),
                 ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int),
-                ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout), ("y_lp", C.c_void_p)]
+                ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout), ("y_lp", C.c_void_p),
+                ("ln_fold", C.c_void_p)]
 
 
 class LossHeadArgs(C.Structure):
@@ -160,6 +172,8 @@ SYMBOLS = {
     "mtn_cast_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(CastDesc), _P]),
     "mtn_fused_enable": (C.c_int, [C.c_int]),
     "mtn_fused_counters": (C.c_int, [C.POINTER(C.c_long)]),
+    "mtn_ln_epilogue_groups": (C.c_long, []),
+    "mtn_ln_fold": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "mtn_sublayer_group_fwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_sublayer_group_bwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_layernorm_bwd_partial_floats": (C.c_long, [C.c_int, C.c_int]),

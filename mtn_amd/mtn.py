@@ -125,6 +125,16 @@ class SublayerConnection(nn.Module):
         self.p = dropout
         self.salt = 0
         self._owner = None          # EncoderDecoder (for compute dtype / dropout seed); set at flatten
+        self._ln_fold = None        # (id(module), float [2K] view): fold vectors of the Linear behind this LayerNorm (EncoderDecoder._build_ln_fold)
+
+    def _fold_for(self, module):
+        f = self._ln_fold
+        if f is None or f[0] != id(module) or not torch.is_grad_enabled():
+            return None
+        o = self._owner
+        if o is not None and o._ln_fold_stale:      # the weights changed since the vectors were computed (a caller that skips encode())
+            o.fold_layer_norms()
+        return f[1]
 
     def _ctx(self):
         o = self._owner
@@ -142,7 +152,7 @@ class SublayerConnection(nn.Module):
                             p_attn=attn.p if self.training else 0.0, p_out=self.p if self.training else 0.0,
                             salt=self.salt, seed=seed, lp_dtype=lp, w_qkv_lp=f["w_qkv_lp"], w_o_lp=f["w_o_lp"],
                             w_qkv_lpT=f.get("w_qkv_lpT"), w_o_lpT=f.get("w_o_lpT"), grads=g,
-                            queue=queue if g is not None else None)
+                            queue=queue if g is not None else None, ln_fold=self._fold_for(attn))
         mem_lp = getattr(mem, "_mtn_lp", None) if mem is not None else None
         if mem_lp is not None and mem_lp.dtype != lp:
             mem_lp = None
@@ -158,14 +168,14 @@ class SublayerConnection(nn.Module):
             cfg = ops.MhaConfig(heads=sublayer.h, eps=self.norm.eps, p_attn=sublayer.p if self.training else 0.0,
                                 p_out=self.p if self.training else 0.0, salt=self.salt, seed=seed, lp_dtype=lp,
                                 w_qkv_lp=f["w_qkv_lp"], w_o_lp=f["w_o_lp"], w_qkv_lpT=f.get("w_qkv_lpT"), w_o_lpT=f.get("w_o_lpT"),
-                                grads=g, queue=queue)
+                                grads=g, queue=queue, ln_fold=self._fold_for(sublayer))
             mem_lp = getattr(mem, "_mtn_lp", None) if mem is not None else None
             if mem_lp is not None and mem_lp.dtype != lp:
                 mem_lp = None
             return ops.GroupMember("mha", cfg, (self.norm.a_2, self.norm.b_2, f["b_qkv"], f["b_o"]), mask, mem_lp)
         cfg = ops.FfnConfig(eps=self.norm.eps, p_hidden=sublayer.p if self.training else 0.0, p_out=self.p if self.training else 0.0,
                             salt=self.salt, seed=seed, lp_dtype=lp, w1_lp=f["w1_lp"], w2_lp=f["w2_lp"], w1_lpT=f.get("w1_lpT"),
-                            w2_lpT=f.get("w2_lpT"), grads=g, queue=queue)
+                            w2_lpT=f.get("w2_lpT"), grads=g, queue=queue, ln_fold=self._fold_for(sublayer))
         return ops.GroupMember("ffn", cfg, (self.norm.a_2, self.norm.b_2, f["b1"], f["b2"]))
 
     def feed(self, x, ff: PositionwiseFeedForward):
@@ -177,7 +187,7 @@ class SublayerConnection(nn.Module):
         cfg = ops.FfnConfig(eps=self.norm.eps, p_hidden=ff.p if self.training else 0.0,
                             p_out=self.p if self.training else 0.0, salt=self.salt, seed=seed, lp_dtype=lp,
                             w1_lp=f["w1_lp"], w2_lp=f["w2_lp"], w1_lpT=f.get("w1_lpT"), w2_lpT=f.get("w2_lpT"), grads=g,
-                            queue=queue if g is not None else None)
+                            queue=queue if g is not None else None, ln_fold=self._fold_for(ff))
         return ops.FFNSublayerFn.apply(x, self.norm.a_2, self.norm.b_2, f["w1"], f["b1"], f["w2"], f["b2"], cfg)
 
     def forward(self, x, sublayer, mem=None, mask=None, self_attention=False):
@@ -537,6 +547,8 @@ class EncoderDecoder(nn.Module):
         self.fused_embed = True                # Embeddings + PositionalEncoding + Encoder LayerNorm in one grouped launch
         self.hoist_kv = os.environ.get("MTN_NO_KV_HOIST") != "1"   # K|V of the constant memories projected ahead of the layer loop
         self._embed_calls = 0
+        self._ln_fold_stale = True
+        self._ln_fold_buf = self._ln_fold_table = None
 
     # ---- flat parameter storage ------------------------------------------------------------------
     def _ordered_params(self):
@@ -697,6 +709,73 @@ class EncoderDecoder(nn.Module):
             for k, s in enumerate(layer.sublayer):
                 object.__setattr__(s, "_owner", self)      # plain attribute: not a registered submodule
                 s.salt = n * 64 + k + 1
+        self._build_ln_fold()
+
+    def _build_ln_fold(self):
+        """Fold vectors u = W a2, c = b + W b2 of every Linear that follows a sublayer's LayerNorm (include/mtn_hip.h,
+        mtn_ln_epilogue): one flat fp32 buffer with a [2K] slot per (sublayer connection, module) pair of the layer schedule
+        (mtn.py:183-218), the device-side descriptor table of mtn_ln_fold, and the views the sublayers hand to the kernels.
+        bf16 on the GPU only (the kernels that use them are the fused bf16 ones)."""
+        self._ln_fold_buf = self._ln_fold_table = None
+        self._ln_fold_stale = True
+        for layer in self.decoder.layers:
+            for sc in layer.sublayer:
+                sc._ln_fold = None
+        dev = self._flat.device
+        if dev.type != "cuda" or self.compute_dtype != torch.bfloat16 or self.auto_encoder_ft not in ("caption", "summary", "query"):
+            return
+        pairs = []                   # (sublayer connection, module, W [K, d] compute dtype, bias [K])
+        for layer in self.decoder.layers:
+            sl, nF = layer.sublayer, len(layer.auto_encoder_vid_attn)
+            if len(sl) != 5 + 4 * nF:
+                continue
+            text = [layer.self_attn, layer.his_attn] + ([layer.src_attn, layer.cap_attn] if self.auto_encoder_ft in ("caption", "summary")
+                                                        else [layer.cap_attn, layer.src_attn])
+            sched = [(sl[j], m, j == 0) for j, m in enumerate(text)]
+            for i in range(nF):
+                sched += [(sl[4 + 4 * i], layer.auto_encoder_self_attn[i], True), (sl[5 + 4 * i], layer.auto_encoder_vid_attn[i], False),
+                          (sl[6 + 4 * i], layer.auto_encoder_feed_forward[i], None), (sl[7 + 4 * i], layer.auto_encoder_attn[i], False)]
+            sched.append((sl[4 + 4 * nF], layer.feed_forward, None))
+            for sc, mod, self_attn in sched:
+                f = mod._fused
+                if f is None or sc.norm._grads is None:
+                    continue
+                if isinstance(mod, MultiHeadedAttention):
+                    d = f["w_o"].size(0)
+                    K = 3 * d if self_attn else d        # a cross-attention's k | v blocks see the memory, not LayerNorm(x)
+                    pairs.append((sc, mod, f["w_qkv_lp"][:K], f["b_qkv"][:K]))
+                else:
+                    pairs.append((sc, mod, f["w1_lp"], f["b1"]))
+        if not pairs:
+            return
+        d = pairs[0][2].size(1)
+        if any(w.size(1) != d for _, _, w, _ in pairs) or d % 8 != 0 or d > 2048:
+            return
+        total = sum(2 * w.size(0) for _, _, w, _ in pairs)
+        buf = torch.zeros(total, device=dev, dtype=torch.float32)
+        descs = (L.LnFoldDesc * len(pairs))()
+        block_desc, off, blocks = [], 0, 0
+        for i, (sc, mod, w, b) in enumerate(pairs):
+            K = w.size(0)
+            view = buf[off:off + 2 * K]
+            descs[i].w, descs[i].bias, descs[i].a2, descs[i].b2 = w.data_ptr(), b.data_ptr(), sc.norm.a_2.data_ptr(), sc.norm.b_2.data_ptr()
+            descs[i].out, descs[i].K, descs[i].block_start = view.data_ptr(), K, blocks
+            nb = (K + 31) // 32
+            block_desc += [i] * nb
+            blocks += nb
+            off += 2 * K
+            sc._ln_fold = (id(mod), view)
+        table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        self._ln_fold_buf = buf
+        self._ln_fold_table = (table, torch.tensor(block_desc, dtype=torch.int32).to(dev), blocks, d)
+
+    def fold_layer_norms(self):
+        """Recompute the fold vectors from the current weights (one launch, mtn_ln_fold): once per forward that will be
+        differentiated — the weights change every step."""
+        t = self._ln_fold_table
+        if t is not None:
+            L.check(L.load().mtn_ln_fold(L.MTN_BF16, t[0].data_ptr(), t[1].data_ptr(), t[2], t[3], L.stream_ptr()))
+        self._ln_fold_stale = False
 
     def _apply(self, fn, *a, **kw):             # .cuda()/.to(): parameters are re-created -> re-flatten
         super()._apply(fn, *a, **kw)
@@ -718,6 +797,7 @@ class EncoderDecoder(nn.Module):
             L.check(L.load().mtn_cast_f32_to_lp(L.dtype_code(self.compute_dtype), self._flat.numel(), self._flat.data_ptr(),
                                                 self._flat_lp.data_ptr(), L.stream_ptr()))
             self._flat_version = ver
+            self._ln_fold_stale = True
             self.refresh_transposed()
         elif self._flat_lp is self._flat and ver != self._flat_version:
             self._flat_version = ver
@@ -839,6 +919,8 @@ class EncoderDecoder(nn.Module):
         """mtn.py:38-56 — every text stream goes through ``query_embed``; returns
         [q_mem, [vid_mem], cap_mem, his_mem, ae] with ae = list of auto-encoder seeds or None."""
         self.prepare()
+        if torch.is_grad_enabled():
+            self.fold_layer_norms()
         if self.training:
             self.advance_dropout_seed()
         self._embed_calls = 0

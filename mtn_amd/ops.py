@@ -396,6 +396,7 @@ class MhaConfig:
     w_o_lpT: Optional[torch.Tensor] = None
     grads: Optional[dict] = None                 # fp32 destinations: ln_a ln_b w_qkv b_qkv w_o b_o (flat-grad views)
     queue: Optional[ParamGradQueue] = None       # defer dW/db/LN-parameter work to the end of backward
+    ln_fold: Optional[torch.Tensor] = None       # fold vectors of w_qkv behind the sublayer's LayerNorm (mtn_ln_fold), float [2K]
 
 
 class MHASublayerFn(torch.autograd.Function):
@@ -479,6 +480,7 @@ class MHASublayerFn(torch.autograd.Function):
         args.d_ln_a, args.d_ln_b = d_ln_a.data_ptr(), d_ln_b.data_ptr()
         args.d_w_qkv, args.d_b_qkv, args.d_w_o, args.d_b_o = d_w_qkv.data_ptr(), d_b_qkv.data_ptr(), d_w_o.data_ptr(), d_b_o.data_ptr()
         args.ws_lp, args.ws_f32 = ws_lp.data_ptr(), ws_f32.data_ptr()
+        args.ln_fold = L.ptr(cfg.ln_fold)
         defer = g is not None and cfg.queue is not None
         args.defer_param_grads = int(defer)
         L.check(lib.mtn_mha_sublayer_bwd(code, C.byref(args), L.stream_ptr()))
@@ -506,6 +508,7 @@ class FfnConfig:
     w2_lpT: Optional[torch.Tensor] = None
     grads: Optional[dict] = None  # ln_a ln_b w1 b1 w2 b2
     queue: Optional[ParamGradQueue] = None
+    ln_fold: Optional[torch.Tensor] = None        # fold vectors of w1 (mtn_ln_fold), float [2 d_ff]
 
 
 class FFNSublayerFn(torch.autograd.Function):
@@ -574,6 +577,7 @@ class FFNSublayerFn(torch.autograd.Function):
         args.d_ln_a, args.d_ln_b = d_ln_a.data_ptr(), d_ln_b.data_ptr()
         args.d_w1, args.d_b1, args.d_w2, args.d_b2 = d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr()
         args.ws_lp, args.ws_f32 = ws_lp.data_ptr(), ws_f32.data_ptr()
+        args.ln_fold = L.ptr(cfg.ln_fold)
         defer = g is not None and cfg.queue is not None
         args.defer_param_grads = int(defer)
         L.check(lib.mtn_ffn_sublayer_bwd(code, C.byref(args), L.stream_ptr()))
@@ -776,6 +780,7 @@ class SublayerGroupFn(torch.autograd.Function):
                 A.d_ln_a, A.d_ln_b = g["ln_a"].data_ptr(), g["ln_b"].data_ptr()
                 A.d_w_qkv, A.d_b_qkv, A.d_w_o, A.d_b_o = g["w_qkv"].data_ptr(), g["b_qkv"].data_ptr(), g["w_o"].data_ptr(), g["b_o"].data_ptr()
                 A.ws_lp, A.ws_f32, A.defer_param_grads = ws_lp.data_ptr(), ws_f32.data_ptr(), 1
+                A.ln_fold = L.ptr(cfg.ln_fold)
                 A.dyl_ready, A.next_dyl = L.ptr(ready), L.ptr(nxt)
                 if nxt is not None:
                     A.next_drop = _drop(f["p"], f["salt"], f["seed"])
@@ -791,6 +796,7 @@ class SublayerGroupFn(torch.autograd.Function):
                 A.d_ln_a, A.d_ln_b = g["ln_a"].data_ptr(), g["ln_b"].data_ptr()
                 A.d_w1, A.d_b1, A.d_w2, A.d_b2 = g["w1"].data_ptr(), g["b1"].data_ptr(), g["w2"].data_ptr(), g["b2"].data_ptr()
                 A.ws_lp, A.ws_f32, A.defer_param_grads = ws_lp.data_ptr(), ws_f32.data_ptr(), 1
+                A.ln_fold = L.ptr(cfg.ln_fold)
                 A.dyl_ready, A.next_dyl = L.ptr(ready), L.ptr(nxt)
                 if nxt is not None:
                     A.next_drop = _drop(f["p"], f["salt"], f["seed"])
