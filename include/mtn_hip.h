@@ -176,11 +176,12 @@ typedef struct {
     int no_ln;
 } mtn_ln_fwd_desc;
 /* Embedding backward: dlut[tokens[row]] += dx[row] * emb_scale * keep(row*d+c)/(1-p).
- * Default: float atomic adds (rounding depends on arrival order — the only run-to-run noise on the whole path).  With
- * MTN_EMBED_DETERMINISTIC=1 in the environment and lut_rows > 0 on every descriptor (the vocabulary size of the table
- * behind dlut) the sum is bitwise reproducible: each vocabulary entry is owned by one wave (frequent entries by one
- * workgroup) that scans the token lists of all streams sharing the table and adds the matching rows in list order —
- * no atomics; measured 31 vs 13 us (uniform tokens) and 175 vs 69 us (ragged, 25 % pads) at cfg2 batch 32. */
+ * Default (lut_rows > 0 on every descriptor: the vocabulary size of the table behind dlut): bitwise reproducible — each
+ * vocabulary entry is owned by one wave (frequent entries by one workgroup) that scans the token lists of all streams sharing
+ * the table and adds the matching rows in list order, no atomics; measured 31 vs 13 us (uniform tokens) and 175 vs 69 us
+ * (ragged, 25 % pads) at cfg2 batch 32 against the alternative.  MTN_EMBED_DETERMINISTIC=0 in the environment (or lut_rows == 0)
+ * selects that alternative: float atomic adds, whose rounding depends on arrival order — then the only run-to-run noise on the
+ * whole path. */
 typedef struct {
     int rows, d;
     const long* tokens;
@@ -532,6 +533,9 @@ int mtn_assemble_features(int count, const mtn_assemble_features_desc* descs /* 
  * 1 <= k <= 16, V < 2^24.
  * ------------------------------------------------------------------------------------------ */
 int mtn_topk_rows(const float* x, int rows, int V, long ldx, int k, int extra_col, float* out, void* stream);
+/* Generator (mtn.py:62-69) at inference: out[row][c] = x[row][c] - logsumexp(x[row][0..V-1]) over logit rows x [rows, V] (row
+ * strides ldx / ldo; out may be x).  The logits themselves are one mtn_gemm (x W^T + b, fp32 out). */
+int mtn_log_softmax_rows(const float* x, int rows, int V, long ldx, float* out, long ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement support (bench.py `roofline`): a census of the GEMM launches of one step.  Between mtn_census_begin() and

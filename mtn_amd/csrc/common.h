@@ -116,12 +116,15 @@ __device__ __forceinline__ DropState drop_init(const mtn_dropout& d) {
     }
     return s;
 }
-// keep(idx) = lowbias32((lo(idx) ^ k0) + hi(idx) * DROP_HI_MUL) ^ k1, top 24 bits against p * 2^24: one 32-bit mixer per element
-// (two integer multiplies — they run at quarter rate on the vector ALU, and the attention kernels hash 16 elements per lane per tile)
+// keep(idx) = lowbias32((lo(idx) ^ k0) + hi(idx) * DROP_HI_MUL + k1), top 24 bits against p * 2^24: one 32-bit mixer per element
+// (two integer multiplies — they run at quarter rate on the vector ALU, and the attention kernels hash 16 elements per lane per tile).
+// BOTH key words enter BEFORE the mixer (round 4).  Until round 3 k1 was XORed onto the mixer's output: two streams with equal k0 —
+// seeds that differ only in their high word — were the same 24-bit values up to a fixed XOR, and their keep bits correlated
+// (rho = -0.11 at p = 0.1, tests/test_dropout_stream_gpu.py).  Same instruction count: an add in front instead of an xor behind.
 static constexpr uint32_t DROP_HI_MUL = 0x9E3779B1u;
 __device__ __forceinline__ bool drop_keep(const DropState& s, uint64_t idx) {
     const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-    const uint32_t r = mix32((lo ^ s.k0) + hi * DROP_HI_MUL) ^ s.k1;
+    const uint32_t r = mix32((lo ^ s.k0) + hi * DROP_HI_MUL + s.k1);
     return (r >> 8) >= s.thresh;
 }
 // The same function for idx = base + off with a (wave-)uniform 64-bit base and a 32-bit offset: the high word's term is prepared once
@@ -134,7 +137,7 @@ __device__ __forceinline__ DropBase drop_base(uint64_t base) {
 }
 __device__ __forceinline__ bool drop_keep_at(const DropState& s, const DropBase& b, uint32_t off) {
     const uint32_t lo = b.lo + off;
-    const uint32_t r = mix32((lo ^ s.k0) + b.hic + (lo < b.lo ? DROP_HI_MUL : 0u)) ^ s.k1;
+    const uint32_t r = mix32((lo ^ s.k0) + (b.hic + s.k1) + (lo < b.lo ? DROP_HI_MUL : 0u));
     return (r >> 8) >= s.thresh;
 }
 

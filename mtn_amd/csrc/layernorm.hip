@@ -823,8 +823,10 @@ __global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const EmbedDetGroup
 
 extern "C" int mtn_embed_bwd_group(int count, const mtn_embed_bwd_desc* descs, void* stream) {
     MTN_CHECK_ARG(count >= 1 && count <= MTN_LN_MAX_GROUP && descs, "bad group");
-    const char* det_env = MTN_ENV("MTN_EMBED_DETERMINISTIC");     // opt-in: 1-3 % of a cfg2 step slower than the atomic adds
-    bool det = det_env && det_env[0] != '0';
+    // Default since round 4: the atomic-free kernel (18 us of a 3.7 ms cfg2 step) — the whole train step is then bitwise reproducible
+    // run to run.  MTN_EMBED_DETERMINISTIC=0 selects the float-atomic scatter (faster on ragged batches with many pad tokens).
+    const char* det_env = MTN_ENV("MTN_EMBED_DETERMINISTIC");
+    bool det = !(det_env && det_env[0] == '0');
     for (int i = 0; i < count; ++i) det = det && descs[i].lut_rows > 0;
     if (det) {
         EmbedDetGroup g;

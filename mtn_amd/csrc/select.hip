@@ -80,3 +80,33 @@ extern "C" int mtn_topk_rows(const float* x, int rows, int V, long ldx, int k, i
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
+
+// ---------------------------------------------------------------- Generator: log-softmax of the logit rows (mtn.py:68-69)
+// out[row][c] = x[row][c] - (max + log sum exp(x - max)); one 256-thread workgroup per row, the row read twice (it sits in L2: a
+// decode step has beam x dialogues rows of |V| floats).  In place when out == x.
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int V, long ldx, float* __restrict__ out, long ldo) {
+    __shared__ float red[4];
+    const float* xr = x + (size_t)blockIdx.x * ldx;
+    float* orow = out + (size_t)blockIdx.x * ldo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int c = tid; c < V; c += 256) mx = fmaxf(mx, xr[c]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = tid; c < V; c += 256) sum += expf(xr[c] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float lse = mx + logf((red[0] + red[1]) + (red[2] + red[3]));
+    for (int c = tid; c < V; c += 256) orow[c] = xr[c] - lse;
+}
+extern "C" int mtn_log_softmax_rows(const float* x, int rows, int V, long ldx, float* out, long ldo, void* stream) {
+    MTN_CHECK_ARG(x && out && rows > 0 && V > 0 && ldx >= V && ldo >= V, "bad row matrix");
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, V, ldx, out, ldo);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}

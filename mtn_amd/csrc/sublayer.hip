@@ -278,9 +278,13 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
     }
     // LayerNorm backward in the epilogue of the stage-4 GEMM (mtn_ln_epilogue): every member brings the fold vectors of the Linear
     // behind its LayerNorm, and the kernels that produce dq | dh can emit the row-sum partials (the fused head backward; the dh GEMM)
-    bool lnepi = dtype == MTN_BF16 && !(MTN_ENV("MTN_LN_EPI") && MTN_ENV("MTN_LN_EPI")[0] == '0');
-    for (int i = 0; i < n_mha; ++i) lnepi = lnepi && mha[i].ln_fold && mha[i].d == 512 && mha[i].h == LN_PART_HEADS;
-    for (int i = 0; i < n_ffn; ++i) lnepi = lnepi && ffn[i].ln_fold && ffn[i].d_ff % 64 == 0 && ffn[i].d % 16 == 0 && ffn[i].d <= 512;
+    // The decision is per MEMBER (a member alone and the same member inside a lockstep group take the same path: the two
+    // schedules stay bitwise equal): a feed-forward member whenever its shapes allow, an attention member when the fused head backward
+    // runs for the group's attention members.
+    const bool epi_on = dtype == MTN_BF16 && !(MTN_ENV("MTN_LN_EPI") && MTN_ENV("MTN_LN_EPI")[0] == '0');
+    bool epi_m[MTN_SUBLAYER_MAX_GROUP], epi_f[MTN_SUBLAYER_MAX_GROUP];
+    for (int i = 0; i < n_mha; ++i) epi_m[i] = epi_on && mha[i].ln_fold && mha[i].d == 512 && mha[i].h == LN_PART_HEADS;
+    for (int i = 0; i < n_ffn; ++i) epi_f[i] = epi_on && ffn[i].ln_fold && ffn[i].d_ff % 64 == 0 && ffn[i].d % 16 == 0 && ffn[i].d <= 512;
     // Fused stage 2 + 3 of the attention members (csrc/fused_bwd.hip): dO of a head and the head's attention backward in one
     // kernel per (sample block, head); dO never goes to HBM
     FbIo io[MTN_SUBLAYER_MAX_GROUP];
@@ -289,16 +293,19 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
         const MhaWs w = mha_ws(a, dtype);
         const int d = a->d;
         io[i].dyl = w.dyl; io[i].dq = w.dqkv;
-        io[i].lnf = a->ln_fold; io[i].ln_part = (lnepi && a->ln_fold) ? w.ln_part : nullptr;
+        io[i].lnf = a->ln_fold; io[i].ln_part = epi_m[i] ? w.ln_part : nullptr;
         if (a->self_attn) { io[i].dk = lp_off(w.dqkv, d, dtype); io[i].dv = lp_off(w.dqkv, 2 * d, dtype); io[i].ldq = io[i].ldkv = 3 * d; }
         else { io[i].dk = w.dkv; io[i].dv = lp_off(w.dkv, d, dtype); io[i].ldq = d; io[i].ldkv = 2 * d; }
     }
     const bool fb = n_mha > 0 && fb_group_eligible(dtype, n_mha, mha, io) != 0;
-    if (n_mha > 0 && !fb) {                       // the per-stage attention backward emits no partials: the group keeps its LayerNorm launch
-        lnepi = false;
-        for (int i = 0; i < n_mha; ++i) io[i].ln_part = nullptr;
+    if (n_mha > 0 && !fb)                         // the per-stage attention backward emits no partials: those members keep the LayerNorm launch
+        for (int i = 0; i < n_mha; ++i) { io[i].ln_part = nullptr; epi_m[i] = false; }
+    {
+        bool any = false;
+        for (int i = 0; i < n_mha; ++i) any = any || epi_m[i];
+        for (int i = 0; i < n_ffn; ++i) any = any || epi_f[i];
+        if (any) ++g_ln_epi_groups;
     }
-    if (lnepi) ++g_ln_epi_groups;
     if (n_mha > 0) ++g_fused_counts[fb ? 2 : 3];
     if (fb) RUN(fb_group_bwd_stage(n_mha, mha, io, stream));
     // 2. dO = dyl Wo ;  dh = (dyl W2) * relu'(h) * hidden-dropout mask (both recovered from the saved hidden: hid > 0)
@@ -321,7 +328,7 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
             p[n].gate = a->hid;
             p[n].gate_scale = (a->drop_hidden.p > 0.f && a->drop_hidden.seed) ? 1.0f / (1.0f - a->drop_hidden.p) : 1.0f;
             p[n].out_lp = w.dh; p[n].ldc = ff;
-            if (lnepi) {                          // dh . u and dh . (pre-activation - c) per row and 64-column block, on the way out
+            if (epi_f[i]) {                       // dh . u and dh . (pre-activation - c) per row and 64-column block, on the way out
                 mtn_ln_epilogue& e = lne[n];
                 memset(&e, 0, sizeof(e));
                 e.mode = MTN_LN_EMIT; e.fold = a->ln_fold; e.gate_inv_scale = 1.0f / p[n].gate_scale; e.part = w.ln_part;
@@ -365,17 +372,17 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
             const MhaWs w = mha_ws(a, dtype);
             const int d = a->d, rows = a->B * a->a, rows_m = a->B * a->m;
             if (a->self_attn) {
-                p[n] = (a->w_qkv_t && !lnepi) ? gemm_init(w.dqkv, 3 * d, a->w_qkv_t, 3 * d, rows, d, 3 * d, 0, 0) : gemm_init(w.dqkv, 3 * d, a->w_qkv, d, rows, d, 3 * d, 0, 1);
+                p[n] = (a->w_qkv_t && !epi_m[i]) ? gemm_init(w.dqkv, 3 * d, a->w_qkv_t, 3 * d, rows, d, 3 * d, 0, 0) : gemm_init(w.dqkv, 3 * d, a->w_qkv, d, rows, d, 3 * d, 0, 1);
                 p[n].out_f32 = w.dxn; p[n].ldc = d;
-                if (lnepi) consume(p[n], a->x, a->ln_a, a->mean, a->rstd, a->ln_eps, a->dy, a->dx, a->next_dyl, a->next_drop, w.ln_part, LN_PART_HEADS, w.ln_partial);
+                if (epi_m[i]) consume(p[n], a->x, a->ln_a, a->mean, a->rstd, a->ln_eps, a->dy, a->dx, a->next_dyl, a->next_drop, w.ln_part, LN_PART_HEADS, w.ln_partial);
                 ++n;
             } else {
-                p[n] = (a->w_qkv_t && !lnepi) ? gemm_init(w.dqkv, d, a->w_qkv_t, 3 * d, rows, d, d, 0, 0) : gemm_init(w.dqkv, d, a->w_qkv, d, rows, d, d, 0, 1);
+                p[n] = (a->w_qkv_t && !epi_m[i]) ? gemm_init(w.dqkv, d, a->w_qkv_t, 3 * d, rows, d, d, 0, 0) : gemm_init(w.dqkv, d, a->w_qkv, d, rows, d, d, 0, 1);
                 p[n].out_f32 = w.dxn; p[n].ldc = d;
-                if (lnepi) consume(p[n], a->x, a->ln_a, a->mean, a->rstd, a->ln_eps, a->dy, a->dx, a->next_dyl, a->next_drop, w.ln_part, LN_PART_HEADS, w.ln_partial);
+                if (epi_m[i]) consume(p[n], a->x, a->ln_a, a->mean, a->rstd, a->ln_eps, a->dy, a->dx, a->next_dyl, a->next_drop, w.ln_part, LN_PART_HEADS, w.ln_partial);
                 ++n;
                 if (a->dmem) {
-                    p[n] = (a->w_qkv_t && !lnepi) ? gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv_t, d, dtype), 3 * d, rows_m, d, 2 * d, 0, 0)
+                    p[n] = (a->w_qkv_t && !epi_m[i]) ? gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv_t, d, dtype), 3 * d, rows_m, d, 2 * d, 0, 0)
                                                   : gemm_init(w.dkv, 2 * d, lp_off(a->w_qkv, (long)d * d, dtype), d, rows_m, d, 2 * d, 0, 1);
                     if (a->dmem_accumulate) { p[n].residual = a->dmem; p[n].ldr = d; }
                     if (a->dmem_lp) { p[n].out_lp = a->dmem_lp; p[n].drop = a->dmem_lp_drop; p[n].lp_drop_after_residual = 1; }
@@ -387,30 +394,32 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
             const mtn_ffn_args* a = &ffn[i];
             const FfnWs w = ffn_ws(a, dtype);
             const int d = a->d, ff = a->d_ff;
-            p[n] = (a->w1_t && !lnepi) ? gemm_init(w.dh, ff, a->w1_t, ff, a->rows, d, ff, 0, 0) : gemm_init(w.dh, ff, a->w1, d, a->rows, d, ff, 0, 1);
+            p[n] = (a->w1_t && !epi_f[i]) ? gemm_init(w.dh, ff, a->w1_t, ff, a->rows, d, ff, 0, 0) : gemm_init(w.dh, ff, a->w1, d, a->rows, d, ff, 0, 1);
             p[n].out_f32 = w.dxn; p[n].ldc = d;
-            if (lnepi) consume(p[n], a->x, a->ln_a, a->mean, a->rstd, a->ln_eps, a->dy, a->dx, a->next_dyl, a->next_drop, w.ln_part, ff / 64, w.ln_partial);
+            if (epi_f[i]) consume(p[n], a->x, a->ln_a, a->mean, a->rstd, a->ln_eps, a->dy, a->dx, a->next_dyl, a->next_drop, w.ln_part, ff / 64, w.ln_partial);
             ++n;
         }
-        RUN(run_gemms(dtype, n, p, stream));      // (lnepi: every problem has b_trans = 1 -> one launch, memory gradients included)
+        RUN(run_gemms(dtype, n, p, stream));      // (one launch: the training step keeps no transposed copies of these weights, b_trans = 1 throughout)
     }
     // 5. LayerNorm backward fused with the residual-branch gradient (critical path: dx only)
-    if (!lnepi) {
+    {
         mtn_ln_bwd_desc L[2 * MTN_SUBLAYER_MAX_GROUP];
         int n = 0;
         for (int i = 0; i < n_mha; ++i) {
+            if (epi_m[i]) continue;               // done in the epilogue of the member's stage-4 problem
             const mtn_mha_args* a = &mha[i];
             const MhaWs w = mha_ws(a, dtype);
             L[n++] = mtn_ln_bwd_desc{a->B * a->a, a->d, a->ln_eps, a->x, a->ln_a, a->mean, a->rstd, w.dxn, a->dy, a->dx, w.ln_partial,
                                      a->next_dyl, dtype, a->next_drop};
         }
         for (int i = 0; i < n_ffn; ++i) {
+            if (epi_f[i]) continue;
             const mtn_ffn_args* a = &ffn[i];
             const FfnWs w = ffn_ws(a, dtype);
             L[n++] = mtn_ln_bwd_desc{a->rows, a->d, a->ln_eps, a->x, a->ln_a, a->mean, a->rstd, w.dxn, a->dy, a->dx, w.ln_partial,
                                      a->next_dyl, dtype, a->next_drop};
         }
-        RUN(mtn_layernorm_bwd_group(n, L, stream));
+        if (n) RUN(mtn_layernorm_bwd_group(n, L, stream));
     }
     // 6. parameter gradients (off the critical path): now, unless the caller batches them across sublayers
     {

@@ -149,6 +149,7 @@ SYMBOLS = {
     "mtn_assemble_tokens": (C.c_int, [C.c_int, C.POINTER(AssembleTokensDesc), _P]),
     "mtn_assemble_features": (C.c_int, [C.c_int, C.POINTER(AssembleFeaturesDesc), _P]),
     "mtn_topk_rows": (C.c_int, [_P, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, _P, _P]),
+    "mtn_log_softmax_rows": (C.c_int, [_P, C.c_int, C.c_int, C.c_long, _P, C.c_long, _P]),
     "mtn_census_begin": (C.c_int, []),
     "mtn_census_end": (C.c_int, []),
     "mtn_census_info": (C.c_int, [C.c_int, C.POINTER(CensusLaunch)]),

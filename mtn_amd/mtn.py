@@ -507,6 +507,12 @@ class Generator(nn.Module):
         self._fused = None          # compute-dtype weight / flat-gradient views (fused loss head), set at flatten
 
     def forward(self, x):                      # mtn.py:68-69
+        f = self._fused
+        if f is not None and x.is_cuda and not torch.is_grad_enabled() and f["w_lp"].device == x.device and x.size(-1) % 8 == 0:
+            # inference (decode, validation): the library's GEMM + row log-softmax (ops.generator_log_probs) — no vendor BLAS /
+            # softmax kernels in a decode step.  The composed form below stays for callers that differentiate through it.
+            f["prepare"]()                     # the compute-dtype weight copy follows the fp32 master (load_state_dict, torch optimisers)
+            return ops.generator_log_probs(x, f["w_lp"], f["bias"])
         return F.log_softmax(self.proj(x), dim=-1)
 
 
@@ -685,6 +691,7 @@ class EncoderDecoder(nn.Module):
                     fusable.append((o_w, vocab, dm))
                     optional.add(o_w)            # its dW reaches the queue only through the fused loss head
                 m._fused["queue"] = self._queue
+                m._fused["prepare"] = self.prepare
             elif isinstance(m, LayerNorm) and id(m.a_2) in path_off:
                 m._grads = (views(m.a_2)[2], views(m.b_2)[2])
                 m._lp_dtype = lp

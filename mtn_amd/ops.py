@@ -818,6 +818,26 @@ class SublayerGroupFn(torch.autograd.Function):
         return (None, *grads_out)
 
 
+def generator_log_probs(x, w_lp, bias):
+    """Generator.forward at inference (mtn.py:68-69: log_softmax(proj(x))) on the HIP path: x (..., d) fp32 or compute dtype ->
+    (..., V) fp32 log-probabilities.  One grouped-GEMM launch (x W^T + b, fp32 logits) and one row kernel (csrc/select.hip) —
+    no vendor BLAS / softmax kernels in a decode step.  No autograd: training goes through GeneratorLossFn (fused loss head)."""
+    _require_cuda(x, w_lp)
+    lib = L.load()
+    lp = w_lp.dtype
+    V, d = w_lp.shape
+    a = x.reshape(-1, d)
+    a = a.contiguous() if a.dtype == lp else cast_to_lp(a.contiguous(), lp)
+    rows = a.size(0)
+    out = torch.empty(rows, V, device=x.device, dtype=torch.float32)
+    pr = L.GemmProblem()
+    pr.A, pr.B, pr.lda, pr.ldb, pr.M, pr.N, pr.K = a.data_ptr(), w_lp.data_ptr(), d, d, rows, V, d
+    pr.bias, pr.gate_scale, pr.out_f32, pr.ldc = bias.data_ptr(), 1.0, out.data_ptr(), V
+    gemm(L.dtype_code(lp), [pr])
+    L.check(lib.mtn_log_softmax_rows(out.data_ptr(), rows, V, V, out.data_ptr(), V, L.stream_ptr()))
+    return out.view(*x.shape[:-1], V)
+
+
 def topk_rows(x, k, extra_col=-1):
     """x (rows, V) fp32 -> (rows, 2k+1) fp32: per row its k largest entries in descending order, their column indices (as floats)
     and x[row, extra_col] — the part of a log-probability row the beam search looks at (data_utils.py:219), csrc/select.hip."""

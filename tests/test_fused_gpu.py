@@ -120,12 +120,15 @@ def _rand_cfg(seed):
     r = random.Random(seed)
     nF = r.choice([1, 2])
     return dict(vocab=r.randint(40, 150), N=1, d_model=512, d_ff=r.choice([1024, 2048]), h=8, ft_sizes=[r.choice([24, 40, 64]) for _ in range(nF)],
-                B=r.randint(1, 9), Q=r.randint(2, 34), H=r.randint(2, 150), C=r.randint(2, 70), T=r.randint(2, 34),
+                B=r.randint(1, 9), Q=r.randint(2, 34), H=r.randint(2, 150), C=r.randint(3, 70), T=r.randint(2, 34),     # (captions: the fixture generator draws >= 3 tokens)
                 frames=[r.randint(2, 40) for _ in range(nF)], diff_encoder=r.random() < 0.7, diff_embed=False, diff_gen=False,
                 auto_encoder_ft=r.choice(["query", "caption"]))
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MTN_FUZZ_N", "10")))))      # (80 seeds were run once: 78 pass, 1 at cosine 0.99896 with 3 samples, 1 shape the fixture generator cannot draw)
+# Round 3 ran 80 seeds once: 78 passed, one sat at cosine 0.99896 (3 samples) and one drew a shape the fixture generator cannot
+# build.  Round 4 (LayerNorm backward in the GEMM epilogue, MTN_FUZZ_N=80): the 78 drawable seeds all pass at the bars below — the
+# near-miss did not reproduce — and the two undrawable ones (a 2-token caption) are gone from the generator above.
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MTN_FUZZ_N", "10")))))
 def test_fused_random_shapes_equal_four_launch_path(dev, seed):
     """Random batch sizes and sequence lengths (1 .. just past the kernels' tilings: 32 query rows, 128-row memories, odd sample
     counts per workgroup, two-row sequences), dropout on: outputs and gradients with the fused launches on vs off.  Shapes outside
@@ -291,3 +294,57 @@ def test_fused_layer_gradients_match_oracle(dev, T):
         got, want = dl[k].grad.float().flatten().cpu(), ol[k].grad.flatten()
         cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
         assert relmax(got, want) < 4e-2 and cos > 0.9995, (k, relmax(got, want), cos)
+
+
+def _round_like_the_device(sd, c):
+    """The fixture weights as the bf16 path sees them: every matrix that is a GEMM operand on the device (the compute-dtype copy of
+    the flat parameter buffer) rounded to bf16; vectors (biases, LayerNorm gains) and the embedding tables stay fp32 there."""
+    out = {}
+    for k, v in sd.items():
+        is_operand = v.dim() == 2 and (".linears." in k or ".w_1." in k or ".w_2." in k or k.startswith("vid_encoder.") or "generator" in k)
+        out[k] = (v.to(torch.bfloat16) if is_operand else v).double()
+    return out
+
+
+@pytest.mark.parametrize("name", ["query_b5", "caption_b3"])
+def test_fused_gradients_match_fp64_oracle_on_rounded_operands(dev, name):
+    """The tight version of the bf16 gradient check: the oracle runs in fp64 on exactly the operands the
+    device path sees (weights and input features rounded to bf16), so what is left between the two is the path's own rounding of
+    ACTIVATIONS (xn, q|k|v, P, o, hidden, the bf16 gradient operands) — not the 2^-9 perturbation of every weight that the plain
+    bf16-vs-fp32 comparison of tests/test_model_gpu.py has to allow for with its 0.25 per-tensor bar.  Fused kernels on (forward,
+    backward, LayerNorm backward in the GEMM epilogue), dropout off, loss = sum of the mean squares of the decoder outputs."""
+    from mtn_amd import lib
+    from oracle.mtn_oracle import OracleMTN
+    c = CFGS[name]
+    model = build_model(c, torch.bfloat16, dev).eval()
+    raw = raw_batch(c)
+    b = dev_batch(raw, dev)
+    n0 = lib.fused_counters()
+    _, got = _run(model, b, fused=True, train=True)
+    n1 = lib.fused_counters()
+    assert n1[0] > n0[0] and n1[2] > n0[2], "the fused kernels did not run"
+    _, ocfg = fx.oracle_from_config(c)
+    sd = {k: v.clone().requires_grad_(True) for k, v in _round_like_the_device(fx.det_state_dict(fx.state_shapes(**c), 0), c).items()}
+    ob = fx.oracle_batch(raw)
+    ob.fts = [f.to(torch.bfloat16).double() for f in ob.fts]
+    out, ae = OracleMTN(ocfg, sd).forward(ob)
+    loss = (out ** 2).mean() + sum((a ** 2).mean() for a in ae)
+    loss.backward()
+    worst, worst_k, dot, n1_, n2_ = 0.0, None, 0.0, 0.0, 0.0
+    for k, g in got.items():
+        ref = sd[k].grad
+        if ref is None or float(ref.abs().max()) == 0.0 or k.endswith("linears.1.bias"):
+            continue
+        g64 = g.double().cpu()
+        e = relmax(g64, ref)
+        if e > worst and ".w_1." not in k:
+            worst, worst_k = e, k
+        dot += float((g64 * ref).sum()); n1_ += float(g64.norm()) ** 2; n2_ += float(ref.norm()) ** 2
+        cos = float((g64 * ref).sum() / (g64.norm() * ref.norm() + 1e-300))
+        # (w_1: a hidden unit whose pre-activation rounds across zero flips its ReLU gate and moves single entries of this gradient
+        #  by a few percent of the largest one — the same effect, and bar, as in test_fused_backward_equals_four_launch_path)
+        assert e < (1e-1 if ".w_1." in k else 3e-2), (k, e)
+        assert cos > 0.9995, (k, cos)
+    cos_all = dot / (n1_ ** 0.5 * n2_ ** 0.5)
+    print(f"{name}: worst per-tensor gradient error (relative to max, w_1 aside) {worst:.2e} at {worst_k}; cosine over all tensors {cos_all:.7f}")
+    assert cos_all > 0.99995, cos_all

@@ -45,13 +45,18 @@ static float bf2f(bf16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f
 template <int KS>
 __global__ __launch_bounds__(512) void seam_kernel(const bf16_t* __restrict__ S, int lds_, const bf16_t* __restrict__ W, int ldw,
                                                    const float* __restrict__ x, const float* __restrict__ bias, float* slabs,
-                                                   unsigned* cnt, float* __restrict__ y, int rows, int mode) {
+                                                   unsigned* cnt, float* __restrict__ y, int rows, int mode, int same_xcd) {
     constexpr int CH = KS / 8;                       // 16-byte chunks per tile row
     constexpr int NK = KS / 32;                      // contraction steps
     __shared__ __attribute__((aligned(16))) unsigned char smem[ROWS_WG * KS * 2 + 16];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rb = blockIdx.x >> 3, slice = blockIdx.x & 7;     // id % 8 = slice: an XCD streams one weight panel
+    // placement 0: id % 8 = slice — an XCD streams one weight panel, the 8 slabs of a row block come from 8 XCDs (round 3);
+    // placement 1 (round 4): the 8 slices of a row block on ONE XCD (workgroup id % 8 = XCD): the last
+    // arriver's slab reads stay inside one L2 (guide, handoff-payload: 104-122 GB/s same-XCD with plain producer stores vs 62-70)
+    int rb = blockIdx.x >> 3, slice = blockIdx.x & 7;
+    if (same_xcd) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; rb = (j >> 3) * 8 + xcd; slice = j & 7; }
+    if (rb * ROWS_WG >= rows) return;
     const int row0 = rb * ROWS_WG;
     const int R = rows - row0 < ROWS_WG ? rows - row0 : ROWS_WG;
     // ---- the slice tile [32][KS] -> LDS (16-byte chunks swizzled with row & 7); the fused kernel holds this image already
@@ -149,14 +154,15 @@ __global__ __launch_bounds__(512) void seam_kernel(const bf16_t* __restrict__ S,
 
 template <int KS>
 static float time_seam(const bf16_t* S, const bf16_t* W, const float* x, const float* bias, float* slabs, unsigned* cnt, float* y, int rows, int mode,
-                       hipStream_t st, int reps) {
-    const int nrb = (rows + ROWS_WG - 1) / ROWS_WG;
+                       hipStream_t st, int reps, int same_xcd = 0) {
+    int nrb = (rows + ROWS_WG - 1) / ROWS_WG;
+    if (same_xcd) nrb = (nrb + 7) / 8 * 8;              // row blocks dealt to the 8 XCDs: padding workgroups leave at once
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(seam_kernel<KS>, dim3(nrb * NSLICE), dim3(512), 0, st, S, NSLICE * KS, W, NSLICE * KS, x, bias, slabs, cnt, y, rows, mode);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(seam_kernel<KS>, dim3(nrb * NSLICE), dim3(512), 0, st, S, NSLICE * KS, W, NSLICE * KS, x, bias, slabs, cnt, y, rows, mode, same_xcd);
     CK(hipEventRecord(e0, st));
     for (int i = 0; i < reps; ++i) {
-        hipLaunchKernelGGL(seam_kernel<KS>, dim3(nrb * NSLICE), dim3(512), 0, st, S, NSLICE * KS, W, NSLICE * KS, x, bias, slabs, cnt, y, rows, mode);
+        hipLaunchKernelGGL(seam_kernel<KS>, dim3(nrb * NSLICE), dim3(512), 0, st, S, NSLICE * KS, W, NSLICE * KS, x, bias, slabs, cnt, y, rows, mode, same_xcd);
         if (mode == 1 || mode == 3) (void)hipMemsetAsync(cnt, 0, nrb * 4, st);      // (no last arriver to reset the tickets; costs the same in every mode-1/3 run)
     }
     CK(hipEventRecord(e1, st));
@@ -185,7 +191,7 @@ static float time_gemm(const bf16_t* S, const bf16_t* W, const float* x, const f
 }
 
 template <int KS> static void run_case(const char* name, int rows, hipStream_t st) {
-    const int K = NSLICE * KS, nrb = (rows + ROWS_WG - 1) / ROWS_WG;
+    const int K = NSLICE * KS, nrb = ((rows + ROWS_WG - 1) / ROWS_WG + 7) / 8 * 8;
     std::vector<bf16_t> hS((size_t)rows * K), hW((size_t)D * K);
     std::vector<float> hx((size_t)rows * D), hb(D);
     uint32_t seed = 12345u + rows + KS;
@@ -207,6 +213,12 @@ template <int KS> static void run_case(const char* name, int rows, hipStream_t s
     const float t_plain = time_seam<KS>(S, W, x, b, slabs, cnt, y, rows, 2, st, reps);
     CK(hipMemset(cnt, 0, nrb * 4));
     const float t_full = time_seam<KS>(S, W, x, b, slabs, cnt, y, rows, 0, st, reps);
+    CK(hipMemset(cnt, 0, nrb * 4));
+    const float x_pub = time_seam<KS>(S, W, x, b, slabs, cnt, y, rows, 1, st, reps, 1);
+    CK(hipMemset(cnt, 0, nrb * 4));
+    const float x_plain = time_seam<KS>(S, W, x, b, slabs, cnt, y, rows, 2, st, reps, 1);
+    CK(hipMemset(cnt, 0, nrb * 4));
+    const float x_full = time_seam<KS>(S, W, x, b, slabs, cnt, y, rows, 0, st, reps, 1);
     // correctness of the full seam against the library GEMM (same operands; different summation order: fp32 rounding only)
     std::vector<float> a((size_t)rows * D), r((size_t)rows * D);
     CK(hipMemcpy(a.data(), y, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r.data(), yref, r.size() * 4, hipMemcpyDeviceToHost));
@@ -215,6 +227,8 @@ template <int KS> static void run_case(const char* name, int rows, hipStream_t s
     printf("%-28s rows %5d K %5d | grouped GEMM launch %6.2f us | seam kernel: floor (launch + tile + panel loads) %6.2f, + MFMA + write-through slabs + ticket %6.2f,"
            " + last-arriver combine %6.2f us (plain stores + release fence instead: %6.2f) | in-kernel cost of the seam %6.2f us vs launch %6.2f us | max|diff|/max|ref| %.2e\n",
            name, rows, K, t_gemm, t_floor, t_pub, t_full, t_plain, t_full - t_floor, t_gemm, md / mr);
+    printf("%-28s   ... a row block's 8 slices on ONE XCD: publish + ticket %6.2f, + combine: write-through slabs %6.2f, plain stores + release fence %6.2f us"
+           " | in-kernel cost %6.2f / %6.2f us vs launch %6.2f us\n", "", x_pub, x_full, x_plain, x_full - t_floor, x_plain - t_floor, t_gemm);
     CK(hipFree(S)); CK(hipFree(W)); CK(hipFree(x)); CK(hipFree(b)); CK(hipFree(slabs)); CK(hipFree(y)); CK(hipFree(yref)); CK(hipFree(cnt));
 }
 
