@@ -282,6 +282,7 @@ struct LnEpiSlot {
     float* dx;
     void* dx_lp;
     float* colpart;
+    void* ya;
     mtn_dropout dx_lp_drop;
     float gate_inv_scale, eps;
 };
@@ -421,7 +422,7 @@ __device__ __forceinline__ void ln_consume_epilogue(const LnEpiSlot& E, LnConsum
 // MTN_LN_EMIT: the row-sum partials of a GEMM that produces dq itself.  p1[i], p2[i]: this lane's sums over its own columns of
 // row tile i; summed over the lane groups, then over the WCN waves that share the tile's rows (through LDS, in wave order), and
 // stored as pair `blk` (the tile's 64-column block) of the row.
-template <int RT, int BMT, int WCN>
+template <int RT, int BMT, int WCN, int GRPW = WCN>       // GRPW = waves (across the columns) that share one partial block
 __device__ __forceinline__ void ln_emit_partials(const LnEpiSlot& E, float (&p1)[RT], float (&p2)[RT], const int M, const int nblk, const int blk,
                                                  const int tile_row0, const int row_base, const int wc, const int l15, const int lg, const int tid, float* lds) {
 #pragma unroll
@@ -435,11 +436,15 @@ __device__ __forceinline__ void ln_emit_partials(const LnEpiSlot& E, float (&p1)
         }
     }
     __syncthreads();
-    if (tid < BMT && tile_row0 + tid < M) {
-        float s1 = 0.f, s2 = 0.f;
+    constexpr int NB = WCN / GRPW;                         // partial blocks per tile row
+    if (tid < BMT * NB) {
+        const int lr = tid / NB, b = tid - lr * NB;
+        if (tile_row0 + lr < M) {
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < WCN; ++w) { s1 += lds[(tid * WCN + w) * 2]; s2 += lds[(tid * WCN + w) * 2 + 1]; }
-        ((float2*)E.part)[(size_t)(tile_row0 + tid) * nblk + blk] = make_float2(s1, s2);
+            for (int w = 0; w < GRPW; ++w) { s1 += lds[(lr * WCN + b * GRPW + w) * 2]; s2 += lds[(lr * WCN + b * GRPW + w) * 2 + 1]; }
+            ((float2*)E.part)[(size_t)(tile_row0 + lr) * nblk + blk + b] = make_float2(s1, s2);
+        }
     }
 }
 
@@ -866,8 +871,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
                 for (int j = 0; j < TN; ++j) {
                     const int col = col0 + wc * (BN / WC) + j * 16 + lg * 4;
                     const int cc = col < N ? col : 0;
-                    emit_u[j] = *(const float4*)(E.fold + cc);
-                    emit_c[j] = *(const float4*)(E.fold + N + cc);
+                    if (E.mode == MTN_LN_FWD_EMIT) emit_u[j] = *(const float4*)(E.a2 + cc);          // the consuming LayerNorm's gains
+                    else {
+                        emit_u[j] = *(const float4*)(E.fold + cc);
+                        emit_c[j] = *(const float4*)(E.fold + N + cc);
+                    }
                 }
             }
         }
@@ -990,8 +998,39 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
                 ln_consume_epilogue<TM, TN, BM>(E, lnq, acc, M, N, row0, row0 + wr * (BM / 2), col0 + wc * (BN / WC), l15, lg, tid, (float*)(smem + NBUF * STAGE_BYTES));
                 return;
             }
-            // MTN_LN_EMIT: the ordinary epilogue, and the two dot products of the stored values on the way
             float p1[TM], p2[TM];
+            if (lne_mode == MTN_LN_FWD_EMIT) {
+                // the ordinary epilogue (y = x + dropout(...) in fp32), y * a2 in the compute dtype for the next sublayer's fused kernel, and the
+                // row's {sum y, sum y^2} per 32-column block for its LayerNorm statistics
+                static_assert(BN / WC == 16 && TN == 1, "a wave owns one 16-column block of the tile's rows");
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    p1[i] = p2[i] = 0.f;
+                    const int row = row0 + wr * (BM / 2) + i * 16 + l15;
+                    if (row >= M) continue;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = col0 + wc * (BN / WC) + j * 16 + lg * 4;
+                        if (col >= N) continue;
+                        float v[4];
+                        epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], nullptr, nullptr, v, nullptr);
+                        p1[i] += (v[0] + v[1]) + (v[2] + v[3]);
+                        p2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                        store_lp4<T>((T*)E.ya + (size_t)row * N + col, make_float4(v[0] * emit_u[j].x, v[1] * emit_u[j].y, v[2] * emit_u[j].z, v[3] * emit_u[j].w));
+                    }
+                }
+                // one pair per row and 16-column block — this wave's own columns: no exchange with the other waves, the stores leave
+                // with the tile's other stores (an LDS round + barrier here put a second store generation at the kernel's tail)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float s1 = fh_cross_sum(p1[i]), s2 = fh_cross_sum(p2[i]);
+                    const int row = row0 + wr * (BM / 2) + i * 16 + l15;
+                    if (lg == 0 && row < M && col0 + wc * (BN / WC) < N)
+                        ((float2*)E.part)[(size_t)row * (N / 16) + (col0 + wc * (BN / WC)) / 16] = make_float2(s1, s2);
+                }
+                return;
+            }
+            // MTN_LN_EMIT: the ordinary epilogue, and the two dot products of the stored values on the way
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 p1[i] = p2[i] = 0.f;
@@ -1764,12 +1803,12 @@ static int launch_dma_impl(const GemmGroup& grp, const typename LnArg<LNE>::type
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
-// `lne` (launches with a LayerNorm-backward epilogue, mtn_ln_epilogue): only the shapes the backward dX GEMMs take are instantiated
-// with it — bf16, B as the weight lies, a tile whose rows are dealt to groups of eight threads
+// `lne` (launches with a LayerNorm epilogue, mtn_ln_epilogue): only the tile shapes the step's launches take are instantiated with it —
+// bf16, a square tile whose rows are dealt to groups of eight threads (64 x 64 on eight waves, 32 x 32 on four), either B layout
 template <typename T, int BM, int BN, int ROWB, bool BTR = false, int NBUF = 2, int NW = 4>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s, const LnEpiGroup* lne = nullptr) {
     if (lne) {
-        if constexpr (sizeof(T) == 2 && BTR && NBUF == 2 && 64 * NW == 8 * BM && BM == BN)
+        if constexpr (sizeof(T) == 2 && NBUF == 2 && 64 * NW == 8 * BM && BM == BN)
             return launch_dma_impl<T, BM, BN, ROWB, BTR, NBUF, NW, true>(grp, *lne, tiles, s);
         mtn_set_error("mtn_gemm: no LayerNorm-epilogue form of this kernel (tile %d x %d, stage %d B, %d waves)", BM, BN, ROWB, NW);
         return MTN_ERR_ARG;
@@ -1881,8 +1920,8 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
     bool btr_ok = bt && sizeof(T) == 2 && MTN_ENV("MTN_GEMM_NT_REG") == nullptr;
     for (int i = 0; i < grp.count && btr_ok; ++i)
         btr_ok = grp.p[i].N % 8 == 0 && grp.p[i].ldb % 8 == 0 && (long)grp.p[i].K * grp.p[i].ldb * 2 < (1L << 31);
-    if (lne && !(!at && dma_ok && btr_ok)) {
-        mtn_set_error("mtn_gemm: a LayerNorm epilogue needs the LDS-DMA kernel (bf16, a_trans = 0, b_trans = 1, aligned operands, <= 4096 tiles)");
+    if (lne && !(!at && dma_ok && (!bt || btr_ok))) {
+        mtn_set_error("mtn_gemm: a LayerNorm epilogue needs the LDS-DMA kernel (bf16, a_trans = 0, aligned operands, a grid of at most 640 / 4096 tiles)");
         return MTN_ERR_ARG;
     }
     if (!at && dma_ok && (!bt || btr_ok)) {
@@ -2028,14 +2067,17 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
         grp.p[i].ln = nullptr;
         if (p.ln && p.ln->mode != 0) {
             const mtn_ln_epilogue& e = *p.ln;
-            MTN_CHECK_ARG(dtype == MTN_BF16 && !p.a_trans && p.b_trans && !p.adam, "LayerNorm epilogue: bf16 dX = dY W problems only");
+            MTN_CHECK_ARG(dtype == MTN_BF16 && !p.a_trans && !p.adam && (p.b_trans || e.mode == MTN_LN_FWD_EMIT), "LayerNorm epilogue: bf16; dX = dY W problems (backward modes) or a forward Linear (MTN_LN_FWD_EMIT)");
             MTN_CHECK_ARG(n_lne < LNE_MAX_SLOTS, "LayerNorm epilogue: too many problems with one in this launch");
             MTN_CHECK_ARG(e.part, "LayerNorm epilogue: null row-sum partial buffer");
             LnEpiSlot& sl = lne.s[n_lne];
             sl.mode = e.mode; sl.np = e.np; sl.fold = e.fold; sl.part = e.part;
             sl.x = e.x; sl.a2 = e.a2; sl.mean = e.mean; sl.rstd = e.rstd; sl.dres = e.dres; sl.dx = e.dx; sl.dx_lp = e.dx_lp;
-            sl.colpart = e.colpart; sl.dx_lp_drop = e.dx_lp_drop; sl.gate_inv_scale = e.gate_inv_scale; sl.eps = e.eps;
-            if (e.mode == MTN_LN_EMIT) {
+            sl.colpart = e.colpart; sl.dx_lp_drop = e.dx_lp_drop; sl.gate_inv_scale = e.gate_inv_scale; sl.eps = e.eps; sl.ya = e.ya;
+            if (e.mode == MTN_LN_FWD_EMIT) {
+                MTN_CHECK_ARG(e.a2 && e.ya && p.N % 32 == 0 && p.out_f32 && ((((uintptr_t)e.a2) | ((uintptr_t)e.ya) | ((uintptr_t)e.part)) & 15) == 0,
+                              "LayerNorm epilogue (forward emit): gains, a compute-dtype ya, N % 32 == 0, an fp32 output");
+            } else if (e.mode == MTN_LN_EMIT) {
                 MTN_CHECK_ARG(e.fold && p.N % 64 == 0 && p.out_lp && (((uintptr_t)e.fold) & 15) == 0, "LayerNorm epilogue (emit): fold vectors, N % 64 == 0, a compute-dtype output");
                 lne_emit = true;
             } else {
@@ -2071,7 +2113,8 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     const char* dmax = MTN_ENV("MTN_GEMM_DMA_MAX_TILES");
     // (b_trans = 1: the register-staged <N,T> fallback is 1.5x slower than <N,N> — 33.7 vs 21.7 us on the memories' dX launch,
     //  the LDS-DMA kernel with half stages 24.2: tools/nt_gemm_probe.py — so the LDS-DMA kernel keeps those too)
-    bool dma_ok = !problems[0].rowsum_out && tiles <= (dmax ? atoi(dmax) : (problems[0].b_trans && !problems[0].a_trans ? 4096 : 640));
+    // (a launch with a LayerNorm epilogue stays on the LDS-DMA kernels whatever its grid: the epilogue lives there)
+    bool dma_ok = !problems[0].rowsum_out && (n_lne > 0 || tiles <= (dmax ? atoi(dmax) : (problems[0].b_trans && !problems[0].a_trans ? 4096 : 640)));
     const long esz = (dtype == MTN_BF16) ? 2 : 4;
     for (int i = 0; i < count; ++i) {
         const mtn_gemm_problem& p = problems[i];

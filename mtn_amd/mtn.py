@@ -33,6 +33,13 @@ ATTN_DROPOUT_DEFAULT = 0.1   # mtn.py:339 builds MultiHeadedAttention(h, d_model
 _HANDOFF = os.environ.get("MTN_NO_HANDOFF") != "1"
 
 
+def _ln_lin_on() -> bool:
+    """LayerNorm FORWARD by linearity (producer-side statistics + pre-scaled bf16 rows, include/mtn_hip.h MTN_LN_FWD_EMIT): built and
+    measured in round 4, OFF by default — the fused kernels gain 58 us per cfg2 step, the producers' epilogues pay 71 (DESIGN.md §11,
+    profiles/r04_k_ln_forward_by_linearity.txt).  MTN_LN_LIN=1 turns it on (read per call: the tests flip it)."""
+    return os.environ.get("MTN_LN_LIN") == "1"
+
+
 # ------------------------------------------------------------------------------------------ leaf modules
 class LayerNorm(nn.Module):
     """a_2 * (x - mean) / (std_unbiased + eps) + b_2  (mtn.py:103-114) on the HIP kernel."""
@@ -129,7 +136,7 @@ class SublayerConnection(nn.Module):
 
     def _fold_for(self, module):
         f = self._ln_fold
-        if f is None or f[0] != id(module) or not torch.is_grad_enabled():
+        if f is None or f[0] != id(module):
             return None
         o = self._owner
         if o is not None and o._ln_fold_stale:      # the weights changed since the vectors were computed (a caller that skips encode())
@@ -228,8 +235,17 @@ class DecoderLayer(nn.Module):
         computed by one lockstep group (ops.SublayerGroupFn: shared launches).  raw_memory_outputs: the feed-forward outputs are
         attended as un-projected memory later (the auto-encoder streams, mtn.py:215): they also leave in the compute dtype."""
         members, tensors = [], []
-        for sc, mod, mem, mask, inp in items:
+        for it in items:
+            sc, mod, mem, mask, inp = it[:5]
+            nxt = it[5] if len(it) > 5 else None          # the SublayerConnection that will read this member's output (or None)
             mb = sc.member(mod, mem, mask)
+            # LayerNorm forward by linearity (include/mtn_hip.h, MTN_LN_FWD_EMIT): the member's output-projection GEMM leaves
+            # y * (the reader's LayerNorm gains) in the compute dtype and the rows' statistics partials; the reader finds them on y
+            if nxt is not None and mb.cfg.lp_dtype == torch.bfloat16 and inp.size(-1) == 512 and _ln_lin_on():
+                mb.next_ln_a = nxt.norm.a_2
+            xa = getattr(inp, "_mtn_xa", None)
+            if xa is not None and xa[0] is sc.norm.a_2 and mb.cfg.ln_fold is not None:
+                mb.xa = xa
             mb.want_lp = raw_memory_outputs and mb.kind == "ffn"
             kv = getattr(sc, "_kv_ready", None)        # K|V of a constant memory projected ahead of the layer loop
             if kv is not None and mb.kind == "mha" and mem is not None and kv.size(0) == mem.size(0) * mem.size(1):
@@ -249,6 +265,8 @@ class DecoderLayer(nn.Module):
                 outs[pos]._mtn_next = members[k].holder
             if members[k].out_lp is not None:
                 outs[pos]._mtn_lp = members[k].out_lp
+            if members[k].out_xa is not None:
+                outs[pos]._mtn_xa = members[k].out_xa
         return res
 
     def _plan(self, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask, ae_features):
@@ -282,14 +300,20 @@ class DecoderLayer(nn.Module):
             ae_fts = seed_ae
         nF = len(vid_fts)
         aes = [ae_fts[i] if isinstance(ae_fts, (list, tuple)) else ae_fts for i in range(nF)]
+        # who reads each output next (its LayerNorm's gains ride into the producer's epilogue): the chain's next sublayer, across the
+        # layer boundary the next layer's first sublayer of the same stream
+        nl = getattr(self, "_next_layer", None)
+        nl_ok = nl is not None and len(nl.sublayer) == len(sl)
+        ffn_sc = sl[4 + 4 * nF]
         for j in range(3):
-            items = [text[j] + (x,)] + [chains[i][j] + (aes[i],) for i in range(nF)]
+            ae_next = [chains[i][j + 1][0] if j < 2 else (nl.sublayer[4 + 4 * i] if nl_ok else None) for i in range(nF)]
+            items = [text[j] + (x, text[j + 1][0])] + [chains[i][j] + (aes[i], ae_next[i]) for i in range(nF)]
             outs = run(items, raw_memory_outputs=(j == 2))
             x, aes = outs[0], list(outs[1:])
-        x = run([text[3] + (x,)])[0]
+        x = run([text[3] + (x, sl[7] if nF > 0 else ffn_sc)])[0]
         for i in range(nF):
-            x = run([(sl[7 + 4 * i], self.auto_encoder_attn[i], aes[i], ae_mask, x)])[0]
-        x = run([(sl[4 + 4 * nF], self.feed_forward, None, None, x)])[0]
+            x = run([(sl[7 + 4 * i], self.auto_encoder_attn[i], aes[i], ae_mask, x, sl[7 + 4 * (i + 1)] if i + 1 < nF else ffn_sc)])[0]
+        x = run([(ffn_sc, self.feed_forward, None, None, x, nl.sublayer[0] if nl_ok else None)])[0]
         return x, aes
 
     def forward_ae_chains(self, cap_memory, cap_mask, q_memory, q_mask, vid_fts, vid_mask, ae_fts, ae_features):
@@ -712,6 +736,7 @@ class EncoderDecoder(nn.Module):
             self._queue.side_streams = []
         for n, layer in enumerate(self.decoder.layers):
             object.__setattr__(layer, "_owner", self)
+            object.__setattr__(layer, "_next_layer", self.decoder.layers[n + 1] if n + 1 < len(self.decoder.layers) else None)
             layer._layer_index = n
             for k, s in enumerate(layer.sublayer):
                 object.__setattr__(s, "_owner", self)      # plain attribute: not a registered submodule
@@ -926,8 +951,7 @@ class EncoderDecoder(nn.Module):
         """mtn.py:38-56 — every text stream goes through ``query_embed``; returns
         [q_mem, [vid_mem], cap_mem, his_mem, ae] with ae = list of auto-encoder seeds or None."""
         self.prepare()
-        if torch.is_grad_enabled():
-            self.fold_layer_norms()
+        self.fold_layer_norms()                # (the forward kernels use the fold vectors too: LayerNorm as a rank-1 correction)
         if self.training:
             self.advance_dropout_seed()
         self._embed_calls = 0
@@ -1014,7 +1038,7 @@ class EncoderDecoder(nn.Module):
 
         def cut(t):
             u = t.detach().requires_grad_()
-            for attr in ("_mtn_lp", "_mtn_next"):      # compute-dtype copy; gradient hand-off to the producer across the cut
+            for attr in ("_mtn_lp", "_mtn_next", "_mtn_xa"):      # compute-dtype copy; gradient hand-off to the producer across the cut; pre-scaled rows + statistics
                 if hasattr(t, attr):
                     setattr(u, attr, getattr(t, attr))
             return u

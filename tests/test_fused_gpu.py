@@ -19,6 +19,10 @@ CFGS = {
                      diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query"),
     "query_b32": dict(vocab=120, N=1, d_model=512, d_ff=2048, h=8, ft_sizes=[64, 32], B=32, Q=20, H=128, C=40, T=20, frames=[32, 32],
                       diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query"),
+    # batch 64 (BASELINE configs[2] per-GPU batch): the attention groups need two rounds of the chip -> two unit sizes, parts of a
+    # sublayer as members of their own (csrc/fused.hip fh_plan): dropout indices and every per-row pointer of the second part
+    "query_b64": dict(vocab=120, N=1, d_model=512, d_ff=2048, h=8, ft_sizes=[64, 32], B=64, Q=20, H=128, C=40, T=20, frames=[32, 32],
+                      diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query"),
     "caption_b3": dict(vocab=90, N=1, d_model=512, d_ff=1024, h=8, ft_sizes=[48], B=3, Q=9, H=70, C=44, T=33, frames=[21],
                        diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="caption"),
     "shared_b7": dict(vocab=60, N=1, d_model=512, d_ff=2048, h=8, ft_sizes=[40, 24], B=7, Q=8, H=5, C=16, T=7, frames=[6, 11],
@@ -84,7 +88,7 @@ def test_fused_model_matches_oracle(dev, name):
         assert relmax(g, r) < 1e-2, relmax(g, r)
 
 
-@pytest.mark.parametrize("name", ["query_b5", "shared_b7"])
+@pytest.mark.parametrize("name", ["query_b5", "shared_b7", "query_b64"])
 @pytest.mark.parametrize("dropout", [0.0, 0.1], ids=["nodrop", "drop"])
 def test_fused_backward_equals_four_launch_path(dev, name, dropout):
     """Gradients of every parameter with the fused launches on vs off — without dropout, and with the same dropout streams (the
