@@ -577,6 +577,17 @@ def main():
                 dt1, _, _ = timed_window(st1 if rank == 0 else (lambda: None), args.steps)
                 secondary["one_rank_no_exchange"] = {"samples_per_s": round(B * args.steps / dt1, 1), "ms_per_step": round(dt1 / args.steps * 1e3, 4),
                                                      "what": "rank 0 alone, same per-GPU batch, no gradient exchange, optimiser fused into the dW launch"}
+                # what data parallelism adds to a rank's step: everything that is not the single-rank step of the same batch — the
+                # schedule's own cost (layer-segmented graphs, separate shard update: bench.py --gpus 1 reports it as
+                # secondary.dp_schedule_one_rank) plus the exchange that backward does not hide
+                nparams = sum(p.numel() for p in model.parameters())
+                lp_gather = step.sharded is not None and step.sharded.lp_mode()
+                secondary["exchange"] = {
+                    "step_minus_one_rank_no_exchange_ms": round(elapsed / args.steps * 1e3 - dt1 / args.steps * 1e3, 4),
+                    "bytes_on_the_links_per_rank_per_step": int(nparams * (4 + (2 if lp_gather else 4)) * (world - 1) / world),
+                    "scheme": ("reduce-scatter fp32 gradients + all-gather " + ("bf16 weight copies (matrices) / fp32 (glue, vectors)" if lp_gather else "fp32 masters")
+                               if step.sharded is not None else "all-reduce fp32 gradients"),
+                    "collectives_per_step": {k: round(v / max(1, args.steps + args.warmup + args.steps * args.windows), 1) for k, v in step.sharded.calls.items()} if step.sharded is not None else None}
         except Exception as e:  # pragma: no cover
             secondary["error"] = str(e)
 

@@ -116,22 +116,33 @@ class FusedAdam:
                                        L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
         self.model.refresh_transposed()
 
-    def step_range(self, off: int, n: int):
+    def step_range(self, off: int, n: int, write_lp: bool = False):
         """The update on flat elements [off, off+n) only (data parallel: this rank's shard of a gradient slice,
-        dp.ShardedOptimizerSync).  The compute-dtype copies are NOT written: the caller refreshes them once all shards of all
-        ranks have arrived (refresh_copies)."""
+        dp.ShardedOptimizerSync).  write_lp = False: the compute-dtype copies are NOT written — the caller refreshes them once all
+        shards of all ranks have arrived (refresh_copies); True: the shard's compute-dtype copy is written by the same pass (the
+        compute-dtype gather: the other ranks receive THAT, not the fp32 master)."""
         flat, flat_lp, grad, lp_ptr = self._buffers()
         assert off % 4 == 0 and n > 0
+        lp = None
+        if write_lp and lp_ptr is not None:
+            lp = lp_ptr + flat_lp.element_size() * off
         L.check(L.load().mtn_adam_step(L.dtype_code(self.model.compute_dtype), n, flat.data_ptr() + 4 * off, grad.data_ptr() + 4 * off,
-                                       self.m.data_ptr() + 4 * off, self.v.data_ptr() + 4 * off, None, self.state.data_ptr(),
+                                       self.m.data_ptr() + 4 * off, self.v.data_ptr() + 4 * off, lp, self.state.data_ptr(),
                                        L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
 
-    def refresh_copies(self):
-        """Compute-dtype weight copy + transposed copies from the fp32 master (after a sharded update + all-gather)."""
+    def step_range_lp(self, off: int, n: int):
+        self.step_range(off, n, write_lp=True)
+
+    def refresh_copies(self, hi: Optional[int] = None):
+        """Compute-dtype weight copy + transposed copies from the fp32 master (after a sharded update + all-gather).  ``hi``:
+        only flat elements [0, hi) are cast (compute-dtype gather: the matrices' copies arrived by all-gather already; what is left
+        is the glue slice — generator / feature Linears — whose masters were gathered in fp32)."""
         m = self.model
         flat, flat_lp, _, lp_ptr = self._buffers()
         if lp_ptr is not None:
-            L.check(L.load().mtn_cast_f32_to_lp(L.dtype_code(m.compute_dtype), flat.numel(), flat.data_ptr(), lp_ptr, L.stream_ptr()))
+            n = flat.numel() if hi is None else min(int(hi), flat.numel())
+            if n > 0:
+                L.check(L.load().mtn_cast_f32_to_lp(L.dtype_code(m.compute_dtype), n, flat.data_ptr(), lp_ptr, L.stream_ptr()))
         m.refresh_transposed()
 
     # ---- optimiser epilogue: the update of the sublayer weight matrices rides on their parameter-gradient GEMMs
@@ -187,6 +198,7 @@ class FusedAdam:
         if sh is not None:          # data parallel with a sharded optimiser: every rank holds the moments of its shards only
             sh.gather(self.m)
             sh.gather(self.v)
+            self.gather_masters()
         out = {"schedule": self.state.detach().cpu().clone(), "exp_avg": {}, "exp_avg_sq": {}}
         names = {id(p): n for n, p in self.model.named_parameters()}
         for p, o in zip(self.model._flat_params, self.model._flat_offsets):
@@ -194,6 +206,14 @@ class FusedAdam:
             out["exp_avg"][n] = self.m[o:o + p.numel()].view(p.shape).detach().cpu().clone()
             out["exp_avg_sq"][n] = self.v[o:o + p.numel()].view(p.shape).detach().cpu().clone()
         return out
+
+    def gather_masters(self):
+        """Data parallel with the compute-dtype gather (dp.ShardedOptimizerSync): a rank keeps the fp32 master of its own shard of
+        every weight matrix current and receives the others' bf16 copies only — bring every rank's masters up to date before
+        anything reads them whole (model.state_dict()).  A collective: every rank calls it."""
+        sh = getattr(self, "_sharded", None)
+        if sh is not None and sh.lp_slices:
+            sh.gather(self.model._flat)
 
     def load_state_dict(self, sd):
         names = {id(p): n for n, p in self.model.named_parameters()}

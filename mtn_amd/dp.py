@@ -138,11 +138,20 @@ class ShardedOptimizerSync:
     ``update(off, n)`` applies the optimiser to flat elements [off, off+n) (HIP: mtn_adam_step on the sub-buffers; the CPU
     tests pass a torch reference).  Slices whose length is not a multiple of 4*world leave a tail of < 4*world elements that
     is all-reduced and updated redundantly on every rank.
+
+    Compute-dtype gather (round 4; ``lp_fn`` + ``update_lp`` given and a slice passed with ``mat_hi``).  The forward and backward
+    passes read the weight MATRICES through their bf16 copy only, so a rank needs the fp32 master of its own shard and nothing
+    else: for a slice laid out [matrices | vectors] = [lo, mat_hi) + [mat_hi, hi) the matrices are reduce-scattered, the shard's
+    update also writes its bf16 copy (``update_lp``), and THAT is all-gathered — 2 B per parameter on the links instead of 4, and
+    no cast pass over every weight after the exchange; the few vectors (biases, LayerNorm gains: read in fp32 by the kernels) are
+    all-reduced and updated on every rank.  fp32 masters of foreign shards go stale and are brought back by ``gather()`` for
+    checkpoints, like the Adam moments.
     Collectives: RCCL in-place reduce_scatter_tensor / all_gather_into_tensor; other backends (gloo on CUDA tensors in the
     single-GPU tests) take an all-reduce + per-shard broadcasts with the same results."""
 
-    def __init__(self, flat_fn, grad_fn, update, group=None, force: Optional[bool] = None):
+    def __init__(self, flat_fn, grad_fn, update, group=None, force: Optional[bool] = None, lp_fn=None, update_lp=None):
         self.flat_fn, self.grad_fn, self.update, self.group = flat_fn, grad_fn, update, group
+        self.lp_fn, self.update_lp = lp_fn, update_lp          # compute-dtype copy of the flat buffer + the update that also writes it
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.native = dist.is_initialized() and dist.get_backend(group) == "nccl"
@@ -154,12 +163,20 @@ class ShardedOptimizerSync:
         self.collective = self.world > 1 or (dist.is_initialized() and bool(force))
         self.side = None
         self._works = []
-        self.slices = set()             # every (lo, hi) this object has been asked to handle (for gather())
+        self.slices = set()             # every (lo, hi) this object split into shards (for gather())
+        self.lp_slices = set()          # ... of them, the matrix ranges whose foreign fp32 masters are stale (gathered in the compute dtype)
         self.calls = {"reduce_scatter": 0, "all_reduce": 0, "all_gather": 0, "broadcast": 0}   # collectives issued (tests, bench line)
 
+    def lp_mode(self) -> bool:
+        """Is the compute-dtype gather available?  (a separate low-precision copy exists and the caller gave the update for it)"""
+        if self.lp_fn is None or self.update_lp is None:
+            return False
+        lp = self.lp_fn()
+        return lp is not None and lp.dtype != torch.float32 and os.environ.get("MTN_DP_LP_GATHER", "1") != "0"
+
     def gather(self, buf: torch.Tensor):
-        """Make a per-element optimiser buffer (Adam moments) complete on every rank: each rank only ever updates its shards.
-        Blocking; checkpoints only."""
+        """Make a per-element buffer complete on every rank — the Adam moments, and (compute-dtype gather) the fp32 master
+        weights: each rank only ever updates its shards.  Blocking; checkpoints only."""
         if self.world == 1:
             return buf
         for lo, hi in sorted(self.slices):
@@ -173,16 +190,23 @@ class ShardedOptimizerSync:
         per = ((hi - lo) // (self.world * 4)) * 4
         return per, lo + self.rank * per, lo + per * self.world
 
-    def reduce_update(self, lo: int, hi: int):
-        """Issue the chain for flat[lo:hi] behind everything queued on the current stream; does not block the current stream."""
+    def reduce_update(self, lo: int, hi: int, mat_hi: Optional[int] = None):
+        """Issue the chain for flat[lo:hi] behind everything queued on the current stream; does not block the current stream.
+        ``mat_hi``: the slice is [matrices | vectors] with the boundary there -> compute-dtype gather of the matrices (see the
+        class docstring) when lp_mode(); None (or no lp_mode): fp32 all-gather of the whole slice."""
         if hi <= lo:
             return
-        self.slices.add((lo, hi))
+        lp_gather = mat_hi is not None and lo < mat_hi <= hi and self.lp_mode()
         flat, grad = self.flat_fn(), self.grad_fn()
-        per, own, tail = self.split(lo, hi)
+        shard_hi = mat_hi if lp_gather else hi            # the range that is cut into per-rank shards
+        self.slices.add((lo, shard_hi))
+        if lp_gather:
+            self.lp_slices.add((lo, shard_hi))
+        per, own, tail = self.split(lo, shard_hi)
         cuda = grad.is_cuda
         if cuda and self.side is None:
             self.side = torch.cuda.Stream()
+        upd = self.update_lp if lp_gather else self.update
         if not self.collective:
             # one rank, no process group: the plain update.  MTN_DP_EMULATE_WORLD (update 1/emu of the slice, as a rank of an
             # emu-GPU job would: the RESULT IS WRONG) is a timing probe and only honoured when the caller opted in explicitly
@@ -192,7 +216,7 @@ class ShardedOptimizerSync:
                 raise RuntimeError("MTN_DP_EMULATE_WORLD produces wrong parameters (timing probe only): run it through "
                                    "`bench.py --no-record`, never in a recorded line or a training run")
             n = hi - lo
-            self.update(lo, n if emu <= 1 else max(4, (n // (emu * 4)) * 4))
+            upd(lo, n if emu <= 1 else max(4, (n // (emu * 4)) * 4))
             return
         works = []
         if per > 0:
@@ -203,7 +227,7 @@ class ShardedOptimizerSync:
                 w = dist.all_reduce(grad[lo:tail], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self.calls["all_reduce"] += 1
             works.append(w)
-        if tail < hi:
+        if tail < hi:                                      # the replicated remainder: < 4 * world matrix elements (+ the slice's vectors)
             works.append(dist.all_reduce(grad[tail:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.calls["all_reduce"] += 1
 
@@ -211,16 +235,17 @@ class ShardedOptimizerSync:
             for w in works:
                 w.wait()                           # the current (side) stream waits; the host does not
             if per > 0:
-                self.update(own, per)
+                upd(own, per)
             if tail < hi:
-                self.update(tail, hi - tail)       # replicated: identical inputs -> identical results on every rank
+                upd(tail, hi - tail)               # replicated: identical inputs -> identical results on every rank
             if per > 0:
+                buf = self.lp_fn() if lp_gather else flat          # what the other ranks need of this shard: its bf16 copy | its fp32 master
                 if self.native:
-                    self._works.append(dist.all_gather_into_tensor(flat[lo:tail], flat[own:own + per], group=self.group, async_op=True))
+                    self._works.append(dist.all_gather_into_tensor(buf[lo:tail], buf[own:own + per], group=self.group, async_op=True))
                     self.calls["all_gather"] += 1
                 else:
                     for r in range(self.world):
-                        self._works.append(dist.broadcast(flat[lo + r * per: lo + (r + 1) * per], src=r, group=self.group, async_op=True))
+                        self._works.append(dist.broadcast(buf[lo + r * per: lo + (r + 1) * per], src=r, group=self.group, async_op=True))
                         self.calls["broadcast"] += 1
 
         if cuda:

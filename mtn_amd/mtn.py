@@ -589,33 +589,42 @@ class EncoderDecoder(nn.Module):
             if p is not None and id(p) not in seen:
                 seen.add(id(p)); lst.append(p)
 
-        def add_mha(m: MultiHeadedAttention):
-            for i in range(3):
-                add(path, m.linears[i].weight)
-            for i in range(3):
-                add(path, m.linears[i].bias)
-            add(path, m.linears[3].weight); add(path, m.linears[3].bias)
+        # Path parameters: all the VECTORS first (Encoder LayerNorm bank, then per layer the biases and the sublayers' LayerNorm gains
+        # / biases, then the decoder's final LayerNorms), then per layer its weight MATRICES.  The kernels read the matrices through
+        # their compute-dtype copy only, so under data parallelism a layer's slice — pure matrices — travels in the compute dtype
+        # (dp.ShardedOptimizerSync, `mat_hi`), while the vectors (read in fp32, 0.25 % of the parameters) sit next to the glue
+        # parameters and are exchanged with them in fp32, in the step's last slice.
+        def layer_modules(layer):
+            mods = [layer.self_attn, layer.his_attn, layer.cap_attn, layer.src_attn]
+            for i in range(len(layer.auto_encoder_vid_attn)):
+                mods += [layer.auto_encoder_self_attn[i], layer.auto_encoder_vid_attn[i], layer.auto_encoder_feed_forward[i], layer.auto_encoder_attn[i]]
+            return mods + [layer.feed_forward]
 
-        def add_ffn(f: PositionwiseFeedForward):
-            for p in (f.w_1.weight, f.w_1.bias, f.w_2.weight, f.w_2.bias):
-                add(path, p)
-
-        layer_marks = []
         for n in self.query_encoder.norm:
             add(path, n.a_2); add(path, n.b_2)
         for layer in self.decoder.layers:
-            start = len(path)
-            for m in (layer.self_attn, layer.his_attn, layer.cap_attn, layer.src_attn):
-                add_mha(m)
-            for i in range(len(layer.auto_encoder_vid_attn)):
-                add_mha(layer.auto_encoder_self_attn[i]); add_mha(layer.auto_encoder_vid_attn[i])
-                add_ffn(layer.auto_encoder_feed_forward[i]); add_mha(layer.auto_encoder_attn[i])
-            add_ffn(layer.feed_forward)
-            for s in layer.sublayer:
-                add(path, s.norm.a_2); add(path, s.norm.b_2)
-            layer_marks.append((start, len(path)))
+            for m in layer_modules(layer):
+                if isinstance(m, MultiHeadedAttention):
+                    for i in range(3):
+                        add(path, m.linears[i].bias)
+                    add(path, m.linears[3].bias)
+                else:
+                    add(path, m.w_1.bias); add(path, m.w_2.bias)
+            for sc in layer.sublayer:
+                add(path, sc.norm.a_2); add(path, sc.norm.b_2)
         for n in [self.decoder.norm] + list(self.decoder.ae_norm):
             add(path, n.a_2); add(path, n.b_2)
+        layer_marks = []
+        for layer in self.decoder.layers:
+            start = len(path)
+            for m in layer_modules(layer):
+                if isinstance(m, MultiHeadedAttention):
+                    for i in range(3):
+                        add(path, m.linears[i].weight)
+                    add(path, m.linears[3].weight)
+                else:
+                    add(path, m.w_1.weight); add(path, m.w_2.weight)
+            layer_marks.append((start, len(path)))
         for p in self.parameters():            # everything else = glue (embeddings, feature Linear, generator)
             if id(p) not in seen:
                 add(glue, p)

@@ -278,13 +278,16 @@ def main(argv=None):
                 print("epoch %d mean train loss per token: %f" % (epoch + 1, mean))
             if args.model:
                 # EVERY rank builds the optimiser state: with the sharded optimiser (dp.ShardedOptimizerSync) a rank holds the
-                # Adam moments of its shards only and state_dict() gathers them with collectives; rank 0 alone writes the files
+                # Adam moments of its shards only (and, with the compute-dtype gather, the current fp32 masters of its shards
+                # only) and state_dict() gathers them with collectives; rank 0 alone writes the files
                 opt_state = the_opt.state_dict()
                 if rank == 0:
                     torch.save(model.state_dict(), f"{args.model}_{epoch + 1}.pth.tar")
                     torch.save(opt_state, f"{args.model}_{epoch + 1}_opt.pth.tar")
                 del opt_state
             if valid is not None:
+                if args.model and hasattr(the_opt.optimizer, "gather_masters"):
+                    the_opt.optimizer.gather_masters()        # (collective) the "best" checkpoint below is written by rank 0 alone
                 from .data_utils import LabelSmoothing as _LS
                 vloss = validate(valid[0], valid[1], model, _LS(args.vocab_size, 1, 0.1), args.auto_encoder_ft, args.loss_l)
                 if rank == 0:

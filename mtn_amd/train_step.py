@@ -62,7 +62,8 @@ class TrainStep:
             sh = getattr(adam, "_sharded", None)          # ONE exchange object per optimiser: every TrainStep over it (one per
             if sh is None or sh.group is not group:       # batch shape, BucketedTrainer) shares the shard ownership and the
                 sh = ShardedOptimizerSync(lambda: model.flat_buffers()[0], lambda: model.flat_buffers()[2], adam.step_range, group=group,
-                                          force=getattr(grad_sync, "force", None))
+                                          force=getattr(grad_sync, "force", None),
+                                          lp_fn=lambda: model.flat_buffers()[1], update_lp=getattr(adam, "step_range_lp", None))
                 adam._sharded = sh                        # slice set that state_dict()'s gather walks
             self.sharded = sh
         self._g_seg = None
@@ -170,21 +171,24 @@ class TrainStep:
             bwd(st["enc_out"], st["enc_leaf"])                  # embeddings, feature Linears, Encoder LayerNorms
             self._st = None
 
-        segs = [(top, (sl[N - 1][0], total))]
-        segs += [(layer(k), sl[k]) for k in range(N - 2, -1, -1)]
-        segs.append((enc, (0, sl[0][0])))                         # glue parameters + the Encoder LayerNorm bank
+        # a layer's slice is its weight matrices (mtn.py _ordered_params): mat_hi = hi -> they travel in the compute dtype; the last
+        # slice = glue parameters + every vector (biases, all LayerNorms): fp32 throughout, complete once the last segment has run
+        assert sl[N - 1][1] == total, "the last layer's matrices end the flat buffer"
+        segs = [(top, (sl[N - 1][0], total, total))]
+        segs += [(layer(k), sl[k] + (sl[k][1],)) for k in range(N - 2, -1, -1)]
+        segs.append((enc, (0, sl[0][0], None)))
         return segs
 
     def _run_segmented(self, runners):
         if self.sharded is not None:
             self.opt.begin_sharded_step()
-            for run, (lo, hi) in runners:
+            for run, (lo, hi, mat_hi) in runners:
                 run()
-                self.sharded.reduce_update(lo, hi)
+                self.sharded.reduce_update(lo, hi, mat_hi)
             self.sharded.finish()
             return
         works = []
-        for run, (lo, hi) in runners:
+        for run, (lo, hi, _) in runners:
             run()
             works.append(self.grad_sync.reduce_range(lo, hi))
         self.grad_sync.wait(works)
@@ -236,7 +240,7 @@ class TrainStep:
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt, pool=pool, capture_error_mode=CAPTURE_MODE):
             if self.sharded is not None:
-                self.opt.optimizer.refresh_copies()          # the updates ran shard by shard between the segment graphs
+                self._refresh_after_exchange()          # the updates ran shard by shard between the segment graphs
             else:
                 self._optim()
         self._g_fb = self._g_seg[0]
@@ -256,7 +260,7 @@ class TrainStep:
             self._g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool(), capture_error_mode=CAPTURE_MODE):
                 if self.sharded is not None:
-                    self.opt.optimizer.refresh_copies()
+                    self._refresh_after_exchange()
                 else:
                     self._optim()
         # the warm-up/capture passes did not run the optimiser outside capture: parameters are untouched
@@ -278,7 +282,7 @@ class TrainStep:
                 elif self.grad_sync is not None:
                     self.grad_sync()
             if self.sharded is not None:
-                self.opt.optimizer.refresh_copies()
+                self._refresh_after_exchange()
             else:
                 self._optim()
             return loss
@@ -297,6 +301,12 @@ class TrainStep:
             self._g_opt.replay()
         return self._loss
 
+    def _refresh_after_exchange(self):
+        """After the sharded exchange: with the compute-dtype gather the matrices' bf16 copies arrived by all-gather, only the glue
+        slice (generator, feature Linears: fp32 masters gathered) is cast; otherwise every weight is (the fp32 masters were gathered)."""
+        lp_gather = self.sharded is not None and self.sharded.lp_mode()
+        self.opt.optimizer.refresh_copies(self.model._layer_slices[0][0] if lp_gather else None)
+
     def _slices(self):
         """The (lo, hi) ranges of the flat buffers the exchange works in, last-finished-first: [top layer .. end], layers
         N-2 .. 0, [glue + encoder norms].  BOTH schedules use them, so which rank owns (and keeps the Adam moments of) an element
@@ -305,13 +315,13 @@ class TrainStep:
         m.prepare()
         sl = m._layer_slices
         total, N = m._flat_grad.numel(), len(sl)
-        return [(sl[N - 1][0], total)] + [sl[k] for k in range(N - 2, -1, -1)] + [(0, sl[0][0])]
+        return [(sl[N - 1][0], total, total)] + [sl[k] + (sl[k][1],) for k in range(N - 2, -1, -1)] + [(0, sl[0][0], None)]
 
     def _whole_buffer_sharded(self):
         """The simple schedule (MTN_DP_OVERLAP=0, or the fallback) with the sharded optimiser: same slices as the segmented one."""
         self.opt.begin_sharded_step()
-        for lo, hi in self._slices():
-            self.sharded.reduce_update(lo, hi)
+        for lo, hi, mat_hi in self._slices():
+            self.sharded.reduce_update(lo, hi, mat_hi)
         self.sharded.finish()
 
 

@@ -141,3 +141,63 @@ def test_sharded_optimizer_exchange_equals_allreduce_plus_full_update(tmp_path):
         g = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 * t + r)) for r in range(2))
         _ref_adam(flat, g, m, v, 1e-2, t=t)
     assert torch.allclose(r0["flat"], flat, rtol=0, atol=1e-6) and torch.allclose(r0["m"], m, atol=1e-6) and torch.allclose(r0["v"], v, atol=1e-6)
+
+
+def _lp_gather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mtn_amd import dp
+    dp.init_distributed("gloo")
+    n = 10_007
+    flat = torch.randn(n, generator=torch.Generator().manual_seed(1))
+    lp = flat.to(torch.bfloat16)
+    m, v = torch.zeros(n), torch.zeros(n)
+    # slices (lo, hi, mat_hi): [matrices | vectors]; one plain fp32 slice (mat_hi None), one whose matrix part is 3 elements long
+    slices = [(6000, n, 9001), (1003, 6000, 5500), (1000, 1003, 1003), (0, 1000, None)]
+
+    def upd(off, cnt, t, with_lp):
+        _ref_adam(flat[off:off + cnt], grad[off:off + cnt], m[off:off + cnt], v[off:off + cnt], 1e-2, t=t)
+        if with_lp:
+            lp[off:off + cnt] = flat[off:off + cnt].to(torch.bfloat16)
+
+    sh = dp.ShardedOptimizerSync(lambda: flat, lambda: grad, None, lp_fn=lambda: lp, update_lp=None)
+    for t in range(1, 4):
+        grad = torch.randn(n, generator=torch.Generator().manual_seed(100 * t + rank))
+        sh.update = lambda off, cnt, t=t: upd(off, cnt, t, False)
+        sh.update_lp = lambda off, cnt, t=t: upd(off, cnt, t, True)
+        for lo, hi, mh in slices:
+            sh.reduce_update(lo, hi, mh)
+        sh.finish()
+        lp[0:1000] = flat[0:1000].to(torch.bfloat16)         # the fp32 slice's copies: a local cast (FusedAdam.refresh_copies(hi))
+    before = flat.clone()
+    sh.gather(m); sh.gather(v); sh.gather(flat)
+    torch.save({"flat": flat, "flat_before_gather": before, "lp": lp, "m": m, "v": v, "calls": dict(sh.calls)}, os.path.join(out_dir, f"lp{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_compute_dtype_gather_keeps_replicas_identical(tmp_path):
+    """dp.ShardedOptimizerSync with the compute-dtype gather (round 4): matrices reduce-scattered, the shard's update writes its
+    bf16 copy and THAT is gathered; vectors all-reduced and updated everywhere.  Two gloo ranks, three steps: the bf16 copies
+    are BIT-identical on both ranks and equal bf16(reference); the fp32 vectors are identical without any gather; the fp32
+    masters of the matrices differ between the ranks until gather() (each rank only has its own shards current) and equal
+    the one-process reference afterwards, as do the moments."""
+    port = _free_port()
+    mp.start_processes(_lp_gather_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "lp0.pt"), torch.load(tmp_path / "lp1.pt")
+    n = 10_007
+    flat = torch.randn(n, generator=torch.Generator().manual_seed(1))
+    m, v = torch.zeros(n), torch.zeros(n)
+    for t in range(1, 4):
+        g = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 * t + r)) for r in range(2))
+        _ref_adam(flat, g, m, v, 1e-2, t=t)
+    assert torch.equal(r0["lp"], r1["lp"])
+    assert torch.equal(r0["lp"].float(), flat.to(torch.bfloat16).float()) or float((r0["lp"].float() - flat).abs().max()) < 2e-2
+    for lo, hi in ((9001, n), (5500, 6000), (0, 1000)):                 # vectors + the fp32 slice: consistent all along
+        assert torch.equal(r0["flat_before_gather"][lo:hi], r1["flat_before_gather"][lo:hi])
+    assert not torch.equal(r0["flat_before_gather"][6000:9001], r1["flat_before_gather"][6000:9001])     # masters of foreign shards were stale
+    for k in ("flat", "m", "v"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert torch.allclose(r0["flat"], flat, rtol=0, atol=1e-6) and torch.allclose(r0["m"], m, atol=1e-6) and torch.allclose(r0["v"], v, atol=1e-6)
+    assert r0["calls"]["all_reduce"] > 0
