@@ -789,6 +789,10 @@ extern "C" int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args
                     if (args[i].a <= q0) continue;
                     mtn_attn_args& t = P.a[P.count++];
                     t = args[i];
+                    // the fp32 dK / dV workspace only matters when the query rows take several passes; a caller built against the
+                    // round-2 header leaves the field uninitialised: never trust it for single-pass shapes, refuse a misaligned one
+                    if (args[i].a <= BQ) t.kv_acc = nullptr;
+                    else if (t.kv_acc && (((uintptr_t)t.kv_acc) & 15) != 0) { mtn_set_error("mtn_attention_bwd: kv_acc must be 16-byte aligned"); return MTN_ERR_ARG; }
                     t.q0 = q0; t.qn = args[i].a - q0 < BQ ? args[i].a - q0 : BQ; t.kv_accum = q0 > 0;
                     t.kv_last = q0 + BQ >= args[i].a;
                     const int kt = (t.m + BK - 1) / BK;

@@ -17,15 +17,24 @@ extern "C" const char* mtn_last_error(void) { return g_err; }
 extern "C" int mtn_version(void) { return 110; }
 
 // ---------------------------------------------------------------- environment switches (common.h: MTN_ENV)
+// The library is entered from the caller's thread AND from autograd's device thread (backward), so a site's cache may be filled by
+// two threads at once: the refresh runs under a mutex and the generation is published with release / read with acquire, so a reader
+// that sees the current generation also sees the value written for it.  (A site's value buffer is only rewritten on a generation
+// change: mtn_reload_env() must not race with launches that are reading switches — the tests call it between steps.)
+#include <mutex>
 static int g_env_gen = 0;
-extern "C" int mtn_reload_env(void) { return __atomic_add_fetch(&g_env_gen, 1, __ATOMIC_RELAXED); }
+static std::mutex g_env_mutex;
+extern "C" int mtn_reload_env(void) { return __atomic_add_fetch(&g_env_gen, 1, __ATOMIC_ACQ_REL); }
 const char* mtn_env_lookup(MtnEnvVar* v) {
-    const int g = __atomic_load_n(&g_env_gen, __ATOMIC_RELAXED);
-    if (v->gen != g) {
-        const char* e = getenv(v->name);
-        v->set = e != nullptr;
-        if (e) { strncpy(v->val, e, sizeof(v->val) - 1); v->val[sizeof(v->val) - 1] = 0; }
-        v->gen = g;
+    const int g = __atomic_load_n(&g_env_gen, __ATOMIC_ACQUIRE);
+    if (__atomic_load_n(&v->gen, __ATOMIC_ACQUIRE) != g) {
+        std::lock_guard<std::mutex> lock(g_env_mutex);
+        if (v->gen != g) {
+            const char* e = getenv(v->name);
+            v->set = e != nullptr;
+            if (e) { strncpy(v->val, e, sizeof(v->val) - 1); v->val[sizeof(v->val) - 1] = 0; }
+            __atomic_store_n(&v->gen, g, __ATOMIC_RELEASE);
+        }
     }
     return v->set ? v->val : nullptr;
 }

@@ -1889,16 +1889,18 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
                 t128 += ((q.M + 127) / 128) * ((q.N + 127) / 128);
                 kmax = q.K > kmax ? q.K : kmax;
             }
-            if (ok && t128 >= x_min && (xmin || kmax >= 768)) {            // (the memory gradient shares its launch with the K = 512 dX of the same group)
-                static bool attr_set = false;
-                if (!attr_set) {
-                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
-                    (void)hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS + LNE_LDS_EXTRA);
-                    attr_set = true;
-                }
+            static int attr_state = 0;                                  // 0 = not tried, 1 = the 128 KiB dynamic-LDS opt-in holds, -1 = refused
+            if (ok && t128 >= x_min && (xmin || kmax >= 768) && attr_state == 0) {
+                const bool good =
+                    hipFuncSetAttribute((const void*)gemm_dma128x_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)gemm_dma128x_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)gemm_dma128x_kernel<true, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS + LNE_LDS_EXTRA) == hipSuccess;
+                attr_state = good ? 1 : -1;                              // refused: this and every later launch take the 64 x 64 / register-staged kernels below
+                if (!good) (void)hipGetLastError();
+            }
+            if (ok && t128 >= x_min && (xmin || kmax >= 768) && attr_state == 1) {            // (the memory gradient shares its launch with the K = 512 dX of the same group)
                 GemmGroup g2 = grp;
                 const int tiles = retile(g2, 128, 128);
                 g_variant = V_DMA128X; g_variant_tiles = tiles;

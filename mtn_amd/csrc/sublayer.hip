@@ -326,11 +326,15 @@ extern "C" int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* 
     if (!fb || n_ffn > 0) {
         mtn_gemm_problem p[2 * MTN_SUBLAYER_MAX_GROUP];
         int n = 0;
+        // (one operand layout per launch: when a feed-forward member reads its weight as it lies (b_trans = 1: no w2_t), the attention
+        //  members' dO problems do too, although their W_o^T exists for the fused head backward — a mixed stage would split in two launches)
+        bool any_bt = false;
+        for (int i = 0; i < n_ffn; ++i) any_bt = any_bt || !ffn[i].w2_t;
         for (int i = 0; i < n_mha && !fb; ++i) {
             const mtn_mha_args* a = &mha[i];
             const MhaWs w = mha_ws(a, dtype);
             const int d = a->d, rows = a->B * a->a;
-            p[n] = a->w_o_t ? gemm_init(w.dyl, d, a->w_o_t, d, rows, d, d, 0, 0) : gemm_init(w.dyl, d, a->w_o, d, rows, d, d, 0, 1);
+            p[n] = (a->w_o_t && !any_bt) ? gemm_init(w.dyl, d, a->w_o_t, d, rows, d, d, 0, 0) : gemm_init(w.dyl, d, a->w_o, d, rows, d, d, 0, 1);
             p[n].out_lp = w.dO; p[n].ldc = d; ++n;
         }
         for (int i = 0; i < n_ffn; ++i) {
