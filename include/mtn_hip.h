@@ -221,7 +221,7 @@ int mtn_layernorm_fwd(int dtype, int rows, int d, float eps, const float* x, con
 /* Fold vectors of the Linears that follow a LayerNorm (see mtn_ln_epilogue): for each descriptor, with W [K, d] in the compute
  * dtype (bf16), out[k] = sum_c W[k][c] a2[c] and out[K + k] = bias[k] + sum_c W[k][c] b2[c].  One launch for the whole model:
  * `descs_device` is a DEVICE array of `count` descriptors, `block_desc` a DEVICE int32 array giving the descriptor of each
- * 32-row block (block_start = the descriptor's first block), total_blocks = sum ceil(K / 32).  d % 8 == 0, d <= 2048. */
+ * 64-row block (block_start = the descriptor's first block), total_blocks = sum ceil(K / 64).  d % 8 == 0, d <= 2048. */
 typedef struct {
     const void* w;
     const float *bias, *a2, *b2;

@@ -563,12 +563,14 @@ extern "C" int mtn_layernorm_bwd(int rows, int d, float eps, const float* x, con
 // u[k] = sum_c W[k][c] a2[c],  c[k] = bias[k] + sum_c W[k][c] b2[c]  for every Linear W [K, d] that follows a LayerNorm (a2, b2):
 // what lets LayerNorm backward ride in the epilogue of g = dq W (mtn_ln_epilogue, include/mtn_hip.h).  Weights change every step,
 // so this runs once per step: one launch for the whole model (~88 MB of bf16 weights at BASELINE configs[1]), a wave per row,
-// 32 rows per 256-thread workgroup, the row as ONE 16-byte load per lane per 512 columns.
+// 64 rows per 512-thread workgroup, the row as ONE 16-byte load per lane per 512 columns.
 template <int NJ>      // 512-column chunks of a row a lane may hold (1: d <= 512)
-__global__ __launch_bounds__(256) void ln_fold_kernel(const mtn_ln_fold_desc* __restrict__ descs, const int* __restrict__ block_desc, const int d) {
+__global__ __launch_bounds__(512) void ln_fold_kernel(const mtn_ln_fold_desc* __restrict__ descs, const int* __restrict__ block_desc, const int d) {
+    // 64 rows per 512-thread workgroup (8 waves x 8 rows, all eight row loads of a wave in flight at once)
     const mtn_ln_fold_desc D = descs[block_desc[blockIdx.x]];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = ((int)blockIdx.x - D.block_start) * 32 + wave * 8;
+    const int k0 = ((int)blockIdx.x - D.block_start) * 64 + wave * 8;
+    if (k0 >= D.K) return;
     const bf16_t* w = (const bf16_t*)D.w;
     uint4 wv[8][NJ];
 #pragma unroll
@@ -614,8 +616,8 @@ extern "C" int mtn_ln_fold(int dtype, const mtn_ln_fold_desc* descs_device, cons
     MTN_CHECK_ARG(dtype == MTN_BF16, "fold vectors exist for the bf16 path only");
     MTN_CHECK_ARG(descs_device && block_desc && total_blocks > 0, "null descriptor table");
     MTN_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 2048, "d must be a multiple of 8, at most 2048");
-    if (d <= 512) hipLaunchKernelGGL(ln_fold_kernel<1>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_device, block_desc, d);
-    else hipLaunchKernelGGL(ln_fold_kernel<4>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_device, block_desc, d);
+    if (d <= 512) hipLaunchKernelGGL(ln_fold_kernel<1>, dim3(total_blocks), dim3(512), 0, (hipStream_t)stream, descs_device, block_desc, d);
+    else hipLaunchKernelGGL(ln_fold_kernel<4>, dim3(total_blocks), dim3(512), 0, (hipStream_t)stream, descs_device, block_desc, d);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
@@ -717,8 +719,55 @@ __device__ __forceinline__ void emb_add_rows(unsigned long long m, int base, con
         }
     }
 }
+// the same for an explicit list of n virtual token indices (ascending): up to EMB_MLP rows in flight per batch, added in list order.
+// Round 4: an entry's occurrences used to be added ballot by ballot while scanning — one dependent global round trip per ballot
+// that had a hit, ~10 of them for the most frequent entry of a uniform batch (40+ us per launch in the step); collecting the hits
+// first makes that ceil(n / 8) round trips.
+__device__ __forceinline__ void emb_add_list(const int* list, const int n_all, const EmbStream* st, int ns, int d, int c0, int lane, float (&acc)[8]) {
+    for (int i0 = 0; i0 < n_all; i0 += EMB_MLP) {
+        const int n = n_all - i0 < EMB_MLP ? n_all - i0 : EMB_MLP;
+        float x[EMB_MLP][8];
+        int row[EMB_MLP], str[EMB_MLP];
+#pragma unroll
+        for (int k = 0; k < EMB_MLP; ++k) {
+            if (k < n) {
+                const int g = list[i0 + k];
+                int si = 0;
+                while (si + 1 < ns && g >= st[si + 1].first) ++si;
+                str[k] = si;
+                row[k] = g - st[si].first;
+                const float* src = st[si].dx + (size_t)row[k] * d + c0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = lane * 4 + 256 * j;
+                    if (c0 + c + 3 < d) {
+                        const float4 q = *reinterpret_cast<const float4*>(src + c);
+                        x[k][4 * j] = q.x; x[k][4 * j + 1] = q.y; x[k][4 * j + 2] = q.z; x[k][4 * j + 3] = q.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[k][4 * j + e] = 0.f;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < EMB_MLP; ++k) {
+            if (k < n) {
+                const EmbStream& S = st[str[k]];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c0 + lane * 4 + 256 * (j >> 2) + (j & 3);
+                    float y = x[k][j] * S.emb_scale;
+                    if (S.ds.on) y = (c < d && drop_keep(S.ds, (uint64_t)row[k] * d + c)) ? y * S.ds.scale : 0.f;
+                    acc[j] += y;
+                }
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const EmbedDetGroup grp) {
     __shared__ int tok[EMB_CH];
+    __shared__ int hits[16][EMB_HEAVY];
     __shared__ float part_sum[16][512];
     __shared__ EmbStream st[MTN_LN_MAX_GROUP];
     __shared__ int count[16];
@@ -776,16 +825,19 @@ __global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const EmbedDetGroup
                     for (int k = 0; k < 4; ++k) t4[k] = b + k * 64 + lane < cnt ? tok[b + k * 64 + lane] : -1;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const unsigned long long m = __ballot(t4[k] == v);
-                        if (m) {
-                            mine += __popcll(m);
-                            if (mine <= EMB_HEAVY) emb_add_rows(m, ch + b + k * 64, st, ns, d, c0, lane, acc);
+                        unsigned long long m = __ballot(t4[k] == v);
+                        while (m) {                                  // (wave-uniform) note the hit; the rows are fetched once the scan is done
+                            if (mine < EMB_HEAVY && lane == 0) hits[wave][mine] = ch + b + k * 64 + __builtin_ctzll(m);
+                            ++mine;
+                            m &= m - 1;
                         }
                     }
                 }
         }
         const bool light = live && mine > 0 && mine <= EMB_HEAVY;
         if (light) {
+            __builtin_amdgcn_wave_barrier();
+            emb_add_list(hits[wave], mine, st, ns, d, c0, lane, acc);
             float* dst = grp.dlut[t] + (size_t)v * d + c0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

@@ -801,7 +801,7 @@ class EncoderDecoder(nn.Module):
             view = buf[off:off + 2 * K]
             descs[i].w, descs[i].bias, descs[i].a2, descs[i].b2 = w.data_ptr(), b.data_ptr(), sc.norm.a_2.data_ptr(), sc.norm.b_2.data_ptr()
             descs[i].out, descs[i].K, descs[i].block_start = view.data_ptr(), K, blocks
-            nb = (K + 31) // 32
+            nb = (K + 63) // 64
             block_desc += [i] * nb
             blocks += nb
             off += 2 * K
