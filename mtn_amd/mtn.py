@@ -8,11 +8,14 @@ What is kept from the reference (so that run.sh / train.py / generate.py-style c
     ``.auto_encoder_generator``                                                         (mtn.py:28-60)
   * the state_dict key schema, so reference checkpoints load with ``load_state_dict``.
 What is different: parameters live in ONE flat fp32 buffer (plus a flat compute-dtype copy and a flat
-gradient buffer) laid out so that the q/k/v Linears of every attention are one [3d,d] matrix; sublayers run as
-LayerNorm -> MFMA GEMM -> attention -> GEMM(+bias,+dropout,+residual) kernel chains; backward writes
-parameter gradients straight into the flat gradient buffer (what the RCCL all-reduce and the fused Adam
-consume).  Embedding lookup, positional encoding, the feature Linear and the generator are plain
-PyTorch-ROCm ops (glue, <5 % of FLOPs).
+gradient buffer) laid out [glue | every vector | per-layer weight matrices] so that the q/k/v Linears of every
+attention are one [3d,d] matrix; sublayers run as lockstep groups of fused HIP launches (LayerNorm + head-slice
+projections + attention in one kernel, output projection / w_2 + bias + dropout + residual in a grouped GEMM;
+backward: fused dO + attention backward, then the dLN-out GEMM with LayerNorm backward in its epilogue); backward
+writes parameter gradients straight into the flat gradient buffer — or, on one rank, applies Adam inside the
+parameter-gradient launch.  Embeddings + positional encoding + Encoder LayerNorm, the feature Linears, the loss
+head and (at inference) the generator run on library kernels too: a captured train step launches nothing but
+libmtn_hip kernels apart from one fill, one scalar sum and one counter add.
 """
 from __future__ import annotations
 
