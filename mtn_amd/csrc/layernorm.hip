@@ -645,19 +645,20 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdGroup grp)
         atomicAdd(dst + c, v);
     }
 }
-// Deterministic variant (no atomics, the same bits on every run).  A workgroup of 16 waves owns 16 vocabulary entries of one
+// Deterministic variant (no atomics, the same bits on every run).  A workgroup of EMB_W = 8 waves owns 8 vocabulary entries of one
 // table, one per wave.  The token lists of all streams that use the table — one virtual list, stream order then row order —
 // are staged through LDS in chunks (coalesced, once per workgroup and pass) and scanned with 64-token ballots:
 //   pass 1  each wave counts the occurrences of its entry and, while there are at most EMB_HEAVY of them, adds those rows of dx
 //           on the spot, in list order, through the stream's scale and dropout mask (up to eight rows' loads in flight); an
 //           entry that stays at or below EMB_HEAVY writes dlut[v] += sum, once (otherwise the partial sum is dropped);
 //   pass 2  a frequent entry (the pad id of a ragged batch, '.', '?', ...) would serialise thousands of rows in one wave, so
-//           all 16 waves take it together: wave w scans ballots w, w+16, ... of every chunk, the 16 partial sums meet in LDS
+//           all 8 waves take it together: wave w scans ballots w, w+8, ... of every chunk, the 8 partial sums meet in LDS
 //           and are added in wave order.
 // Which wave adds which row depends only on the token values and shapes, so the rounding is the same on every run.
-#define EMB_CH 16384                       // tokens per staged chunk (int32 in LDS)
+#define EMB_CH 8192                        // tokens per staged chunk (int32 in LDS)
+#define EMB_W 8                            // waves (= vocabulary entries) per workgroup: 512 threads keep 256 VGPRs per lane (1 024 spilled), ~50 KB of LDS: three workgroups per CU
 #define EMB_HEAVY 24
-#define EMB_MLP 8
+#define EMB_MLP 6
 struct EmbedDetGroup {
     int n_lut;
     float* dlut[MTN_LN_MAX_GROUP];
@@ -722,7 +723,7 @@ __device__ __forceinline__ void emb_add_rows(unsigned long long m, int base, con
 // the same for an explicit list of n virtual token indices (ascending): up to EMB_MLP rows in flight per batch, added in list order.
 // Round 4: an entry's occurrences used to be added ballot by ballot while scanning — one dependent global round trip per ballot
 // that had a hit, ~10 of them for the most frequent entry of a uniform batch (40+ us per launch in the step); collecting the hits
-// first makes that ceil(n / 8) round trips.
+// first makes that ceil(n / EMB_MLP) round trips.
 __device__ __forceinline__ void emb_add_list(const int* list, const int n_all, const EmbStream* st, int ns, int d, int c0, int lane, float (&acc)[8]) {
     for (int i0 = 0; i0 < n_all; i0 += EMB_MLP) {
         const int n = n_all - i0 < EMB_MLP ? n_all - i0 : EMB_MLP;
@@ -765,16 +766,16 @@ __device__ __forceinline__ void emb_add_list(const int* list, const int n_all, c
         }
     }
 }
-__global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const EmbedDetGroup grp) {
+__global__ __launch_bounds__(64 * EMB_W, 4) void embed_bwd_det_kernel(const EmbedDetGroup grp) {
     __shared__ int tok[EMB_CH];
-    __shared__ int hits[16][EMB_HEAVY];
-    __shared__ float part_sum[16][512];
+    __shared__ int hits[EMB_W][EMB_HEAVY];
+    __shared__ float part_sum[EMB_W][512];
     __shared__ EmbStream st[MTN_LN_MAX_GROUP];
-    __shared__ int count[16];
+    __shared__ int count[EMB_W];
     const int t = blockIdx.y;
-    if (blockIdx.x * 16 >= grp.V[t]) return;               // table shorter than the longest one in the launch (uniform)
+    if (blockIdx.x * EMB_W >= grp.V[t]) return;               // table shorter than the longest one in the launch (uniform)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int v = blockIdx.x * 16 + wave;
+    const int v = blockIdx.x * EMB_W + wave;
     const bool live = v < grp.V[t];
     const int d = grp.d[t], total = grp.total[t], ns = grp.n[t];
     if (threadIdx.x < MTN_LN_MAX_GROUP) {
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const EmbedDetGroup
             const int first = st[si].first, last = si + 1 < ns ? st[si + 1].first : total;
             const int lo = max(first, ch), hi = min(last, ch + cnt);
             const long* src = st[si].tokens - first;
-            for (int g = lo + (int)threadIdx.x; g < hi; g += 1024) tok[g - ch] = (int)src[g];
+            for (int g = lo + (int)threadIdx.x; g < hi; g += 64 * EMB_W) tok[g - ch] = (int)src[g];
         }
         __syncthreads();
     };
@@ -847,16 +848,16 @@ __global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const EmbedDetGroup
         }
         if (lane == 0) count[wave] = live ? mine : 0;
         __syncthreads();
-        // pass 2: frequent entries, all 16 waves on one entry at a time
-        for (int h = 0; h < 16; ++h) {
+        // pass 2: frequent entries, all EMB_W waves on one entry at a time
+        for (int h = 0; h < EMB_W; ++h) {
             if (count[h] <= EMB_HEAVY) continue;           // uniform over the workgroup
-            const int vh = blockIdx.x * 16 + h;
+            const int vh = blockIdx.x * EMB_W + h;
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
             for (int ch = 0; ch < total; ch += EMB_CH) {
                 const int cnt = min(EMB_CH, total - ch);
                 if (!one_chunk) stage(ch, cnt);
-                for (int b = wave * 64; b < cnt; b += 16 * 64)
+                for (int b = wave * 64; b < cnt; b += EMB_W * 64)
                     emb_add_rows(__ballot(b + lane < cnt && tok[b + lane] == vh), ch + b, st, ns, d, c0, lane, acc);
             }
             __syncthreads();
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const EmbedDetGroup
             if (threadIdx.x < 512 && c0 + (int)threadIdx.x < d) {
                 float sum = 0.f;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) sum += part_sum[q][threadIdx.x];
+                for (int q = 0; q < EMB_W; ++q) sum += part_sum[q][threadIdx.x];
                 grp.dlut[t][(size_t)vh * d + c0 + threadIdx.x] += sum;
             }
         }
@@ -898,7 +899,7 @@ extern "C" int mtn_embed_bwd_group(int count, const mtn_embed_bwd_desc* descs, v
             g.first[t][++g.n[t]] = g.total[t];
             if (g.V[t] > vmax) vmax = g.V[t];
         }
-        hipLaunchKernelGGL(embed_bwd_det_kernel, dim3((vmax + 15) / 16, g.n_lut), dim3(1024), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(embed_bwd_det_kernel, dim3((vmax + EMB_W - 1) / EMB_W, g.n_lut), dim3(64 * EMB_W), 0, (hipStream_t)stream, g);
         MTN_CHECK_LAUNCH();
         return MTN_OK;
     }

@@ -88,6 +88,7 @@ class ParamGradQueue:
 
     def __init__(self):
         self.gemm, self.ln, self.keep = [], [], []
+        self.embed = []             # deferred embedding-table scatters (EmbedBwdDesc): every table of the step in ONE grouped launch
         self.dtype = None
         self.side_streams = []
         self._armed = False
@@ -153,20 +154,37 @@ class ParamGradQueue:
             self._armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
+    def add_embed(self, descs, keep):
+        """Defer embedding-table gradient scatters (mtn_embed_bwd_group) to the flush: the text streams' table and the target
+        table are separate autograd nodes, but one grouped launch serves both (one workgroup grid per table)."""
+        self.embed.extend(descs)
+        self.keep.extend(keep)
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
     def reset(self):
         """Drop everything queued and disarm.  A backward pass that raises never reaches the engine's final callbacks, so the
         queue would stay armed with stale problems and no later backward would register a flush: the step's error path and
         the start of every step call this."""
-        self.gemm, self.ln, self.keep = [], [], []
+        self.gemm, self.ln, self.keep, self.embed = [], [], [], []
         self._armed = False
         self.adam = None
 
     def flush(self):
         self._armed = False
-        if not self.gemm and not self.ln:
+        if not self.gemm and not self.ln and not self.embed:
             return
         lib = L.load()
         cur = torch.cuda.current_stream()
+        for i in range(0, len(self.embed), 8):            # (MTN_LN_MAX_GROUP descriptors per launch)
+            chunk = self.embed[i:i + 8]
+            arr = (L.EmbedBwdDesc * len(chunk))(*chunk)
+            L.check(lib.mtn_embed_bwd_group(len(chunk), arr, cur.cuda_stream))
+        self.embed = []
+        if not self.gemm and not self.ln:
+            self.keep = []
+            return
         for s in self.side_streams:
             cur.wait_stream(s)
         for t in self.keep:
@@ -988,7 +1006,12 @@ class EmbedNormFn(torch.autograd.Function):
             else:
                 farr = (L.LnFinalizeDesc * len(ln_final))(*[f[0] for f in ln_final])
                 L.check(lib.mtn_layernorm_bwd_finalize(len(ln_final), farr, L.stream_ptr()))
-        L.check(lib.mtn_embed_bwd_group(len(streams), emb, L.stream_ptr()))
+        if queue is not None and all(r is None for r in ret):
+            # every table's gradient lives in the flat gradient buffer: the scatter can wait for the end of backward and share its
+            # launch with the other tables' (the queue's flush); dx / dy stay alive in the queue until then
+            queue.add_embed([emb[i] for i in range(len(streams))], keep)
+        else:
+            L.check(lib.mtn_embed_bwd_group(len(streams), emb, L.stream_ptr()))
         return (None, *ret)
 
 
