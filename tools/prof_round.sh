@@ -17,6 +17,6 @@ print(int(m.rest_tables(frozenset(t[0] for t in m._fusable))[0][1].sum()))
 PY
 )
 echo NREST=$NREST
-python tools/prof_summary.py /tmp/pj_stats gpurun_out/${TAG:-r03_a}_kernel_stats.csv 2>&1 | tail -3
-python tools/prof_breakdown.py /tmp/pj_stats 60 gpurun_out/${TAG:-r03_a}_step_sequence.txt > gpurun_out/${TAG:-r03_a}_one_step_breakdown.txt
-python tools/pmc_summary.py /tmp/pj_fetch /tmp/pj_write gpurun_out/${TAG:-r03_a}_pmc_traffic.json $NREST 2>&1 | tail -20
+python tools/prof_summary.py /tmp/pj_stats gpurun_out/${TAG:-r04_z}_kernel_stats.csv 2>&1 | tail -3
+python tools/prof_breakdown.py /tmp/pj_stats 60 gpurun_out/${TAG:-r04_z}_step_sequence.txt > gpurun_out/${TAG:-r04_z}_one_step_breakdown.txt
+python tools/pmc_summary.py /tmp/pj_fetch /tmp/pj_write gpurun_out/${TAG:-r04_z}_pmc_traffic.json $NREST 2>&1 | tail -20
