@@ -37,7 +37,8 @@ extern "C" {
 const char* mtn_last_error(void);
 /* 100: rounds 1-3.  110 (round 4): mtn_gemm_problem gained `ln`, mtn_mha_args / mtn_ffn_args gained `ln_fold` (callers must zero
  * the structs or set them), mtn_attn_args gained kv_acc / kv_last in round 3, and mtn_mha_bwd_ws_f32_floats() /
- * mtn_ffn_bwd_ws_f32_floats() return larger workspaces (multi-pass dK / dV sums; LayerNorm row-sum partials). */
+ * mtn_ffn_bwd_ws_f32_floats() return larger workspaces (multi-pass dK / dV sums; LayerNorm row-sum partials).
+ * 111: mtn_transpose_desc gained `dst_off` (the transposed copies have a compact buffer of their own). */
 int mtn_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -493,13 +494,15 @@ int mtn_losshead_fwd(const mtn_losshead_args* args, void* stream);
 int mtn_losshead_bwd(int dtype, const mtn_losshead_args* args, void* stream);
 
 /* Transposed compute-dtype weight copies (operand of dX = dY W on the LDS-DMA GEMM path): for each descriptor the
- * [rows, cols] matrix at src+off is written as [cols, rows] at dst+off.  `descs_device` is a DEVICE array (built once),
+ * [rows, cols] matrix at src+off is written as [cols, rows] at dst+dst_off (v111: the copies have a compact buffer of
+ * their own — by default only the W_o^T matrices are kept).  `descs_device` is a DEVICE array (built once),
  * tile_start = running sum of ceil(rows/64)*ceil(cols/64), total_tiles = the final sum. */
 typedef struct {
-    long off;       /* element offset of the matrix in both flat buffers */
+    long off;       /* element offset of the matrix in the source buffer */
     int rows, cols;
     int tile_start;
     int reserved;
+    long dst_off;   /* element offset of the transposed copy in dst */
 } mtn_transpose_desc;
 int mtn_transpose_group(int dtype, const void* src, void* dst, const mtn_transpose_desc* descs_device, int count,
                         int total_tiles, void* stream);

@@ -14,7 +14,7 @@ void mtn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* mtn_last_error(void) { return g_err; }
-extern "C" int mtn_version(void) { return 110; }
+extern "C" int mtn_version(void) { return 111; }
 
 // ---------------------------------------------------------------- environment switches (common.h: MTN_ENV)
 // The library is entered from the caller's thread AND from autograd's device thread (backward), so a site's cache may be filled by
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256) void transpose_group_kernel(const T* __restric
     const int t = b - D.tile_start;
     const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
     const T* s = src + D.off;
-    T* d = dst + D.off;
-    const bool full = (r0 + 64 <= D.rows) && (c0 + 64 <= D.cols) && (D.rows % V == 0) && (D.cols % V == 0) && (D.off % V == 0);
+    T* d = dst + D.dst_off;
+    const bool full = (r0 + 64 <= D.rows) && (c0 + 64 <= D.cols) && (D.rows % V == 0) && (D.cols % V == 0) && (D.off % V == 0) && (D.dst_off % V == 0);
     if (full) {
         constexpr int VPR = 64 / V;                      // vectors per tile row (8 bf16 / 16 fp32)
         for (int i = threadIdx.x; i < 64 * VPR; i += 256) {

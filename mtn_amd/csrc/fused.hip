@@ -116,7 +116,8 @@ __host__ __device__ inline int fh_pad_rows(int kind, int mk) { return kind == FH
 #endif
 
 // NP = 64-column weight blocks per workgroup (3: q|k|v or 192 FFN columns; 1: q only), MT = row tiles (16 rows).
-template <int NP, int MT>
+// LIN: the launch has members that take LayerNorm by linearity (opt-in, MTN_LN_LIN=1); the default kernels are compiled without that path
+template <int NP, int MT, bool LIN>
 __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, const int slice, const int rb, unsigned char* smem) {
     constexpr int NG = (MT * 4 + 7) / 8;           // row groups (4 rows) a wave normalises at most
     constexpr int NT = NP * MT;                    // accumulator tiles per wave
@@ -136,7 +137,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     const int qa = M.mask_sq ? a : 1;
     const int mask_bytes = ffn ? 0 : nsamp * qa * m;   // the mask image always exists (all ones without a mask): no branch per score
     const bool late_v = kind == FH_CROSS_READY && M.late_v != 0;
-    const bool lin = M.xa != nullptr;              // LayerNorm by linearity: rows arrive as bf16(x * a_2), statistics from the producer's partials
+    const bool lin = LIN ? M.xa != nullptr : false;      // LayerNorm by linearity: rows arrive as bf16(x * a_2), statistics from the producer's partials
     const FhLds L = fh_lds_map(MT, raw, key_rows, fh_pad_rows(kind, mk), mask_bytes, ffn ? NP : 0, late_v);
     unsigned char* xn_s = smem + L.xn;
     unsigned char* xm_s = smem + L.xm;
@@ -700,7 +701,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
 #endif
 }
 
-template <int NP>
+template <int NP, bool LIN = false>
 __global__ __launch_bounds__(FH_THREADS) void fused_head_fwd_kernel(const FhGroup G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef FH_TIMELINE
@@ -726,12 +727,12 @@ __global__ __launch_bounds__(FH_THREADS) void fused_head_fwd_kernel(const FhGrou
 #endif
     if (rb * M.rows_per_wg >= M.rows) return;                  // padding workgroup (row-block count rounded up to the map's grid)
     if constexpr (NP == 4) {                       // 4 weight blocks: 128 VGPRs of fragments -> at most 64 rows (two row groups per wave)
-        if (M.mt <= 2) fh_body<NP, 2>(G, M, slice, rb, smem);
-        else fh_body<NP, 4>(G, M, slice, rb, smem);
+        if (M.mt <= 2) fh_body<NP, 2, LIN>(G, M, slice, rb, smem);
+        else fh_body<NP, 4, LIN>(G, M, slice, rb, smem);
     } else {
-        if (M.mt <= 2) fh_body<NP, 2>(G, M, slice, rb, smem);
-        else if (M.mt == 3) fh_body<NP, 3>(G, M, slice, rb, smem);
-        else fh_body<NP, 5>(G, M, slice, rb, smem);
+        if (M.mt <= 2) fh_body<NP, 2, LIN>(G, M, slice, rb, smem);
+        else if (M.mt == 3) fh_body<NP, 3, LIN>(G, M, slice, rb, smem);
+        else fh_body<NP, 5, LIN>(G, M, slice, rb, smem);
     }
 }
 
@@ -953,17 +954,22 @@ int fh_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, 
     return fh_plan(n_mha, mha, n_ffn, ffn, P) ? 1 : 0;
 }
 
-template <int NP> static int fh_launch(const FhGroup& G, int wgs, size_t lds, hipStream_t s) {
+template <int NP, bool LIN> static int fh_launch_lin(const FhGroup& G, int wgs, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)fused_head_fwd_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)fused_head_fwd_kernel<NP, LIN>, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX) != hipSuccess) {
             mtn_set_error("fused_head_fwd_kernel: cannot raise the dynamic LDS limit");
             return MTN_ERR_LAUNCH;
         }
         attr = true;
     }
-    hipLaunchKernelGGL((fused_head_fwd_kernel<NP>), dim3(wgs), dim3(FH_THREADS), lds, s, G);
+    hipLaunchKernelGGL((fused_head_fwd_kernel<NP, LIN>), dim3(wgs), dim3(FH_THREADS), lds, s, G);
     return MTN_OK;
+}
+template <int NP> static int fh_launch(const FhGroup& G, int wgs, size_t lds, hipStream_t s) {
+    bool any_lin = false;
+    for (int i = 0; i < G.count; ++i) any_lin = any_lin || G.m[i].xa != nullptr;
+    return any_lin ? fh_launch_lin<NP, true>(G, wgs, lds, s) : fh_launch_lin<NP, false>(G, wgs, lds, s);
 }
 
 static long g_lin_members = 0;                // members launched with LayerNorm by linearity since the library was loaded (tests)

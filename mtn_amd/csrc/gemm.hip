@@ -16,6 +16,7 @@
 struct GemmGroup {
     int count;
     int plain_tile_order;      // ablation (MTN_GEMM_PLAIN_TILES=1): row-major tile order, no XCD-aware mapping
+    int epi_pre;               // LDS-DMA kernels: epilogue operands (bias, gate, residual) loaded ahead of the contraction (MTN_GEMM_EPI_PRE=0: off)
     // 2-D XCD map of the LDS-DMA kernels (xcd_tile2d): problem g's tiles form rg x (8 / rg) blocks, one per XCD; 0 = band map
     unsigned char xcd_rg[MTN_GEMM_MAX_GROUP];
     int tile_start[MTN_GEMM_MAX_GROUP + 1];
@@ -197,7 +198,11 @@ template <typename T, bool TR> struct Stage {
 // Epilogue for 4 consecutive output columns of one row: v += bias; relu; dropout; gate; v += residual; store fp32 / lowp.
 template <typename T, bool ADAM = false>
 __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropState& ds, bool vec, int row, int col, int N, const f32x4_t& acc,
-                                          const AdamSlot* adam = nullptr, const AdamCoef* coef = nullptr, float* v_out = nullptr, float* gate_out = nullptr) {
+                                          const AdamSlot* adam = nullptr, const AdamCoef* coef = nullptr, float* v_out = nullptr, float* gate_out = nullptr,
+                                          const bool pre = false, const float4 pre_bias = float4{0.f, 0.f, 0.f, 0.f},
+                                          const float4 pre_res = float4{0.f, 0.f, 0.f, 0.f}, const uint2 pre_gate = uint2{0u, 0u}) {
+    // pre: bias / gate / residual of these four outputs, loaded by the caller while its contraction ran (vec layouts only; by value:
+    // through a pointer or a reference the caller's register arrays went to scratch memory)
     float v[4] = {acc[0], acc[1], acc[2], acc[3]};
     const size_t o = (size_t)row * P.ldc + col;
     const int nv = (col + 4 <= N) ? 4 : N - col;
@@ -211,7 +216,7 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
         }
     }
     if (P.bias) {
-        if (vec) { float4 b = *(const float4*)(P.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        if (vec) { const float4 b = pre ? pre_bias : *(const float4*)(P.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         else for (int r = 0; r < nv; ++r) v[r] += P.bias[col + r];
     }
     if (P.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -224,7 +229,7 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
         const T* gp = (const T*)P.gate + o;
         if (vec) {
             if constexpr (sizeof(T) == 2) {
-                uint2 u = *(const uint2*)gp;
+                const uint2 u = pre ? pre_gate : *(const uint2*)gp;
                 const float g0 = __uint_as_float(u.x << 16), g1 = __uint_as_float(u.x & 0xffff0000u), g2 = __uint_as_float(u.y << 16), g3 = __uint_as_float(u.y & 0xffff0000u);
                 v[0] = g0 > 0.f ? v[0] * P.gate_scale : 0.f; v[1] = g1 > 0.f ? v[1] * P.gate_scale : 0.f;
                 v[2] = g2 > 0.f ? v[2] * P.gate_scale : 0.f; v[3] = g3 > 0.f ? v[3] * P.gate_scale : 0.f;
@@ -238,7 +243,7 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
     }
     if (P.residual) {
         const float* rp = P.residual + (size_t)row * P.ldr + col;
-        if (vec) { float4 q = *(const float4*)rp; v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+        if (vec) { const float4 q = pre ? pre_res : *(const float4*)rp; v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
         else for (int r = 0; r < nv; ++r) v[r] += rp[r];
     }
     if (P.out_f32) {
@@ -308,7 +313,8 @@ struct LnConsumeLoads {               // everything the consume epilogue reads f
 // round trip then hides under the contraction instead of following it.
 template <int RT, int CT>
 __device__ __forceinline__ void ln_consume_issue(const LnEpiSlot& E, LnConsumeLoads<RT, CT>& Q, const int M, const int N, const int tile_row0,
-                                                 const int row_base, const int col_base, const int l15, const int lg, const int tid) {
+                                                 const int row_base, const int col_base, const int l15, const int lg, const int tid, const bool sums = true) {
+    // (sums: this thread is one of the 8 x tile-rows threads that gather the row-sum partials; a sixteen-wave workgroup has twice as many)
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         const int row = row_base + 16 * i + l15, rc = row < M ? row : M - 1;
@@ -333,7 +339,7 @@ __device__ __forceinline__ void ln_consume_issue(const LnEpiSlot& E, LnConsumeLo
 #ifdef LNE_ABL_NO_PART
     if (false) {
 #else
-    if (pr < M) {
+    if (pr < M && sums) {
 #endif
         const float2* pp = (const float2*)E.part + (size_t)pr * E.np;
         for (int k = tid & 7; k < E.np; k += 8) { const float2 t = pp[k]; Q.p1 += t.x; Q.p2 += t.y; }
@@ -343,10 +349,10 @@ __device__ __forceinline__ void ln_consume_issue(const LnEpiSlot& E, LnConsumeLo
 // its loads have landed and BEFORE a workgroup barrier that precedes the epilogue — the kernels use the barrier of their last stage,
 // so the epilogue itself needs none.
 template <int RT, int CT>
-__device__ __forceinline__ void ln_consume_publish(const LnConsumeLoads<RT, CT>& Q, const int tid, float* lds) {
+__device__ __forceinline__ void ln_consume_publish(const LnConsumeLoads<RT, CT>& Q, const int tid, float* lds, const bool sums = true) {
     const float p1 = fh_row8_sum(Q.p1);                    // the row's eight threads are eight consecutive lanes: fixed summation order
     const float p2 = fh_row8_sum(Q.p2);
-    if ((tid & 7) == 0) *(float2*)(lds + 2 * (tid >> 3)) = make_float2(p1, p2);
+    if ((tid & 7) == 0 && sums) *(float2*)(lds + 2 * (tid >> 3)) = make_float2(p1, p2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 template <int RT, int CT, int BMT>
@@ -804,8 +810,9 @@ __device__ __forceinline__ uint4 kn_frag(const unsigned char* img, int n_off, in
 template <typename T, int BM, int BN, int DMA_ROWB, bool BTR = false, int NBUF = 2, int NW = 4, bool LNE = false>
 __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, const typename LnArg<LNE>::type lne) {
     constexpr int BK = DMA_ROWB / (int)sizeof(T);            // 256 / 128 bf16, 128 / 64 fp32
-    constexpr int WC = NW / 2;                               // waves across the columns (2 or 4); two across the rows
-    constexpr int TM = BM / 32, TN = BN / (16 * WC);         // MFMA tiles per wave
+    constexpr int WR = NW == 16 ? 4 : 2;                     // waves across the rows (NW = 16: a 4 x 4 grid of 16 x 16 wave tiles on the 64 x 64 tile)
+    constexpr int WC = NW / WR;                              // waves across the columns (2 or 4)
+    constexpr int TM = BM / (16 * WR), TN = BN / (16 * WC);  // MFMA tiles per wave
     constexpr int A_BYTES = BM * DMA_ROWB, B_BYTES = BN * DMA_ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int NDMA = (BM + BN) * DMA_ROWB / (1024 * NW); // LDS-DMA instructions per wave per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -813,12 +820,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
     int g = 0;
     while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
     const mtn_gemm_problem& P = grp.p[g];
+    const int xcd_rg = grp.xcd_rg[g];
+    const int first_tile = grp.tile_start[g];
+    int lne_sl = 0;
+    if constexpr (LNE) lne_sl = lne.slot_of[g];
     const int M = P.M, N = P.N, K = P.K;
     const int tiles_n = (N + BN - 1) / BN;
-    const int t = (int)blockIdx.x - grp.tile_start[g];
+    const int t = (int)blockIdx.x - first_tile;
     const int tiles_m = (M + BM - 1) / BM;
     int tm_, tn_;
-    if (grp.xcd_rg[g]) xcd_tile2d(grp.xcd_rg[g], t, tiles_m, tiles_n, tm_, tn_);
+    if (xcd_rg) xcd_tile2d(xcd_rg, t, tiles_m, tiles_n, tm_, tn_);
     else xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
     const int row0 = tm_ * BM, col0 = tn_ * BN;
     const int lane = tid & 63;
@@ -860,12 +871,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
     typename std::conditional<LNE, LnConsumeLoads<TM, TN>, NoLn>::type lnq;
     float4 emit_u[TN], emit_c[TN];
     int lne_mode = 0;
+    // the ordinary epilogue's operands (bias, gate, residual of this lane's outputs) likewise: one memory round trip less behind the
+    // last MFMA (bf16 launches with 16-byte layouts; MTN_GEMM_EPI_PRE=0: load them in the epilogue as before)
+    const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
+    float4 pre_b[TN], pre_r[TM][TN];
+    uint2 pre_g[TM][TN];
+    bool pre_on = sizeof(T) == 2 && vec_ok && grp.epi_pre;
     if constexpr (LNE) {
-        const int sl = lne.slot_of[g];
+        const int sl = lne_sl;
         if (sl != 0) {
             const LnEpiSlot& E = lne.s[sl - 1];
             lne_mode = E.mode;
-            if (E.mode == MTN_LN_CONSUME) ln_consume_issue<TM, TN>(E, lnq, M, N, row0, row0 + wr * (BM / 2), col0 + wc * (BN / WC), l15, lg, tid);
+            if (E.mode == MTN_LN_CONSUME) ln_consume_issue<TM, TN>(E, lnq, M, N, row0, row0 + wr * (BM / WR), col0 + wc * (BN / WC), l15, lg, tid, tid < 8 * BM);
             else {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -877,6 +894,23 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
                         emit_c[j] = *(const float4*)(E.fold + N + cc);
                     }
                 }
+            }
+        }
+    }
+    if (lne_mode == MTN_LN_CONSUME) pre_on = false;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int colj = col0 + wc * (BN / WC) + j * 16 + lg * 4, col = colj + 3 < N ? colj : 0;
+        pre_b[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pre_on && P.bias) pre_b[j] = *(const float4*)(P.bias + col);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rowi = row0 + wr * (BM / WR) + i * 16 + l15, row = rowi < M ? rowi : M - 1;
+            pre_r[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pre_g[i][j] = make_uint2(0u, 0u);
+            if (pre_on && P.residual) pre_r[i][j] = *(const float4*)(P.residual + (size_t)row * P.ldr + col);
+            if constexpr (sizeof(T) == 2) {
+                if (pre_on && P.gate) pre_g[i][j] = *(const uint2*)((const T*)P.gate + (size_t)row * P.ldc + col);
             }
         }
     }
@@ -900,7 +934,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (LNE) {                   // last stage: everything has landed, the epilogue's loads included — its row sums
-                if (lne_mode == MTN_LN_CONSUME) ln_consume_publish<TM, TN>(lnq, tid, (float*)(smem + NBUF * STAGE_BYTES));     // ride on this barrier
+                if (lne_mode == MTN_LN_CONSUME) ln_consume_publish<TM, TN>(lnq, tid, (float*)(smem + NBUF * STAGE_BYTES), tid < 8 * BM);     // ride on this barrier
             }
         }
         __builtin_amdgcn_s_barrier();
@@ -928,7 +962,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
             auto load = [&](int ks, u32x4_t* a, u32x4_t* b) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const int ra = wr * (BM / 2) + i * 16 + l15;
+                    const int ra = wr * (BM / WR) + i * 16 + l15;
                     const unsigned addr = (unsigned)(size_t)(sA + ra * DMA_ROWB + (((ks * 4 + lg) ^ (ra & 15)) << 4));
                     asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(addr));
                 }
@@ -988,14 +1022,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
     // ---- epilogue.  The MFMAs were issued with the operands swapped (acc = W-tile x X-tile^T), so a lane holds, for ONE
     //      output row m = l15, FOUR CONSECUTIVE output columns n = 4*lg + r of each 16x16 tile: bias, residual, gate and
     //      both outputs move as 8/16-byte vectors (4x fewer memory instructions than the row-per-register layout).
-    const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
     if constexpr (LNE) {
-        static_assert(64 * NW == 8 * BM, "the LayerNorm epilogue deals a tile's rows to groups of eight threads");
-        const int sl = lne.slot_of[g];
+        static_assert(64 * NW >= 8 * BM, "the LayerNorm epilogue deals a tile's rows to groups of eight threads");
+        const int sl = lne_sl;
         if (sl != 0) {
             const LnEpiSlot& E = lne.s[sl - 1];
             if (lne_mode == MTN_LN_CONSUME) {
-                ln_consume_epilogue<TM, TN, BM>(E, lnq, acc, M, N, row0, row0 + wr * (BM / 2), col0 + wc * (BN / WC), l15, lg, tid, (float*)(smem + NBUF * STAGE_BYTES));
+                ln_consume_epilogue<TM, TN, BM>(E, lnq, acc, M, N, row0, row0 + wr * (BM / WR), col0 + wc * (BN / WC), l15, lg, tid, (float*)(smem + NBUF * STAGE_BYTES));
                 return;
             }
             float p1[TM], p2[TM];
@@ -1006,14 +1039,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     p1[i] = p2[i] = 0.f;
-                    const int row = row0 + wr * (BM / 2) + i * 16 + l15;
+                    const int row = row0 + wr * (BM / WR) + i * 16 + l15;
                     if (row >= M) continue;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int col = col0 + wc * (BN / WC) + j * 16 + lg * 4;
                         if (col >= N) continue;
                         float v[4];
-                        epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], nullptr, nullptr, v, nullptr);
+                        epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], nullptr, nullptr, v, nullptr, pre_on && col + 3 < N, pre_b[j], pre_r[i][j], pre_g[i][j]);
                         p1[i] += (v[0] + v[1]) + (v[2] + v[3]);
                         p2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                         store_lp4<T>((T*)E.ya + (size_t)row * N + col, make_float4(v[0] * emit_u[j].x, v[1] * emit_u[j].y, v[2] * emit_u[j].z, v[3] * emit_u[j].w));
@@ -1024,7 +1057,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const float s1 = fh_cross_sum(p1[i]), s2 = fh_cross_sum(p2[i]);
-                    const int row = row0 + wr * (BM / 2) + i * 16 + l15;
+                    const int row = row0 + wr * (BM / WR) + i * 16 + l15;
                     if (lg == 0 && row < M && col0 + wc * (BN / WC) < N)
                         ((float2*)E.part)[(size_t)row * (N / 16) + (col0 + wc * (BN / WC)) / 16] = make_float2(s1, s2);
                 }
@@ -1034,14 +1067,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 p1[i] = p2[i] = 0.f;
-                const int row = row0 + wr * (BM / 2) + i * 16 + l15;
+                const int row = row0 + wr * (BM / WR) + i * 16 + l15;
                 if (row >= M) continue;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int col = col0 + wc * (BN / WC) + j * 16 + lg * 4;
                     if (col >= N) continue;
                     float v[4], gt[4] = {0.f, 0.f, 0.f, 0.f};
-                    epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], nullptr, nullptr, v, gt);
+                    epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], nullptr, nullptr, v, gt, pre_on && col + 3 < N, pre_b[j], pre_r[i][j], pre_g[i][j]);
                     const float4 u4 = emit_u[j], c4 = emit_c[j];
                     const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
@@ -1052,19 +1085,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
                     }
                 }
             }
-            ln_emit_partials<TM, BM, WC>(E, p1, p2, M, N / 64, col0 / 64, row0, row0 + wr * (BM / 2), wc, l15, lg, tid, (float*)(smem + NBUF * STAGE_BYTES));
+            ln_emit_partials<TM, BM, WC>(E, p1, p2, M, N / 64, col0 / 64, row0, row0 + wr * (BM / WR), wc, l15, lg, tid, (float*)(smem + NBUF * STAGE_BYTES));
             return;
         }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int row = row0 + wr * (BM / 2) + i * 16 + l15;
+        const int row = row0 + wr * (BM / WR) + i * 16 + l15;
         if (row >= M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = col0 + wc * (BN / WC) + j * 16 + lg * 4;
             if (col >= N) continue;
-            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j]);
+            epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], nullptr, nullptr, nullptr, nullptr, pre_on && col + 3 < N, pre_b[j], pre_r[i][j], pre_g[i][j]);
         }
     }
 }
@@ -1808,7 +1841,7 @@ static int launch_dma_impl(const GemmGroup& grp, const typename LnArg<LNE>::type
 template <typename T, int BM, int BN, int ROWB, bool BTR = false, int NBUF = 2, int NW = 4>
 static int launch_dma(const GemmGroup& grp, int tiles, hipStream_t s, const LnEpiGroup* lne = nullptr) {
     if (lne) {
-        if constexpr (sizeof(T) == 2 && NBUF == 2 && 64 * NW == 8 * BM && BM == BN)
+        if constexpr (sizeof(T) == 2 && NBUF == 2 && (64 * NW == 8 * BM || (NW == 16 && BM == 64)) && BM == BN)
             return launch_dma_impl<T, BM, BN, ROWB, BTR, NBUF, NW, true>(grp, *lne, tiles, s);
         mtn_set_error("mtn_gemm: no LayerNorm-epilogue form of this kernel (tile %d x %d, stage %d B, %d waves)", BM, BN, ROWB, NW);
         return MTN_ERR_ARG;
@@ -1973,6 +2006,13 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
                 if (lne || (MTN_ENV("MTN_GEMM_NW4") == nullptr && MTN_ENV("MTN_GEMM_NW4H") == nullptr)) return launch_dma_any<T, 64, 64, 256, 2, 8>(g2, t, bt, s, lne);
                 return launch_dma_any<T, 64, 64, 256>(g2, t, bt, s);
             }
+            if constexpr (sizeof(T) == 2) {
+                // sixteen waves (a 4 x 4 grid of 16 x 16 wave tiles): cfg2 step +0.6 %, batch 64 +0.4 % against eight (profiles/r04_s_nw16_ab.txt).
+                // MTN_GEMM_NW16 = 0 none, 1 plain launches only, 2 launches with a LayerNorm epilogue only (default 3: both)
+                const char* n16 = MTN_ENV("MTN_GEMM_NW16");
+                const int m16 = n16 ? atoi(n16) : 3;
+                if (((m16 & 1) && !lne) || ((m16 & 2) && lne)) return launch_dma_any<T, 64, 64, 512, 2, 16>(g2, t, bt, s, lne);
+            }
             if (lne || MTN_ENV("MTN_GEMM_NW4") == nullptr) return launch_dma_any<T, 64, 64, 512, 2, 8>(g2, t, bt, s, lne);     // eight waves: see the kernel
             return launch_dma_any<T, 64, 64, 512>(g2, t, bt, s);
         }
@@ -2049,6 +2089,7 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     bool lne_emit = false;
     grp.count = count;
     grp.plain_tile_order = MTN_ENV("MTN_GEMM_PLAIN_TILES") != nullptr;
+    grp.epi_pre = !(MTN_ENV("MTN_GEMM_EPI_PRE") && MTN_ENV("MTN_GEMM_EPI_PRE")[0] == '0');
     int tiles = 0;
     const int align = (dtype == MTN_BF16) ? 8 : 4;
     for (int i = 0; i < count; ++i) {

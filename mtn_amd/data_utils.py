@@ -168,7 +168,7 @@ class FusedAdam:
         self._armed = dict(fusable=m._fusable, starts=[t[0] for t in m._fusable], optional=m._fusable_optional, covered=frozenset(),
                            grad=grad.data_ptr(), p=flat.data_ptr(), m=self.m.data_ptr(), v=self.v.data_ptr(), lp=lp_ptr,
                            lpT=m._flat_lpT.data_ptr() if m._flat_lpT is not None else None,
-                           t_offsets=frozenset(t[0] for t in m._tdescs_all), esz=esz, write_grad=write_grad,
+                           t_map=dict(m._t_off), esz=esz, write_grad=write_grad,
                            state=self.state.data_ptr(), grad_scale=L.ptr(self.grad_scale), betas=self.betas, eps=self.eps, applied=False)
         m._queue.adam = self._armed
 

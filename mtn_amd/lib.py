@@ -99,7 +99,7 @@ class LossHeadArgs(C.Structure):
 
 
 class TransposeDesc(C.Structure):
-    _fields_ = [("off", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("tile_start", C.c_int), ("reserved", C.c_int)]
+    _fields_ = [("off", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("tile_start", C.c_int), ("reserved", C.c_int), ("dst_off", C.c_long)]
 
 
 class LnFwdDesc(C.Structure):

@@ -657,7 +657,12 @@ class EncoderDecoder(nn.Module):
         lp = self.compute_dtype
         self._flat_lp = torch.empty(total, device=dev, dtype=lp) if lp != torch.float32 else flat
         self._flat_version = -1
-        self._flat_lpT = torch.zeros(total, device=dev, dtype=lp) if dev.type == "cuda" else None
+        # the transposed copies live in a compact buffer of their own (allocated below, once the kept copies are known):
+        # _t_off maps a weight's offset in the flat buffers to its copy's offset there
+        want_t = dev.type == "cuda"
+        self._flat_lpT = None
+        self._t_off = {}
+        t_views = []         # (dict, key, flat offset, rows, cols) of every kept transposed copy
         # (offset, rows, cols) of every 2-D path weight that gets a transposed copy.  Only W_o does (the fused head backward
         # reads W_o^T rows, csrc/fused_bwd.hip): every other dX = dY W runs on the LDS-DMA GEMM with W as it lies (b_trans = 1:
         # [k][n] tiles + transposing LDS reads, csrc/gemm.hip), so the optimiser epilogue writes no transposed copy for them —
@@ -691,12 +696,12 @@ class EncoderDecoder(nn.Module):
                 bo, _, gbo = views(m.linears[3].bias)
                 m._fused = dict(w_qkv=w, b_qkv=b, w_o=wo, b_o=bo, w_qkv_lp=wl, w_o_lp=wol, lp_dtype=lp,
                                 grads=dict(w_qkv=gw, b_qkv=gb, w_o=gwo, b_o=gbo))
-                if self._flat_lpT is not None:
+                if want_t:
                     oq, oo = path_off[id(m.linears[0].weight)], path_off[id(m.linears[3].weight)]
-                    m._fused["w_o_lpT"] = self._flat_lpT[oo:oo + d * d].view(d, d)
+                    t_views.append((m._fused, "w_o_lpT", oo, d, d))
                     tdescs += [(oo, d, d)]
                     if "qkv" in keep:
-                        m._fused["w_qkv_lpT"] = self._flat_lpT[oq:oq + 3 * d * d].view(d, 3 * d)
+                        t_views.append((m._fused, "w_qkv_lpT", oq, 3 * d, d))
                         tdescs += [(oq, 3 * d, d)]
                     fusable += [(oq, 3 * d, d), (oo, d, d)]
             elif isinstance(m, PositionwiseFeedForward) and id(m.w_1.weight) in path_off:
@@ -704,14 +709,14 @@ class EncoderDecoder(nn.Module):
                 w2, w2l, g2 = views(m.w_2.weight); b2, _, gb2 = views(m.w_2.bias)
                 m._fused = dict(w1=w1, b1=b1, w2=w2, b2=b2, w1_lp=w1l, w2_lp=w2l, lp_dtype=lp,
                                 grads=dict(w1=g1, b1=gb1, w2=g2, b2=gb2))
-                if self._flat_lpT is not None:
+                if want_t:
                     o1, o2 = path_off[id(m.w_1.weight)], path_off[id(m.w_2.weight)]
                     ffd, dm = m.w_1.weight.shape
                     if "w1" in keep:
-                        m._fused["w1_lpT"] = self._flat_lpT[o1:o1 + ffd * dm].view(dm, ffd)
+                        t_views.append((m._fused, "w1_lpT", o1, ffd, dm))
                         tdescs += [(o1, ffd, dm)]
                     if "w2" in keep:
-                        m._fused["w2_lpT"] = self._flat_lpT[o2:o2 + ffd * dm].view(ffd, dm)
+                        t_views.append((m._fused, "w2_lpT", o2, dm, ffd))
                         tdescs += [(o2, dm, ffd)]
                     fusable += [(o1, ffd, dm), (o2, dm, ffd)]
             elif isinstance(m, Generator):
@@ -720,9 +725,9 @@ class EncoderDecoder(nn.Module):
                 m._fused = dict(w_lp=self._flat_lp[o_w:o_w + nw].view(m.proj.weight.shape), bias=flat[o_b:o_b + nb],
                                 grad_w=grad[o_w:o_w + nw].view(m.proj.weight.shape), grad_b=grad[o_b:o_b + nb], lp_dtype=lp, w_lpT=None)
                 vocab, dm = m.proj.weight.shape
-                if self._flat_lpT is not None and vocab % 8 == 0 and not any(t[0] == o_w for t in fusable):
+                if want_t and vocab % 8 == 0 and not any(t[0] == o_w for t in fusable):
                     if "gen" in keep:
-                        m._fused["w_lpT"] = self._flat_lpT[o_w:o_w + nw].view(dm, vocab)
+                        t_views.append((m._fused, "w_lpT", o_w, vocab, dm))
                         tdescs.append((o_w, vocab, dm))
                     fusable.append((o_w, vocab, dm))
                     optional.add(o_w)            # its dW reaches the queue only through the fused loss head
@@ -732,6 +737,14 @@ class EncoderDecoder(nn.Module):
                 m._grads = (views(m.a_2)[2], views(m.b_2)[2])
                 m._lp_dtype = lp
                 m._queue = self._queue
+        if t_views:
+            t_total = 0
+            for _, _, o, r, c in t_views:
+                self._t_off[o] = t_total
+                t_total += pad(r * c)
+            self._flat_lpT = torch.zeros(t_total, device=dev, dtype=lp)
+            for dct, key, o, r, c in t_views:
+                dct[key] = self._flat_lpT[self._t_off[o]:self._t_off[o] + r * c].view(c, r)
         self._tdesc = self._tdesc_table(tdescs)
         # optimiser-epilogue bookkeeping (ops.ParamGradQueue / data_utils.FusedAdam): the fusable weights sorted by offset,
         # the transposed copies that still need the transpose pass, and the rest of the flat buffer as <= 4096-element chunks
@@ -855,7 +868,7 @@ class EncoderDecoder(nn.Module):
         arr = (L.TransposeDesc * len(descs))()
         tiles = 0
         for i, (o, r, c) in enumerate(descs):
-            arr[i].off, arr[i].rows, arr[i].cols, arr[i].tile_start = o, r, c, tiles
+            arr[i].off, arr[i].dst_off, arr[i].rows, arr[i].cols, arr[i].tile_start = o, self._t_off[o], r, c, tiles
             tiles += ((r + 63) // 64) * ((c + 63) // 64)
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self._flat.device)
         return (raw, len(descs), tiles)

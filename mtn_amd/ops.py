@@ -124,7 +124,7 @@ class ParamGradQueue:
             f = L.AdamFuse()
             f.p, f.m, f.v = A["p"] + 4 * off, A["m"] + 4 * off, A["v"] + 4 * off
             f.p_lp = A["lp"] + esz * off if A["lp"] else None
-            f.p_lpT = A["lpT"] + esz * (o + r0) if (A["lpT"] and o in A["t_offsets"]) else None
+            f.p_lpT = A["lpT"] + esz * (A["t_map"][o] + r0) if (A["lpT"] and o in A["t_map"]) else None     # (compact buffer of the kept copies)
             f.ldT = rows
             f.write_grad = 1 if A["write_grad"] else 0
             f.state, f.grad_scale = A["state"], A["grad_scale"]
