@@ -252,7 +252,11 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             if (act[p]) {
                 const bf16_t* wrow = M.w + (size_t)(ncol[p] + 16 * wc + (lane >> 2)) * FH_D + kh * 256 + (lane & 3) * 8;
 #pragma unroll
+#ifdef FH_W_NT      // development A/B: the weight slice as non-temporal loads (each workgroup reads its slice once)
+                for (int s = 0; s < 8; ++s) wf[p][s] = as_uint4(__builtin_nontemporal_load((const u32x4_t*)(wrow + s * 32)));
+#else
                 for (int s = 0; s < 8; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
+#endif
             } else {                                    // inactive block (q-only member in a 3-block launch, attention member in a 4-block one)
 #pragma unroll
                 for (int s = 0; s < 8; ++s) wf[p][s] = make_uint4(0, 0, 0, 0);

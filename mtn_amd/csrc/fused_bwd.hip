@@ -54,8 +54,10 @@ struct FbMember {
 };
 #ifdef FB_TIMELINE
 // development build (tools/fb_timeline.py): 16 wall-clock stamps (100 MHz) per workgroup of the launch selected with MTN_FB_TL_LAUNCH
-__device__ unsigned long long fb_timeline[256 * 16];
+__device__ unsigned long long fb_timeline[1024 * 16];
 #define FB_STAMP(k) do { if (tl && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) fb_timeline[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+// slot 15: where the workgroup ran — XCC_ID (hardware register 20) << 32 | HW_ID (register 4: wave / SIMD / CU / SH / SE ids)
+#define FB_WHERE() do { if (tl && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) fb_timeline[(size_t)blockIdx.x * 16 + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804); } while (0)
 #else
 #define FB_STAMP(k) do { } while (0)
 #endif
@@ -151,6 +153,9 @@ template <int MT, int NQB, bool RING>
 __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, const int rb, unsigned char* smem, const int stop, const int tl) {
     const int tid = threadIdx.x;
     FB_STAMP(0);
+#ifdef FB_TIMELINE
+    FB_WHERE();
+#endif
     const int row0 = rb * M.rows_per_wg;
     const int R = (M.rows - row0) < M.rows_per_wg ? (M.rows - row0) : M.rows_per_wg;
     const int lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
@@ -706,6 +711,6 @@ int fb_group_bwd_stage(int n_mha, const mtn_mha_args* mha, const FbIo* io, void*
 }
 #ifdef FB_TIMELINE
 extern "C" int mtn_fb_timeline_read(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_timeline), sizeof(unsigned long long) * 256 * 16) == hipSuccess ? MTN_OK : MTN_ERR_LAUNCH;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_timeline), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? MTN_OK : MTN_ERR_LAUNCH;
 }
 #endif
