@@ -687,6 +687,9 @@ def main():
                            "window_ms_per_step": [round(w, 4) for w in windows],
                            "median_window_ms_per_step": round(sorted(windows)[len(windows) // 2], 4),
                            "normalised_loss_last_step": round(loss_val, 4),
+                           **({"per_gpu_work": f"{B} samples per GPU at every N > 1 (BASELINE configs[2] = cfg3: 64 per GPU); the N = 1 default line is "
+                                               "configs[1] (cfg2, batch 32): the single-GPU figure of THIS per-GPU batch is secondary.one_rank_no_exchange "
+                                               "(same job) / the N = 1 line's secondary.batch64_one_gpu"} if world > 1 else {}),
                            "secondary": secondary},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
