@@ -668,3 +668,57 @@ def test_gemm_128x128_four_stage_kernel(dev, bt):
     for of, ol, v, K, _keep in checks:
         assert relmax(of, v) < 1e-5 * math.sqrt(K)
         assert relmax(ol.float(), v) < 1e-2
+
+
+@pytest.mark.parametrize("bt", [0, 1])
+def test_gemm_wave_count_and_epilogue_prefetch_do_not_change_a_bit(dev, bt):
+    """Round 4: the 64 x 64 LDS-DMA tile runs on sixteen waves (MTN_GEMM_NW16, default) and the ordinary epilogue's operands are
+    loaded ahead of the contraction (MTN_GEMM_EPI_PRE, default).  Neither changes the arithmetic — same contraction order per
+    output, same epilogue — so eight waves / epilogue-time loads must give the SAME BITS: bias + dropout + residual (the forward
+    second launch), gate + residual (the FFN backward), ragged rows, K = 512 and a K with a tail, both B layouts."""
+    import os
+    from mtn_amd import lib as L, ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(33)
+    seed = torch.full((1,), 1234567, device=dev, dtype=torch.int64)
+    shapes = [(640, 512, 512), (1000, 512, 2048), (200, 192, 520)]
+    keep, probs, outs = [], [], []
+    for (M, N, K) in shapes:
+        a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        A = a.to(dev, dtype)
+        B = (b.t().contiguous() if bt else b).to(dev, dtype)
+        bias, res, gate = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev, dtype)
+        for mode in ("bias_drop_res", "gate_res"):
+            of = torch.full((M, N), float("nan"), device=dev)
+            ol = torch.empty(M, N, device=dev, dtype=dtype)
+            p = _gemm_problem(L, A, B, M, N, K, 0, bt, K, N if bt else K)
+            p.residual, p.ldr, p.out_f32, p.out_lp, p.ldc = res.data_ptr(), N, of.data_ptr(), ol.data_ptr(), N
+            if mode == "bias_drop_res":
+                p.bias = bias.data_ptr()
+                p.drop.p, p.drop.salt, p.drop.seed = 0.1, 17, seed.data_ptr()
+            else:
+                p.gate, p.gate_scale = gate.data_ptr(), 1.0 / 0.9
+            probs.append(p); outs.append((of, ol))
+        keep.append((A, B, bias, res, gate))
+
+    def run(env):
+        os.environ.update(env)
+        L.reload_env()
+        try:
+            for i in range(0, len(probs), 2):
+                ops.gemm(L.MTN_BF16, [probs[i]])
+                ops.gemm(L.MTN_BF16, [probs[i + 1]])
+            torch.cuda.synchronize()
+            return [(of.clone(), ol.clone()) for of, ol in outs]
+        finally:
+            for k in env:
+                del os.environ[k]
+            L.reload_env()
+
+    base = run({"MTN_GEMM_TILE": "64"})
+    assert all(torch.isfinite(of).all() for of, _ in base)
+    for env in ({"MTN_GEMM_TILE": "64", "MTN_GEMM_NW16": "0"}, {"MTN_GEMM_TILE": "64", "MTN_GEMM_EPI_PRE": "0"},
+                {"MTN_GEMM_TILE": "64", "MTN_GEMM_NW16": "0", "MTN_GEMM_EPI_PRE": "0"}, {"MTN_GEMM_TILE": "32"}, {"MTN_GEMM_TILE": "32", "MTN_GEMM_EPI_PRE": "0"}):
+        got = run(env)
+        for (rf, rl), (gf, gl) in zip(base, got):
+            assert torch.equal(rf, gf) and torch.equal(rl, gl), env

@@ -191,3 +191,29 @@ def test_forward_layernorm_by_linearity_equals_in_kernel_layernorm(dev, name, dr
         assert cos > 0.9995, (k, cos)                              # measured down to 0.99988
         assert rel < 3e-2, (k, rel)
     print(f"{name} dropout={dropout}: members by linearity {ran}, output relmax {max(relmax(g, r) for r, g in zip(oref, ogot)):.2e}, worst gradient ||diff||/||ref|| {worst:.2e}")
+
+
+def test_epilogue_kernels_on_eight_and_sixteen_waves_agree_bitwise(dev):
+    """The LayerNorm-epilogue GEMMs run the 64 x 64 tile on sixteen waves by default (MTN_GEMM_NW16 bit 1); the row-sum gather keeps
+    its eight threads per row and its order, so every gradient must have the same bits as with the eight-wave kernels."""
+    from mtn_amd import lib
+    c = CFGS["query_b32"]
+    torch.manual_seed(0)
+    model = build_model(c, torch.bfloat16, dev, dropout=0.1, attn_dropout=0.1).train()
+    _randomise_layer_norms(model)
+    b = dev_batch(raw_batch(c), dev)
+    model.prepare()
+    model._seed.fill_(777)
+    seed0 = model._seed.clone()
+    res = []
+    try:
+        for nw in ("3", "0"):
+            os.environ["MTN_GEMM_NW16"] = nw
+            lib.reload_env()
+            model._seed.copy_(seed0)
+            res.append(_grads(model, b))
+    finally:
+        os.environ.pop("MTN_GEMM_NW16", None)
+        lib.reload_env()
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
