@@ -968,6 +968,9 @@ template <int NP, bool LIN> static int fh_launch_lin(const FhGroup& G, int wgs, 
         attr = true;
     }
     hipLaunchKernelGGL((fused_head_fwd_kernel<NP, LIN>), dim3(wgs), dim3(FH_THREADS), lds, s, G);
+#ifdef MTN_DBG_TWICE      // development probe: every launch issued twice — the second finds all of its operands in the L2s (tools/twice_probe.py)
+    hipLaunchKernelGGL((fused_head_fwd_kernel<NP, LIN>), dim3(wgs), dim3(FH_THREADS), lds, s, G);
+#endif
     return MTN_OK;
 }
 template <int NP> static int fh_launch(const FhGroup& G, int wgs, size_t lds, hipStream_t s) {

@@ -706,6 +706,9 @@ int fb_group_bwd_stage(int n_mha, const mtn_mha_args* mha, const FbIo* io, void*
 #endif
     if (P.wide) hipLaunchKernelGGL(fused_head_bwd_kernel<true>, dim3(P.wgs), dim3(FH_THREADS), P.lds, (hipStream_t)stream, P.G);
     else hipLaunchKernelGGL(fused_head_bwd_kernel<false>, dim3(P.wgs), dim3(FH_THREADS), P.lds, (hipStream_t)stream, P.G);
+#ifdef MTN_DBG_TWICE      // development probe (tools/twice_probe.py)
+    if (!P.wide) hipLaunchKernelGGL(fused_head_bwd_kernel<false>, dim3(P.wgs), dim3(FH_THREADS), P.lds, (hipStream_t)stream, P.G);
+#endif
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }

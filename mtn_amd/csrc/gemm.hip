@@ -1833,6 +1833,9 @@ static int launch_dma_impl(const GemmGroup& grp, const typename LnArg<LNE>::type
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF, NW, LNE>), dim3(tiles), dim3(64 * NW), LDS, s, grp, lne);
+#ifdef MTN_DBG_TWICE      // development probe: every launch issued twice (results of in-place epilogues are WRONG; timing only — tools/twice_probe.py)
+    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF, NW, LNE>), dim3(tiles), dim3(64 * NW), LDS, s, grp, lne);
+#endif
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
