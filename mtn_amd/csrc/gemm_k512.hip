@@ -38,7 +38,11 @@ __global__ __launch_bounds__(GK_THREADS) void gemm_k512_kernel(const GkGroup G) 
     {
         const unsigned ldab = (unsigned)P.lda * 2u;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)row0 * P.lda), 0, (R - 1) * ldab + FH_ROWB, 0x00020000);
+#ifdef GK_ABLATE_NO_X      // development (tools/k512_probe.py ablation builds): no x image traffic
+        for (int r = wave; r < 0; r += 8) {
+#else
         for (int r = wave; r < 128; r += 8) {
+#endif
             const unsigned vo = r < R ? (unsigned)r * ldab + (unsigned)((lane ^ (r & 15)) << 4) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (fh_lds_void_t*)(smem + r * FH_ROWB), 16, vo, 0, 0, 0);
         }
@@ -49,7 +53,11 @@ __global__ __launch_bounds__(GK_THREADS) void gemm_k512_kernel(const GkGroup G) 
         n = n < P.N ? n : P.N - 1;
         const bf16_t* wrow = P.B + (size_t)n * P.ldb + (lane & 3) * 8;
 #pragma unroll
+#ifdef GK_ABLATE_NO_W
+        for (int s = 0; s < 16; ++s) wf[s] = make_uint4((unsigned)(size_t)wrow + s, 1u, 2u, 3u);
+#else
         for (int s = 0; s < 16; ++s) wf[s] = *(const uint4*)(wrow + s * 32);
+#endif
     }
     const int colq = col0 + 16 * wave + 4 * lg;                  // this lane's four output columns
     float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -73,7 +81,11 @@ __global__ __launch_bounds__(GK_THREADS) void gemm_k512_kernel(const GkGroup G) 
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
+#ifdef GK_ABLATE_NO_MFMA
+    for (int s = 0; s < 1; ++s)
+#else
     for (int s = 0; s < 16; ++s)
+#endif
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) mma16<bf16_t>(acc[mt], wf[s], fh_xfrag(smem, mt * 16 + l15, s * 4 + lg));
     __syncthreads();                                             // the x image is dead: it becomes the output staging area
@@ -89,8 +101,100 @@ __global__ __launch_bounds__(GK_THREADS) void gemm_k512_kernel(const GkGroup G) 
     for (int ps = 0; ps < 4; ++ps) {
         const int r = ps * 32 + (tid >> 4), c = tid & 15;
         const int col = col0 + c * 8;
+#ifdef GK_ABLATE_NO_STORE
+        if (r < R && col < P.N && acc[0][0] == 1.2345e33f)
+#else
         if (r < R && col < P.N)                                  // N % 8 == 0: the 8 columns are in or out together
+#endif
             *(uint4*)(P.out + (size_t)(row0 + r) * P.ldc + col) = *(const uint4*)(smem + r * GK_CPITCH + c * 16);
+    }
+}
+
+// ====================================================================================================================
+// Wide form (round 4): the same one-shot construction on a 128 x 256 tile.  An ablation of the kernel above
+// (profiles/r04_ae_k512_ablation.txt: 76 us per launch; without the x image 65, without the W loads 51, without the stores 69,
+// with 1/16 of the MFMAs and of their LDS reads 32) showed that its COMPUTE phase is the largest part: every MFMA (16 K FLOP)
+// reads a 1 KiB x fragment from LDS — 16 FLOP per LDS byte against the 32 the matrix cores need at 128 B/clk — so the phase runs
+// at LDS speed.  Here a wave owns two 16-column blocks (32 of the tile's 256 columns): an x fragment feeds two MFMAs, the LDS
+// reads per FLOP halve, and an x row tile is re-read for 4 column tiles instead of 8.  W fragments: 128 VGPRs.
+// ====================================================================================================================
+static constexpr int GW_CPITCH = 528;                     // bytes per staged output row (512 + 16)
+__global__ __launch_bounds__(GK_THREADS) void gemm_k512w_kernel(const GkGroup G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int g = 0;
+    while (g + 1 < G.count && (int)blockIdx.x >= G.tile_start[g + 1]) ++g;
+    const GkProblem& P = G.p[g];
+    const int t = (int)blockIdx.x - G.tile_start[g];
+    const int tn = t / P.tiles_m, tm = t - tn * P.tiles_m;      // row tiles vary fastest (see gemm_k512_kernel)
+    const int row0 = tm * 128, col0 = tn * 256;
+    const int R = (P.M - row0) < 128 ? (P.M - row0) : 128;
+    {
+        const unsigned ldab = (unsigned)P.lda * 2u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)row0 * P.lda), 0, (R - 1) * ldab + FH_ROWB, 0x00020000);
+        for (int r = wave; r < 128; r += 8) {
+            const unsigned vo = r < R ? (unsigned)r * ldab + (unsigned)((lane ^ (r & 15)) << 4) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (fh_lds_void_t*)(smem + r * FH_ROWB), 16, vo, 0, 0, 0);
+        }
+    }
+    uint4 wf[2][16];                                             // column block cb: columns col0 + 128 cb + 16 wave .. + 15
+    float4 bq[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        int n = col0 + 128 * cb + 16 * wave + (lane >> 2);
+        n = n < P.N ? n : P.N - 1;
+        const bf16_t* wrow = P.B + (size_t)n * P.ldb + (lane & 3) * 8;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wf[cb][s] = *(const uint4*)(wrow + s * 32);
+        const int colq = col0 + 128 * cb + 16 * wave + 4 * lg;
+        bq[cb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.bias && colq < P.N) bq[cb] = *(const float4*)(P.bias + colq);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const int src = (4 * l15 + lg) * 4;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                wf[cb][s].x = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].x);
+                wf[cb][s].y = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].y);
+                wf[cb][s].z = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].z);
+                wf[cb][s].w = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].w);
+            }
+    }
+    f32x4_t acc[2][8];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc[cb][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const uint4 xf = fh_xfrag(smem, mt * 16 + l15, s * 4 + lg);
+            mma16<bf16_t>(acc[0][mt], wf[0][s], xf);
+            mma16<bf16_t>(acc[1][mt], wf[1][s], xf);
+        }
+    __syncthreads();                                             // the x image is dead: it becomes the output staging area
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int r = mt * 16 + l15;
+            *(uint2*)(smem + r * GW_CPITCH + (128 * cb + 16 * wave + 4 * lg) * 2) =
+                make_uint2(fh_pack2(acc[cb][mt][0] + bq[cb].x, acc[cb][mt][1] + bq[cb].y), fh_pack2(acc[cb][mt][2] + bq[cb].z, acc[cb][mt][3] + bq[cb].w));
+        }
+    __syncthreads();
+    // whole 512-byte row segments: 32 lanes per row, 16 rows per pass
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const int r = ps * 16 + (tid >> 5), c = tid & 31;
+        const int col = col0 + c * 8;
+        if (r < R && col < P.N)
+            *(uint4*)(P.out + (size_t)(row0 + r) * P.ldc + col) = *(const uint4*)(smem + r * GW_CPITCH + c * 16);
     }
 }
 
@@ -363,6 +467,23 @@ int gemm_k512_try(int count, const mtn_gemm_problem* p, int min_tiles, hipStream
         hipLaunchKernelGGL(gemm_k512p_kernel, dim3(GP_GRID), dim3(GK_THREADS), GP_LDS, s, G);
         if (hipGetLastError() != hipSuccess) return -1;
         if (tiles_out) *tiles_out = GP_GRID;
+        return 1;
+    }
+    // wide tiles (128 x 256) when every problem's N fills them: half the LDS reads per FLOP (MTN_K512_WIDE=0: 128 x 128 tiles)
+    bool wide = !(MTN_ENV("MTN_K512_WIDE") && MTN_ENV("MTN_K512_WIDE")[0] == '0');
+    for (int i = 0; i < count; ++i) wide = wide && (p[i].N % 256) == 0;
+    if (wide) {
+        static bool attr_w = false;
+        if (!attr_w) {
+            if (hipFuncSetAttribute((const void*)gemm_k512w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GK_LDS) != hipSuccess) return 0;
+            attr_w = true;
+        }
+        int tw = 0;
+        for (int i = 0; i < count; ++i) { G.tile_start[i] = tw; tw += G.p[i].tiles_m * (p[i].N / 256); }
+        for (int i = count; i <= MTN_GEMM_MAX_GROUP; ++i) G.tile_start[i] = tw;
+        hipLaunchKernelGGL(gemm_k512w_kernel, dim3(tw), dim3(GK_THREADS), GK_LDS, s, G);
+        if (hipGetLastError() != hipSuccess) return -1;
+        if (tiles_out) *tiles_out = tw;
         return 1;
     }
     hipLaunchKernelGGL(gemm_k512_kernel, dim3(tiles), dim3(GK_THREADS), GK_LDS, s, G);
