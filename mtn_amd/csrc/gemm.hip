@@ -246,6 +246,9 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
         if (vec) { const float4 q = pre ? pre_res : *(const float4*)rp; v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
         else for (int r = 0; r < nv; ++r) v[r] += rp[r];
     }
+#ifdef MTN_DBG_NO_STORE      // development ablation (tools/r04_ag_run.sh): the epilogue's stores never happen (timing only)
+    if (v[0] != 1.2345e33f) return;
+#endif
     if (P.out_f32) {
         if (vec) *(float4*)(P.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
         else for (int r = 0; r < nv; ++r) P.out_f32[o + r] = v[r];
@@ -393,7 +396,11 @@ __device__ __forceinline__ void ln_consume_epilogue(const LnEpiSlot& E, LnConsum
                 ga[k] = live ? g[k] * e * r : 0.f;
                 gb[k] = live ? g[k] : 0.f;
             }
+#ifdef MTN_DBG_NO_STORE
+            if (live && o[0] == 1.2345e33f) {
+#else
             if (live) {
+#endif
                 const size_t eo = (size_t)row * N + col;
                 *(float4*)(E.dx + eo) = make_float4(o[0], o[1], o[2], o[3]);
 #ifdef LNE_ABL_NO_LP
@@ -409,7 +416,7 @@ __device__ __forceinline__ void ln_consume_epilogue(const LnEpiSlot& E, LnConsum
                     store_lp4<bf16_t>((bf16_t*)E.dx_lp + eo, make_float4(o[0], o[1], o[2], o[3]));
                 }
             }
-#ifdef LNE_ABL_NO_COLPART
+#if defined(LNE_ABL_NO_COLPART) || defined(MTN_DBG_NO_STORE)
             if (false) {
 #else
             if (E.colpart) {
