@@ -263,6 +263,19 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             }
         }
     };
+    // One block WITHOUT a condition (an inactive block re-reads block 0's rows — L1 / L2 hits — and its products are never kept):
+    // with every load of the kernel unconditional the compiler knows exactly how many are younger than the x rows a LayerNorm row
+    // group waits for, and the blocks can be issued BETWEEN the row groups (below).
+    auto issue_block = [&](const int p_) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (p != p_) continue;
+            const int nc = act[p] ? ncol[p] : ncol[0];
+            const bf16_t* wrow = M.w + (size_t)(nc + 16 * wc + (lane >> 2)) * FH_D + kh * 256 + (lane & 3) * 8;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
+        }
+    };
 #ifdef FH_SPLIT_ORDER
     const bool w_first = wave < 4;                 // (experiment: waves 4-7 normalise first; wave w and w + 4 share a SIMD)
 #else
@@ -285,7 +298,16 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // (raw: __syncthreads would wait for every load in flight)
     FH_STAMP(3);
+    // A wave's memory instructions are accepted at the rate its earlier ones return (about a dozen in flight): issuing the 24 weight
+    // loads takes ~4 us during which the wave does nothing else, and the LayerNorm — 3.4 us of arithmetic on rows that landed long
+    // before — only started behind them (profiles/r03_fh_order.txt).  Interleaved (round 4): block 0, row group 0, block 1, row
+    // group 1, ...: the arithmetic runs while the queue drains.  -DFH_NO_INTERLEAVE: all blocks first, as before.
+#ifdef FH_NO_INTERLEAVE
     if (w_first) issue_weights();
+#else
+    (void)w_first;
+    issue_block(0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     FH_STAMP(13);                                  // first half of the waves: all loads issued
     const DropState ds = drop_init(M.drop);
@@ -313,8 +335,11 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     }
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-        if (lin) break;
-        if (wave + 8 * i >= MT * 4) break;
+#ifndef FH_NO_INTERLEAVE
+        if (i > 0 && i < NP) { __builtin_amdgcn_sched_barrier(0); issue_block(i); __builtin_amdgcn_sched_barrier(0); }
+#endif
+        if (lin) continue;
+        if (wave + 8 * i >= MT * 4) continue;
         const int r = 4 * (wave + 8 * i) + lg;
         float s = 0.f;
 #pragma unroll
@@ -343,7 +368,12 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef FH_NO_INTERLEAVE
     if (!w_first) issue_weights();
+#else
+#pragma unroll
+    for (int p = NG > 1 ? NG : 1; p < NP; ++p) issue_block(p);          // the blocks that found no row group to precede
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // zero padding behind the key images (a key chunk may run past the last key: its V rows must be finite)
     if (!ffn && kind != FH_CROSS_READY) {
