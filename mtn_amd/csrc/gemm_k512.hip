@@ -138,46 +138,57 @@ __global__ __launch_bounds__(GK_THREADS) void gemm_k512w_kernel(const GkGroup G)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (fh_lds_void_t*)(smem + r * FH_ROWB), 16, vo, 0, 0, 0);
         }
     }
-    uint4 wf[2][16];                                             // column block cb: columns col0 + 128 cb + 16 wave .. + 15
     float4 bq[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-        int n = col0 + 128 * cb + 16 * wave + (lane >> 2);
-        n = n < P.N ? n : P.N - 1;
-        const bf16_t* wrow = P.B + (size_t)n * P.ldb + (lane & 3) * 8;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) wf[cb][s] = *(const uint4*)(wrow + s * 32);
         const int colq = col0 + 128 * cb + 16 * wave + 4 * lg;
         bq[cb] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (P.bias && colq < P.N) bq[cb] = *(const float4*)(P.bias + colq);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    // W fragments in CONTRACTION order (step s of both column blocks, then step s + 1, ...): the MFMAs of step s start as soon as its
+    // two fragments have landed, while the later ones are still being accepted — a wave's 32 loads take ~6 us to issue, and the kernel
+    // used to wait for all of them before its first MFMA.
+    uint4 wf[2][16];                                             // column block cb: columns col0 + 128 cb + 16 wave .. + 15
     {
-        const int src = (4 * l15 + lg) * 4;
+        const bf16_t* wrow[2];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < 2; ++cb) {
+            int n = col0 + 128 * cb + 16 * wave + (lane >> 2);
+            n = n < P.N ? n : P.N - 1;
+            wrow[cb] = P.B + (size_t)n * P.ldb + (lane & 3) * 8;
+        }
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                wf[cb][s].x = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].x);
-                wf[cb][s].y = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].y);
-                wf[cb][s].z = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].z);
-                wf[cb][s].w = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].w);
-            }
+        for (int s = 0; s < 16; ++s) { wf[0][s] = *(const uint4*)(wrow[0] + s * 32); wf[1][s] = *(const uint4*)(wrow[1] + s * 32); }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // the x image (and the bias) has landed once at most the 32 W loads behind it fly: s_waitcnt vmcnt(32) lgkmcnt(15) expcnt(7) as a
+    // BUILTIN, so that the compiler's own counter knows that no LDS-DMA is outstanding any more (behind an inline-asm wait it would put
+    // vmcnt(0) in front of the first LDS read it sees)
+    __builtin_amdgcn_s_waitcnt(0x8F70);
+    __builtin_amdgcn_s_barrier();
     f32x4_t acc[2][8];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) acc[cb][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int src = (4 * l15 + lg) * 4;
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+    for (int s = 0; s < 16; ++s) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {                         // coalesced load order -> MFMA operand order
+            wf[cb][s].x = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].x);
+            wf[cb][s].y = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].y);
+            wf[cb][s].z = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].z);
+            wf[cb][s].w = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[cb][s].w);
+        }
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             const uint4 xf = fh_xfrag(smem, mt * 16 + l15, s * 4 + lg);
             mma16<bf16_t>(acc[0][mt], wf[0][s], xf);
             mma16<bf16_t>(acc[1][mt], wf[1][s], xf);
         }
+    }
     __syncthreads();                                             // the x image is dead: it becomes the output staging area
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
