@@ -108,7 +108,10 @@ __device__ __forceinline__ DropState drop_init(const mtn_dropout& d) {
     s.on = (d.p > 0.f) && (d.seed != nullptr);
     s.k0 = s.k1 = s.thresh = 0; s.scale = 1.f;
     if (s.on) {
-        uint64_t sd = *d.seed;
+        // the seed as a SCALAR load with its own wait (lgkmcnt): as a vector load its consumer — the key hashing right below — made the
+        // compiler wait for vmcnt(0), i.e. for every load and LDS-DMA the kernel had in flight (the seed is the youngest of them)
+        uint64_t sd;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sd) : "s"(d.seed) : "memory");
         s.k0 = mix32((uint32_t)sd ^ (d.salt * 0x9E3779B9u));
         s.k1 = mix32((uint32_t)(sd >> 32) + d.salt * 0x85EBCA6Bu + 0x165667B1u);
         s.thresh = (uint32_t)(d.p * 16777216.0f);

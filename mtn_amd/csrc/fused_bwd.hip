@@ -182,14 +182,11 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     float* Ds = (float*)(smem + L.scratch + 2 * FB_TEAM_SCRATCH + wave * FB_DS_BYTES);    // D_q of the wave's sample
 
     // ================================================================ everything this workgroup reads, issued now
-    uint8_t mkb[FH_MASKB];
-    const uint8_t* mask_g = M.mask ? M.mask + (size_t)b0 * M.mask_sb : nullptr;
-#pragma unroll
-    for (int i = 0; i < FH_MASKB; ++i) {
-        const int idx = tid + FH_THREADS * i;
-        mkb[i] = 1;
-        if (M.mask && idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * mk)];
-    }
+    // Order of issue (round 4): what the FIRST stage (dO = dy W_o^T) reads goes out first — the LDS-DMA images, then the W_o^T
+    // fragments — and the loads only later stages need (mask bytes, softmax statistics, fold values: 8 + 4 NQB + 1 per thread, ALL of
+    // them unconditional so that the count is exact) behind them: the kernel waits for all but those, and the dO stage runs while they
+    // are being accepted (a wave's memory instructions are accepted at the rate its earlier ones return: the whole issue phase took 3-4 us
+    // with nothing running under it).
     {   // dy rows [R][512] (rows past R: zeros), 16-byte slots swizzled with row & 15
         const fh_rsrc_t rs = fh_make_rsrc(M.dyl + (size_t)row0 * FH_D, (unsigned)(R * FH_ROWB));
         for (int r = wave; r < MT * 16; r += 8) {
@@ -220,6 +217,20 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
 #pragma unroll
         for (int s = 0; s < 8; ++s) wf[s] = *(const uint4*)(wrow + s * 32);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // mask bytes of the block's samples: always FH_MASKB loads per thread (without a mask: of the statistics buffer, ignored)
+    uint8_t mkb[FH_MASKB];
+    {
+        const uint8_t* mask_g = M.mask ? M.mask + (size_t)b0 * M.mask_sb : (const uint8_t*)M.lse;
+        const bool bcast = M.mask != nullptr && M.mask_sb == 0;
+#pragma unroll
+        for (int i = 0; i < FH_MASKB; ++i) {
+            const int idx = tid + FH_THREADS * i;
+            int src = (M.mask && idx < mask_bytes) ? idx : 0;
+            if (bcast) src = src % (qa * mk);                      // (uniform branch: the division only for masks shared by the samples)
+            mkb[i] = mask_g[src];                                  // (whether the byte counts is decided where it is stored: a select here would wait for the load)
+        }
+    }
     // softmax statistics {row max, 1 / row sum} of the team's first sample (queries 8lg + 4qt + r): in flight with everything else
     float mxq[NQB][4], invq[NQB][4];
     {
@@ -235,22 +246,24 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
             }
     }
     const bool lnon = M.lnf != nullptr;
-    float fold_v = 0.f;
-    if (lnon && tid < (M.self_attn ? FB_FOLD_FLOATS : 2 * 64))      // thread -> (part q|k|v, u|c, head column)
-        fold_v = M.lnf[((tid >> 6) & 1) * M.lnK + (tid >> 7) * FH_D + slice * FH_DK + (tid & 63)];
+    float fold_v;
+    {   // thread -> (part q|k|v, u|c, head column); one load per thread whatever the member (statistics buffer when there is nothing to read)
+        const bool fon = lnon && tid < (M.self_attn ? FB_FOLD_FLOATS : 2 * 64);
+        const float* fp = fon ? M.lnf + (((tid >> 6) & 1) * M.lnK + (tid >> 7) * FH_D + slice * FH_DK + (tid & 63)) : M.lse;
+        const float fv = *fp;
+        fold_v = fon ? fv : 0.f;
+    }
     float* fold_s = (float*)(smem + L.scratch + FB_SCRATCH);
     float* rs_s = fold_s + FB_FOLD_FLOATS;
     const DropState ds = drop_init(M.drop);
     FB_STAMP(1);
 
     // ================================================================ on chip from here
-#pragma unroll
-    for (int i = 0; i < FH_MASKB; ++i) {
-        const int idx = tid + FH_THREADS * i;
-        if (idx < mask_bytes) mk_s[idx] = mkb[i];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // LDS-DMA images and weight fragments have landed
-    __syncthreads();
+    // LDS-DMA images and weight fragments have landed once at most the FH_MASKB + 4 NQB + 1 loads issued behind them fly
+    static_assert(FH_MASKB == 8 && (NQB == 1 || NQB == 2), "the counted wait below spells the number of younger loads out");
+    if constexpr (NQB == 1) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     FB_STAMP(2);
     if (stop == 1) return;
     {
@@ -288,7 +301,12 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                 *(uint2*)(doi_s + r * FH_HROWB + (((2 * wc + (lg >> 1)) ^ (r & 7)) << 4) + (lg & 1) * 8) = u;
             }
     }
-    __syncthreads();                                            // dO image complete; the exchange area (in the dy image) is dead too
+#pragma unroll
+    for (int i = 0; i < FH_MASKB; ++i) {                        // (their loads were accepted under the dO stage)
+        const int idx = tid + FH_THREADS * i;
+        if (idx < mask_bytes) mk_s[idx] = M.mask ? mkb[i] : (uint8_t)1;
+    }
+    __syncthreads();                                            // dO image complete; the exchange area (in the dy image) is dead too; mask image written
     FB_STAMP(4);
     if (stop == 2) return;
     // the lane's fold-vector values: parts q | k | v, head columns 16 w4 + 4 lg .. +3 (registers for the whole attention stage)
