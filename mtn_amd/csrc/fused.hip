@@ -383,8 +383,20 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         }
     }
     FH_STAMP(4);                                   // LayerNorm done
+#ifdef FH_NO_INTERLEAVE
     if (raw || kind == FH_CROSS_READY || lin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA images have landed
     __syncthreads();
+#else
+    // Everything OLDER than the weight blocks has landed — the x rows, the LDS-DMA images — once at most the 8 NP weight loads (every
+    // wave issues exactly that many, and they are its youngest loads) are still in flight; the normalised rows are in LDS once the
+    // LDS counter is down.  No vmcnt(0) here (__syncthreads has one): the last weight block has only just been asked for, and the
+    // projections below start on the fragments that have landed (counted waits by the compiler, fragment by fragment).
+    static_assert(NP == 1 || NP == 3 || NP == 4, "the counted wait below spells 8 * NP out");
+    if constexpr (NP == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
     FH_STAMP(5);
     if (G.stop == 1) return;
     if (lin) {
@@ -410,18 +422,18 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         }
     }
 
-    {   // weight fragments into operand order: lane 16c + r takes the 16 bytes lane 4r + c loaded
-        const int src = (4 * l15 + lg) * 4;
+    // weight fragments into operand order (lane 16c + r takes the 16 bytes lane 4r + c loaded): step by step INSIDE the projection loops,
+    // so that a step's MFMAs only wait for that step's fragments
+    const int wsrc = (4 * l15 + lg) * 4;
+    auto permute_step = [&](const int s) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                wf[p][s].x = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[p][s].x);
-                wf[p][s].y = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[p][s].y);
-                wf[p][s].z = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[p][s].z);
-                wf[p][s].w = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)wf[p][s].w);
-            }
-    }
+        for (int p = 0; p < NP; ++p) {
+            wf[p][s].x = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc, (int)wf[p][s].x);
+            wf[p][s].y = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc, (int)wf[p][s].y);
+            wf[p][s].z = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc, (int)wf[p][s].z);
+            wf[p][s].w = (unsigned)__builtin_amdgcn_ds_bpermute(wsrc, (int)wf[p][s].w);
+        }
+    };
     // ---- projections: acc[p][mt] = W block p (A operand: 16 output columns) x rows of tile mt (B operand), this wave's half of k
     f32x4_t acc[NP][MT];
 #pragma unroll
@@ -431,6 +443,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     if (!raw) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
+            permute_step(s);
             uint4 xf[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xf[mt] = fh_xfrag(xn_s, mt * 16 + l15, (kh * 8 + s) * 4 + lg);
@@ -442,6 +455,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     } else if constexpr (NP >= 3) {           // q from the normalised rows, k | v from the memory rows
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
+            permute_step(s);
             uint4 xf[MT], mf[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
