@@ -227,7 +227,11 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             const unsigned voff = r < Rm ? (unsigned)r * FH_ROWB + (unsigned)((lane ^ (r & 15)) << 4) : 0x80000000u;
             fh_dma16(rsrc, (unsigned)(size_t)(xm_s + r * FH_ROWB), voff);
         }
-    } else if (kind == FH_CROSS_READY) {
+    }
+    // ... K and V head rows of a memory projected ahead of the layer loop: only the attention stage reads them, so (round 4) they are
+    // asked for BETWEEN the LayerNorm row groups, behind the first weight block — in front of the x rows' consumers they only made
+    // the wave's issue phase longer (a 128-key memory: 16 instructions per wave) before its first row group could start
+    auto issue_kv_dma = [&]() {
         const int Kr = nsamp * m;
         const bf16_t* kbase = M.kv + (size_t)rm0 * (2 * FH_D) + slice * FH_DK;
         const fh_rsrc_t rk = fh_make_rsrc(kbase, (unsigned)((Kr - 1) * (4 * FH_D) + FH_HROWB));
@@ -240,7 +244,10 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             fh_dma16(rk, (unsigned)(size_t)(ki_s + i * 1024), vk);
             if (!late_v) fh_dma16(rv, (unsigned)(size_t)(vi_s + i * 1024), vv);
         }
-    }
+    };
+#ifdef FH_NO_INTERLEAVE
+    if (kind == FH_CROSS_READY) issue_kv_dma();
+#endif
     // (5) weight fragments.  The MFMA A-operand layout (lane 16c + r <-> row r, 16-byte chunk c of the 64-byte step) would make every
     // quad of adjacent lanes touch four different weight rows: the texture addresser then takes 64 cycles per wave-instruction
     // instead of 16.  So the loads are issued COALESCED — lane 4r + c reads (row r, chunk c): a quad = 64 contiguous bytes — and the
@@ -337,6 +344,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     for (int i = 0; i < NG; ++i) {
 #ifndef FH_NO_INTERLEAVE
         if (i > 0 && i < NP) { __builtin_amdgcn_sched_barrier(0); issue_block(i); __builtin_amdgcn_sched_barrier(0); }
+        if (i == 1 && kind == FH_CROSS_READY) issue_kv_dma();
 #endif
         if (lin) continue;
         if (wave + 8 * i >= MT * 4) continue;
@@ -373,6 +381,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
 #else
 #pragma unroll
     for (int p = NG > 1 ? NG : 1; p < NP; ++p) issue_block(p);          // the blocks that found no row group to precede
+    if (NG == 1 && kind == FH_CROSS_READY) issue_kv_dma();
 #endif
     __builtin_amdgcn_sched_barrier(0);
     // zero padding behind the key images (a key chunk may run past the last key: its V rows must be finite)
@@ -591,7 +600,12 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
 
     // ---- attention of this head, on chip.  Item = (sample, 16 query rows[, key range]), one wave each.
     FH_STAMP(8);
+#ifdef FH_NO_INTERLEAVE
     if (late_v) {                                  // the V image's DMA (issued after the projections) has landed
+#else
+    if (late_v || kind == FH_CROSS_READY) {        // ... and the K | V images asked for between the LayerNorm row groups: EXPLICITLY (the
+                                                   // LDS-DMA is inline asm: the compiler may drop the vmcnt(0) of a __syncthreads as redundant)
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
