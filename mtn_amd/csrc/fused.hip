@@ -180,13 +180,21 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         if (on && lnb) u_v = M.lnf[nc + (tid & 63)];
     }
     // (1) mask bytes of the block's samples
+    // (wide form — the block's bytes start on a dword, a multiple of 8 of them, not shared between samples: thread t takes bytes
+    //  8t .. 8t+7 as two dword loads instead of eight byte loads: these loads sit in front of the x rows in the wave's queue)
     uint8_t mkb[FH_MASKB];
     const uint8_t* mask_g = M.mask ? M.mask + (size_t)b0 * M.mask_sb : nullptr;   // contiguous: mask_sb is 0 or qa * m
+    const bool mask_wide = M.mask == nullptr || (M.mask_sb != 0 && (((size_t)mask_g | (size_t)mask_bytes) & 7) == 0);
+    unsigned mkw0 = 0x01010101u, mkw1 = 0x01010101u;
+    if (mask_wide) {
+        if (M.mask && 8 * tid < mask_bytes) { mkw0 = *(const unsigned*)(mask_g + 8 * tid); mkw1 = *(const unsigned*)(mask_g + 8 * tid + 4); }
+    } else {
 #pragma unroll
-    for (int i = 0; i < FH_MASKB; ++i) {
-        const int idx = tid + FH_THREADS * i;
-        mkb[i] = 1;
-        if (M.mask && idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * m)];
+        for (int i = 0; i < FH_MASKB; ++i) {
+            const int idx = tid + FH_THREADS * i;
+            mkb[i] = 1;
+            if (idx < mask_bytes) mkb[i] = mask_g[M.mask_sb ? idx : idx % (qa * m)];
+        }
     }
     // (3) x rows: row group rg = wave + 8i holds rows 4rg .. 4rg+3, one per 16-lane row; lane l15 reads columns 64j + 4*l15
     const float* __restrict__ xg = M.x + (size_t)row0 * FH_D;
@@ -289,10 +297,14 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     const bool w_first = true;
 #endif
     // masks, gains and biases -> LDS (they were asked for first: the x rows, the images and the weights may still fly)
+    if (mask_wide) {
+        if (8 * tid < mask_bytes) *(uint2*)(mk_s + 8 * tid) = make_uint2(mkw0, mkw1);
+    } else {
 #pragma unroll
-    for (int i = 0; i < FH_MASKB; ++i) {
-        const int idx = tid + FH_THREADS * i;
-        if (idx < mask_bytes) mk_s[idx] = mkb[i];
+        for (int i = 0; i < FH_MASKB; ++i) {
+            const int idx = tid + FH_THREADS * i;
+            if (idx < mask_bytes) mk_s[idx] = mkb[i];
+        }
     }
     // lin: floats [0, 64) a_2 and [64, 128) b_2 of the slice's xn columns, [128, 128 + 64 NP) u, [512, 592) row means, [592, 672) 1 / (std + eps)
     if (!lin) { if (tid < 256) *(float4*)(smem + L.gains + tid * 16) = gv; }

@@ -218,15 +218,23 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
         for (int s = 0; s < 8; ++s) wf[s] = *(const uint4*)(wrow + s * 32);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // mask bytes of the block's samples: always FH_MASKB loads per thread (without a mask: of the statistics buffer, ignored)
+    // mask bytes of the block's samples.  Wide form (the block's bytes start on a dword, a multiple of 8 of them, no sharing between
+    // samples): thread t takes bytes 8t .. 8t+7 as TWO dword loads; otherwise FH_MASKB byte loads per thread (without a mask: of the
+    // statistics buffer, ignored).  Either way an exact count per thread for the wait below.
+    const uint8_t* mask_g = M.mask ? M.mask + (size_t)b0 * M.mask_sb : (const uint8_t*)M.lse;
+    const bool mask_wide = M.mask != nullptr && M.mask_sb != 0 && (((size_t)mask_g | (size_t)mask_bytes) & 7) == 0 || M.mask == nullptr;
     uint8_t mkb[FH_MASKB];
-    {
-        const uint8_t* mask_g = M.mask ? M.mask + (size_t)b0 * M.mask_sb : (const uint8_t*)M.lse;
-        const bool bcast = M.mask != nullptr && M.mask_sb == 0;
+    unsigned mkw0 = 0x01010101u, mkw1 = 0x01010101u;
+    if (mask_wide) {
+        const int o8 = (M.mask && 8 * tid < mask_bytes) ? 8 * tid : 0;
+        mkw0 = *(const unsigned*)(mask_g + o8);
+        mkw1 = *(const unsigned*)(mask_g + o8 + 4);
+    } else {
+        const bool bcast = M.mask_sb == 0;
 #pragma unroll
         for (int i = 0; i < FH_MASKB; ++i) {
             const int idx = tid + FH_THREADS * i;
-            int src = (M.mask && idx < mask_bytes) ? idx : 0;
+            int src = idx < mask_bytes ? idx : 0;
             if (bcast) src = src % (qa * mk);                      // (uniform branch: the division only for masks shared by the samples)
             mkb[i] = mask_g[src];                                  // (whether the byte counts is decided where it is stored: a select here would wait for the load)
         }
@@ -260,9 +268,14 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
 
     // ================================================================ on chip from here
     // LDS-DMA images and weight fragments have landed once at most the FH_MASKB + 4 NQB + 1 loads issued behind them fly
-    static_assert(FH_MASKB == 8 && (NQB == 1 || NQB == 2), "the counted wait below spells the number of younger loads out");
-    if constexpr (NQB == 1) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    static_assert(FH_MASKB == 8 && (NQB == 1 || NQB == 2), "the counted waits below spell the number of younger loads out");
+    if (mask_wide) {                                            // 2 (mask dwords) + 4 NQB (statistics) + 1 (fold value)
+        if constexpr (NQB == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    } else {                                                    // 8 mask bytes instead
+        if constexpr (NQB == 1) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     FB_STAMP(2);
     if (stop == 1) return;
@@ -301,10 +314,14 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                 *(uint2*)(doi_s + r * FH_HROWB + (((2 * wc + (lg >> 1)) ^ (r & 7)) << 4) + (lg & 1) * 8) = u;
             }
     }
+    if (mask_wide) {                                            // (the loads were accepted under the dO stage)
+        if (8 * tid < mask_bytes) *(uint2*)(mk_s + 8 * tid) = M.mask ? make_uint2(mkw0, mkw1) : make_uint2(0x01010101u, 0x01010101u);
+    } else {
 #pragma unroll
-    for (int i = 0; i < FH_MASKB; ++i) {                        // (their loads were accepted under the dO stage)
-        const int idx = tid + FH_THREADS * i;
-        if (idx < mask_bytes) mk_s[idx] = M.mask ? mkb[i] : (uint8_t)1;
+        for (int i = 0; i < FH_MASKB; ++i) {
+            const int idx = tid + FH_THREADS * i;
+            if (idx < mask_bytes) mk_s[idx] = mkb[i];
+        }
     }
     __syncthreads();                                            // dO image complete; the exchange area (in the dy image) is dead too; mask image written
     FB_STAMP(4);
