@@ -15,6 +15,7 @@
 typedef __attribute__((address_space(3))) void lds_void_t;
 __device__ __forceinline__ unsigned long long wall() { return __builtin_readcyclecounter() * 0 + wall_clock64(); }
 
+template <int AUX>    // cache-policy bits of the LDS-DMA loads: 0 plain, 1 sc0, 16 sc1, 17 sc0 sc1, 2 nt
 __global__ __launch_bounds__(512) void pull_kernel(const unsigned char* __restrict__ buf, int slice_bytes, unsigned long long* stamps, uint4* sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(512) void pull_kernel(const unsigned char* __restri
     const unsigned long long t0 = wall_clock64();
     const int ninst = slice_bytes / 1024;                  // 1 KiB per wave-instruction
     for (int i = wave; i < ninst; i += 8)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)(sm + i * 1024), 16, (unsigned)(i * 1024 + lane * 16), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t*)(sm + i * 1024), 16, (unsigned)(i * 1024 + lane * 16), 0, 0, AUX);
     const unsigned long long t1 = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -53,7 +54,11 @@ int main() {
     const long junk_n = (1L << 30) / 16;
     hipMalloc(&buf, (size_t)nwg * 192 * 1024); hipMemset(buf, 1, (size_t)nwg * 192 * 1024);
     hipMalloc(&sink, nwg * 512 * 16); hipMalloc(&junk, junk_n * 16); hipMalloc(&stamps, nwg * 4 * 8);
-    hipFuncSetAttribute((const void*)pull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)pull_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)pull_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)pull_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)pull_kernel<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)pull_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     std::vector<unsigned long long> h(nwg * 4);
     for (int slice_kb : {128, 192}) {
         const int sb = slice_kb * 1024;
@@ -61,7 +66,7 @@ int main() {
             std::vector<double> issue, land, span;
             float touch_ms = 0;
             for (int rep = 0; rep < 12; ++rep) {
-                if (mode == 3) hipLaunchKernelGGL(pull_kernel, dim3(nwg), dim3(512), sb > 160 * 1024 ? 160 * 1024 : sb, st, buf, sb > 160 * 1024 ? 160 * 1024 : sb, stamps, sink);
+                if (mode == 3) hipLaunchKernelGGL(pull_kernel<0>, dim3(nwg), dim3(512), sb > 160 * 1024 ? 160 * 1024 : sb, st, buf, sb > 160 * 1024 ? 160 * 1024 : sb, stamps, sink);
                 else hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(256), 0, st, junk, junk_n);
                 if (mode == 1 || mode == 2) {
                     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -71,7 +76,7 @@ int main() {
                     float ms; hipEventElapsedTime(&ms, e0, e1); touch_ms += ms;
                 }
                 const int lds = sb > 160 * 1024 ? 160 * 1024 : sb;
-                hipLaunchKernelGGL(pull_kernel, dim3(nwg), dim3(512), lds, st, buf, lds, stamps, sink);
+                hipLaunchKernelGGL(pull_kernel<0>, dim3(nwg), dim3(512), lds, st, buf, lds, stamps, sink);
                 hipStreamSynchronize(st);
                 hipMemcpy(h.data(), stamps, nwg * 4 * 8, hipMemcpyDeviceToHost);
                 if (rep < 2) continue;
@@ -92,5 +97,26 @@ int main() {
             printf("\n");
         }
     }
+    // cache-policy bits on the pull itself: slices prefetched on the same XCD (L2 hits) and from the MALL (prefetched by the next XCD)
+    for (int mode = 1; mode <= 2; ++mode)
+        for (int aux : {0, 1, 16, 17, 2}) {
+            std::vector<double> land;
+            const int sb = 128 * 1024;
+            for (int rep = 0; rep < 10; ++rep) {
+                hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(256), 0, st, junk, junk_n);
+                hipLaunchKernelGGL(touch_kernel, dim3(nwg), dim3(256), 0, st, buf, sb, mode == 2 ? 1 : 0, nwg, sink);
+                if (aux == 0) hipLaunchKernelGGL(pull_kernel<0>, dim3(nwg), dim3(512), sb, st, buf, sb, stamps, sink);
+                if (aux == 1) hipLaunchKernelGGL(pull_kernel<1>, dim3(nwg), dim3(512), sb, st, buf, sb, stamps, sink);
+                if (aux == 16) hipLaunchKernelGGL(pull_kernel<16>, dim3(nwg), dim3(512), sb, st, buf, sb, stamps, sink);
+                if (aux == 17) hipLaunchKernelGGL(pull_kernel<17>, dim3(nwg), dim3(512), sb, st, buf, sb, stamps, sink);
+                if (aux == 2) hipLaunchKernelGGL(pull_kernel<2>, dim3(nwg), dim3(512), sb, st, buf, sb, stamps, sink);
+                hipStreamSynchronize(st);
+                hipMemcpy(h.data(), stamps, nwg * 4 * 8, hipMemcpyDeviceToHost);
+                if (rep < 2) continue;
+                for (int b = 0; b < nwg; ++b) land.push_back((h[b * 4 + 2] - h[b * 4 + 0]) / 100.0);
+            }
+            std::sort(land.begin(), land.end());
+            printf("policy aux=%2d  128 KiB %s: landed median %5.2f us = %5.1f GB/s per CU\n", aux, mode == 1 ? "prefetched on the SAME XCD" : "prefetched by the NEXT XCD", land[land.size() / 2], 128 * 1.024 / land[land.size() / 2]);
+        }
     return 0;
 }
