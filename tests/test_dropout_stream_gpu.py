@@ -71,3 +71,50 @@ def test_eight_element_neighbourhoods_follow_the_binomial_law(dev, p):
     exp = (N // 8) * (1.0 - p) ** kept * p ** (8 - kept)
     chi2 = float(((obs - exp) ** 2 / exp).sum())
     assert chi2 < 255 + 5 * 22.6, chi2
+
+
+def test_seed_advanced_inside_a_graph_is_seen_by_the_next_kernel(dev):
+    """The kernels read the dropout seed with a SCALAR load (common.h drop_init: a vector load made its consumer wait for every load in
+    flight).  The seed is advanced on the device once per step by an ordinary kernel (EncoderDecoder.advance_dropout_seed), inside
+    the captured step: every replay's dropout kernels must see THAT replay's seed — never a value a CU's scalar cache kept from the
+    replay before.  300 replays of {seed += step; mask = dropout(ones)} against masks made eagerly from the same seed values."""
+    from mtn_amd import lib as L
+    from mtn_amd import ops
+    n, p, salt = 1 << 16, 0.3, 77
+    seed0 = 0x0123456789ABCDEF
+    src = torch.ones(n, device=dev, dtype=torch.float32)
+    dst = torch.empty(n, device=dev, dtype=torch.float32)
+    seed = torch.full((1,), seed0, device=dev, dtype=torch.int64)
+    drop = ops._drop(p, salt, seed)
+    lib = L.load()
+
+    def body():
+        seed.add_(SEED_STEP)
+        seed.bitwise_and_(0x7FFFFFFFFFFFFFFF)
+        # two launches per replay: the second must see the same seed as the first (it runs on whatever CUs are free)
+        L.check(lib.mtn_dropout_bwd_to_lp(L.MTN_F32, n, src.data_ptr(), drop, dst.data_ptr(), L.stream_ptr()))
+        L.check(lib.mtn_dropout_bwd_to_lp(L.MTN_F32, n, src.data_ptr(), drop, dst2.data_ptr(), L.stream_ptr()))
+
+    dst2 = torch.empty_like(dst)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        body()                                              # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    seed.fill_(seed0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    seed.fill_(seed0)
+    torch.cuda.synchronize()
+    value = seed0
+    for it in range(300):
+        g.replay()
+        torch.cuda.synchronize()
+        value = (value + SEED_STEP) & 0x7FFFFFFFFFFFFFFF
+        assert int(seed.item()) == value
+        if it % 25 == 0 or it > 290:
+            want = _mask(dev, p, salt, value, n)
+            assert torch.equal(dst > 0, want), it
+        assert torch.equal(dst, dst2), it
