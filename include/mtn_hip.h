@@ -38,7 +38,9 @@ const char* mtn_last_error(void);
 /* 100: rounds 1-3.  110 (round 4): mtn_gemm_problem gained `ln`, mtn_mha_args / mtn_ffn_args gained `ln_fold` (callers must zero
  * the structs or set them), mtn_attn_args gained kv_acc / kv_last in round 3, and mtn_mha_bwd_ws_f32_floats() /
  * mtn_ffn_bwd_ws_f32_floats() return larger workspaces (multi-pass dK / dV sums; LayerNorm row-sum partials).
- * 111: mtn_transpose_desc gained `dst_off` (the transposed copies have a compact buffer of their own). */
+ * 111: mtn_transpose_desc gained `dst_off` (the transposed copies have a compact buffer of their own).
+ * 112 (round 5): new entry points only (mtn_measure_mfma_peak_shapes, ...: see INTEGRATION.md); mtn_measure_mfma_peak now reports
+ * the better of two MFMA shapes. */
 int mtn_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -586,9 +588,13 @@ int mtn_census_end(void);
 int mtn_census_info(int i, mtn_census_launch* out);
 int mtn_census_replay(int i, int reps, void* stream);
 const char* mtn_census_variant_name(int variant);
-/* Achievable dense bf16 MFMA rate of this box (register-only v_mfma_f32_16x16x32_bf16 issue, synchronises on its own
- * events): the measured denominator bench.py reports beside the 2.5 PFLOP/s spec figure.  scratch: >= 2048*256 floats. */
+/* Achievable dense bf16 MFMA rate of this box (register-only MFMA issue on independent accumulator chains, synchronises on its
+ * own events): the measured denominator bench.py reports beside the 2.5 PFLOP/s spec figure.  scratch: >= 2048*256 floats.
+ * mtn_measure_mfma_peak: the better of the two instruction shapes; mtn_measure_mfma_peak_shapes (112): both — v_mfma_f32_16x16x32_bf16
+ * (the shape the path's kernels issue) and v_mfma_f32_32x32x16_bf16 (half the operand bytes per FLOP: the shape the guide's
+ * 2 495 TFLOP/s figure is measured with). */
 int mtn_measure_mfma_peak(int iters, float* scratch, void* stream, double* tflops);
+int mtn_measure_mfma_peak_shapes(int iters, float* scratch, void* stream, double* tflops_16x16x32, double* tflops_32x32x16);
 /* Achievable HBM rate of this box: a 16-byte-per-lane streaming copy src -> dst of `bytes` bytes (both buffers >= bytes, well
  * beyond the 256 MiB Infinity Cache; synchronises on its own events), (read + written bytes) / time in GB/s — the measured
  * denominator bench.py reports beside the 8 TB/s spec for the HBM-bound parameter-gradient + optimiser launch. */

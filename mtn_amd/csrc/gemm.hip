@@ -2428,42 +2428,76 @@ extern "C" int mtn_census_replay(int i, int reps, void* stream) {
 
 
 // ---------------------------------------------------------------- on-box MFMA peak (measurement support, bench.py)
-// Register-only v_mfma_f32_16x16x32_bf16 issue on 8 independent accumulator chains per wave, 8 workgroups per CU: the
-// achievable dense bf16 rate of THIS box at its sustained clock — the measured denominator next to the 2.5 PFLOP/s spec.
+// Register-only MFMA issue on independent accumulator chains, 8 workgroups of 4 waves per CU: the achievable dense bf16 rate of
+// THIS box at its sustained clock — the measured denominator next to the 2.5 PFLOP/s spec.  Two instruction shapes: the
+// 16x16x32 form every kernel of the path uses (8 chains per wave) and the 32x32x16 form (4 chains of 16 accumulators), which is
+// the one /opt/skills/guides/MI355X_MICROARCH.md quotes 2 495 TFLOP/s for (half the operand bytes per FLOP).
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+template <int SHAPE>
 __global__ __launch_bounds__(256) void mfma_spin_kernel(float* out, int iters) {
     bf16x8_t a, b;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (float)(threadIdx.x + i)); b[i] = (__bf16)(0.002f * (float)((int)threadIdx.x - i)); }
-    f32x4_t c[8];
+    if (SHAPE == 16) {
+        f32x4_t c[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < iters; ++i) {
+        for (int j = 0; j < 8; ++j) c[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < iters; ++i) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c[j], 0, 0, 0);
+            for (int j = 0; j < 8; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c[j], 0, 0, 0);
+        }
+        f32x4_t s = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+        if (s[0] == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s[1];
+    } else {
+        f32x16_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) c[j][k] = 0.f;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[j], 0, 0, 0);
+        }
+        f32x16_t s = c[0] + c[1] + c[2] + c[3];
+        if (s[0] == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s[1] + s[15];
     }
-    f32x4_t s = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
-    if (s[0] == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s[1];
 }
 
-extern "C" int mtn_measure_mfma_peak(int iters, float* scratch, void* stream, double* tflops) {
-    MTN_CHECK_ARG(iters > 0 && scratch && tflops, "bad arguments");
-    hipStream_t s = (hipStream_t)stream;
+static int measure_mfma(int shape, int iters, float* scratch, hipStream_t s, double* tflops) {
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { mtn_set_error("hipEventCreate failed"); return MTN_ERR_LAUNCH; }
     const int wgs = 256 * 8;
     double best = 0.0;
     for (int rep = 0; rep < 10; ++rep) {              // the clock ramps over the first repetitions: report the best
         (void)hipEventRecord(e0, s);
-        hipLaunchKernelGGL(mfma_spin_kernel, dim3(wgs), dim3(256), 0, s, scratch, iters);
+        if (shape == 16) hipLaunchKernelGGL(mfma_spin_kernel<16>, dim3(wgs), dim3(256), 0, s, scratch, iters);
+        else hipLaunchKernelGGL(mfma_spin_kernel<32>, dim3(wgs), dim3(256), 0, s, scratch, iters);
         (void)hipEventRecord(e1, s);
         (void)hipEventSynchronize(e1);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        const double tf = (double)wgs * 4 * iters * 8 * (2.0 * 16 * 16 * 32) / (ms * 1e-3) / 1e12;
+        const double per_iter = shape == 16 ? 8 * (2.0 * 16 * 16 * 32) : 4 * (2.0 * 32 * 32 * 16);
+        const double tf = (double)wgs * 4 * iters * per_iter / (ms * 1e-3) / 1e12;
         if (tf > best) best = tf;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     MTN_CHECK_LAUNCH();
     *tflops = best;
     return MTN_OK;
+}
+
+extern "C" int mtn_measure_mfma_peak(int iters, float* scratch, void* stream, double* tflops) {
+    MTN_CHECK_ARG(iters > 0 && scratch && tflops, "bad arguments");
+    double a = 0.0, b = 0.0;
+    int rc = measure_mfma(16, iters, scratch, (hipStream_t)stream, &a);
+    if (rc == MTN_OK) rc = measure_mfma(32, iters, scratch, (hipStream_t)stream, &b);
+    *tflops = a > b ? a : b;
+    return rc;
+}
+
+extern "C" int mtn_measure_mfma_peak_shapes(int iters, float* scratch, void* stream, double* tflops_16x16x32, double* tflops_32x32x16) {
+    MTN_CHECK_ARG(iters > 0 && scratch && tflops_16x16x32 && tflops_32x32x16, "bad arguments");
+    int rc = measure_mfma(16, iters, scratch, (hipStream_t)stream, tflops_16x16x32);
+    if (rc == MTN_OK) rc = measure_mfma(32, iters, scratch, (hipStream_t)stream, tflops_32x32x16);
+    return rc;
 }

@@ -212,8 +212,9 @@ class FusedAdam:
         every weight matrix current and receives the others' bf16 copies only — bring every rank's masters up to date before
         anything reads them whole (model.state_dict()).  A collective: every rank calls it."""
         sh = getattr(self, "_sharded", None)
-        if sh is not None and sh.lp_slices:
+        if sh is not None and sh.lp_slices and sh.masters_stale:
             sh.gather(self.model._flat)
+            sh.masters_stale = False
 
     def load_state_dict(self, sd):
         names = {id(p): n for n, p in self.model.named_parameters()}

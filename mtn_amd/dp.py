@@ -165,6 +165,7 @@ class ShardedOptimizerSync:
         self._works = []
         self.slices = set()             # every (lo, hi) this object split into shards (for gather())
         self.lp_slices = set()          # ... of them, the matrix ranges whose foreign fp32 masters are stale (gathered in the compute dtype)
+        self.masters_stale = False      # a step ran the compute-dtype gather since the last gather() of the fp32 masters
         self.calls = {"reduce_scatter": 0, "all_reduce": 0, "all_gather": 0, "broadcast": 0}   # collectives issued (tests, bench line)
 
     def lp_mode(self) -> bool:
@@ -202,6 +203,7 @@ class ShardedOptimizerSync:
         self.slices.add((lo, shard_hi))
         if lp_gather:
             self.lp_slices.add((lo, shard_hi))
+            self.masters_stale = self.world > 1
         per, own, tail = self.split(lo, shard_hi)
         cuda = grad.is_cuda
         if cuda and self.side is None:

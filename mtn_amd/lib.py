@@ -159,6 +159,7 @@ SYMBOLS = {
     "mtn_census_replay": (C.c_int, [C.c_int, C.c_int, _P]),
     "mtn_census_variant_name": (C.c_char_p, [C.c_int]),
     "mtn_measure_mfma_peak": (C.c_int, [C.c_int, _P, _P, C.POINTER(C.c_double)]),
+    "mtn_measure_mfma_peak_shapes": (C.c_int, [C.c_int, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mtn_measure_hbm_peak": (C.c_int, [_P, _P, C.c_long, _P, C.POINTER(C.c_double)]),
     "mtn_reload_env": (C.c_int, []),
     "mtn_stream_create_cu_masked": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -570,6 +570,7 @@ class EncoderDecoder(nn.Module):
         self.compute_dtype = compute_dtype
         self._flat = self._flat_lp = self._flat_grad = None
         self._flat_version = -1
+        self._master_sync = None               # data parallel, compute-dtype gather: brings stale fp32 masters back (collective)
         self._glue_numel = 0
         self._layer_slices = []
         self._seed = None
@@ -834,6 +835,14 @@ class EncoderDecoder(nn.Module):
             L.check(L.load().mtn_ln_fold(L.MTN_BF16, t[0].data_ptr(), t[1].data_ptr(), t[2], t[3], L.stream_ptr()))
         self._ln_fold_stale = False
 
+    def state_dict(self, *a, **kw):
+        """The reference's key schema.  Data parallel with the compute-dtype gather: a rank holds current fp32
+        masters of its own shards only, so the masters are gathered first — a COLLECTIVE: every rank calls state_dict(), rank 0
+        writes the file."""
+        if self._master_sync is not None:
+            self._master_sync()
+        return super().state_dict(*a, **kw)
+
     def _apply(self, fn, *a, **kw):             # .cuda()/.to(): parameters are re-created -> re-flatten
         super()._apply(fn, *a, **kw)
         self._flat = None
@@ -850,6 +859,11 @@ class EncoderDecoder(nn.Module):
         if self._flat is None:
             self._flatten()
         ver = sum(p._version for p in self._flat_params)     # `.data = view` gives every parameter its own counter
+        if self._flat_lp is not self._flat and ver != self._flat_version and self._flat_version != -1 and self._master_sync is not None:
+            # something other than the fused optimiser touched a parameter while (data parallel, compute-dtype gather) this rank's
+            # fp32 masters of the other ranks' shards are stale: recasting them would revert (world-1)/world of every matrix.  Every
+            # rank sees the same modification (replicas), so every rank arrives here: gather the masters first (a collective).
+            self._master_sync()
         if self._flat_lp is not self._flat and ver != self._flat_version:
             L.check(L.load().mtn_cast_f32_to_lp(L.dtype_code(self.compute_dtype), self._flat.numel(), self._flat.data_ptr(),
                                                 self._flat_lp.data_ptr(), L.stream_ptr()))

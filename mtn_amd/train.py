@@ -281,13 +281,13 @@ def main(argv=None):
                 # Adam moments of its shards only (and, with the compute-dtype gather, the current fp32 masters of its shards
                 # only) and state_dict() gathers them with collectives; rank 0 alone writes the files
                 opt_state = the_opt.state_dict()
+                model_state = model.state_dict()              # (collective under the compute-dtype gather: fp32 masters)
                 if rank == 0:
-                    torch.save(model.state_dict(), f"{args.model}_{epoch + 1}.pth.tar")
+                    torch.save(model_state, f"{args.model}_{epoch + 1}.pth.tar")
                     torch.save(opt_state, f"{args.model}_{epoch + 1}_opt.pth.tar")
-                del opt_state
+                del opt_state, model_state
             if valid is not None:
-                if args.model and hasattr(the_opt.optimizer, "gather_masters"):
-                    the_opt.optimizer.gather_masters()        # (collective) the "best" checkpoint below is written by rank 0 alone
+                best_state = model.state_dict() if args.model else None    # (collective) written by rank 0 alone if validation improves
                 from .data_utils import LabelSmoothing as _LS
                 vloss = validate(valid[0], valid[1], model, _LS(args.vocab_size, 1, 0.1), args.auto_encoder_ft, args.loss_l)
                 if rank == 0:
@@ -296,7 +296,7 @@ def main(argv=None):
                         print("validation loss reduced %.4f -> %.4f" % (min_valid, vloss))
                         min_valid = vloss
                         if args.model:
-                            torch.save(model.state_dict(), f"{args.model}_best.pth.tar")
+                            torch.save(best_state, f"{args.model}_best.pth.tar")
         if world > 1:
             torch.distributed.destroy_process_group()
         return means
@@ -314,8 +314,11 @@ def main(argv=None):
                 dt = time.time() - t0
                 print("Epoch: %d Step: %d Loss: %f Tokens per Sec: %f" % (epoch + 1, j + 1, float(loss), tokens / dt))   # train.py:46
                 t0, tokens = time.time(), 0
-        if args.model and rank == 0:
-            torch.save(model.state_dict(), f"{args.model}_{epoch + 1}.pth.tar")      # reference key schema
+        if args.model:
+            model_state = model.state_dict()      # every rank: under the sharded optimiser's compute-dtype gather this gathers the fp32
+            if rank == 0:                         # masters of the other ranks' shards (a collective) — rank 0 alone writes
+                torch.save(model_state, f"{args.model}_{epoch + 1}.pth.tar")      # reference key schema
+            del model_state
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -65,6 +65,9 @@ class TrainStep:
                                           force=getattr(grad_sync, "force", None),
                                           lp_fn=lambda: model.flat_buffers()[1], update_lp=getattr(adam, "step_range_lp", None))
                 adam._sharded = sh                        # slice set that state_dict()'s gather walks
+                # nobody may read the fp32 masters whole while foreign shards are stale (compute-dtype gather):
+                # model.state_dict() and model.prepare() bring them up to date through this hook (a collective)
+                model._master_sync = adam.gather_masters
             self.sharded = sh
         self._g_seg = None
         self._st = None
