@@ -376,6 +376,69 @@ def pmc_step_traffic():
         return None
 
 
+def corpus_loop_measure(model, cfg, dev, videos=24, epochs=2):
+    """The REAL loop (a step starts with "batch build on device"; train.py:29-40): `train_step.BucketedTrainer` over a
+    synthetic ragged `DeviceCorpus` at AVSD lengths (answers <= 52, questions <= 42 tokens, captions 10-40, histories growing turn by
+    turn, 20-40 frames per video), batch 32 planned by `make_batch_indices` exactly as the reference plans its batches, every step =
+    device-side batch assembly (two grouped launches refilling the static batch of the padded shape) + one replay of that shape's
+    captured train step.  Epoch 0 captures the shapes (untimed); `epochs` further epochs are timed.  Reports samples/s and the
+    reference's own unit, target tokens/s (train.py:47-48)."""
+    from mtn_amd.data_handler import DeviceCorpus, make_batch_indices
+    from mtn_amd.train import synthetic_corpus
+    from mtn_amd.train_step import BucketedTrainer
+    data = synthetic_corpus(videos, cfg["vocab"], cfg["ft_sizes"], 5, max_answer=52, max_question=42)
+    indices, n_samples = make_batch_indices(data, batchsize=32, max_length=256, separate_caption=True)
+    corpus = DeviceCorpus(data, dev)
+    trainer = BucketedTrainer(model, corpus, cfg["vocab"], pad=1, warmup=4000, bucket=8)
+    t_cap = time.perf_counter()
+    for idx in indices:
+        trainer.step(idx)
+    torch.cuda.synchronize()
+    t_cap = time.perf_counter() - t_cap
+    tok = torch.zeros((), device=dev, dtype=torch.float64)
+    samples = 0
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        for idx in indices:
+            _, b = trainer.step(idx)
+            tok += b._norms_global[0].double()
+            samples += int(idx[-1])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = epochs * len(indices)
+    return {"samples_per_s": round(samples / dt, 1), "target_tokens_per_s": round(float(tok.item()) / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+            "steps_timed": steps, "batches_per_epoch": len(indices), "dialog_turns": n_samples, "padded_shapes_captured": len(trainer.steps),
+            "capture_epoch_s": round(t_cap, 1),
+            "what": f"BucketedTrainer over a synthetic ragged DeviceCorpus ({videos} videos x 10 turns, AVSD lengths: answers <= 52, questions <= 42 tokens), batch 32 "
+                    "as make_batch_indices plans it (long histories shrink the batch), lengths padded to multiples of 8; every timed step = device-side batch "
+                    "assembly + one replay of the padded shape's captured train step (forward, loss, backward, fused Adam); dropout on, bf16"}
+
+
+def exchange_timeline(step, ref_ms):
+    """One more step with HIP events on the exchange chain (dp.ShardedOptimizerSync.timeline): per slice, when its gradients were ready,
+    reduce-scattered, updated and all-gathered, relative to the step's start; where the compute chain ended; the step's end."""
+    step()
+    torch.cuda.synchronize()
+    e_start, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    step.sharded.timeline = []
+    e_start.record()
+    step()
+    e_end.record()
+    torch.cuda.synchronize()
+    tl, step.sharded.timeline = step.sharded.timeline, None
+    us = lambda e: round(e_start.elapsed_time(e) * 1e3, 1)
+    slices = [{"flat_range": [t["lo"], t["hi"]], "MB_reduced": round(t["bytes_reduced"] / 1e6, 1), "MB_gathered": round(t["bytes_gathered"] / 1e6, 1),
+               **{k + "_us": us(t[k]) for k in ("ready", "reduced", "updated", "gathered") if k in t}} for t in tl if "lo" in t]
+    chain_end = [us(t["chain_end"]) for t in tl if "chain_end" in t]
+    return {"what": "this rank, one step: offsets from the step's start (HIP events on the stream the exchange chain runs on): a slice's gradients "
+                    "ready (its segment graph done) -> reduce-scatter done -> Adam on the shard done -> all-gather done; compute_chain_end = the last "
+                    "segment graph finished, step_end = the exchange drained and the copies refreshed.  exposed = step_end - compute_chain_end; the "
+                    "chain's stretch under the exchange = compute_chain_end / the exchange-free single-rank step of the same batch (optimiser inside its dW launch)",
+            "slices": slices, "compute_chain_end_us": chain_end[0] if chain_end else None, "step_end_us": us(e_end),
+            "exposed_exchange_us": round(us(e_end) - chain_end[0], 1) if chain_end else None,
+            "chain_stretch_vs_single_rank_step": round(chain_end[0] / (ref_ms * 1e3), 3) if (chain_end and ref_ms) else None}
+
+
 def dp_schedule_one_rank(args):
     """The data-parallel schedule of an N-GPU job on ONE rank with every collective through RCCL, measured in a FRESH process
     (`bench.py --dp-one-rank-probe`): the process group is created first, the model and its flat buffers afterwards — the order
@@ -448,6 +511,11 @@ def dp_one_rank_probe(args):
         st2.sharded.collective = False
         out["ms_per_step_collectives_skipped"] = round(timed(st2), 4)
         st2.sharded.collective = True
+        if st.overlap and not args.no_graph:
+            try:
+                out["timeline"] = exchange_timeline(st, None)
+            except Exception as e:  # pragma: no cover
+                out["timeline"] = {"error": str(e)}
     import ctypes
     ctypes.CDLL(None).fflush(None)
     print(json.dumps(out), flush=True)
@@ -567,6 +635,37 @@ def main():
                 secondary["dp_schedule_one_rank"] = dp_schedule_one_rank(args)
                 # BASELINE configs[4]: decode on the same weights (never `value`)
                 secondary["decode"] = decode_measure(model, cfg, dev, use_graph=not args.no_graph, cpu=not args.no_cpu_baseline)
+                # where this design saturates: the same captured step at growing batch (samples/s, whole-step TFLOP/s against 2.5 PF) — the
+                # evidence that separates "the problem is too small for the chip" from "the kernels are slow"
+                sweep = {}
+                peak_sw = PEAK_BF16_TFLOPS if lp == torch.bfloat16 else PEAK_FP32_TFLOPS
+                for Bs in (128, 256):
+                    bb = synthetic_batch(cfg["vocab"], Bs, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=11, ragged=False)
+                    stb = TrainStep(model, bb, cfg["vocab"], pad=1, warmup=4000, grad_sync=None, use_graph=not args.no_graph)
+                    for _ in range(3):
+                        stb()
+                    dtb, _, _ = timed_window(stb, max(5, args.steps // 2))
+                    spsb = Bs * max(5, args.steps // 2) / dtb
+                    sweep[str(Bs)] = {"samples_per_s": round(spsb, 1), "ms_per_step": round(dtb / max(5, args.steps // 2) * 1e3, 4),
+                                      "step_TFLOPs": round(spsb * SURVEY_GFLOP_PER_SAMPLE["cfg2"] / 1e3, 1),
+                                      "frac_of_2.5PF": round(spsb * SURVEY_GFLOP_PER_SAMPLE["cfg2"] / 1e3 / peak_sw, 4)}
+                    del stb, bb
+                secondary["batch_sweep"] = {"what": "same model, same captured step, batch per GPU 32 (= `value`) / 64 (= batch64_one_gpu) / 128 / 256: 15.90 GFLOP/sample x "
+                                                    "samples/s against the dense bf16 MFMA peak", "batches": sweep}
+                # BASELINE configs[3] (cfg4: 512-token history, 256 + 256 frames, batch 8) on the same model
+                from mtn_amd.synthetic import CONFIGS as _C
+                c4 = dict(_C["cfg4"])
+                b4 = synthetic_batch(c4["vocab"], c4["B"], c4["Q"], c4["H"], c4["C"], c4["T"], c4["frames"], c4["ft_sizes"], device=dev, seed=13, ragged=False)
+                st4 = TrainStep(model, b4, c4["vocab"], pad=1, warmup=4000, grad_sync=None, use_graph=not args.no_graph)
+                for _ in range(3):
+                    st4()
+                dt4, _, _ = timed_window(st4, args.steps)
+                secondary["cfg4_long_context"] = {"samples_per_s": round(c4["B"] * args.steps / dt4, 1), "ms_per_step": round(dt4 / args.steps * 1e3, 4),
+                                                  "step_TFLOPs": round(c4["B"] * args.steps / dt4 * SURVEY_GFLOP_PER_SAMPLE["cfg4"] / 1e3, 1),
+                                                  "what": f"BASELINE configs[3]: batch {c4['B']}, history {c4['H']} tokens, frames {c4['frames']}, same model and captured step"}
+                del st4, b4
+                # the real loop: ragged corpus, per-step device batch assembly, one captured graph per padded shape
+                secondary["corpus_loop"] = corpus_loop_measure(model, cfg, dev)
             if world > 1:
                 # the same per-GPU batch on ONE rank without any exchange (graph of forward+backward+optimiser epilogue): the
                 # figure a DP rank is compared with, measured in the same job; the other ranks idle at the barriers
@@ -582,12 +681,14 @@ def main():
                 # secondary.dp_schedule_one_rank) plus the exchange that backward does not hide
                 nparams = sum(p.numel() for p in model.parameters())
                 lp_gather = step.sharded is not None and step.sharded.lp_mode()
+                timeline = exchange_timeline(step, dt1 / args.steps * 1e3) if (step.sharded is not None and step.overlap) else None
                 secondary["exchange"] = {
                     "step_minus_one_rank_no_exchange_ms": round(elapsed / args.steps * 1e3 - dt1 / args.steps * 1e3, 4),
                     "bytes_on_the_links_per_rank_per_step": int(nparams * (4 + (2 if lp_gather else 4)) * (world - 1) / world),
                     "scheme": ("reduce-scatter fp32 gradients + all-gather " + ("bf16 weight copies (matrices) / fp32 (glue, vectors)" if lp_gather else "fp32 masters")
                                if step.sharded is not None else "all-reduce fp32 gradients"),
-                    "collectives_per_step": {k: round(v / max(1, args.steps + args.warmup + args.steps * args.windows), 1) for k, v in step.sharded.calls.items()} if step.sharded is not None else None}
+                    "collectives_per_step": {k: round(v / max(1, args.steps + args.warmup + args.steps * args.windows), 1) for k, v in step.sharded.calls.items()} if step.sharded is not None else None,
+                    "timeline": timeline}
         except Exception as e:  # pragma: no cover
             secondary["error"] = str(e)
 
@@ -616,9 +717,14 @@ def main():
         try:
             import ctypes as C
             scratch = torch.empty(2048 * 256, device=dev, dtype=torch.float32)
-            tf = C.c_double(0.0)
-            lib.check(lib.load().mtn_measure_mfma_peak(20000, scratch.data_ptr(), torch.cuda.current_stream().cuda_stream, C.byref(tf)))
+            tf16, tf32 = C.c_double(0.0), C.c_double(0.0)
+            lib.check(lib.load().mtn_measure_mfma_peak_shapes(20000, scratch.data_ptr(), torch.cuda.current_stream().cuda_stream, C.byref(tf16), C.byref(tf32)))
+            tf = C.c_double(max(tf16.value, tf32.value))
             step_info["mfma_peak_measured_TFLOPs"] = round(tf.value, 1)
+            step_info["mfma_peak_measured_by_shape"] = {"v_mfma_f32_16x16x32_bf16": round(tf16.value, 1), "v_mfma_f32_32x32x16_bf16": round(tf32.value, 1),
+                                                        "guide_32x32x16": 2495.0,
+                                                        "note": "register-only issue on independent accumulator chains, this box, this run; `frac` is against the 2.5 PFLOP/s "
+                                                                "spec, `frac_of_measured_peak` against the better of the two shapes"}
             step_info["frac_of_measured_peak"] = round(step_tf / world / tf.value, 5) if lp == torch.bfloat16 else None
             b64s = secondary.get("batch64_one_gpu", {}).get("roofline", {}).get("step")
             if b64s is not None and lp == torch.bfloat16:
@@ -652,9 +758,10 @@ def main():
                         "launches_per_step": d["launches_per_step"], "avg_us_per_launch": d["avg_us"],
                         "gflop_per_launch": d["gflop_per_launch"], "algorithmic_bytes_per_launch": int(d["algorithmic_MB_per_launch"] * 1e6),
                         "achieved_TFLOPs": d["achieved_TFLOPs"],
-                        "peak_measured": hbm_peak,
+                        "peak_measured": hbm_peak, "peak_guide_copy": 6290.0,
                         "frac_of_measured_peak": round(d["achieved_GBps_algorithmic"] / hbm_peak, 4) if hbm_peak else None,
-                        "peak_measured_what": "GB/s of a 16-byte-per-lane streaming copy (1 GiB read + 1 GiB written) on this box: best over non-temporal / plain accesses, 1 / 4 loads in flight per thread, 8-32 workgroups per CU"}
+                        "frac_of_guide_copy": round(d["achieved_GBps_algorithmic"] / 6290.0, 4),
+                        "peak_measured_what": "peak_guide_copy = the 6.29 TB/s float4 copy of MI355X_MICROARCH.md; peak_measured = GB/s of a 16-byte-per-lane streaming copy (1 GiB read + 1 GiB written) on this box: best over non-temporal / plain accesses, 1 / 4 loads in flight per thread, 8-32 workgroups per CU"}
                 second = max((n for n in table if n != TABLE), key=lambda nm: table[nm]["total_us_per_step"])
                 roof["next_kernel"] = mfma_roof(second)
             else:

@@ -157,6 +157,25 @@ int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems /* host arra
  * resident workgroups then drift out of phase and the epilogue's HBM streaming overlaps other tiles' contractions).  The
  * problem list is staged to device memory on `stream`; safe under hipGraph capture. */
 int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* problems /* host array */, void* stream);
+/* The same launch also carrying the REST of the optimiser step (round 5, version 112) — `opt.step()` of data_utils.py:154 for the
+ * parameters no dW epilogue covers, so that nothing runs behind the launch:
+ *   ln[]        LayerNorm gains / biases: gradient = the sum of the partial rows left by the LayerNorm-backward kernels (what
+ *               mtn_layernorm_bwd_finalize computes, same summation order, same bits; stored at g + a_off / g + b_off) + Adam;
+ *   chunks      ranges of the flat buffers whose gradient is COMPLETE before the launch (embedding tables): Adam as
+ *               mtn_adam_step_chunks;
+ *   bias_adam   every problem whose rowsum_out lies inside [g, g + n_flat): that bias is updated by the tile that sums its gradient.
+ * All with the arithmetic of mtn_adam_step (bit-identical results).  The caller leaves exactly these ranges out of any later pass.
+ * ln / chunk_off / chunk_len are HOST arrays read during the call; offsets and n_flat are in elements of the flat buffers. */
+typedef struct { const float* partial; int nparts, d; long a_off, b_off; } mtn_tt_ln_unit;
+typedef struct {
+    float *p, *g, *m, *v; void* lp;          /* flat fp32 parameters, gradients, both moments; compute-dtype copy (NULL = none) */
+    long n_flat;
+    int n_ln; const mtn_tt_ln_unit* ln;
+    int n_chunks; const long* chunk_off; const int* chunk_len;   /* <= 4096 elements each, multiples of 4 */
+    int bias_adam;
+    const float* state; const float* grad_scale; float beta1, beta2, eps;     /* as mtn_adam_fuse */
+} mtn_tt_aux;
+int mtn_gemm_tt_table_aux(int dtype, int count, const mtn_gemm_problem* problems /* host array */, const mtn_tt_aux* aux /* host, NULL = none */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm, MTN variant (mtn.py:103-114): y = a2 * (x-mean) / (std_unbiased + eps) + b2.
@@ -232,6 +251,13 @@ typedef struct {
     int K, block_start;
 } mtn_ln_fold_desc;
 int mtn_ln_fold(int dtype, const mtn_ln_fold_desc* descs_device, const int* block_desc, int total_blocks, int d, void* stream);
+/* Head of a train step in ONE launch (round 5, version 112): the fold vectors above (total_blocks may be 0: fp32 mode), the
+ * schedule tick of mtn_noam_tick on `state` (NULL = none), the dropout seed advance *seed += seed_inc (NULL = none) and a zero fill
+ * of zero[0, zero_n) (the autograd-accumulated glue gradients; zero_n a multiple of 4 floats) — replaces three launches of 5-7 us
+ * in front of the first path kernel (train.py:29-40's loop head: opt.zero_grad() of data_utils.py:155 included). */
+int mtn_step_head(int dtype, const mtn_ln_fold_desc* descs_device, const int* block_desc, int total_blocks, int d,
+                  float* state, float factor, int model_size, int warmup, float beta1, float beta2,
+                  long long* seed, long long seed_inc, float* zero, long zero_n, void* stream);
 long mtn_layernorm_bwd_partial_floats(int rows, int d);
 int mtn_layernorm_bwd_nparts(int rows);
 /* da2/db2 == NULL: only dx is produced now and `partial` is left for a later grouped mtn_layernorm_bwd_finalize()
@@ -599,6 +625,43 @@ int mtn_measure_mfma_peak_shapes(int iters, float* scratch, void* stream, double
  * beyond the 256 MiB Infinity Cache; synchronises on its own events), (read + written bytes) / time in GB/s — the measured
  * denominator bench.py reports beside the 8 TB/s spec for the HBM-bound parameter-gradient + optimiser launch. */
 int mtn_measure_hbm_peak(const void* src, void* dst, long bytes, void* stream, double* gbps);
+/* ------------------------------------------------------------------------------------------
+ * One decode step of the target stream as ONE persistent launch (round 5, version 112; csrc/decode.hip).  Replaces, for W <= 8 live
+ * hypotheses, the per-token pass of `beam_search_decode` / `greedy_decode` (data_utils.py:197-208: `model.decode` + final LayerNorm)
+ * in its cached form: the newest position of every hypothesis through N layers x (self-attention over the prefix cache, cross-attentions
+ * over hoisted K|V, feed-forward), walking `stages` (a DEVICE array, built once per dialogue shape) with a grid barrier between stages.
+ * bf16 weights.  `grid` workgroups must all be resident (<= 256: one per CU).  Buffers: x [W][d] fp32, q / o [W][d] and hid [W][d_ff]
+ * bf16 scratch; out_lp [W][d] bf16 = final LayerNorm output (the generator's operand); sync: 2 unsigned (the library zeroes sync[0]
+ * before the launch; sync[1] != 0 afterwards = a barrier timed out and the results are invalid).
+ * ------------------------------------------------------------------------------------------ */
+#define MTN_DEC_EMBED 0     /* x = lut[token] * emb_scale + pe[pos] */
+#define MTN_DEC_SELF_QKV 1  /* q | k | v = LayerNorm(x) W^T + b (N = 3d): q -> scratch, k | v -> cache row (hypothesis, pos) */
+#define MTN_DEC_SELF_ATT 2  /* softmax(q K^T / sqrt(dk)) V over prefix positions 0..pos; position t of hypothesis j lives in cache slot anc[j][t] */
+#define MTN_DEC_OUT 3       /* x += o W^T + b  (K = d) */
+#define MTN_DEC_CROSS 4     /* q = LayerNorm(x) W_q^T + b_q per head, attention over the memory's hoisted K|V (kv, m keys, mask) */
+#define MTN_DEC_FFN1 5      /* hid = relu(LayerNorm(x) W1^T + b1)  (N = d_ff) */
+#define MTN_DEC_FFN2 6      /* x += hid W2^T + b2  (K = d_ff) */
+#define MTN_DEC_FINAL 7     /* out_lp = LayerNorm(x) */
+typedef struct {
+    int kind, N, K;
+    const void* w;              /* [N][K] bf16 (nn.Linear layout); MTN_DEC_CROSS: the q block of the packed q|k|v weight ([d][d]) */
+    const float* bias;          /* [N] */
+    const float* ln_a; const float* ln_b; float ln_eps;
+    const void* kv;             /* MTN_DEC_CROSS: [W * m][2d] bf16, k | v of hypothesis j's memory rows j*m .. */
+    int m;
+    const unsigned char* mask; long mask_stride;     /* MTN_DEC_CROSS: key mask [W][mask_stride] uint8 (0 = masked: score -1e9); NULL = none */
+    void* cache;                /* MTN_DEC_SELF_QKV / _ATT: this layer's prefix cache [W][L][2d] bf16 */
+} mtn_decode_stage;
+typedef struct {
+    int W, d, h, L, n_stages;
+    float* x; void* q; void* o; void* hid; void* out_lp;
+    const long* tokens;         /* [W] newest token of every hypothesis */
+    const float* lut; float emb_scale; const float* pe;     /* target embedding table [V][d], sqrt(d), positional encodings [>= L][d] */
+    const int* pos;             /* device scalar: the position being decoded (0-based) */
+    const int* anc;             /* [W][L] cache slot that holds position t of hypothesis j's prefix (anc[j][pos] = j) */
+    unsigned* sync;
+} mtn_decode_args;
+int mtn_decode_step(const mtn_decode_args* args /* host */, const mtn_decode_stage* stages_device, int grid, void* stream);
 /* The library's development / test switches (MTN_GEMM_*, MTN_ATTN_*, MTN_LN_*, MTN_EMBED_DETERMINISTIC, ...) are read from the
  * environment once per call site and cached: a process that changes one after the library has used it calls this to make the
  * next launches re-read them.  Returns the new generation number. */

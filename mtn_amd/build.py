@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmtn_hip.so")
-SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "fused.hip", "fused_bwd.hip", "elementwise.hip", "sublayer.hip", "losshead.hip", "assemble.hip", "select.hip", "gemm_k512.hip"]
+SOURCES = ["gemm.hip", "layernorm.hip", "attention.hip", "fused.hip", "fused_bwd.hip", "elementwise.hip", "sublayer.hip", "losshead.hip", "assemble.hip", "select.hip", "gemm_k512.hip", "decode.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 

@@ -144,6 +144,16 @@ __device__ __forceinline__ bool drop_keep_at(const DropState& s, const DropBase&
     return (r >> 8) >= s.thresh;
 }
 
+// ---------------------------------------------------------------- Noam schedule tick (data_utils.py:111-117), one thread
+// state = [step, lr, 1 - b1^step, 1 - b2^step]; shared by noam_tick_kernel and the step-head launch (same bits)
+__device__ __forceinline__ void noam_tick_body(float* state, float factor, float model_size, float warmup, float beta1, float beta2) {
+    const float step = state[0] + 1.0f;
+    state[0] = step;
+    state[1] = factor * rsqrtf(model_size) * fminf(rsqrtf(step), step * powf(warmup, -1.5f));
+    state[2] = 1.0f - powf(beta1, step);
+    state[3] = 1.0f - powf(beta2, step);
+}
+
 // ---------------------------------------------------------------- Adam (torch.optim.Adam semantics), one element
 // m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).
 // Roundings pinned with explicit fma so that every kernel that applies the update (adam_kernel, adam_chunks_kernel, the

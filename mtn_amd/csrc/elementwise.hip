@@ -192,13 +192,7 @@ extern "C" int mtn_transpose_group(int dtype, const void* src, void* dst, const 
 
 // ---------------------------------------------------------------- Noam schedule + Adam
 __global__ void noam_tick_kernel(float* state, float factor, float model_size, float warmup, float beta1, float beta2) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const float step = state[0] + 1.0f;
-        state[0] = step;
-        state[1] = factor * rsqrtf(model_size) * fminf(rsqrtf(step), step * powf(warmup, -1.5f));  // data_utils.py:111-117
-        state[2] = 1.0f - powf(beta1, step);
-        state[3] = 1.0f - powf(beta2, step);
-    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) noam_tick_body(state, factor, model_size, warmup, beta1, beta2);   // data_utils.py:111-117
 }
 extern "C" int mtn_noam_tick(float* state, float factor, int model_size, int warmup, float beta1, float beta2, void* stream) {
     MTN_CHECK_ARG(state && model_size > 0 && warmup > 0, "bad arguments");

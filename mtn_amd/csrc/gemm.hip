@@ -1291,9 +1291,12 @@ __device__ __forceinline__ uint4 ttb_frag(const unsigned char* img, int n_off, i
     return f;
 }
 
+// Bias of the Linear whose weight gradient this problem is (table form, round 5): db = the row sums this tile produces anyway, so the
+// bias's Adam update is applied right there (p, m, v, compute-dtype copy at the bias's flat offset) instead of by a later pass.
+struct BiasAdam { float *p, *m, *v; bf16_t* lp; };
 // One 128 x 128 tile of dW = dY^T X (+ optimiser epilogue): shared by the kernel-argument form and the table form below.
 __device__ __forceinline__ void tt128_tile(const mtn_gemm_problem& P, const AdamSlot& S, const bool lds_epilogue, const AdamCoef& coef,
-                                           const int row0, const int col0, unsigned char* smem) {
+                                           const int row0, const int col0, unsigned char* smem, const BiasAdam bz = BiasAdam{nullptr, nullptr, nullptr, nullptr}) {
     typedef bf16_t T;
     const int tid = threadIdx.x;
     const int M = P.M, N = P.N, K = P.K;
@@ -1367,7 +1370,15 @@ __device__ __forceinline__ void tt128_tile(const mtn_gemm_problem& P, const Adam
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + wr * 64 + i * 16 + l15;
-            if (row < M) P.rowsum_out[row] = rs[i][0];
+            if (row < M) {
+                P.rowsum_out[row] = rs[i][0];
+                if (bz.p) {                          // same arithmetic as adam_chunks_kernel on the stored gradient: the same bits
+                    float pv = bz.p[row], mv = bz.m[row], vv = bz.v[row];
+                    adam_update(pv, mv, vv, rs[i][0], coef);
+                    bz.p[row] = pv; bz.m[row] = mv; bz.v[row] = vv;
+                    if (bz.lp) bz.lp[row] = f32_to_bf16(pv);
+                }
+            }
         }
     }
     const DropState ds = drop_init(P.drop);
@@ -1499,18 +1510,97 @@ struct TTProblem {
     float *p, *m, *v; void* lp; void* lpT;
     int lda, ldb, M, N, K, ldc, ldT, write_grad;
     int tiles_m, tiles_n, first_tile, pad_;
+    long bias_off;                             // >= 0: flat offset of the bias whose gradient `rowsum` is -> its Adam update rides on the tile (round 5)
 };
+// Front tiles (round 5, mtn_tt_aux): the optimiser for what no dW epilogue covers — the LayerNorm gains / biases (their gradient = the
+// sum of the partial rows the LayerNorm-backward kernels left: the finalize pass, same summation order, + Adam) and chunks of the flat
+// buffers whose gradient is complete before the launch (embedding tables).  They sit at the FRONT of the grid: the first resident
+// dW tiles are all in their contraction phase then and leave HBM idle.  Replaces the ln_bwd_finalize and adam_chunks launches.
+struct TTLnUnit { const float* partial; int nparts, d, col0, pad_; long a_off, b_off; };      // 256 columns of one LayerNorm's [da2 | db2]
 struct TTHeader {
     const float* state; const float* grad_scale;
     float beta1, beta2, eps;
     int any, lds_epilogue, n_problems, n_tiles, plain_tile_order;
     long problems_off, tilemap_off;            // byte offsets from the header
+    int n_front, n_ln_units, n_chunks, pad_;
+    long ln_off, chunk_off_off, chunk_len_off; // byte offsets from the header: TTLnUnit[], long[], int[]
+    float *fp, *fg, *fm, *fv; bf16_t* flp;     // the flat parameter / gradient / moment buffers and the compute-dtype copy
 };
+__device__ __forceinline__ void tt_front_tile(const TTHeader* __restrict__ hdr, const int idx) {
+    const unsigned char* base = (const unsigned char*)hdr;
+    const AdamCoef coef = adam_coef(hdr->state, hdr->grad_scale, hdr->beta1, hdr->beta2, hdr->eps);
+    if (idx < hdr->n_ln_units) {
+        // ln_bwd_finalize_kernel's arithmetic for one column (16 interleaved groups of partial rows, four chains each, the same
+        // combination order), then Adam on that one LayerNorm gain / bias
+        const TTLnUnit U = ((const TTLnUnit*)(base + hdr->ln_off))[idx];
+        const int c = U.col0 + (int)threadIdx.x;
+        if (c >= 2 * U.d) return;
+        const float* p = U.partial + c;
+        const size_t ld = (size_t)2 * U.d;
+        float red[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int i = q;
+            for (; i + 112 < U.nparts; i += 128) {
+                const float a0 = p[(size_t)(i + 0) * ld], a1 = p[(size_t)(i + 16) * ld], a2 = p[(size_t)(i + 32) * ld], a3 = p[(size_t)(i + 48) * ld];
+                const float a4 = p[(size_t)(i + 64) * ld], a5 = p[(size_t)(i + 80) * ld], a6 = p[(size_t)(i + 96) * ld], a7 = p[(size_t)(i + 112) * ld];
+                s0 += a0; s1 += a1; s2 += a2; s3 += a3; s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+            }
+            for (; i + 48 < U.nparts; i += 64) {
+                s0 += p[(size_t)(i + 0) * ld]; s1 += p[(size_t)(i + 16) * ld];
+                s2 += p[(size_t)(i + 32) * ld]; s3 += p[(size_t)(i + 48) * ld];
+            }
+            for (; i < U.nparts; i += 16) s0 += p[(size_t)i * ld];
+            red[q] = (s0 + s1) + (s2 + s3);
+        }
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) t += (red[k] + red[k + 1]) + (red[k + 2] + red[k + 3]);
+        const long o = c < U.d ? U.a_off + c : U.b_off + (c - U.d);
+        hdr->fg[o] = t;
+        float pv = hdr->fp[o], mv = hdr->fm[o], vv = hdr->fv[o];
+        adam_update(pv, mv, vv, t, coef);
+        hdr->fp[o] = pv; hdr->fm[o] = mv; hdr->fv[o] = vv;
+        if (hdr->flp) hdr->flp[o] = f32_to_bf16(pv);
+        return;
+    }
+    const int ci = idx - hdr->n_ln_units;
+    if (ci >= hdr->n_chunks) return;                               // (the front is padded to a multiple of 8 tiles: the XCD map of the dW tiles)
+    // adam_chunks_kernel's body: a whole chunk (<= 4096 elements) in flight before the first update
+    const long cb = ((const long*)(base + hdr->chunk_off_off))[ci];
+    const int n4 = ((const int*)(base + hdr->chunk_len_off))[ci] >> 2;
+    float* __restrict__ p = hdr->fp; const float* __restrict__ g = hdr->fg; float* __restrict__ m = hdr->fm; float* __restrict__ v = hdr->fv;
+    float4 pv[4], gv[4], mv[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = threadIdx.x + 256 * u;
+        const long i = cb + (long)(q < n4 ? q : 0) * 4;
+        pv[u] = *(const float4*)(p + i); gv[u] = *(const float4*)(g + i); mv[u] = *(const float4*)(m + i); vv[u] = *(const float4*)(v + i);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = threadIdx.x + 256 * u;
+        if (q >= n4) continue;
+        const long i = cb + (long)q * 4;
+        float* pp = &pv[u].x; float* gp = &gv[u].x; float* mp = &mv[u].x; float* vp = &vv[u].x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) adam_update(pp[k], mp[k], vp[k], gp[k], coef);
+        *(float4*)(p + i) = pv[u]; *(float4*)(m + i) = mv[u]; *(float4*)(v + i) = vv[u];
+        if (hdr->flp) {
+            uint2 w;
+            w.x = (uint32_t)f32_to_bf16(pv[u].x) | ((uint32_t)f32_to_bf16(pv[u].y) << 16);
+            w.y = (uint32_t)f32_to_bf16(pv[u].z) | ((uint32_t)f32_to_bf16(pv[u].w) << 16);
+            *(uint2*)(hdr->flp + i) = w;
+        }
+    }
+}
 __global__ __launch_bounds__(256, 2) void gemm_tt_dma128_table_kernel(const TTHeader* __restrict__ hdr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned char* base = (const unsigned char*)hdr;
     const uint32_t* tilemap = (const uint32_t*)(base + hdr->tilemap_off);
-    const uint32_t e = tilemap[blockIdx.x];                       // problem << 12 | tile inside the problem
+    const uint32_t e = tilemap[blockIdx.x];                       // problem << 12 | tile inside the problem, or 0x80000000 | optimiser unit
+    if (e & 0x80000000u) { tt_front_tile(hdr, (int)(e & 0x7fffffffu)); return; }
     const int g = (int)(e >> 12), t = (int)(e & 0xfff);
     const TTProblem& Q = ((const TTProblem*)(base + hdr->problems_off))[g];
     mtn_gemm_problem P;
@@ -1539,7 +1629,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_dma128_table_kernel(const TTHe
     if (hdr->plain_tile_order & 8) S.lpT = nullptr;              // no transposed compute-dtype copy
     if (hdr->plain_tile_order & 16) S.lp = nullptr;              // no compute-dtype copy
 #endif
-    tt128_tile(P, S, hdr->lds_epilogue != 0, coef, tm_ * 128, tn_ * 128, smem);
+    BiasAdam bz{nullptr, nullptr, nullptr, nullptr};
+    if (Q.bias_off >= 0) { bz.p = hdr->fp + Q.bias_off; bz.m = hdr->fm + Q.bias_off; bz.v = hdr->fv + Q.bias_off; bz.lp = hdr->flp ? hdr->flp + Q.bias_off : nullptr; }
+    tt128_tile(P, S, hdr->lds_epilogue != 0, coef, tm_ * 128, tn_ * 128, smem, bz);
 }
 
 // ====================================================================================================================
@@ -1817,7 +1909,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma128x_kernel(const GemmGroup g
 #include <algorithm>
 #include <vector>
 struct CensusEntry { int dtype, count, variant, tiles; mtn_gemm_problem p[MTN_GEMM_MAX_GROUP]; mtn_adam_fuse adam[MTN_GEMM_MAX_GROUP]; mtn_ln_epilogue ln[MTN_GEMM_MAX_GROUP]; int table; };
-struct CensusTable { std::vector<mtn_gemm_problem> p; std::vector<mtn_adam_fuse> adam; };     // a table-form launch (any number of problems)
+struct CensusTable {                                                                            // a table-form launch (any number of problems)
+    std::vector<mtn_gemm_problem> p; std::vector<mtn_adam_fuse> adam;
+    bool has_aux; mtn_tt_aux aux; std::vector<mtn_tt_ln_unit> ln; std::vector<long> chunk_off; std::vector<int> chunk_len;    // its front tiles (mtn_tt_aux)
+};
 static std::vector<CensusEntry> g_census;
 static std::vector<CensusTable> g_census_tables;
 static bool g_census_on = false;
@@ -2219,6 +2314,10 @@ static int tt_slot_alloc(TTSlot& sl) {
 }
 
 extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* problems, void* stream) {
+    return mtn_gemm_tt_table_aux(dtype, count, problems, nullptr, stream);
+}
+
+extern "C" int mtn_gemm_tt_table_aux(int dtype, int count, const mtn_gemm_problem* problems, const mtn_tt_aux* aux, void* stream) {
     MTN_CHECK_ARG(dtype == MTN_BF16, "the table form is bf16 only");
     MTN_CHECK_ARG(count >= 1 && count <= 1024 && problems, "bad problem count");
     hipStream_t s = (hipStream_t)stream;
@@ -2235,7 +2334,26 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
         MTN_CHECK_ARG(t <= 4095, "at most 4095 tiles per problem");
         tiles += t;
     }
-    const long need = (long)sizeof(TTHeader) + (long)count * sizeof(TTProblem) + tiles * 4;
+    // front tiles (mtn_tt_aux): 256 columns of a LayerNorm's [da2 | db2] per unit, one chunk per tile; padded to a multiple of 8 so
+    // that dW tile i still runs on XCD i % 8 (the tile map below deals problems to XCDs by grid index)
+    int n_ln_units = 0, n_chunks = 0, n_front = 0;
+    if (aux) {
+        MTN_CHECK_ARG(aux->p && aux->g && aux->m && aux->v && aux->n_flat > 0, "mtn_tt_aux: flat buffers are required");
+        MTN_CHECK_ARG(aux->n_ln >= 0 && aux->n_chunks >= 0 && (aux->n_ln == 0 || aux->ln) && (aux->n_chunks == 0 || (aux->chunk_off && aux->chunk_len)), "mtn_tt_aux: bad lists");
+        for (int i = 0; i < aux->n_ln; ++i) {
+            const mtn_tt_ln_unit& u = aux->ln[i];
+            MTN_CHECK_ARG(u.partial && u.nparts > 0 && u.d > 0 && u.a_off >= 0 && u.b_off >= 0 && u.a_off + u.d <= aux->n_flat && u.b_off + u.d <= aux->n_flat,
+                          "mtn_tt_aux: LayerNorm unit outside the flat buffers");
+            n_ln_units += (2 * u.d + 255) / 256;
+        }
+        for (int i = 0; i < aux->n_chunks; ++i)
+            MTN_CHECK_ARG(aux->chunk_off[i] >= 0 && aux->chunk_len[i] > 0 && aux->chunk_len[i] <= 4096 && aux->chunk_off[i] % 4 == 0 && aux->chunk_len[i] % 4 == 0 &&
+                          aux->chunk_off[i] + aux->chunk_len[i] <= aux->n_flat, "mtn_tt_aux: chunks are <= 4096 elements, offsets and lengths multiples of 4");
+        n_chunks = aux->n_chunks;
+        n_front = (n_ln_units + n_chunks + 7) / 8 * 8;
+    }
+    const long ln_bytes = (long)n_ln_units * sizeof(TTLnUnit);
+    const long need = ((long)sizeof(TTHeader) + (long)count * sizeof(TTProblem) + (tiles + n_front) * 4 + 15) / 16 * 16 + ln_bytes + (long)n_chunks * 12 + 16;
     MTN_CHECK_ARG(need <= MTN_TT_SLOT_BYTES, "problem list too large for one table");
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
@@ -2257,12 +2375,33 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
     TTProblem* Q = (TTProblem*)(sl->host + H->problems_off);
     uint32_t* map = (uint32_t*)(sl->host + H->tilemap_off);
     bool lds_ok = MTN_ENV("MTN_ADAM_EPILOGUE_DIRECT") == nullptr;
+    if (aux) {
+        H->n_front = n_front; H->n_ln_units = n_ln_units; H->n_chunks = n_chunks;
+        H->fp = aux->p; H->fg = aux->g; H->fm = aux->m; H->fv = aux->v; H->flp = (bf16_t*)aux->lp;
+        H->ln_off = ((long)sizeof(TTHeader) + (long)count * sizeof(TTProblem) + (tiles + n_front) * 4 + 15) / 16 * 16;
+        H->chunk_off_off = H->ln_off + ln_bytes;                                    // (ln_bytes is a multiple of 8: longs stay aligned)
+        H->chunk_len_off = H->chunk_off_off + (long)n_chunks * 8;
+        TTLnUnit* U = (TTLnUnit*)(sl->host + H->ln_off);
+        int k = 0;
+        for (int i = 0; i < aux->n_ln; ++i)
+            for (int c0 = 0; c0 < 2 * aux->ln[i].d; c0 += 256) {
+                TTLnUnit& u = U[k++];
+                memset(&u, 0, sizeof(u));
+                u.partial = aux->ln[i].partial; u.nparts = aux->ln[i].nparts; u.d = aux->ln[i].d; u.col0 = c0; u.a_off = aux->ln[i].a_off; u.b_off = aux->ln[i].b_off;
+            }
+        if (n_chunks) {
+            memcpy(sl->host + H->chunk_off_off, aux->chunk_off, (size_t)n_chunks * 8);
+            memcpy(sl->host + H->chunk_len_off, aux->chunk_len, (size_t)n_chunks * 4);
+        }
+    }
     int first = 0;
     for (int i = 0; i < count; ++i) {
         const mtn_gemm_problem& p = problems[i];
         TTProblem& q = Q[i];
         memset(&q, 0, sizeof(q));
         q.A = p.A; q.B = p.B; q.out = p.out_f32; q.rowsum = p.rowsum_out;
+        q.bias_off = -1;
+        if (aux && aux->bias_adam && p.rowsum_out && p.rowsum_out >= aux->g && p.rowsum_out + p.M <= aux->g + aux->n_flat) q.bias_off = (long)(p.rowsum_out - aux->g);
         q.lda = p.lda; q.ldb = p.ldb; q.M = p.M; q.N = p.N; q.K = p.K; q.ldc = p.ldc;
         q.tiles_m = (p.M + 127) / 128; q.tiles_n = (p.N + 127) / 128; q.first_tile = first;
         if (p.adam) {
@@ -2277,6 +2416,12 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
                 lds_ok = false;
         }
         first += q.tiles_m * q.tiles_n;
+    }
+    if (aux && (n_front > 0 || aux->bias_adam)) {
+        MTN_CHECK_ARG(aux->state, "mtn_tt_aux: the optimiser state is required");
+        if (!H->any) { H->state = aux->state; H->grad_scale = aux->grad_scale; H->beta1 = aux->beta1; H->beta2 = aux->beta2; H->eps = aux->eps; H->any = 1; }
+        MTN_CHECK_ARG(H->state == aux->state && H->grad_scale == aux->grad_scale && H->beta1 == aux->beta1 && H->beta2 == aux->beta2 && H->eps == aux->eps,
+                      "mtn_tt_aux: one set of optimiser hyper-parameters per launch");
     }
     H->lds_epilogue = (H->any && lds_ok) ? 1 : 0;
     // Tile map.  Workgroups are dealt to the 8 XCDs round-robin by grid index and each XCD has its own L2, so a problem whose
@@ -2325,6 +2470,23 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
             map[i] = queue[c][head[c]++];
         }
     }
+    if (n_front > 0) {
+        // Where the optimiser units sit in the grid (a multiple of 8 of them, so that a dW tile keeps its grid index mod 8 and with it its
+        // XCD).  Measured, same box, cfg2 step (profiles/r05_d_tail_head_ab.txt): ALL AT THE FRONT 3.559 -> 3.529 ms (the first resident dW
+        // tiles are in their contraction phase and leave HBM idle); dealt in between the dW tiles, eight behind every `gap` tiles: +-0 (they
+        // compete with the tiles' streaming phases); all at the end: -14 us.  MTN_TT_AUX_GAP = n > 0 selects the dealt form (A/B).
+        std::vector<uint32_t> dmap(map, map + tiles);
+        long gap = 0;
+        if (const char* ge = MTN_ENV("MTN_TT_AUX_GAP")) { const long v = atol(ge) / 8 * 8; if (v >= 0) gap = v; }
+        long pos = 0, di = 0, au = 0;
+        if (gap == 0) while (au < n_front) map[pos++] = 0x80000000u | (uint32_t)au++;
+        while (di < tiles) {
+            const long take = gap == 0 ? tiles - di : (tiles - di < gap ? tiles - di : gap);
+            for (long k = 0; k < take; ++k) map[pos++] = dmap[di++];
+            for (int k = 0; k < 8 && au < n_front; ++k) map[pos++] = 0x80000000u | (uint32_t)au++;
+        }
+        while (au < n_front) map[pos++] = 0x80000000u | (uint32_t)au++;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tt_dma128_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TTB_LDS);
@@ -2345,7 +2507,7 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
         e = hipMemcpyAsync(sl->dev, sl->host, (size_t)need, hipMemcpyHostToDevice, s);
     }
     if (e != hipSuccess) { mtn_set_error("mtn_gemm_tt_table: staging copy failed: %s", hipGetErrorString(e)); return MTN_ERR_LAUNCH; }
-    hipLaunchKernelGGL(gemm_tt_dma128_table_kernel, dim3((unsigned)tiles), dim3(256), TTB_LDS, s, (const TTHeader*)sl->dev);
+    hipLaunchKernelGGL(gemm_tt_dma128_table_kernel, dim3((unsigned)(tiles + n_front)), dim3(256), TTB_LDS, s, (const TTHeader*)sl->dev);
     MTN_CHECK_LAUNCH();
     if (cap == hipStreamCaptureStatusNone) { (void)hipEventRecord(sl->ev, s); sl->fresh = false; }
     if (g_census_on) {
@@ -2354,6 +2516,13 @@ extern "C" int mtn_gemm_tt_table(int dtype, int count, const mtn_gemm_problem* p
         t.adam.resize(count);
         for (int i = 0; i < count; ++i)
             if (problems[i].adam) t.adam[i] = *problems[i].adam;
+        t.has_aux = aux != nullptr;
+        if (aux) {
+            t.aux = *aux;
+            t.ln.assign(aux->ln, aux->ln + aux->n_ln);
+            t.chunk_off.assign(aux->chunk_off, aux->chunk_off + aux->n_chunks);
+            t.chunk_len.assign(aux->chunk_len, aux->chunk_len + aux->n_chunks);
+        }
         CensusEntry e;
         memset(&e, 0, sizeof(e));
         e.dtype = dtype; e.count = count; e.variant = V_TT_TABLE; e.tiles = (int)tiles; e.table = (int)g_census_tables.size();
@@ -2385,6 +2554,16 @@ extern "C" int mtn_census_info(int i, mtn_census_launch* out) {
             out->bytes += ((double)p.M + p.N) * p.K * esz + (double)p.M * p.N * per;
             if (k < 4) { out->M[k] = p.M; out->N[k] = p.N; out->K[k] = p.K; }
         }
+        if (t.has_aux) {
+            // front tiles: chunks move p, g, m, v in (16 B) and p, m, v + the compute-dtype copy out (12 B + esz) per element; a LayerNorm
+            // unit reads its partial rows and does the same for 2d elements (+ the gradient written); a fused bias: 12 B in, 16 B + esz out
+            for (size_t c = 0; c < t.chunk_len.size(); ++c) out->bytes += (double)t.chunk_len[c] * (28.0 + (t.aux.lp ? esz : 0.0));
+            for (size_t u = 0; u < t.ln.size(); ++u) out->bytes += 2.0 * t.ln[u].d * (4.0 * t.ln[u].nparts + 28.0 + (t.aux.lp ? esz : 0.0));
+            if (t.aux.bias_adam)
+                for (int k = 0; k < e.count; ++k)
+                    if (t.p[k].rowsum_out && t.p[k].rowsum_out >= t.aux.g && t.p[k].rowsum_out + t.p[k].M <= t.aux.g + t.aux.n_flat)
+                        out->bytes += (double)t.p[k].M * (28.0 + (t.aux.lp ? esz : 0.0));
+        }
         return MTN_OK;
     }
     for (int k = 0; k < e.count; ++k) {
@@ -2411,7 +2590,8 @@ extern "C" int mtn_census_replay(int i, int reps, void* stream) {
             if (t.p[k].adam) t.p[k].adam = &t.adam[k];
         g_census_on = false;
         int rc = MTN_OK;
-        for (int r = 0; r < reps && rc == MTN_OK; ++r) rc = mtn_gemm_tt_table(e.dtype, e.count, t.p.data(), stream);
+        if (t.has_aux) { t.aux.ln = t.ln.data(); t.aux.chunk_off = t.chunk_off.data(); t.aux.chunk_len = t.chunk_len.data(); }
+        for (int r = 0; r < reps && rc == MTN_OK; ++r) rc = mtn_gemm_tt_table_aux(e.dtype, e.count, t.p.data(), t.has_aux ? &t.aux : nullptr, stream);
         g_census_on = was;
         return rc;
     }

@@ -98,6 +98,7 @@ class FusedAdam:
         self.state = torch.zeros(8, device=flat.device, dtype=torch.float32)   # step, lr, 1-b1^t, 1-b2^t
         self.param_groups = [{"lr": 0.0, "params": list(model.parameters())}]
         self.grad_scale: Optional[torch.Tensor] = None                        # device scalar multiplied into every gradient
+        self._aux_cache = {}                      # host-side chunk lists of the table launch's front tiles (ops.ParamGradQueue._table_aux)
 
     def tick(self, factor: float, model_size: int, warmup: int):
         L.check(L.load().mtn_noam_tick(self.state.data_ptr(), factor, model_size, warmup, self.betas[0], self.betas[1], L.stream_ptr()))
@@ -169,7 +170,8 @@ class FusedAdam:
                            grad=grad.data_ptr(), p=flat.data_ptr(), m=self.m.data_ptr(), v=self.v.data_ptr(), lp=lp_ptr,
                            lpT=m._flat_lpT.data_ptr() if m._flat_lpT is not None else None,
                            t_map=dict(m._t_off), esz=esz, write_grad=write_grad,
-                           state=self.state.data_ptr(), grad_scale=L.ptr(self.grad_scale), betas=self.betas, eps=self.eps, applied=False)
+                           state=self.state.data_ptr(), grad_scale=L.ptr(self.grad_scale), betas=self.betas, eps=self.eps, applied=False,
+                           n_flat=flat.numel(), rest_done=False, aux_cache=self._aux_cache)
         m._queue.adam = self._armed
 
     def step_rest(self):
@@ -180,9 +182,10 @@ class FusedAdam:
             raise L.MtnHipError("optimiser epilogue was armed but the backward pass did not run its parameter-gradient GEMMs")
         flat, flat_lp, grad, lp_ptr = self._buffers()
         (off, ln, n), trest = m.rest_tables(armed["covered"])
-        L.check(L.load().mtn_adam_step_chunks(L.dtype_code(m.compute_dtype), n, off.data_ptr(), ln.data_ptr(), flat.data_ptr(),
-                                              grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), lp_ptr, self.state.data_ptr(),
-                                              L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
+        if not armed["rest_done"]:                 # (round 5: normally the table launch's front tiles have done this — ops.ParamGradQueue._table_aux)
+            L.check(L.load().mtn_adam_step_chunks(L.dtype_code(m.compute_dtype), n, off.data_ptr(), ln.data_ptr(), flat.data_ptr(),
+                                                  grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), lp_ptr, self.state.data_ptr(),
+                                                  L.ptr(self.grad_scale), self.betas[0], self.betas[1], self.eps, L.stream_ptr()))
         if trest is not None:
             m.refresh_transposed(trest)
 
@@ -240,11 +243,13 @@ class NoamOpt:
         self.optimizer.tick(self.factor, self.model_size, self.warmup)
         self.optimizer.step()
 
-    def begin_fused_step(self, write_grad: bool = False):
+    def begin_fused_step(self, write_grad: bool = False, tick: bool = True):
         """step() split around the backward pass (FusedAdam.fuse_into_backward): advance the schedule and arm the epilogue
-        before it, finish_fused_step() after it.  Same arithmetic as step(), element for element."""
+        before it, finish_fused_step() after it.  Same arithmetic as step(), element for element.  ``tick=False``: the caller
+        has advanced the schedule itself (model.step_head: the tick rides in the step's first launch)."""
         self._step += 1
-        self.optimizer.tick(self.factor, self.model_size, self.warmup)
+        if tick:
+            self.optimizer.tick(self.factor, self.model_size, self.warmup)
         self.optimizer.fuse_into_backward(write_grad)
 
     def finish_fused_step(self):

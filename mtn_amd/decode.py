@@ -250,17 +250,190 @@ class DecodeSession:
         return [self.logp[d * self.width:d * self.width + len(p)] for d, p in enumerate(prefix_lists)]
 
 
+class MegaDecodeSession(DecodeSession):
+    """The per-token pass as ONE persistent launch (csrc/decode.hip, include/mtn_hip.h mtn_decode_step) + the generator's three small
+    launches, for sessions of at most 8 live hypotheses on a bf16 model: the newest position of every hypothesis walks a
+    device-resident stage list (per layer: self-attention over its prefix cache, the cross-attentions over the K|V hoisted by load(),
+    the feed-forward) with grid barriers instead of ~90 dependent launches.  The prefix cache is never copied when a beam step
+    re-orders hypotheses: position t of hypothesis j's prefix is read from cache slot anc[j][t], a (W, L) int table the host updates
+    from the parents (the slot of row j at position l-1 is j itself).  Same search results as the launch-per-sublayer pass (tested)."""
+
+    MAX_W = 8
+
+    @staticmethod
+    def supported(model, batch, max_len, width) -> bool:
+        if os.environ.get("MTN_DECODE_MEGA", "1") == "0" or not batch.query.is_cuda:
+            return False
+        try:
+            layer = model.decoder.layers[0]
+            d, h = layer.size, layer.self_attn.h
+            dff = layer.feed_forward.w_1.weight.size(0)
+        except AttributeError:
+            return False
+        W = batch.query.size(0) * width
+        if model.compute_dtype != torch.bfloat16 or W > MegaDecodeSession.MAX_W or d not in (128, 256, 512, 1024) or d % h or d // h not in (32, 64, 128):
+            return False
+        if dff > 4096 or dff % 32 or max_len > 1024 or model.auto_encoder_ft not in ("query", "caption", "summary"):
+            return False
+        if max(batch.his.size(1), batch.cap.size(1), batch.query.size(1)) > 1024:
+            return False
+        grid = max(W * h, -(-max(dff, 3 * d) // 64))
+        return grid <= 256 and all(len(l.sublayer) == 5 + 4 * len(l.auto_encoder_attn) for l in model.decoder.layers)
+
+    def __init__(self, model, batch, max_len, width, pad=1, use_graph=True, select=None):
+        super().__init__(model, batch, max_len, width, pad=pad, use_graph=use_graph, kv_cache=False, select=select)
+        from . import lib as L
+        dev = batch.query.device
+        layers = model.decoder.layers
+        d, h = layers[0].size, layers[0].self_attn.h
+        dff = layers[0].feed_forward.w_1.weight.size(0)
+        W, Lm, nl = self.D * width, max_len, len(layers)
+        lp = torch.bfloat16
+        self._W = W
+        self._mcache = torch.zeros(nl, W, Lm, 2 * d, device=dev, dtype=lp)
+        self._x = torch.zeros(W, d, device=dev, dtype=torch.float32)
+        self._q = torch.zeros(W, d, device=dev, dtype=lp)
+        self._o = torch.zeros(W, d, device=dev, dtype=lp)
+        self._hid = torch.zeros(W, dff, device=dev, dtype=lp)
+        self._out_lp = torch.zeros(W, d, device=dev, dtype=lp)
+        self._sync = torch.zeros(2, device=dev, dtype=torch.int32)
+        # what the host changes every step, in ONE pinned block -> ONE copy: [W newest tokens (int64) | position (int32, padded) | anc (W x L int32)]
+        self._off_pos, self._off_anc = 8 * W, 8 * W + 8
+        nbytes = self._off_anc + 4 * W * Lm
+        self._host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        self._devblk = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
+        self._h_tok = self._host[:8 * W].view(torch.int64)
+        self._h_pos = self._host[self._off_pos:self._off_pos + 8].view(torch.int32)
+        self._h_anc = self._host[self._off_anc:].view(torch.int32).view(W, Lm)
+        self._h_anc.copy_(torch.arange(W, dtype=torch.int32).view(W, 1).expand(W, Lm))
+        self._prev = None
+        self._grid = max(W * h, -(-max(dff, 3 * d) // 64))
+        self._build_stages(L, d, h, dff)
+        emb, pe = model.tgt_embed[0], model.tgt_embed[1]
+        a = L.DecodeArgs()
+        a.W, a.d, a.h, a.L, a.n_stages = W, d, h, Lm, self._n_stages
+        a.x, a.q, a.o, a.hid, a.out_lp = self._x.data_ptr(), self._q.data_ptr(), self._o.data_ptr(), self._hid.data_ptr(), self._out_lp.data_ptr()
+        a.tokens = self._devblk.data_ptr()
+        a.lut, a.emb_scale, a.pe = emb.lut.weight.data_ptr(), float(d) ** 0.5, pe.pe.data_ptr()
+        a.pos, a.anc, a.sync = self._devblk.data_ptr() + self._off_pos, self._devblk.data_ptr() + self._off_anc, self._sync.data_ptr()
+        self._args = a
+        if pe.pe.size(1) < Lm or not emb.lut.weight.is_contiguous():
+            raise ValueError("positional-encoding table shorter than max_len")
+
+    def _build_stages(self, L, d, h, dff):
+        """The stage list of one decode step (include/mtn_hip.h MTN_DEC_*): per decoder layer the schedule of mtn.py:183-218 for the
+        target stream — self-attention, history, caption | query (order by auto_encoder_ft), one attention per auto-encoder stream,
+        feed-forward — every attention followed by its output projection; pointers into the model's flat buffers and this session's
+        hoisted K|V / masks (all refreshed IN PLACE by load(), so the table is built once)."""
+        import ctypes as C
+        m = self.model
+        cap_mask, his_mask, q_mask = self.masks
+        kvmap = {id(sc): kv for sc, kv in self._kv_pairs}
+        st = []
+
+        def stage(kind, **kw):
+            s_ = L.DecodeStage()
+            s_.kind = kind
+            for k, v in kw.items():
+                setattr(s_, k, v)
+            st.append(s_)
+
+        def ln(sc):
+            return dict(ln_a=sc.norm.a_2.data_ptr(), ln_b=sc.norm.b_2.data_ptr(), ln_eps=float(sc.norm.eps))
+
+        stage(L.DEC_EMBED)
+        for k, layer in enumerate(m.decoder.layers):
+            sl, nF = layer.sublayer, len(layer.auto_encoder_attn)
+            f = layer.self_attn.fused()
+            cache = self._mcache[k].data_ptr()
+            stage(L.DEC_SELF_QKV, N=3 * d, K=d, w=f["w_qkv_lp"].data_ptr(), bias=f["b_qkv"].data_ptr(), cache=cache, **ln(sl[0]))
+            stage(L.DEC_SELF_ATT, cache=cache)
+            stage(L.DEC_OUT, N=d, K=d, w=f["w_o_lp"].data_ptr(), bias=f["b_o"].data_ptr())
+            text, _, _, ae_mask = layer._plan(self.cp, cap_mask, self.hs, his_mask, self.q, q_mask, None, [None] * nF, [None] * nF, m.auto_encoder_ft)
+            cross = list(text[1:]) + [(sl[7 + 4 * i], layer.auto_encoder_attn[i], self.aes[k][i], ae_mask) for i in range(nF)]
+            for sc, mod, mem, mask in cross:
+                f = mod.fused()
+                kv = kvmap.get(id(sc))
+                if kv is None or kv.dtype != torch.bfloat16:
+                    raise ValueError("a memory's K|V were not hoisted")
+                mk = getattr(mask, "_mtn_u8", None)
+                stage(L.DEC_CROSS, N=d, K=d, w=f["w_qkv_lp"].data_ptr(), bias=f["b_qkv"].data_ptr(), kv=kv.data_ptr(), m=mem.size(1),
+                      mask=mk.data_ptr() if mk is not None else None, mask_stride=mem.size(1), **ln(sc))
+                stage(L.DEC_OUT, N=d, K=d, w=f["w_o_lp"].data_ptr(), bias=f["b_o"].data_ptr())
+            ff = layer.feed_forward.fused()
+            stage(L.DEC_FFN1, N=dff, K=d, w=ff["w1_lp"].data_ptr(), bias=ff["b1"].data_ptr(), **ln(sl[4 + 4 * nF]))
+            stage(L.DEC_FFN2, N=d, K=dff, w=ff["w2_lp"].data_ptr(), bias=ff["b2"].data_ptr())
+        nrm = m.decoder.norm
+        stage(L.DEC_FINAL, ln_a=nrm.a_2.data_ptr(), ln_b=nrm.b_2.data_ptr(), ln_eps=float(nrm.eps))
+        arr = (L.DecodeStage * len(st))(*st)
+        self._n_stages = len(st)
+        self._stages_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self._x.device)
+
+    def _pass_mega(self):
+        import ctypes as C
+        from . import lib as L
+        m = self.model
+        L.check(L.load().mtn_decode_step(C.byref(self._args), self._stages_dev.data_ptr(), self._grid, L.stream_ptr()))
+        g = m.generator._fused
+        self.logp = ops.generator_log_probs(self._out_lp, g["w_lp"], g["bias"])          # (W, V) fp32 log-probabilities (mtn.py:68-69)
+        if self.select is not None:
+            self.top = ops.topk_rows(self.logp, min(self.select[0], self.logp.size(1)), self.select[1])
+
+    def check(self):
+        """Raises if a grid barrier of any step since the session was built timed out (the results would be garbage)."""
+        if int(self._sync[1].item()) != 0:
+            raise RuntimeError("mtn_decode_step: a grid barrier timed out (not every workgroup of the launch was resident?)")
+
+    def step_many(self, prefix_lists):
+        if len(prefix_lists) != self.D:
+            raise ValueError("one prefix list per dialogue of the session")
+        l = len(prefix_lists[0][0])
+        W = self.width
+        if max(len(p) for p in prefix_lists) > W or l > self.max_len:
+            raise ValueError("more hypotheses / longer prefix than the session was built for")
+        anc_old = self._h_anc.clone() if l > 1 else None
+        self._h_tok.fill_(self.pad)
+        for d_, prefixes in enumerate(prefix_lists):
+            for i, p in enumerate(prefixes):
+                j = d_ * W + i
+                self._h_tok[j] = int(p[-1])
+                if l > 1:
+                    parent = d_ * W + self._prev[d_].index(list(p[:-1]))          # the hypothesis this one extends
+                    self._h_anc[j, :l - 1] = anc_old[parent, :l - 1]
+                self._h_anc[j, l - 1] = j
+        self._prev = [[list(p) for p in prefixes] for prefixes in prefix_lists]
+        self._h_pos[0] = l - 1
+        self._devblk.copy_(self._host, non_blocking=True)
+        with torch.no_grad():
+            if not self.use_graph:
+                self._pass_mega()
+            else:
+                if self._graph is None:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        self._pass_mega()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._pass_mega()
+                self._graph.replay()
+        return [self.logp[d_ * W:d_ * W + len(p)] for d_, p in enumerate(prefix_lists)]
+
+
 _SESSIONS: dict = {}
 SELECT_MAX_K = 16        # csrc/select.hip SEL_MAX_K
 KV_CACHE_FROM = 32      # prefix K/V cache by default for searches longer than this (at the reference's max_len = 20 the full-prefix
                         # pass is launch-latency-bound and as fast; the cache makes a token cost O(l) instead of O(l^2) work beyond it)
 
 
-def _session(model, batch, max_len, width, pad, use_graph, kv_cache=False, select=None) -> DecodeSession:
+def _session(model, batch, max_len, width, pad, use_graph, kv_cache=False, select=None, mega=False) -> DecodeSession:
     """Sessions are kept per (model, shapes): a dialogue with the shapes of an earlier one reuses its buffers and graph.
     The cache is dropped when the model's weights change (prepare() version) or it grows past a few shapes."""
-    key = DecodeSession.signature(model, batch, max_len, width) + (bool(use_graph), bool(kv_cache), select)
     model.prepare()
+    mega = bool(mega) and MegaDecodeSession.supported(model, batch, max_len, width)
+    key = DecodeSession.signature(model, batch, max_len, width) + (bool(use_graph), bool(kv_cache), select, mega)
     ver = getattr(model, "_flat_version", None)
     hit = _SESSIONS.get(key)
     if hit is not None and hit[1] == ver and hit[0].model is model:
@@ -268,7 +441,10 @@ def _session(model, batch, max_len, width, pad, use_graph, kv_cache=False, selec
         return hit[0]
     if len(_SESSIONS) >= 8:
         _SESSIONS.clear()
-    sess = DecodeSession(model, batch, max_len, width, pad=pad, use_graph=use_graph, kv_cache=kv_cache, select=select)
+    if mega:
+        sess = MegaDecodeSession(model, batch, max_len, width, pad=pad, use_graph=use_graph, select=select)
+    else:
+        sess = DecodeSession(model, batch, max_len, width, pad=pad, use_graph=use_graph, kv_cache=bool(kv_cache), select=select)
     _SESSIONS[key] = (sess, ver)
     return sess
 
@@ -330,12 +506,13 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
     """beam_search_decode for a Batch of D dialogues at once: the D x beam live hypotheses are the batch dimension of ONE
     target-stream pass per generated token (the pass is launch-latency-bound, so D dialogues cost little more than one).
     Returns a list of D (n-best list, best score) pairs, each equal to what the single-dialogue search returns."""
+    auto = kv_cache is None          # the caller leaves the pass to us: one persistent launch per token where it applies (<= 8 hypotheses, bf16)
     if kv_cache is None:
         kv_cache = max_len > KV_CACHE_FROM
     k = beam + 2
     # device-side candidate selection (csrc/select.hip) holds at most SELECT_MAX_K entries per row: wider beams keep torch.topk
     sel = (k + 1, end_symbol) if k + 1 <= SELECT_MAX_K else None
-    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph, kv_cache, select=sel)
+    sess = _session(model, batch, max_len, beam, pad_symbol, use_graph, kv_cache, select=sel, mega=auto)
     beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
     for l in range(max_len):
         logps = sess.step_many([bm.prefixes() for bm in beams])
@@ -364,6 +541,8 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
             else:
                 bm.advance(None, l, top=(vals[o:o + n, :k], idx[o:o + n, :k], eos[o:o + n]))
             o += n
+    if isinstance(sess, MegaDecodeSession):
+        sess.check()
     return [bm.result(nbest) for bm in beams]
 
 
@@ -381,7 +560,7 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
 def greedy_decode(model, batch, max_len, start_symbol, pad_symbol=1, use_graph=True, kv_cache=None):
     """data_utils.py:159-186 (the reference's own greedy_decode cannot run: it calls decode() with the wrong arity, SURVEY
     §8c) — pinned to: argmax of the generator's log-probabilities at every step, (1, max_len) tokens incl. <sos>."""
-    sess = _session(model, batch, max_len, 1, pad_symbol, use_graph, max_len > KV_CACHE_FROM if kv_cache is None else kv_cache)
+    sess = _session(model, batch, max_len, 1, pad_symbol, use_graph, max_len > KV_CACHE_FROM if kv_cache is None else kv_cache, mega=kv_cache is None)
     ys = [start_symbol]
     for _ in range(max_len - 1):
         nxt = int(sess.step([ys]).argmax(dim=-1)[0])

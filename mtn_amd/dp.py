@@ -166,6 +166,9 @@ class ShardedOptimizerSync:
         self.slices = set()             # every (lo, hi) this object split into shards (for gather())
         self.lp_slices = set()          # ... of them, the matrix ranges whose foreign fp32 masters are stale (gathered in the compute dtype)
         self.masters_stale = False      # a step ran the compute-dtype gather since the last gather() of the fp32 masters
+        # measurement (bench.py secondary.exchange.timeline): when a list, every reduce_update() appends HIP events of its chain —
+        # gradient slice ready / reduced / shard updated / gathered — recorded on the side stream the chain runs on
+        self.timeline = None
         self.calls = {"reduce_scatter": 0, "all_reduce": 0, "all_gather": 0, "broadcast": 0}   # collectives issued (tests, bench line)
 
     def lp_mode(self) -> bool:
@@ -233,22 +236,43 @@ class ShardedOptimizerSync:
             works.append(dist.all_reduce(grad[tail:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.calls["all_reduce"] += 1
 
+        tl = None
+        if self.timeline is not None and cuda:
+            tl = {"lo": lo, "hi": hi, "bytes_reduced": 4 * (tail - lo) if per > 0 else 0, "bytes_gathered": 0}
+            self.timeline.append(tl)
+
+        def mark(name):
+            if tl is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                tl[name] = e
+
         def chain():
+            mark("ready")                          # (side stream: behind everything the compute stream had queued = the slice's gradients)
             for w in works:
                 w.wait()                           # the current (side) stream waits; the host does not
+            mark("reduced")
             if per > 0:
                 upd(own, per)
             if tail < hi:
                 upd(tail, hi - tail)               # replicated: identical inputs -> identical results on every rank
+            mark("updated")
             if per > 0:
                 buf = self.lp_fn() if lp_gather else flat          # what the other ranks need of this shard: its bf16 copy | its fp32 master
+                mine = []
                 if self.native:
-                    self._works.append(dist.all_gather_into_tensor(buf[lo:tail], buf[own:own + per], group=self.group, async_op=True))
+                    mine.append(dist.all_gather_into_tensor(buf[lo:tail], buf[own:own + per], group=self.group, async_op=True))
                     self.calls["all_gather"] += 1
                 else:
                     for r in range(self.world):
-                        self._works.append(dist.broadcast(buf[lo + r * per: lo + (r + 1) * per], src=r, group=self.group, async_op=True))
+                        mine.append(dist.broadcast(buf[lo + r * per: lo + (r + 1) * per], src=r, group=self.group, async_op=True))
                         self.calls["broadcast"] += 1
+                self._works += mine
+                if tl is not None:                 # measurement only: the side stream waits for the gather so that its end can be stamped
+                    tl["bytes_gathered"] = buf.element_size() * (tail - lo)
+                    for w in mine:
+                        w.wait()
+                    mark("gathered")
 
         if cuda:
             self.side.wait_stream(torch.cuda.current_stream())

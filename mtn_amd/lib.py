@@ -124,6 +124,32 @@ class CastDesc(C.Structure):
     _fields_ = [("n", C.c_long), ("src", C.c_void_p), ("dst", C.c_void_p), ("drop", Dropout), ("gate", C.c_void_p)]
 
 
+class TtLnUnit(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("nparts", C.c_int), ("d", C.c_int), ("a_off", C.c_long), ("b_off", C.c_long)]
+
+
+class TtAux(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("lp", C.c_void_p), ("n_flat", C.c_long),
+                ("n_ln", C.c_int), ("ln", C.POINTER(TtLnUnit)), ("n_chunks", C.c_int), ("chunk_off", C.POINTER(C.c_long)),
+                ("chunk_len", C.POINTER(C.c_int)), ("bias_adam", C.c_int), ("state", C.c_void_p), ("grad_scale", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+
+
+class DecodeStage(C.Structure):
+    _fields_ = [("kind", C.c_int), ("N", C.c_int), ("K", C.c_int), ("w", C.c_void_p), ("bias", C.c_void_p), ("ln_a", C.c_void_p),
+                ("ln_b", C.c_void_p), ("ln_eps", C.c_float), ("kv", C.c_void_p), ("m", C.c_int), ("mask", C.c_void_p),
+                ("mask_stride", C.c_long), ("cache", C.c_void_p)]
+
+
+class DecodeArgs(C.Structure):
+    _fields_ = [("W", C.c_int), ("d", C.c_int), ("h", C.c_int), ("L", C.c_int), ("n_stages", C.c_int), ("x", C.c_void_p), ("q", C.c_void_p),
+                ("o", C.c_void_p), ("hid", C.c_void_p), ("out_lp", C.c_void_p), ("tokens", C.c_void_p), ("lut", C.c_void_p),
+                ("emb_scale", C.c_float), ("pe", C.c_void_p), ("pos", C.c_void_p), ("anc", C.c_void_p), ("sync", C.c_void_p)]
+
+
+DEC_EMBED, DEC_SELF_QKV, DEC_SELF_ATT, DEC_OUT, DEC_CROSS, DEC_FFN1, DEC_FFN2, DEC_FINAL = range(8)
+
+
 class LnFinalizeDesc(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("nparts", C.c_int), ("d", C.c_int), ("da2", C.c_void_p), ("db2", C.c_void_p)]
 
@@ -168,6 +194,8 @@ SYMBOLS = {
     "mtn_version": (C.c_int, []),
     "mtn_gemm": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
     "mtn_gemm_tt_table": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
+    "mtn_decode_step": (C.c_int, [C.POINTER(DecodeArgs), _P, C.c_int, _P]),
+    "mtn_gemm_tt_table_aux": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), C.POINTER(TtAux), _P]),
     "mtn_layernorm_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mtn_layernorm_fwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(LnFwdDesc), _P]),
     "mtn_embed_bwd_group": (C.c_int, [C.c_int, C.POINTER(EmbedBwdDesc), _P]),
@@ -180,6 +208,8 @@ SYMBOLS = {
     "mtn_ln_epilogue_groups": (C.c_long, []),
     "mtn_ln_linear_members": (C.c_long, []),
     "mtn_ln_fold": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+    "mtn_step_head": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float,
+                                _P, C.c_longlong, _P, C.c_long, _P]),
     "mtn_sublayer_group_fwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_sublayer_group_bwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_layernorm_bwd_partial_floats": (C.c_long, [C.c_int, C.c_int]),

@@ -738,6 +738,16 @@ class EncoderDecoder(nn.Module):
                 m._grads = (views(m.a_2)[2], views(m.b_2)[2])
                 m._lp_dtype = lp
                 m._queue = self._queue
+        # the feature Linears (glue parameters, mtn.py:378): their dW is ONE deferred GEMM of the table launch too (ops.FeatureEncodeFn)
+        # — optional, because feature widths the GEMM cannot take go through PyTorch's Linear instead
+        if dev.type == "cuda":
+            for seq in self.vid_encoder:
+                lin = seq[0]
+                o_w = path_off[id(lin.weight)]
+                dm, fs = lin.weight.shape
+                if fs % 8 == 0 and dm % 8 == 0 and not any(t[0] == o_w for t in fusable):
+                    fusable.append((o_w, dm, fs))
+                    optional.add(o_w)
         if t_views:
             t_total = 0
             for _, _, o, r, c in t_views:
@@ -826,6 +836,27 @@ class EncoderDecoder(nn.Module):
         table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
         self._ln_fold_buf = buf
         self._ln_fold_table = (table, torch.tensor(block_desc, dtype=torch.int32).to(dev), blocks, d)
+
+    def step_head(self, opt=None, zero_grads: bool = True):
+        """Everything a train step does before its first path kernel, in ONE launch (include/mtn_hip.h mtn_step_head): the fold
+        vectors (fold_layer_norms), the optimiser's schedule tick (``opt`` = (FusedAdam, factor, model_size, warmup) or None), the
+        dropout seed advance and the zero fill of the glue gradients.  The encode() that follows skips its own fold / seed launches."""
+        self.prepare()
+        t = self._ln_fold_table
+        st = (None, 0.0, 1, 1, 0.0, 0.0)
+        if opt is not None:
+            adam, factor, model_size, warmup = opt
+            st = (adam.state.data_ptr(), float(factor), int(model_size), int(warmup), adam.betas[0], adam.betas[1])
+        seed = self._seed if (self.training and self._seed is not None) else None
+        zn = self._glue_numel // 4 * 4 if zero_grads else 0
+        L.check(L.load().mtn_step_head(L.MTN_BF16, t[0].data_ptr() if t is not None else None, t[1].data_ptr() if t is not None else None,
+                                       t[2] if t is not None else 0, t[3] if t is not None else 8, *st,
+                                       seed.data_ptr() if seed is not None else None, 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF,
+                                       self._flat_grad.data_ptr() if zn else None, zn, L.stream_ptr()))
+        if zero_grads and zn < self._glue_numel:
+            self._flat_grad[zn:self._glue_numel].zero_()
+        self._ln_fold_stale = False
+        self._head_done = True
 
     def fold_layer_norms(self):
         """Recompute the fold vectors from the current weights (one launch, mtn_ln_fold): once per forward that will be
@@ -990,9 +1021,12 @@ class EncoderDecoder(nn.Module):
         """mtn.py:38-56 — every text stream goes through ``query_embed``; returns
         [q_mem, [vid_mem], cap_mem, his_mem, ae] with ae = list of auto-encoder seeds or None."""
         self.prepare()
-        self.fold_layer_norms()                # (the forward kernels use the fold vectors too: LayerNorm as a rank-1 correction)
-        if self.training:
-            self.advance_dropout_seed()
+        if getattr(self, "_head_done", False):
+            self._head_done = False            # step_head() has folded and advanced the seed in its one launch
+        else:
+            self.fold_layer_norms()            # (the forward kernels use the fold vectors too: LayerNorm as a rank-1 correction)
+            if self.training:
+                self.advance_dropout_seed()
         self._embed_calls = 0
         if self._fused_embed_ok(query):
             nF = len(vid)

@@ -143,6 +143,60 @@ class ParamGradQueue:
         A["applied"] = True
         return keep
 
+    def _table_aux(self, tt):
+        """The rest of the optimiser step as FRONT tiles of the table launch (include/mtn_hip.h mtn_tt_aux), when the optimiser
+        epilogue is armed: LayerNorm gains / biases (finalize + Adam per 256 columns), the bias of every Linear whose weight
+        gradient is one of the launch's problems (updated by the tile that sums it), and every other range of the flat buffers no dW
+        epilogue covers — the embedding tables, whose gradient the scatter launch above has completed — as <= 4096-element chunks.
+        Nothing is left behind the launch: FusedAdam.step_rest() then only refreshes transposed copies.  Returns (aux, keep-alive)
+        or None (MTN_TT_AUX=0, or a gradient that does not live in the model's flat buffer)."""
+        A = self.adam
+        if A is None or os.environ.get("MTN_TT_AUX") == "0" or not A.get("n_flat"):
+            return None
+        g0, n_flat = A["grad"], A["n_flat"]
+        inside = lambda ptr, n: ptr is not None and g0 <= ptr and ptr + 4 * n <= g0 + 4 * n_flat and (ptr - g0) % 4 == 0
+        ln_units, taken = [], []                    # taken: (offset, length) ranges updated inside the launch
+        for d_ in self.ln:
+            if not (inside(d_.da2, d_.d) and inside(d_.db2, d_.d)):
+                return None
+            a_off, b_off = (d_.da2 - g0) // 4, (d_.db2 - g0) // 4
+            ln_units.append((d_.partial, d_.nparts, d_.d, a_off, b_off))
+            taken += [(a_off, d_.d), (b_off, d_.d)]
+        for p in tt:
+            if p.rowsum_out and inside(p.rowsum_out, p.M):
+                taken.append(((p.rowsum_out - g0) // 4, p.M))
+            if not p.adam and inside(p.out_f32, 1):
+                return None                         # a weight gradient this very launch STORES (no epilogue): not complete when the front tiles run
+        for o, r, c in A["fusable"]:
+            if o in A["covered"]:
+                taken.append((o, r * c))
+        taken.sort()
+        if any(taken[i][0] + taken[i][1] > taken[i + 1][0] for i in range(len(taken) - 1)):
+            return None                             # a gradient with two producers (shared module): keep the separate passes
+        key = tuple(taken)
+        hit = A["aux_cache"].get(key)
+        if hit is None:
+            offs, lens, cur = [], [], 0
+            for o, n in taken + [(n_flat, 0)]:
+                lo, hi = (cur + 3) // 4 * 4, o // 4 * 4            # (every parameter starts on a multiple of 8 elements; paddings are inert)
+                while lo < hi:
+                    k = min(4096, hi - lo)
+                    offs.append(lo); lens.append(k); lo += k
+                cur = o + n
+            hit = ((C.c_long * max(1, len(offs)))(*offs), (C.c_int * max(1, len(lens)))(*lens), len(offs))
+            A["aux_cache"][key] = hit
+        ln_arr = (L.TtLnUnit * max(1, len(ln_units)))()
+        for i, (partial, nparts, d, a_off, b_off) in enumerate(ln_units):
+            ln_arr[i].partial, ln_arr[i].nparts, ln_arr[i].d, ln_arr[i].a_off, ln_arr[i].b_off = partial, nparts, d, a_off, b_off
+        aux = L.TtAux()
+        aux.p, aux.g, aux.m, aux.v, aux.lp, aux.n_flat = A["p"], g0, A["m"], A["v"], A["lp"], n_flat
+        aux.n_ln, aux.ln = len(ln_units), ln_arr
+        aux.n_chunks, aux.chunk_off, aux.chunk_len = hit[2], hit[0], hit[1]
+        aux.bias_adam = 1
+        aux.state, aux.grad_scale = A["state"], A["grad_scale"]
+        aux.beta1, aux.beta2, aux.eps = A["betas"][0], A["betas"][1], A["eps"]
+        return aux, (ln_arr, hit)
+
     def add(self, dtype, problems, ln_desc, keep):
         assert self.dtype in (None, dtype)
         self.dtype = dtype
@@ -206,9 +260,15 @@ class ParamGradQueue:
                     if lo <= hi:
                         order.append(tt[hi]); hi -= 1
                 arr = (L.GemmProblem * len(order))(*order)
-                L.check(lib.mtn_gemm_tt_table(self.dtype, len(order), arr, cur.cuda_stream))
-                taken = set(id(p) for p in tt)
-                self.gemm = [p for p in self.gemm if id(p) not in taken]
+                rest = [p for p in self.gemm if id(p) not in set(id(q) for q in tt)]
+                aux = self._table_aux(tt) if (self.adam is not None and not rest) else None
+                if aux is not None:
+                    L.check(lib.mtn_gemm_tt_table_aux(self.dtype, len(order), arr, C.byref(aux[0]), cur.cuda_stream))
+                    self.adam["rest_done"] = True          # LayerNorm finalize + every remaining Adam update ran as front tiles
+                    self.ln = []
+                else:
+                    L.check(lib.mtn_gemm_tt_table(self.dtype, len(order), arr, cur.cuda_stream))
+                self.gemm = rest
         # ... and at most 512 of the 128x128 tiles (two resident workgroups per CU x 256 CUs) per launch: a launch that
         # spills into a second round pays for a whole extra round
         chunk, tiles = [], 0

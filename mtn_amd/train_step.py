@@ -24,6 +24,7 @@ from .data_utils import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
 # with hipErrorStreamCaptureInvalidated (seen on hardware: tools/dp_rccl_probe.py, round 3).  Only this thread's calls matter here:
 # the kernels come from this thread and from autograd's device thread, both onto the capturing stream.
 CAPTURE_MODE = os.environ.get("MTN_CAPTURE_MODE", "thread_local")
+_CUT_GACC = os.environ.get("MTN_DP_CUT_GACC", "1") != "0"      # gradients across a layer cut meet in the memory-gradient buffer (no autograd add)
 
 
 class TrainStep:
@@ -100,11 +101,16 @@ class TrainStep:
     def _fwd_bwd(self, fuse: bool = False):
         m, b = self.model, self.batch
         self._refresh_norms()
-        m.zero_glue_grads()
+        head = os.environ.get("MTN_STEP_HEAD", "0") == "1" and hasattr(m, "step_head") and m._flat is not None and m._flat.is_cuda
         if m._queue is not None and (m._queue.gemm or m._queue.ln or m._queue._armed):
             m._queue.reset()               # left over from a step that raised: never mix it into this one
+        if head:
+            # ONE launch for the step's head: glue-gradient zero fill, schedule tick (fused optimiser), dropout seed, fold vectors
+            m.step_head((self.opt.optimizer, self.opt.factor, self.opt.model_size, self.opt.warmup) if fuse else None)
+        else:
+            m.zero_glue_grads()
         if fuse:
-            self.opt.begin_fused_step()
+            self.opt.begin_fused_step(tick=not head)
         try:
             out, ae_out = m.forward(b)
             loss = self.lc.loss(out, b.trg_y, self._norms[0], ae_out, self._ae_y, self._norms[1])
@@ -112,6 +118,7 @@ class TrainStep:
         except BaseException:
             if m._queue is not None:
                 m._queue.reset()
+            m._head_done = False
             raise
         return loss.detach()
 
@@ -146,9 +153,29 @@ class TrainStep:
         assert all(sl[k][1] == sl[k + 1][0] for k in range(N - 1)), "layer slices not contiguous"
 
         def bwd(outs, leaves):
-            pairs = [(o, l.grad) for o, l in zip(outs, leaves) if l.grad is not None]
-            if pairs:
-                torch.autograd.backward([p[0] for p in pairs], [p[1] for p in pairs])
+            # An auto-encoder output is BOTH the next layer's chain input (across the cut: its gradient arrives as leaf.grad) and the
+            # memory of x's attention inside this layer.  In the monolithic graph the two gradients meet in one buffer (ops.py, the
+            # `_mtn_gacc` protocol: first writer = the chain input's dx, the memory-gradient GEMM accumulates into it); across a cut
+            # autograd would ADD them (12 torch add launches per step, 112 us at batch 64: profiles/r04_x_*).  Here the leaf's gradient
+            # is handed to that buffer slot instead of to autograd: same summation order as the monolithic step, no add launch.
+            roots, grads = [], []
+            for o, l in zip(outs, leaves):
+                if l.grad is None:
+                    continue
+                ga = getattr(o, "_mtn_gacc", None)
+                if (_CUT_GACC and ga is not None and ga["remaining"] > 0 and ga["buf"] is None and l.grad.is_contiguous()
+                        and l.grad.dtype == torch.float32 and l.grad.shape == o.shape):
+                    ga["buf"] = l.grad
+                    # the next layer handed THIS tensor (its dx, through the producer's output dropout, compute dtype) to the producer
+                    # of `o` as a ready-made dy, valid while the tensor is untouched — it is about to be accumulated into: withdraw
+                    # it (in bf16 mode the memory-gradient GEMM's epilogue hands the full sum over again; fp32 mode casts it)
+                    h = getattr(o, "_mtn_next", None)
+                    if h is not None and h.get("dx_ptr") == l.grad.data_ptr():
+                        h["dyl"] = h["dx_ptr"] = None
+                    continue
+                roots.append(o); grads.append(l.grad)
+            if roots:
+                torch.autograd.backward(roots, grads)
 
         def top():
             b = self.batch
@@ -188,6 +215,10 @@ class TrainStep:
             for run, (lo, hi, mat_hi) in runners:
                 run()
                 self.sharded.reduce_update(lo, hi, mat_hi)
+            if self.sharded.timeline is not None and torch.cuda.is_available():
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()                              # the compute chain (every segment graph) ends here; what follows is exposed exchange
+                self.sharded.timeline.append({"chain_end": e})
             self.sharded.finish()
             return
         works = []

@@ -204,3 +204,81 @@ def test_cfg5_full_depth_first_decode_steps_match_oracle(dev, dtype):
                 nxt += [p + [t] for t in top]
             # the next step's prefixes: the oracle's best `beam` extensions (by its own log-probabilities; scores are not needed here)
             prefixes = nxt[:beam]
+
+
+def _mega_vs_launch_pass(dev, model, b, width, max_len, steps):
+    """log-probabilities of `steps` decode steps of a greedy-ish walk on the persistent launch (csrc/decode.hip) and on the
+    launch-per-sublayer pass, same bf16 weights, same prefixes"""
+    from mtn_amd.decode import DecodeSession, MegaDecodeSession
+    assert MegaDecodeSession.supported(model, b, max_len, width)
+    mega = MegaDecodeSession(model, b, max_len, width, pad=fx.PAD)
+    ref = DecodeSession(model, b, max_len, width, pad=fx.PAD)
+    prefixes = [[fx.SOS]]
+    worst = 0.0
+    for l in range(steps):
+        got = mega.step(prefixes).clone()
+        want = ref.step(prefixes).clone()
+        mega.check()
+        err = float((got - want).abs().max() / want.abs().max())
+        worst = max(worst, err)
+        assert err < 2e-2, (l, err)
+        assert torch.equal(got.argmax(-1), want.argmax(-1)) or float((want.max(-1).values - want.gather(1, got.argmax(-1, keepdim=True)).squeeze(1)).abs().max()) < 2e-2
+        # next prefixes: every live hypothesis extended by its best and (while the beam fills) its second-best token, as a beam step would
+        nxt = []
+        top2 = want.topk(2, dim=-1).indices.tolist()
+        for p, t2 in zip(prefixes, top2):
+            for t in t2:
+                if len(nxt) < width and t not in (fx.EOS, fx.UNK):
+                    nxt.append(p + [int(t)])
+        prefixes = nxt[:width] if nxt else [p + [5] for p in prefixes]
+    return worst
+
+
+@pytest.mark.parametrize("name,width", [("cfg1_query", 5), ("cfg1_caption", 3), ("small_shared", 1)])
+def test_persistent_decode_step_matches_launch_pass_small(dev, name, width):
+    """csrc/decode.hip against the launch-per-sublayer pass on the golden configurations (d_model 128, 4 heads of 32: the two-tile /
+    k-split plans of the small-M Linear, caption-mode order of the cross-attentions, a shared encoder, one hypothesis = greedy):
+    log-probabilities of 7 steps of a beam-like walk within 2e-2 of the row's largest magnitude (both paths bf16)."""
+    c = fx.GOLDEN_CONFIGS[name]
+    model = build_model(c, torch.bfloat16, dev).eval()
+    b = dev_batch(one_dialogue(c, seed=9), dev)
+    worst = _mega_vs_launch_pass(dev, model, b, width, 9, 7)
+    print(f"{name} width {width}: worst relative log-probability difference {worst:.2e}")
+
+
+def test_persistent_decode_step_matches_launch_pass_cfg5(dev):
+    """The benchmark's decode shape (cfg5: d_model 512, 6 layers, 8 heads, beam 4, H = 128, frames 32): 10 steps."""
+    from mtn_amd import make_model
+    from mtn_amd.synthetic import CONFIGS, synthetic_batch
+    cfg = dict(CONFIGS["cfg2"])
+    torch.manual_seed(0)
+    model = make_model(cfg["vocab"], cfg["vocab"], N=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"], dropout=0.1,
+                       ft_sizes=cfg["ft_sizes"], diff_encoder=True, auto_encoder_ft="query", compute_dtype=torch.bfloat16).to(dev).eval()
+    b = synthetic_batch(cfg["vocab"], 1, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=100, ragged=True)
+    worst = _mega_vs_launch_pass(dev, model, b, 4, 20, 10)
+    print(f"cfg5: worst relative log-probability difference {worst:.2e}")
+
+
+def test_persistent_decode_beam_search_equals_launch_pass(dev):
+    """Whole searches (beam 5, reference defaults) through beam_search_decode with the persistent launch on (default for <= 8
+    hypotheses on a bf16 model) and off (MTN_DECODE_MEGA=0): same number of hypotheses, best score within 1e-2 — and against the
+    reference's golden best score within the bf16 bar."""
+    from mtn_amd import decode as D
+    name = "cfg1_query"
+    c = fx.GOLDEN_CONFIGS[name]
+    g = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    model = build_model(c, torch.bfloat16, dev).eval()
+    b = dev_batch(one_dialogue(c), dev)
+    D._SESSIONS.clear()
+    n1, best1 = D.beam_search_decode(model, b, 8, fx.SOS, fx.UNK, fx.EOS, fx.PAD)
+    assert any(isinstance(s[0], D.MegaDecodeSession) for s in D._SESSIONS.values()), "the persistent launch was not taken"
+    os.environ["MTN_DECODE_MEGA"] = "0"
+    try:
+        D._SESSIONS.clear()
+        n0, best0 = D.beam_search_decode(model, b, 8, fx.SOS, fx.UNK, fx.EOS, fx.PAD)
+    finally:
+        del os.environ["MTN_DECODE_MEGA"]
+        D._SESSIONS.clear()
+    assert len(n1) == len(n0) == int(g["beam.n"])
+    assert abs(best1 - best0) < 1e-2 * max(1.0, abs(best0))
+    assert abs(best1 - float(g["beam.best"])) < 1e-2 * max(1.0, abs(float(g["beam.best"])))

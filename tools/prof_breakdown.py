@@ -4,6 +4,9 @@ db = sorted(glob.glob(sys.argv[1] + '/**/*_results.db', recursive=True))[-1]
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end, grid_x, workgroup_x, queue_id from kernels order by start").fetchall()
 adam = [i for i,r in enumerate(rows) if 'adam_kernel' in r[0] or 'adam_chunks_kernel' in r[0]]
+if len(adam) < 3:
+    # round 5: the rest of the optimiser rides in the table launch (no adam_chunks launch behind it): a step ends with the table launch
+    adam = [i for i,r in enumerate(rows) if 'gemm_tt_dma128_table_kernel' in r[0]]
 # the last few optimiser-to-optimiser intervals; the shortest one is a replayed graph step (bench.py's eager census pass, which
 # also ends in an optimiser kernel, is longer)
 cands = [rows[adam[i]+1:adam[i+1]+1] for i in range(max(0, len(adam)-5), len(adam)-1)]
