@@ -555,7 +555,6 @@ def main():
     model = make_model(cfg["vocab"], cfg["vocab"], N=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"],
                        dropout=args.dropout, ft_sizes=cfg["ft_sizes"], diff_encoder=True, diff_embed=False, diff_gen=False,
                        auto_encoder_ft="query", compute_dtype=lp, attn_dropout=0.1 if args.dropout > 0 else 0.0)
-    model.multi_stream = os.environ.get("MTN_MULTI_STREAM", "0") == "1"      # per-chain HIP streams (superseded by lockstep groups)
     model.to(dev).train()
     model.prepare()
     sync = None

@@ -251,13 +251,6 @@ typedef struct {
     int K, block_start;
 } mtn_ln_fold_desc;
 int mtn_ln_fold(int dtype, const mtn_ln_fold_desc* descs_device, const int* block_desc, int total_blocks, int d, void* stream);
-/* Head of a train step in ONE launch (round 5, version 112): the fold vectors above (total_blocks may be 0: fp32 mode), the
- * schedule tick of mtn_noam_tick on `state` (NULL = none), the dropout seed advance *seed += seed_inc (NULL = none) and a zero fill
- * of zero[0, zero_n) (the autograd-accumulated glue gradients; zero_n a multiple of 4 floats) — replaces three launches of 5-7 us
- * in front of the first path kernel (train.py:29-40's loop head: opt.zero_grad() of data_utils.py:155 included). */
-int mtn_step_head(int dtype, const mtn_ln_fold_desc* descs_device, const int* block_desc, int total_blocks, int d,
-                  float* state, float factor, int model_size, int warmup, float beta1, float beta2,
-                  long long* seed, long long seed_inc, float* zero, long zero_n, void* stream);
 long mtn_layernorm_bwd_partial_floats(int rows, int d);
 int mtn_layernorm_bwd_nparts(int rows);
 /* da2/db2 == NULL: only dx is produced now and `partial` is left for a later grouped mtn_layernorm_bwd_finalize()
@@ -653,13 +646,15 @@ typedef struct {
     void* cache;                /* MTN_DEC_SELF_QKV / _ATT: this layer's prefix cache [W][L][2d] bf16 */
 } mtn_decode_stage;
 typedef struct {
-    int W, d, h, L, n_stages;
+    int W, d, h, L, n_stages, d_ff;
     float* x; void* q; void* o; void* hid; void* out_lp;
     const long* tokens;         /* [W] newest token of every hypothesis */
     const float* lut; float emb_scale; const float* pe;     /* target embedding table [V][d], sqrt(d), positional encodings [>= L][d] */
     const int* pos;             /* device scalar: the position being decoded (0-based) */
     const int* anc;             /* [W][L] cache slot that holds position t of hypothesis j's prefix (anc[j][pos] = j) */
     unsigned* sync;
+    void* dbg;                  /* NULL, or 4 x n_stages uint64: workgroup 0's 100 MHz wall-clock stamps per stage (behind the barrier / operands
+                                   ready / computed / stores issued) — tools/decode_timeline.py */
 } mtn_decode_args;
 int mtn_decode_step(const mtn_decode_args* args /* host */, const mtn_decode_stage* stages_device, int grid, void* stream);
 /* The library's development / test switches (MTN_GEMM_*, MTN_ATTN_*, MTN_LN_*, MTN_EMBED_DETERMINISTIC, ...) are read from the

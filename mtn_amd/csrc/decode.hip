@@ -29,8 +29,18 @@
 #define DEC_MAX_W 8
 
 typedef unsigned long long u64;
-__device__ __forceinline__ u64 ld_ag(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_ag(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+// Agent-scope (sc1) accesses to the buffers workgroups exchange activations through, as BUFFER loads / stores with the sc1 cache-policy
+// bit (aux = 16): to the compiler they are ordinary memory operations, so a thread's loads of a stage are issued back to back under ONE
+// wait (the first version used relaxed agent atomics, 8 bytes each, and every one of them waited for its own round trip: 9 us per
+// stage, profiles/r05_decode_*).
+#define DEC_SC1 16
+typedef __amdgpu_buffer_rsrc_t dec_rsrc_t;
+__device__ __forceinline__ dec_rsrc_t dec_rsrc(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ uint4 ld16(dec_rsrc_t r, unsigned off) { const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, DEC_SC1); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ u64 ld8(dec_rsrc_t r, unsigned off) { const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, DEC_SC1); return (u64)v.x | ((u64)v.y << 32); }
+__device__ __forceinline__ void st16(dec_rsrc_t r, unsigned off, uint4 v) { __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, r, (int)off, 0, DEC_SC1); }
+__device__ __forceinline__ void st8(dec_rsrc_t r, unsigned off, u64 v) { __builtin_amdgcn_raw_buffer_store_b64(v2u_t{(unsigned)v, (unsigned)(v >> 32)}, r, (int)off, 0, DEC_SC1); }
 __device__ __forceinline__ unsigned ld_ag32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct DecKernelArgs {
@@ -53,39 +63,42 @@ __device__ __forceinline__ void dec_grid_sync(unsigned* sync, const unsigned tar
     __syncthreads();
 }
 
-// ---- LayerNorm of one row held 2*NP elements per lane by one wave (mtn.py:111-114: unbiased std, eps added to std) -> bf16 into LDS
-template <int NP>       // u64 (= 2 floats) per lane: d = 128 * NP
-__device__ __forceinline__ void dec_ln_row(const u64* xrow, const float* __restrict__ a2, const float* __restrict__ b2, const float eps,
-                                           const int d, const int lane, bf16_t* dst) {
-    float v[2 * NP];
+// ---- LayerNorm of one row by one wave (mtn.py:111-114: unbiased std, eps added to std): lane holds 4 consecutive floats per 256 columns;
+// the result goes out as bf16 through `put(column, four values)` (an LDS image, or global memory for the final norm)
+template <typename PUT>
+__device__ __forceinline__ void dec_ln_row(const dec_rsrc_t rx, const unsigned row_off, const float* __restrict__ a2, const float* __restrict__ b2,
+                                           const float eps, const int d, const int lane, PUT put) {
+    float4 v[4];                                   // d <= 1024
+    const int nv = (d + 255) >> 8;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const u64 q = ld_ag(xrow + lane + 64 * i);
-        v[2 * i] = __uint_as_float((unsigned)q); v[2 * i + 1] = __uint_as_float((unsigned)(q >> 32));
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < d) { const uint4 q = ld16(rx, row_off + c * 4); v[i] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)); }
+        else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2 * NP; ++i) s += v[i];
+    for (int i = 0; i < 4; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = fh_cross_sum(fh_row16_sum(s)) / (float)d;
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2 * NP; ++i) { const float c = v[i] - mean; ss += c * c; }
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < d) { const float a = v[i].x - mean, b = v[i].y - mean, e = v[i].z - mean, f = v[i].w - mean; ss += (a * a + b * b) + (e * e + f * f); }
+    }
     const float var = fh_cross_sum(fh_row16_sum(ss)) / (float)(d - 1);
     const float inv = 1.0f / (sqrtf(var) + eps);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int c = 2 * (lane + 64 * i);
-        const float y0 = a2[c] * (v[2 * i] - mean) * inv + b2[c], y1 = a2[c + 1] * (v[2 * i + 1] - mean) * inv + b2[c + 1];
-        *(unsigned*)(dst + c) = (unsigned)f32_to_bf16(y0) | ((unsigned)f32_to_bf16(y1) << 16);
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < d) {
+            const float4 ga = *(const float4*)(a2 + c), gb = *(const float4*)(b2 + c);
+            put(c, make_float4(ga.x * (v[i].x - mean) * inv + gb.x, ga.y * (v[i].y - mean) * inv + gb.y, ga.z * (v[i].z - mean) * inv + gb.z, ga.w * (v[i].w - mean) * inv + gb.w));
+        }
     }
 }
-__device__ __forceinline__ void dec_ln_row_any(const u64* xrow, const float* a2, const float* b2, float eps, int d, int lane, bf16_t* dst) {
-    switch (d >> 7) {
-        case 1: dec_ln_row<1>(xrow, a2, b2, eps, d, lane, dst); break;
-        case 2: dec_ln_row<2>(xrow, a2, b2, eps, d, lane, dst); break;
-        case 4: dec_ln_row<4>(xrow, a2, b2, eps, d, lane, dst); break;
-        default: dec_ln_row<8>(xrow, a2, b2, eps, d, lane, dst); break;       // d = 1024
-    }
+__device__ __forceinline__ u64 dec_pack4(const float4 y) {
+    return (u64)f32_to_bf16(y.x) | ((u64)f32_to_bf16(y.y) << 16) | ((u64)f32_to_bf16(y.z) << 32) | ((u64)f32_to_bf16(y.w) << 48);
 }
 
 // ---- the weight side of a small-M Linear on MFMA: out[row r < W][feature n] = sum_k act[r][k] w[n][k]
@@ -171,12 +184,12 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
     const mtn_decode_args& A = KA.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x, wg = blockIdx.x;
-    const int W = A.W, d = A.d, dk = d / A.h;
+    const int W = A.W, d = A.d, dk = d / A.h, dff = A.d_ff;
     const int pos = *A.pos;
-    u64* X = (u64*)A.x;                           // [W][d] fp32
-    u64* Qb = (u64*)A.q;                          // [W][d] bf16
-    u64* Ob = (u64*)A.o;                          // [W][d] bf16
-    u64* Hb = (u64*)A.hid;                        // [W][d_ff] bf16
+    const dec_rsrc_t rX = dec_rsrc(A.x, (unsigned)W * d * 4);          // [W][d] fp32 residual stream
+    const dec_rsrc_t rQ = dec_rsrc(A.q, (unsigned)W * d * 2);          // [W][d] bf16
+    const dec_rsrc_t rO = dec_rsrc(A.o, (unsigned)W * d * 2);
+    const dec_rsrc_t rH = dec_rsrc(A.hid, (unsigned)W * dff * 2);      // [W][d_ff] bf16
     unsigned char* act = smem + DEC_ACT_OFF;
     float* red = (float*)(smem + DEC_RED_OFF);
     float* qs = (float*)(smem + DEC_Q_OFF);
@@ -185,6 +198,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
     float* misc = (float*)(smem + DEC_MISC_OFF);
     const float scale = rsqrtf((float)dk);
     unsigned epoch = 0;
+    u64* dbg = (A.dbg && wg == 0 && tid == 0) ? (u64*)A.dbg : nullptr;       // per stage: after the barrier / operands ready / computed / stores issued
 
     DecWRegs R;
     DecWPlan plan;
@@ -221,89 +235,136 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
     prefetch(S);
     for (int si = 0; si < n_stages; ++si) {
         if (si > 0) { ++epoch; dec_grid_sync(A.sync, epoch * (unsigned)G); }
+        if (dbg) dbg[si * 4 + 0] = wall_clock64();
         const int K = S.K, pitch = K * 2 + 16;
         switch (S.kind) {
-        case MTN_DEC_EMBED: {          // x = lut[token] * sqrt(d) + PE[pos]   (mtn.py:289, 308; eval: no dropout): columns dealt to the workgroups
-            const int per = ((d / 2 + G - 1) / G);                 // u64 (column pairs) per workgroup
-            const int c0 = wg * per, c1 = min(d / 2, c0 + per);
+        case MTN_DEC_EMBED: {          // x = lut[token] * sqrt(d) + PE[pos]   (mtn.py:289, 308; eval: no dropout): column quads dealt to the workgroups
+            const int per = ((d / 4 + G - 1) / G);
+            const int c0 = wg * per, c1 = min(d / 4, c0 + per);
             for (int i = tid; i < W * (c1 - c0); i += DEC_THREADS) {
-                const int j = i / (c1 - c0), c = 2 * (c0 + i % (c1 - c0));
-                const float* e = A.lut + (size_t)A.tokens[j] * d + c;
-                const float* pe = A.pe + (size_t)pos * d + c;
-                const float y0 = e[0] * A.emb_scale + pe[0], y1 = e[1] * A.emb_scale + pe[1];
-                st_ag(X + ((size_t)j * d + c) / 2, (u64)__float_as_uint(y0) | ((u64)__float_as_uint(y1) << 32));
+                const int j = i / (c1 - c0), c = 4 * (c0 + i % (c1 - c0));
+                const float4 e = *(const float4*)(A.lut + (size_t)A.tokens[j] * d + c), pe = *(const float4*)(A.pe + (size_t)pos * d + c);
+                st16(rX, ((unsigned)j * d + c) * 4, make_uint4(__float_as_uint(e.x * A.emb_scale + pe.x), __float_as_uint(e.y * A.emb_scale + pe.y),
+                                                               __float_as_uint(e.z * A.emb_scale + pe.z), __float_as_uint(e.w * A.emb_scale + pe.w)));
             }
         } break;
         case MTN_DEC_SELF_QKV: case MTN_DEC_FFN1: {    // LayerNorm(x) of every row -> act; features n0..n1 of the Linear
-            for (int j = wave; j < W; j += 4) dec_ln_row_any(X + (size_t)j * d / 2, S.ln_a, S.ln_b, S.ln_eps, d, lane, (bf16_t*)(act + (size_t)j * pitch));
+            for (int j = wave; j < W; j += 4) {
+                bf16_t* row = (bf16_t*)(act + (size_t)j * pitch);
+                dec_ln_row(rX, (unsigned)j * d * 4, S.ln_a, S.ln_b, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
+            }
             __syncthreads();
+            if (dbg) dbg[si * 4 + 1] = wall_clock64();
             f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, W, lane);
             spill(acc);
+            if (dbg) dbg[si * 4 + 2] = wall_clock64();
             const int Sn = n1 - n0, S4 = Sn >> 2;                          // (slices are multiples of 4 features: one 8-byte store of four bf16)
+            const dec_rsrc_t rC = dec_rsrc(S.cache, (unsigned)W * A.L * 2 * d * 2);
             for (int i = tid; i < S4 * W; i += DEC_THREADS) {
                 const int f = (i % S4) * 4, r = i / S4, n = n0 + f;
-                u64 pk = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float y = gather(Sn, f + k, r) + S.bias[n + k];
-                    if (S.kind == MTN_DEC_FFN1) y = fmaxf(y, 0.f);
-                    pk |= (u64)f32_to_bf16(y) << (16 * k);
-                }
-                u64* dst;
-                if (S.kind == MTN_DEC_FFN1) dst = Hb + ((size_t)r * S.N + n) / 4;
-                else if (n < d) dst = Qb + ((size_t)r * d + n) / 4;
-                else dst = (u64*)S.cache + (((size_t)r * A.L + pos) * (2 * d) + (n - d)) / 4;            // k | v of the new row into the prefix cache
-                st_ag(dst, pk);
+                float4 y;
+                y.x = gather(Sn, f, r) + S.bias[n]; y.y = gather(Sn, f + 1, r) + S.bias[n + 1];
+                y.z = gather(Sn, f + 2, r) + S.bias[n + 2]; y.w = gather(Sn, f + 3, r) + S.bias[n + 3];
+                if (S.kind == MTN_DEC_FFN1) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); st8(rH, ((unsigned)r * S.N + n) * 2, dec_pack4(y)); }
+                else if (n < d) st8(rQ, ((unsigned)r * d + n) * 2, dec_pack4(y));
+                else st8(rC, (((unsigned)r * A.L + pos) * (2 * d) + (n - d)) * 2, dec_pack4(y));         // k | v of the new row into the prefix cache
             }
         } break;
         case MTN_DEC_OUT: case MTN_DEC_FFN2: {         // act = attention output (OUT) | FFN hidden (FFN2), bf16 [W][K]; + bias + residual -> x
-            const u64* src = S.kind == MTN_DEC_OUT ? Ob : Hb;
-            for (int i = tid; i < W * K / 4; i += DEC_THREADS) {
-                const int j = i / (K / 4), c = i % (K / 4);
-                *(u64*)(act + (size_t)j * pitch + c * 8) = ld_ag(src + (size_t)j * K / 4 + c);
+            const dec_rsrc_t rS = S.kind == MTN_DEC_OUT ? rO : rH;
+            const int K8 = K / 8;
+            for (int i = tid; i < W * K8; i += DEC_THREADS) {
+                const int j = i / K8, c = i % K8;
+                *(uint4*)(act + (size_t)j * pitch + c * 16) = ld16(rS, ((unsigned)j * K + c * 8) * 2);
+            }
+            const int Sn = n1 - n0, S4 = Sn >> 2;
+            // the residual quads this thread will add: asked for now, beside the operand rows
+            uint4 xr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = tid + u * DEC_THREADS;
+                if (i < S4 * W) xr[u] = ld16(rX, ((unsigned)(i / S4) * d + n0 + (i % S4) * 4) * 4);
             }
             __syncthreads();
+            if (dbg) dbg[si * 4 + 1] = wall_clock64();
             f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, W, lane);
             spill(acc);
-            const int Sn = n1 - n0;
-            for (int i = tid; i < Sn * W; i += DEC_THREADS) {
-                const int f = i % Sn, r = i / Sn, n = n0 + f;
-                unsigned* xp = (unsigned*)X + (size_t)r * d + n;
-                const float y = gather(Sn, f, r) + S.bias[n] + __uint_as_float(ld_ag32(xp));
-                __hip_atomic_store(xp, __float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dbg) dbg[si * 4 + 2] = wall_clock64();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = tid + u * DEC_THREADS;
+                if (i < S4 * W) {
+                    const int f = (i % S4) * 4, r = i / S4, n = n0 + f;
+                    const float y0 = gather(Sn, f, r) + S.bias[n] + __uint_as_float(xr[u].x), y1 = gather(Sn, f + 1, r) + S.bias[n + 1] + __uint_as_float(xr[u].y);
+                    const float y2 = gather(Sn, f + 2, r) + S.bias[n + 2] + __uint_as_float(xr[u].z), y3 = gather(Sn, f + 3, r) + S.bias[n + 3] + __uint_as_float(xr[u].w);
+                    st16(rX, ((unsigned)r * d + n) * 4, make_uint4(__float_as_uint(y0), __float_as_uint(y1), __float_as_uint(y2), __float_as_uint(y3)));
+                }
             }
         } break;
         case MTN_DEC_CROSS: case MTN_DEC_SELF_ATT: {
             if (wg >= W * A.h) break;
             const int j = wg / A.h, hd = wg % A.h;
-            if (S.kind == MTN_DEC_CROSS) {
+            const bool self = S.kind == MTN_DEC_SELF_ATT;
+            const int m = self ? pos + 1 : S.m;
+            const dec_rsrc_t rC = dec_rsrc(S.cache, self ? (unsigned)W * A.L * 2 * d * 2 : 0u);
+            // this thread's first key row (one key per thread, 16-byte pieces): requested before q is ready.  Cross: hoisted K|V rows
+            // [j * m + t][2d] (read-only, plain loads); self: cache row of position t of THIS hypothesis' prefix = slot anc[j][t]
+            // (agent-scope loads: the newest row was written by other workgroups one stage ago)
+            uint4 kr[16];                                        // dk <= 128: 16 pieces of 8 bf16
+            const int npc = dk / 8;
+            {
+                const int t = tid;
+                if (t < m) {
+                    if (self) {
+                        const unsigned off = (((unsigned)A.anc[j * A.L + t] * A.L + t) * (2 * d) + hd * dk) * 2;
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = ld16(rC, off + c * 16);
+                    } else {
+                        const uint4* krow = (const uint4*)((const bf16_t*)S.kv + ((size_t)j * S.m + t) * (2 * d) + hd * dk);
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = krow[c];
+                    }
+                }
+            }
+            if (!self) {
                 // q_h = LayerNorm(x_j) W_q,h^T + b_q,h  (the head's dk rows of W_q: prefetched), rounded to bf16 as the training kernels store q
-                if (wave == 0) dec_ln_row_any(X + (size_t)j * d / 2, S.ln_a, S.ln_b, S.ln_eps, d, lane, (bf16_t*)act);
+                if (wave == 0) dec_ln_row(rX, (unsigned)j * d * 4, S.ln_a, S.ln_b, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)((bf16_t*)act + c) = dec_pack4(y); });
                 __syncthreads();
+                if (dbg) dbg[si * 4 + 1] = wall_clock64();
                 f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, 1, lane);
                 spill(acc);
                 if (tid < dk) qs[tid] = bf16_to_f32(f32_to_bf16(gather(dk, tid, 0) + S.bias[n0 + tid]));
             } else {
                 if (tid < dk / 4) {
-                    const u64 q4 = ld_ag(Qb + ((size_t)j * d + hd * dk) / 4 + tid);
+                    const u64 q4 = ld8(rQ, ((unsigned)j * d + hd * dk + tid * 4) * 2);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) qs[4 * tid + k] = bf16_to_f32((bf16_t)(q4 >> (16 * k)));
                 }
+                if (dbg) dbg[si * 4 + 1] = wall_clock64();
             }
             __syncthreads();
-            // scores: one key per thread.  Cross: hoisted K|V rows [j * m + t][2d] (read-only, plain loads); self: cache row of position t of
-            // THIS hypothesis' prefix = slot anc[j][t] (agent-scope loads: the newest row was written by other workgroups one stage ago)
-            const int m = S.kind == MTN_DEC_CROSS ? S.m : pos + 1;
-            const bool self = S.kind == MTN_DEC_SELF_ATT;
             float mx = -3.0e38f;
             for (int t = tid; t < m; t += DEC_THREADS) {
-                const bf16_t* krow = self ? (const bf16_t*)S.cache + ((size_t)A.anc[j * A.L + t] * A.L + t) * (2 * d) + hd * dk
-                                          : (const bf16_t*)S.kv + ((size_t)j * S.m + t) * (2 * d) + hd * dk;
-                float s = 0.f;
-                for (int c = 0; c < dk; c += 4) {
-                    const u64 k4 = self ? ld_ag((const u64*)(krow + c)) : *(const u64*)(krow + c);
+                if (t >= DEC_THREADS) {                              // keys beyond the first 256: loaded here
+                    if (self) {
+                        const unsigned off = (((unsigned)A.anc[j * A.L + t] * A.L + t) * (2 * d) + hd * dk) * 2;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) s += qs[c + k] * bf16_to_f32((bf16_t)(k4 >> (16 * k)));
+                        for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = ld16(rC, off + c * 16);
+                    } else {
+                        const uint4* krow = (const uint4*)((const bf16_t*)S.kv + ((size_t)j * S.m + t) * (2 * d) + hd * dk);
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = krow[c];
+                    }
+                }
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (c < npc) {
+                        const unsigned w4[4] = {kr[c].x, kr[c].y, kr[c].z, kr[c].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            s += qs[c * 8 + 2 * e] * __uint_as_float(w4[e] << 16) + qs[c * 8 + 2 * e + 1] * __uint_as_float(w4[e] & 0xffff0000u);
+                    }
                 }
                 s *= scale;
                 if (!self && S.mask && S.mask[(size_t)j * S.mask_stride + t] == 0) s = -1.0e9f;      // masked_fill(mask == 0, -1e9), mtn.py:226
@@ -318,34 +379,47 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
             // o[c] = sum_t P[t] V[t][c], P rounded to bf16 (the training kernels feed P to the MFMA in bf16): thread = (four columns, key part)
             const int c4 = tid % (dk / 4), qt = tid / (dk / 4), nq = DEC_THREADS / (dk / 4);
             float o[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int t = qt; t < m; t += nq) {
-                const bf16_t* vrow = self ? (const bf16_t*)S.cache + ((size_t)A.anc[j * A.L + t] * A.L + t) * (2 * d) + d + hd * dk
-                                          : (const bf16_t*)S.kv + ((size_t)j * S.m + t) * (2 * d) + d + hd * dk;
-                const u64 v4 = self ? ld_ag((const u64*)vrow + c4) : ((const u64*)vrow)[c4];
-                const float p = bf16_to_f32(f32_to_bf16(sc[t] * inv));
+            for (int t0 = qt; t0 < m; t0 += 4 * nq) {               // four keys' V quads in flight per round trip
+                u64 v4[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] += p * bf16_to_f32((bf16_t)(v4 >> (16 * k)));
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * nq;
+                    v4[u] = 0;
+                    if (t < m) {
+                        if (self) v4[u] = ld8(rC, (((unsigned)A.anc[j * A.L + t] * A.L + t) * (2 * d) + d + hd * dk + c4 * 4) * 2);
+                        else v4[u] = ((const u64*)((const bf16_t*)S.kv + ((size_t)j * S.m + t) * (2 * d) + d + hd * dk))[c4];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * nq;
+                    if (t < m) {
+                        const float p = bf16_to_f32(f32_to_bf16(sc[t] * inv));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] += p * bf16_to_f32((bf16_t)(v4[u] >> (16 * k)));
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) part[qt * dk + c4 * 4 + k] = o[k];
             __syncthreads();
+            if (dbg) dbg[si * 4 + 2] = wall_clock64();
             if (tid < dk / 4) {
-                u64 pk = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float y = 0.f;
-                    for (int q = 0; q < nq; ++q) y += part[q * dk + tid * 4 + k];
-                    pk |= (u64)f32_to_bf16(y) << (16 * k);
-                }
-                st_ag(Ob + ((size_t)j * d + hd * dk) / 4 + tid, pk);
+                float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < nq; ++q) { y.x += part[q * dk + tid * 4]; y.y += part[q * dk + tid * 4 + 1]; y.z += part[q * dk + tid * 4 + 2]; y.w += part[q * dk + tid * 4 + 3]; }
+                st8(rO, ((unsigned)j * d + hd * dk + tid * 4) * 2, dec_pack4(y));
             }
         } break;
         case MTN_DEC_FINAL: {          // the decoder's final LayerNorm (mtn.py:161) -> the generator's bf16 operand (read by the NEXT kernel: plain stores)
-            if (wg < W && wave == 0) dec_ln_row_any(X + (size_t)wg * d / 2, S.ln_a, S.ln_b, S.ln_eps, d, lane, (bf16_t*)A.out_lp + (size_t)wg * d);
+            if (wg < W && wave == 0) {
+                bf16_t* row = (bf16_t*)A.out_lp + (size_t)wg * d;
+                dec_ln_row(rX, (unsigned)wg * d * 4, S.ln_a, S.ln_b, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
+            }
         } break;
         default: break;
         }
-        if (si + 1 < n_stages) { S = KA.stages[si + 1]; __syncthreads(); prefetch(S); }
+        if (dbg) dbg[si * 4 + 3] = wall_clock64();
+        if (si + 1 < n_stages) { S = KA.stages[si + 1]; prefetch(S); }
     }
 }
 
@@ -357,6 +431,7 @@ extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage*
     MTN_CHECK_ARG(a->n_stages >= 1 && a->L >= 1 && a->L <= 1024, "bad stage count / maximum length");
     MTN_CHECK_ARG(grid >= a->W * a->h && grid <= 256, "grid: at least one workgroup per (hypothesis, head), at most one per CU");
     MTN_CHECK_ARG(a->x && a->q && a->o && a->hid && a->out_lp && a->tokens && a->lut && a->pe && a->pos && a->anc && a->sync, "null buffer");
+    MTN_CHECK_ARG(a->d_ff >= a->d && a->d_ff <= 4096 && a->d_ff % 32 == 0, "d_ff: a multiple of 32, at most 4096");
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {

@@ -946,52 +946,13 @@ static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn
         ++n;
     };
     FhPlan plan[MTN_SUBLAYER_MAX_GROUP];
-    int uniform_wgs = 0;
     for (int i = 0; i < n_mha; ++i) {
         plan[i] = fh_plan_mha(mha[i], budget, np);
         if (plan[i].blk == 0) return false;
-        uniform_wgs += ((mha[i].B + plan[i].blk - 1) / plan[i].blk) * (FH_D / FH_DK);
     }
-    // Two unit sizes (round 4, batch 64; opt-in: MTN_FH_TWO_SIZE=1 — measured, it LOSES).  When the attention members need more than
-    // one round of the chip even at their largest units (3 self-attentions of 64 samples: 384 workgroups of 4 samples = a full
-    // round and a half-empty one, 42 us where one round takes 19), every member is cut in two parts: units of the largest size for
-    // ONE full round (the member's share of the 32 workgroups per head), the remaining samples in as many smaller units for a second
-    // full round — e.g. 11 x 4 + 10 x 2 samples.  The parts are members of their own (same weights, pointers at the part's first
-    // row, b_off for the dropout indices); all first parts come first in the grid.  Result (profiles/r04_l_two_unit_sizes_batch64.txt):
-    // 480 workgroups take 43.5 us where 384 took 42.4 — a unit's time is mostly FIXED (weight slice + dependent chain: 12.8 us for
-    // 20 rows, 19.3 for 80), so two full rounds of smaller units cost what a full and a half-empty round of large ones do.
-    bool two_size = false;
-    int slots[MTN_SUBLAYER_MAX_GROUP], n1[MTN_SUBLAYER_MAX_GROUP];
-    FhPlan lo[MTN_SUBLAYER_MAX_GROUP];
-    static const bool two_ok = [] { const char* e = getenv("MTN_FH_TWO_SIZE"); return e && e[0] == '1'; }();
-    if (two_ok && n_ffn == 0 && uniform_wgs > 256 && 2 * n_mha <= FH_MAX_MEMBERS) {
-        // the 32 per-head workgroups of a round, dealt in proportion to the members' rows
-        double rows_all = 0;
-        for (int i = 0; i < n_mha; ++i) rows_all += (double)mha[i].B * mha[i].a;
-        int given = 0;
-        for (int i = 0; i < n_mha; ++i) { slots[i] = (int)(32.0 * mha[i].B * mha[i].a / rows_all); given += slots[i]; }
-        for (int i = 0; given < 32; i = (i + 1) % n_mha) { ++slots[i]; ++given; }
-        two_size = true;
-        for (int i = 0; i < n_mha && two_size; ++i) {
-            const int B = mha[i].B, hi = plan[i].blk;
-            n1[i] = slots[i] < (B + hi - 1) / hi ? slots[i] : (B + hi - 1) / hi;
-            const int left = B - n1[i] * hi;
-            lo[i] = FhPlan{0, 0, 0, 0};
-            if (left > 0) {
-                const int blk_lo = (left + slots[i] - 1) / slots[i];
-                if (blk_lo >= hi) two_size = false;           // a third round would be needed: keep the uniform units
-                else lo[i] = fh_plan_mha_at(mha[i], np, blk_lo);
-                if (two_size && lo[i].blk == 0) two_size = false;
-            }
-        }
-    }
-    if (two_size) {
-        for (int i = 0; i < n_mha; ++i) emit_mha(mha[i], plan[i], 0, n1[i] * plan[i].blk < mha[i].B ? n1[i] * plan[i].blk : mha[i].B);
-        for (int i = 0; i < n_mha; ++i)
-            if (lo[i].blk) emit_mha(mha[i], lo[i], n1[i] * plan[i].blk, mha[i].B - n1[i] * plan[i].blk);
-    } else {
-        for (int i = 0; i < n_mha; ++i) emit_mha(mha[i], plan[i], 0, mha[i].B);
-    }
+    // (Two unit sizes for launches that need a round and a half of the chip — batch 64 — were measured in round 4 and LOSE: a unit's time is
+    // mostly fixed, profiles/r04_l_two_unit_sizes_batch64.txt.  Every member keeps its uniform units.)
+    for (int i = 0; i < n_mha; ++i) emit_mha(mha[i], plan[i], 0, mha[i].B);
     for (int i = 0; i < n_ffn; ++i) {
         const mtn_ffn_args& a = ffn[i];
         FhMember& M = G.m[n];

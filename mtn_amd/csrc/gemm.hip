@@ -634,93 +634,6 @@ template <typename T> struct StageT128 {      // one 128-row x 128-byte contract
     }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_tt128_kernel(const GemmGroup grp, const AdamGroup adam) {
-    constexpr int BK = 128 / (int)sizeof(T);
-    constexpr int BT = 128;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * LDSROW];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + BT * LDSROW;
-    const int tid = threadIdx.x;
-    int g = 0;
-    while (g + 1 < grp.count && (int)blockIdx.x >= grp.tile_start[g + 1]) ++g;
-    const mtn_gemm_problem& P = grp.p[g];
-    const int M = P.M, N = P.N, K = P.K;
-    const int tiles_n = (N + BT - 1) / BT;
-    const int t = (int)blockIdx.x - grp.tile_start[g];
-    const int tiles_m = (M + BT - 1) / BT;
-    int tm_, tn_;
-    xcd_tile(grp, g, t, tiles_m * tiles_n, tiles_m, tiles_n, M >= N, tm_, tn_);
-    const int row0 = tm_ * BT, col0 = tn_ * BT;
-    const T* __restrict__ A = (const T*)P.A;
-    const T* __restrict__ B = (const T*)P.B;
-    const bool do_rowsum = (P.rowsum_out != nullptr) && (col0 == 0);
-    const int lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1, lg = lane >> 4, l15 = lane & 15;
-
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float rsum = 0.f;
-    StageT128<T> stA, stB;
-    stA.load(A, P.lda, M, K, row0, 0, tid);
-    stB.load(B, P.ldb, N, K, col0, 0, tid);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        stA.store(sA, tid);
-        stB.store(sB, tid);
-        __syncthreads();
-        if (k0 + BK < K) {
-            stA.load(A, P.lda, M, K, row0, k0 + BK, tid);
-            stB.load(B, P.ldb, N, K, col0, k0 + BK, tid);
-        }
-        if (do_rowsum && tid < BT) {
-            const uint4* rp = (const uint4*)(sA + tid * LDSROW);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                uint4 u = rp[q];
-                if constexpr (sizeof(T) == 2) {
-                    rsum += __uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u) + __uint_as_float(u.y << 16) +
-                            __uint_as_float(u.y & 0xffff0000u) + __uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u) +
-                            __uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u);
-                } else {
-                    rsum += __uint_as_float(u.x) + __uint_as_float(u.y) + __uint_as_float(u.z) + __uint_as_float(u.w);
-                }
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = *(const uint4*)(sA + (wr * 64 + i * 16 + l15) * LDSROW + ks * 64 + lg * 16);
-                b[i] = *(const uint4*)(sB + (wc * 64 + i * 16 + l15) * LDSROW + ks * 64 + lg * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], b[j], a[i]);     // transposed accumulator (vector epilogue)
-        }
-        __syncthreads();
-    }
-    if (do_rowsum && tid < BT && row0 + tid < M) P.rowsum_out[row0 + tid] = rsum;
-    const DropState ds = drop_init(P.drop);
-    const bool vec_ok = ((N | P.ldc | (P.residual ? P.ldr : 0)) & 3) == 0;
-    AdamCoef coef;
-    if (adam.any) coef = adam_coef(adam);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + wr * 64 + i * 16 + l15;
-        if (row >= M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = col0 + wc * 64 + j * 16 + lg * 4;
-            if (col >= N) continue;
-            epilogue4<T, true>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], &adam.a[g], &coef);
-        }
-    }
-}
 
 // ====================================================================================================================
 // Fast path for row-major x row-major problems (forward Linears, and dX = dY (W^T)^T through the transposed weight
@@ -1920,7 +1833,7 @@ static int g_variant = 0, g_variant_tiles = 0;     // set by launch_gemm: which 
 enum { V_REG_NN = 0, V_REG_NT, V_REG_TN, V_REG_TT, V_DMA64, V_DMA3264, V_DMA32, V_TT_DMA, V_TT128, V_TT_DMA128, V_DMA128, V_DMA64H, V_DMA32H, V_TT_TABLE, V_K512, V_DMA128X, V_COUNT };
 static const char* const g_variant_name[V_COUNT] = {
     "gemm_kernel<N,N> 64x64 reg-staged", "gemm_kernel<N,T>", "gemm_kernel<T,N>", "gemm_kernel<T,T> 64x64 reg-staged",
-    "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "gemm_tt128_kernel",
+    "gemm_dma_kernel<64,64>", "gemm_dma_kernel<32,64>", "gemm_dma_kernel<32,32>", "gemm_tt_dma_kernel", "(gemm_tt128_kernel: removed in round 5)",
     "gemm_tt_dma128_kernel", "gemm_dma128_kernel", "gemm_dma_kernel<64,64> half stages", "gemm_dma_kernel<32,32> half stages", "gemm_tt_dma128_table_kernel", "gemm_k512_kernel", "gemm_dma128x_kernel (128x128, four stages)"};
 
 template <typename T, int BM, int BN, int ROWB, bool BTR = false, int NBUF = 2, int NW = 4, bool LNE = false>
@@ -2098,15 +2011,9 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
             const char* sc = MTN_ENV("MTN_GEMM_C64_SCALE");
             c64 *= sc ? atof(sc) : 0.8;
         }
-        // long contractions in ONE round of workgroups on the ring of four half-size stages: opt-in (MTN_GEMM_DEEP=1) — measured
-        // -0.8 % on the cfg2 step, +-0 at batch 64 (profiles/r03_x_deep_ring_ab.txt): twice the barriers for stages half the size
-        // cost more than the third stage in flight brings at these sizes
-        int kmax = 0;
-        for (int i = 0; i < grp.count; ++i) kmax = grp.p[i].K > kmax ? grp.p[i].K : kmax;
-        const bool deep = sizeof(T) == 2 && kmax * (int)sizeof(T) > 1024 && MTN_ENV("MTN_GEMM_DEEP") && MTN_ENV("MTN_GEMM_DEEP")[0] == '1';
+        // (a ring of four half-size stages for long contractions was measured at -0.8 % on the cfg2 step, profiles/r03_x_deep_ring_ab.txt: not kept)
         if (f == 64 || (!f && c64 <= c32)) {
             const int t = retile(g2, 64, 64, true);
-            if (deep && t <= 256 && !half_force && !lne) return launch_dma_any<T, 64, 64, 256, 4>(g2, t, bt, s);
             if (half_force || (half_ok && t > 256)) {
                 if (lne || (MTN_ENV("MTN_GEMM_NW4") == nullptr && MTN_ENV("MTN_GEMM_NW4H") == nullptr)) return launch_dma_any<T, 64, 64, 256, 2, 8>(g2, t, bt, s, lne);
                 return launch_dma_any<T, 64, 64, 256>(g2, t, bt, s);
@@ -2123,16 +2030,11 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         }
         if (f == 3264) return launch_dma_any<T, 32, 64, 512>(g2, retile(g2, 32, 64, true), bt, s);
         const int t = retile(g2, 32, 32, true);
-        if (deep && t <= 512 && !half_force && !lne) return launch_dma_any<T, 32, 32, 256, 4>(g2, t, bt, s);
         if (half_force || (half_ok && t > 1024)) return launch_dma_any<T, 32, 32, 256>(g2, t, bt, s, lne);   // (measured in the step: 640 tiles 10.7 vs 10.1 us, 1280 tiles 12.7 vs 13.8 us)
         return launch_dma_any<T, 32, 32, 512>(g2, t, bt, s, lne);
     } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp, NoAdam{});
     else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp, NoAdam{});
     else if (at && bt) {
-        // measured on the train step: 2 x 128x128 workgroups per CU hide latency worse than 8 x 64x64 ones (7.51 vs 7.25 ms per
-        // step) although they pull half the bytes — kept behind MTN_GEMM_TT128=1 for larger batches.
-        bool big = MTN_ENV("MTN_GEMM_TT128") != nullptr;
-        for (int i = 0; i < grp.count; ++i) big = big && grp.p[i].M >= 128 && grp.p[i].N >= 128;
         bool ttd = (sizeof(T) == 2) && MTN_ENV("MTN_GEMM_TT_REG") == nullptr;      // LDS-DMA + transposing LDS reads (bf16)
         for (int i = 0; i < grp.count; ++i)
             ttd = ttd && grp.p[i].M % 8 == 0 && grp.p[i].N % 8 == 0 && (long)grp.p[i].K * grp.p[i].lda * 2 < (1L << 31) &&
@@ -2169,11 +2071,6 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         } else if (ttd) {
             g_variant = V_TT_DMA;
             if constexpr (sizeof(T) == 2) hipLaunchKernelGGL(gemm_tt_dma_kernel, grid, block, TTD_LDS, s, grp, adam);
-        } else if (big) {
-            GemmGroup g2 = grp;
-            const int tiles = retile(g2, 128, 128);
-            g_variant = V_TT128; g_variant_tiles = tiles;
-            hipLaunchKernelGGL((gemm_tt128_kernel<T>), dim3(tiles), block, 0, s, g2, adam);
         } else hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, s, grp, adam);
     }
     else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, s, grp, NoAdam{});

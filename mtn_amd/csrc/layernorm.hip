@@ -564,34 +564,15 @@ extern "C" int mtn_layernorm_bwd(int rows, int d, float eps, const float* x, con
 // what lets LayerNorm backward ride in the epilogue of g = dq W (mtn_ln_epilogue, include/mtn_hip.h).  Weights change every step,
 // so this runs once per step: one launch for the whole model (~88 MB of bf16 weights at BASELINE configs[1]), a wave per row,
 // 64 rows per 512-thread workgroup, the row as ONE 16-byte load per lane per 512 columns.
-// Step head (round 5, mtn_step_head): the other things a train step does before its first path kernel ride in the same launch as
-// extra workgroups behind the fold blocks — the Noam / bias-correction tick (one thread), the dropout seed advance (one thread), and
-// the zero fill of the glue gradients (embedding tables: the scatter kernels accumulate) — instead of three tiny launches of 5-7 us.
-struct StepHeadExtras {
-    int fold_blocks;                       // workgroups [0, fold_blocks) fold; [fold_blocks] = tick + seed; the rest zero
-    float* state; float factor, model_size, warmup, beta1, beta2;
-    unsigned long long* seed; unsigned long long seed_inc;
-    float* zero; long zero_n;              // floats, a multiple of 4
-};
 template <int NJ>      // 512-column chunks of a row a lane may hold (1: d <= 512)
-__global__ __launch_bounds__(512) void ln_fold_kernel(const mtn_ln_fold_desc* __restrict__ descs, const int* __restrict__ block_desc, const int d,
-                                                      const StepHeadExtras X) {
-    if ((int)blockIdx.x >= X.fold_blocks) {
-        const int b = (int)blockIdx.x - X.fold_blocks;
-        if (b == 0) {
-            if (threadIdx.x == 0 && X.state) noam_tick_body(X.state, X.factor, X.model_size, X.warmup, X.beta1, X.beta2);
-            if (threadIdx.x == 64 && X.seed) *X.seed += X.seed_inc;
-            return;
-        }
-        const long n4 = X.zero_n >> 2;
-        const long per = (long)(gridDim.x - X.fold_blocks - 1) * 512;
-        for (long i = (long)(b - 1) * 512 + threadIdx.x; i < n4; i += per) ((float4*)X.zero)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
+__global__ __launch_bounds__(512) void ln_fold_kernel(const mtn_ln_fold_desc* __restrict__ descs, const int* __restrict__ block_desc, const int d) {
     // 64 rows per 512-thread workgroup (8 waves x 8 rows, all eight row loads of a wave in flight at once)
-    const mtn_ln_fold_desc D = descs[block_desc[blockIdx.x]];
+    // (round 5: the step's other head launches — zero fill of the glue gradients, schedule tick, dropout seed — were merged into this
+    //  launch as extra workgroups and measured SLOWER, +10-13 us per step in either dispatch order: profiles/r05_d_tail_head_ab.txt)
+    const int fb = (int)blockIdx.x;
+    const mtn_ln_fold_desc D = descs[block_desc[fb]];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = ((int)blockIdx.x - D.block_start) * 64 + wave * 8;
+    const int k0 = (fb - D.block_start) * 64 + wave * 8;
     if (k0 >= D.K) return;
     const bf16_t* w = (const bf16_t*)D.w;
     uint4 wv[8][NJ];
@@ -635,33 +616,11 @@ __global__ __launch_bounds__(512) void ln_fold_kernel(const mtn_ln_fold_desc* __
     }
 }
 extern "C" int mtn_ln_fold(int dtype, const mtn_ln_fold_desc* descs_device, const int* block_desc, int total_blocks, int d, void* stream) {
+    MTN_CHECK_ARG(dtype == MTN_BF16, "fold vectors exist for the bf16 path only");
     MTN_CHECK_ARG(descs_device && block_desc && total_blocks > 0, "null descriptor table");
-    return mtn_step_head(dtype, descs_device, block_desc, total_blocks, d, nullptr, 0.f, 1, 1, 0.f, 0.f, nullptr, 0, nullptr, 0, stream);
-}
-
-extern "C" int mtn_step_head(int dtype, const mtn_ln_fold_desc* descs_device, const int* block_desc, int total_blocks, int d,
-                             float* state, float factor, int model_size, int warmup, float beta1, float beta2,
-                             long long* seed, long long seed_inc, float* zero, long zero_n, void* stream) {
-    MTN_CHECK_ARG(total_blocks >= 0 && (total_blocks == 0 || (descs_device && block_desc)), "null descriptor table");
-    MTN_CHECK_ARG(total_blocks == 0 || dtype == MTN_BF16, "fold vectors exist for the bf16 path only");
-    MTN_CHECK_ARG(total_blocks == 0 || (d > 0 && d % 8 == 0 && d <= 2048), "d must be a multiple of 8, at most 2048");
-    MTN_CHECK_ARG(!state || (model_size > 0 && warmup > 0), "bad schedule arguments");
-    MTN_CHECK_ARG(zero_n >= 0 && zero_n % 4 == 0 && (zero_n == 0 || (zero && (((uintptr_t)zero) & 15) == 0)), "zero range: a 16-byte aligned multiple of 4 floats");
-    StepHeadExtras X;
-    memset(&X, 0, sizeof(X));
-    X.fold_blocks = total_blocks;
-    X.state = state; X.factor = factor; X.model_size = (float)model_size; X.warmup = (float)warmup; X.beta1 = beta1; X.beta2 = beta2;
-    X.seed = (unsigned long long*)seed; X.seed_inc = (unsigned long long)seed_inc;
-    X.zero = zero; X.zero_n = zero ? zero_n : 0;
-    int extra = (state || seed) ? 1 : 0;
-    if (X.zero_n > 0) {
-        long zb = (X.zero_n / 4 + 512 * 4 - 1) / (512 * 4);          // four float4 per thread
-        if (zb > 1024) zb = 1024;
-        extra = 1 + (int)zb;
-    }
-    if (total_blocks + extra == 0) return MTN_OK;
-    if (d <= 512) hipLaunchKernelGGL(ln_fold_kernel<1>, dim3(total_blocks + extra), dim3(512), 0, (hipStream_t)stream, descs_device, block_desc, d, X);
-    else hipLaunchKernelGGL(ln_fold_kernel<4>, dim3(total_blocks + extra), dim3(512), 0, (hipStream_t)stream, descs_device, block_desc, d, X);
+    MTN_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 2048, "d must be a multiple of 8, at most 2048");
+    if (d <= 512) hipLaunchKernelGGL(ln_fold_kernel<1>, dim3(total_blocks), dim3(512), 0, (hipStream_t)stream, descs_device, block_desc, d);
+    else hipLaunchKernelGGL(ln_fold_kernel<4>, dim3(total_blocks), dim3(512), 0, (hipStream_t)stream, descs_device, block_desc, d);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }

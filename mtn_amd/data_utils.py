@@ -243,13 +243,11 @@ class NoamOpt:
         self.optimizer.tick(self.factor, self.model_size, self.warmup)
         self.optimizer.step()
 
-    def begin_fused_step(self, write_grad: bool = False, tick: bool = True):
+    def begin_fused_step(self, write_grad: bool = False):
         """step() split around the backward pass (FusedAdam.fuse_into_backward): advance the schedule and arm the epilogue
-        before it, finish_fused_step() after it.  Same arithmetic as step(), element for element.  ``tick=False``: the caller
-        has advanced the schedule itself (model.step_head: the tick rides in the step's first launch)."""
+        before it, finish_fused_step() after it.  Same arithmetic as step(), element for element."""
         self._step += 1
-        if tick:
-            self.optimizer.tick(self.factor, self.model_size, self.warmup)
+        self.optimizer.tick(self.factor, self.model_size, self.warmup)
         self.optimizer.fuse_into_backward(write_grad)
 
     def finish_fused_step(self):

@@ -302,16 +302,20 @@ class MegaDecodeSession(DecodeSession):
         nbytes = self._off_anc + 4 * W * Lm
         self._host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
         self._devblk = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
-        self._h_tok = self._host[:8 * W].view(torch.int64)
-        self._h_pos = self._host[self._off_pos:self._off_pos + 8].view(torch.int32)
-        self._h_anc = self._host[self._off_anc:].view(torch.int32).view(W, Lm)
-        self._h_anc.copy_(torch.arange(W, dtype=torch.int32).view(W, 1).expand(W, Lm))
+        import numpy as np
+        hb = self._host.numpy()                       # numpy views of the pinned block: the per-step bookkeeping below is plain numpy slicing
+        self._h_tok = hb[:8 * W].view(np.int64)
+        self._h_pos = hb[self._off_pos:self._off_pos + 8].view(np.int32)
+        self._h_anc = hb[self._off_anc:].view(np.int32).reshape(W, Lm)
+        self._h_anc[:] = np.arange(W, dtype=np.int32)[:, None]
         self._prev = None
         self._grid = max(W * h, -(-max(dff, 3 * d) // 64))
         self._build_stages(L, d, h, dff)
         emb, pe = model.tgt_embed[0], model.tgt_embed[1]
         a = L.DecodeArgs()
-        a.W, a.d, a.h, a.L, a.n_stages = W, d, h, Lm, self._n_stages
+        a.W, a.d, a.h, a.L, a.n_stages, a.d_ff = W, d, h, Lm, self._n_stages, dff
+        self._dbg = torch.zeros(4 * self._n_stages, device=dev, dtype=torch.int64) if os.environ.get("MTN_DECODE_TIMELINE") == "1" else None
+        a.dbg = self._dbg.data_ptr() if self._dbg is not None else None
         a.x, a.q, a.o, a.hid, a.out_lp = self._x.data_ptr(), self._q.data_ptr(), self._o.data_ptr(), self._hid.data_ptr(), self._out_lp.data_ptr()
         a.tokens = self._devblk.data_ptr()
         a.lut, a.emb_scale, a.pe = emb.lut.weight.data_ptr(), float(d) ** 0.5, pe.pe.data_ptr()
@@ -391,8 +395,8 @@ class MegaDecodeSession(DecodeSession):
         W = self.width
         if max(len(p) for p in prefix_lists) > W or l > self.max_len:
             raise ValueError("more hypotheses / longer prefix than the session was built for")
-        anc_old = self._h_anc.clone() if l > 1 else None
-        self._h_tok.fill_(self.pad)
+        anc_old = self._h_anc.copy() if l > 1 else None
+        self._h_tok[:] = self.pad
         for d_, prefixes in enumerate(prefix_lists):
             for i, p in enumerate(prefixes):
                 j = d_ * W + i

@@ -142,9 +142,9 @@ class DecodeStage(C.Structure):
 
 
 class DecodeArgs(C.Structure):
-    _fields_ = [("W", C.c_int), ("d", C.c_int), ("h", C.c_int), ("L", C.c_int), ("n_stages", C.c_int), ("x", C.c_void_p), ("q", C.c_void_p),
+    _fields_ = [("W", C.c_int), ("d", C.c_int), ("h", C.c_int), ("L", C.c_int), ("n_stages", C.c_int), ("d_ff", C.c_int), ("x", C.c_void_p), ("q", C.c_void_p),
                 ("o", C.c_void_p), ("hid", C.c_void_p), ("out_lp", C.c_void_p), ("tokens", C.c_void_p), ("lut", C.c_void_p),
-                ("emb_scale", C.c_float), ("pe", C.c_void_p), ("pos", C.c_void_p), ("anc", C.c_void_p), ("sync", C.c_void_p)]
+                ("emb_scale", C.c_float), ("pe", C.c_void_p), ("pos", C.c_void_p), ("anc", C.c_void_p), ("sync", C.c_void_p), ("dbg", C.c_void_p)]
 
 
 DEC_EMBED, DEC_SELF_QKV, DEC_SELF_ATT, DEC_OUT, DEC_CROSS, DEC_FFN1, DEC_FFN2, DEC_FINAL = range(8)
@@ -208,8 +208,6 @@ SYMBOLS = {
     "mtn_ln_epilogue_groups": (C.c_long, []),
     "mtn_ln_linear_members": (C.c_long, []),
     "mtn_ln_fold": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P]),
-    "mtn_step_head": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float,
-                                _P, C.c_longlong, _P, C.c_long, _P]),
     "mtn_sublayer_group_fwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_sublayer_group_bwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_layernorm_bwd_partial_floats": (C.c_long, [C.c_int, C.c_int]),

@@ -390,12 +390,6 @@ class DecoderLayer(nn.Module):
             return self._forward_lockstep(x, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts,
                                           vid_mask, ae_fts, ae_features)
         sl = self.sublayer
-        streams = owner._streams if (owner is not None and x.is_cuda) else None
-        entry = None
-        if streams and getattr(self, "_layer_index", 0) == 0:
-            # first layer: the auto-encoder seeds and the video memories were produced on the current stream
-            entry = torch.cuda.Event()
-            entry.record(torch.cuda.current_stream())
         x = sl[0](x, self.self_attn, None, tgt_mask, True)
         x = sl[1](x, self.his_attn, his_memory, his_mask)
         if ae_features in ("caption", "summary"):
@@ -412,34 +406,20 @@ class DecoderLayer(nn.Module):
             ae_mask = q_mask
         else:
             raise ValueError("auto_encoder_ft must be 'query', 'caption' or 'summary' (reference: mtn.py:187-202)")
-        # The query-aware auto-encoder chains (self-attn -> attend-to-video -> FFN, one per modality) depend only on the
-        # previous layer's auto-encoder outputs, not on x: each runs on its own HIP stream, concurrently with the four
-        # text attentions of x above; x joins a chain right before it attends to that chain's output.  (Backward runs
-        # each node on its forward stream, so the concurrency carries over; graph capture records the fork/join.)
-        main = torch.cuda.current_stream() if streams else None
+        # The query-aware auto-encoder chains (self-attn -> attend-to-video -> FFN, one per modality) depend only on the previous
+        # layer's auto-encoder outputs, not on x: the lockstep schedule above runs them in the same launches as x's text attentions
+        # (per-chain HIP streams were the round-1 form: hipGraph serialised them); this is the one-sublayer-at-a-time form.
         nF = len(vid_fts)
         aes = []
         for i, vid_ft in enumerate(vid_fts):
             ae = ae_fts[i] if isinstance(ae_fts, (list, tuple)) else ae_fts
             k = 4 + 4 * i
-            if streams:
-                side = streams[i]
-                if entry is not None:
-                    side.wait_event(entry)
-                with torch.cuda.stream(side):
-                    ae = sl[k](ae, self.auto_encoder_self_attn[i], None, ae_mask, True)
-                    ae = sl[k + 1](ae, self.auto_encoder_vid_attn[i], vid_ft, vid_mask[i])
-                    ae = sl[k + 2](ae, self.auto_encoder_feed_forward[i])
-                ae.record_stream(main)
-            else:
-                ae = sl[k](ae, self.auto_encoder_self_attn[i], None, ae_mask, True)
-                ae = sl[k + 1](ae, self.auto_encoder_vid_attn[i], vid_ft, vid_mask[i])
-                ae = sl[k + 2](ae, self.auto_encoder_feed_forward[i])
+            ae = sl[k](ae, self.auto_encoder_self_attn[i], None, ae_mask, True)
+            ae = sl[k + 1](ae, self.auto_encoder_vid_attn[i], vid_ft, vid_mask[i])
+            ae = sl[k + 2](ae, self.auto_encoder_feed_forward[i])
             aes.append(ae)
         out_ae = []
         for i in range(nF):
-            if streams:
-                main.wait_stream(streams[i])
             x = sl[4 + 4 * i + 3](x, self.auto_encoder_attn[i], aes[i], ae_mask)
             out_ae.append(aes[i])
         k = 4 + 4 * nF
@@ -575,8 +555,6 @@ class EncoderDecoder(nn.Module):
         self._layer_slices = []
         self._seed = None
         self._queue = ops.ParamGradQueue()     # dW/db/LN-parameter work batched at the end of backward
-        self._streams = None                   # side streams for the two auto-encoder chains (sequential schedule only)
-        self.multi_stream = False
         self.lockstep = True                   # independent sublayers of a layer share launches (ops.SublayerGroupFn)
         self.fused_embed = True                # Embeddings + PositionalEncoding + Encoder LayerNorm in one grouped launch
         self.hoist_kv = os.environ.get("MTN_NO_KV_HOIST") != "1"   # K|V of the constant memories projected ahead of the layer loop
@@ -763,13 +741,6 @@ class EncoderDecoder(nn.Module):
         self._fusable_optional = frozenset(optional)
         self._tdescs_all = list(tdescs)
         self._rest_cache = {}
-        if dev.type == "cuda" and self.multi_stream:
-            n_side = max(len(l.auto_encoder_vid_attn) for l in self.decoder.layers)
-            self._streams = [torch.cuda.Stream(device=dev) for _ in range(n_side)]
-            self._queue.side_streams = self._streams
-        else:
-            self._streams = None
-            self._queue.side_streams = []
         for n, layer in enumerate(self.decoder.layers):
             object.__setattr__(layer, "_owner", self)
             object.__setattr__(layer, "_next_layer", self.decoder.layers[n + 1] if n + 1 < len(self.decoder.layers) else None)
@@ -836,27 +807,6 @@ class EncoderDecoder(nn.Module):
         table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
         self._ln_fold_buf = buf
         self._ln_fold_table = (table, torch.tensor(block_desc, dtype=torch.int32).to(dev), blocks, d)
-
-    def step_head(self, opt=None, zero_grads: bool = True):
-        """Everything a train step does before its first path kernel, in ONE launch (include/mtn_hip.h mtn_step_head): the fold
-        vectors (fold_layer_norms), the optimiser's schedule tick (``opt`` = (FusedAdam, factor, model_size, warmup) or None), the
-        dropout seed advance and the zero fill of the glue gradients.  The encode() that follows skips its own fold / seed launches."""
-        self.prepare()
-        t = self._ln_fold_table
-        st = (None, 0.0, 1, 1, 0.0, 0.0)
-        if opt is not None:
-            adam, factor, model_size, warmup = opt
-            st = (adam.state.data_ptr(), float(factor), int(model_size), int(warmup), adam.betas[0], adam.betas[1])
-        seed = self._seed if (self.training and self._seed is not None) else None
-        zn = self._glue_numel // 4 * 4 if zero_grads else 0
-        L.check(L.load().mtn_step_head(L.MTN_BF16, t[0].data_ptr() if t is not None else None, t[1].data_ptr() if t is not None else None,
-                                       t[2] if t is not None else 0, t[3] if t is not None else 8, *st,
-                                       seed.data_ptr() if seed is not None else None, 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF,
-                                       self._flat_grad.data_ptr() if zn else None, zn, L.stream_ptr()))
-        if zero_grads and zn < self._glue_numel:
-            self._flat_grad[zn:self._glue_numel].zero_()
-        self._ln_fold_stale = False
-        self._head_done = True
 
     def fold_layer_norms(self):
         """Recompute the fold vectors from the current weights (one launch, mtn_ln_fold): once per forward that will be
@@ -1021,12 +971,9 @@ class EncoderDecoder(nn.Module):
         """mtn.py:38-56 — every text stream goes through ``query_embed``; returns
         [q_mem, [vid_mem], cap_mem, his_mem, ae] with ae = list of auto-encoder seeds or None."""
         self.prepare()
-        if getattr(self, "_head_done", False):
-            self._head_done = False            # step_head() has folded and advanced the seed in its one launch
-        else:
-            self.fold_layer_norms()            # (the forward kernels use the fold vectors too: LayerNorm as a rank-1 correction)
-            if self.training:
-                self.advance_dropout_seed()
+        self.fold_layer_norms()                # (the forward kernels use the fold vectors too: LayerNorm as a rank-1 correction)
+        if self.training:
+            self.advance_dropout_seed()
         self._embed_calls = 0
         if self._fused_embed_ok(query):
             nF = len(vid)

@@ -90,7 +90,6 @@ class ParamGradQueue:
         self.gemm, self.ln, self.keep = [], [], []
         self.embed = []             # deferred embedding-table scatters (EmbedBwdDesc): every table of the step in ONE grouped launch
         self.dtype = None
-        self.side_streams = []
         self._armed = False
         self.adam = None            # set by FusedAdam.fuse_into(): the next flush applies the optimiser in the GEMM epilogues
 
@@ -239,8 +238,6 @@ class ParamGradQueue:
         if not self.gemm and not self.ln:
             self.keep = []
             return
-        for s in self.side_streams:
-            cur.wait_stream(s)
         for t in self.keep:
             t.record_stream(cur)
         adam_keep = self._attach_adam() if self.adam is not None else None      # noqa: F841 (descriptors live until the launches)

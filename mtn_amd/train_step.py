@@ -101,16 +101,11 @@ class TrainStep:
     def _fwd_bwd(self, fuse: bool = False):
         m, b = self.model, self.batch
         self._refresh_norms()
-        head = os.environ.get("MTN_STEP_HEAD", "0") == "1" and hasattr(m, "step_head") and m._flat is not None and m._flat.is_cuda
+        m.zero_glue_grads()
         if m._queue is not None and (m._queue.gemm or m._queue.ln or m._queue._armed):
             m._queue.reset()               # left over from a step that raised: never mix it into this one
-        if head:
-            # ONE launch for the step's head: glue-gradient zero fill, schedule tick (fused optimiser), dropout seed, fold vectors
-            m.step_head((self.opt.optimizer, self.opt.factor, self.opt.model_size, self.opt.warmup) if fuse else None)
-        else:
-            m.zero_glue_grads()
         if fuse:
-            self.opt.begin_fused_step(tick=not head)
+            self.opt.begin_fused_step()
         try:
             out, ae_out = m.forward(b)
             loss = self.lc.loss(out, b.trg_y, self._norms[0], ae_out, self._ae_y, self._norms[1])
@@ -118,7 +113,6 @@ class TrainStep:
         except BaseException:
             if m._queue is not None:
                 m._queue.reset()
-            m._head_done = False
             raise
         return loss.detach()
 

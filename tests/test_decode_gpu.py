@@ -234,10 +234,11 @@ def _mega_vs_launch_pass(dev, model, b, width, max_len, steps):
     return worst
 
 
-@pytest.mark.parametrize("name,width", [("cfg1_query", 5), ("cfg1_caption", 3), ("small_shared", 1)])
+@pytest.mark.parametrize("name,width", [("cfg1_query", 5), ("cfg1_caption", 3), ("wide_n1", 1), ("wide_n1", 8)])
 def test_persistent_decode_step_matches_launch_pass_small(dev, name, width):
     """csrc/decode.hip against the launch-per-sublayer pass on the golden configurations (d_model 128, 4 heads of 32: the two-tile /
-    k-split plans of the small-M Linear, caption-mode order of the cross-attentions, a shared encoder, one hypothesis = greedy):
+    k-split plans of the small-M Linear, caption-mode order of the cross-attentions; d_model 512 with one hypothesis = greedy and with
+    eight = the launch's maximum):
     log-probabilities of 7 steps of a beam-like walk within 2e-2 of the row's largest magnitude (both paths bf16)."""
     c = fx.GOLDEN_CONFIGS[name]
     model = build_model(c, torch.bfloat16, dev).eval()

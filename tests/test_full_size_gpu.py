@@ -297,30 +297,42 @@ def test_cfg2_loss_and_gradients_match_oracle_through_the_captured_step(case, wo
             om64 = OracleMTN(ocfg, sd64)
             o64, ae64 = om64.forward(ob64)
             om64.loss(ob64, o64, ae64).backward()
-            # Bars per tensor (error relative to the tensor's largest entry; cosine):
-            #   weight matrices                                   5e-2 ("<= 5e-2"), cosine 0.999
-            #   vectors (biases, LayerNorm gains / biases)        1e-1: column sums of bf16-rounded gradient rows over ALL rows of the batch
-            #                                                     (640 - 8 192 terms, heavy cancellation): measured 7.0e-2 on a LayerNorm gain at
-            #                                                     batch 32, 5.1e-2 on a query-projection bias at batch 64
-            #   Linears followed by a ReLU (w_1, feature encoder) 0.25: a unit whose pre-activation rounds across zero flips its gate and moves
-            #                                                     single entries by a visible share of the largest one (0.15 measured)
+            # Per tensor: max |got - ref| against bar x scale, where scale = max(the tensor's own largest reference entry, the MEDIAN largest
+            # entry of the tensors of its shape) — at random init the softmax of the target self-attention is nearly uniform, so the
+            # gradients of its query / key projections are 2-3 orders of magnitude below those of their siblings and are rounding noise
+            # in bf16 whatever the kernel (measured: 0.3-0.55 of their own largest entry at 6 layers, fused kernels on or off); such a
+            # tensor is held to the absolute size of its siblings' gradients, every other tensor to its own.
+            #   weight matrices                                    5e-2 ("<= 5e-2")
+            #   vectors (biases, LayerNorm gains / biases)         1e-1: column sums of bf16-rounded rows over all rows of the batch (measured 7.0e-2)
+            #   Linears followed by a ReLU (w_1, feature encoder)  0.25: gate flips of units whose pre-activation rounds across zero (measured 0.15)
+            # and the cosine (0.999 / 0.998 gated) for every tensor that is not noise-dominated (own scale >= 10 % of its family's).
+            fam = {}
+            for k, v in sd64.items():
+                if v.grad is not None:
+                    fam.setdefault(tuple(v.grad.shape), []).append(float(v.grad.abs().max()))
+            fam = {sh: sorted(vs)[len(vs) // 2] for sh, vs in fam.items()}
             worst = {"matrix": (0.0, None), "vector": (0.0, None), "gated": (0.0, None)}
-            bad = []
+            worst_own, bad = (0.0, None), []
             for k, v in sd64.items():
                 ref = v.grad
                 if ref is None or float(ref.abs().max()) < 1e-9 or k.endswith("linears.1.bias"):
                     continue
                 g64 = got[k].double().cpu()
-                e = relmax(g64, ref)
+                own, fs = float(ref.abs().max()), fam[tuple(ref.shape)]
+                e_abs = float((g64 - ref).abs().max())
+                e = e_abs / max(own, fs)
                 c64 = float((g64 * ref).sum() / (g64.norm() * ref.norm() + 1e-300))
                 cls = "gated" if (".w_1.weight" in k or (k.startswith("vid_encoder.") and k.endswith("weight"))) else ("matrix" if ref.dim() == 2 else "vector")
                 bar, cbar = {"matrix": (5e-2, 0.999), "vector": (1e-1, 0.999), "gated": (0.25, 0.998)}[cls]
                 if e > worst[cls][0]:
                     worst[cls] = (e, k)
-                if not (e < bar and c64 > cbar):
-                    bad.append((k, cls, round(e, 4), round(c64, 5)))
-            print(f"{case}: bf16 gradients vs fp64 oracle on rounded operands, worst error relative to max: " +
-                  "; ".join(f"{c} {w[0]:.2e} ({w[1]})" for c, w in worst.items()))
+                if e_abs / own > worst_own[0]:
+                    worst_own = (e_abs / own, k, own / fs)
+                if not (e < bar and (c64 > cbar or own < 0.1 * fs)):
+                    bad.append((k, cls, round(e, 4), round(c64, 5), round(own / fs, 4)))
+            print(f"{case}: bf16 gradients vs fp64 oracle on rounded operands, worst error / max(own, family median) scale: " +
+                  "; ".join(f"{c} {w[0]:.2e} ({w[1]})" for c, w in worst.items()) +
+                  f"; worst relative to the tensor's OWN largest entry {worst_own[0]:.2e} ({worst_own[1]}, whose scale is {worst_own[2]:.1e} of its family's)")
             assert not bad, (case, bad[:8])
             if B >= 32:
                 # same launches as the benchmark's step?  (the optimiser is separate here: compare everything but the table launch)

@@ -11,3 +11,6 @@ timeout 900 python -m pytest "tests/test_full_size_gpu.py::test_cfg2_loss_and_gr
 cat gpurun_out/r05_g_pytest_fs.txt
 timeout 300 python bench_decode.py 2>&1 | tail -3 > gpurun_out/r05_g_bench_decode.txt
 cat gpurun_out/r05_g_bench_decode.txt
+one() { env $1 timeout 300 python bench.py --no-cpu-baseline --no-secondary --windows 4 --steps 30 $2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1 $2', d['ms_per_step'], d['config']['median_window_ms_per_step'], d['roofline'].get('avg_us_per_launch'))"; }
+{ for i in 1 2; do one "MTN_STEP_HEAD=0" ""; one "MTN_STEP_HEAD=1" ""; done; } > gpurun_out/r05_g_head_ab.txt 2>&1
+grep -v "^+" gpurun_out/r05_g_head_ab.txt
