@@ -102,16 +102,9 @@ typedef struct {
  *   mode MTN_LN_CONSUME (g = dq W, N = d_model <= 512):  out_f32 / out_lp of the problem are ignored (may be NULL);
  *       part[row][np][2] are summed in index order; dx, dx_lp (through dx_lp_drop, as mtn_ln_bwd_desc) are written;
  *       colpart [ceil(M/8)][2N] receives the da2 | db2 partial rows of mtn_layernorm_bwd (same layout: finalize unchanged).
- *   mode MTN_LN_FWD_EMIT (forward twin, round 4: the GEMM that PRODUCES a residual stream y = x + dropout(f W^T + b), N % 16 == 0):
- *       besides its ordinary outputs the epilogue writes ya[row][c] = lowp(y[row][c] * a2[c]) — y pre-multiplied by the gains of the
- *       LayerNorm that will read it — and part[row][N/16][2] = {sum y, sum y^2} over each 16-column block of the row.  The fused
- *       forward kernel of the NEXT sublayer then takes its rows as ya by LDS-DMA (2 B/element, no register pass), finishes
- *       mean / rstd from the partials and applies LayerNorm as a rank-1 correction of its projections,
- *           W LN(y) + b = rstd (W ya - mean u) + c,      u, c = the fold vectors above,
- *       instead of every head's workgroup re-reading the fp32 rows and normalising them (mtn_mha_args.xa / .x_stats). */
+ *   (mode 3, round 4's forward twin — LayerNorm FORWARD by linearity — was measured without net gain and removed in version 112.) */
 #define MTN_LN_EMIT 1
 #define MTN_LN_CONSUME 2
-#define MTN_LN_FWD_EMIT 3
 typedef struct mtn_ln_epilogue_s {
     int mode;
     const float* fold;     /* EMIT: u[N] then c[N] */
@@ -124,7 +117,6 @@ typedef struct mtn_ln_epilogue_s {
     void* dx_lp;           /* optional, compute dtype */
     mtn_dropout dx_lp_drop;
     float* colpart;        /* optional */
-    void* ya;              /* FWD_EMIT: compute dtype [M, N]; a2 = the consuming LayerNorm's gains, part = {sum, sum of squares} per 16 columns */
 } mtn_ln_epilogue;
 
 typedef struct {
@@ -373,17 +365,7 @@ typedef struct {
        q block sees LN(x)).  With them (bf16, fused head backward) LayerNorm backward rides in the dLN-out GEMM's epilogue
        (mtn_ln_epilogue) and the group's LayerNorm-backward launch disappears; NULL = the separate launch. */
     const float* ln_fold;
-    /* forward, optional (round 4, LayerNorm forward by linearity — mtn_ln_epilogue, MTN_LN_FWD_EMIT; bf16, d = 512):
-       ya / y_stats / next_ln_a: the output-projection GEMM also writes y * next_ln_a in the compute dtype [B*a, d] and the rows'
-                  {sum, sum of squares} per 16 columns [B*a][d/16][2] for the sublayer that will read y (next_ln_a = ITS LayerNorm gains);
-       xa / x_stats: the same two buffers for THIS sublayer's input x, written by whoever produced x.  With them (and ln_fold) the
-                  fused forward kernel reads x as xa by LDS-DMA and applies LayerNorm as a rank-1 correction of its projections; xn,
-                  mean and rstd are still written for backward.  NULL = the kernel reads x and normalises it itself. */
-    const void* xa;
-    const float* x_stats;
-    void* ya;
-    float* y_stats;
-    const float* next_ln_a;
+    /* (version 112: the five trailing fields of round 4's LayerNorm FORWARD by linearity — xa, x_stats, ya, y_stats, next_ln_a — are gone) */
 } mtn_mha_args;
 int mtn_mha_sublayer_fwd(int dtype, const mtn_mha_args* args, void* stream);
 int mtn_mha_sublayer_bwd(int dtype, const mtn_mha_args* args, void* stream);
@@ -431,11 +413,6 @@ typedef struct {
        attends as un-projected memory (an auto-encoder stream, mtn.py:215), which otherwise costs a cast launch */
     void* y_lp;
     const float* ln_fold; /* optional: fold vectors of w1 (float [2 d_ff]), as mtn_mha_args.ln_fold */
-    const void* xa;       /* forward, optional: as mtn_mha_args.xa / x_stats / ya / y_stats / next_ln_a */
-    const float* x_stats;
-    void* ya;
-    float* y_stats;
-    const float* next_ln_a;
 } mtn_ffn_args;
 int mtn_ffn_sublayer_fwd(int dtype, const mtn_ffn_args* args, void* stream);
 int mtn_ffn_sublayer_bwd(int dtype, const mtn_ffn_args* args, void* stream);
@@ -463,9 +440,6 @@ int mtn_fused_counters(long* out4);
 /* Backward groups (since the library was loaded) whose LayerNorm backward rode in the epilogue of the dLN-out GEMM (mtn_ln_epilogue)
  * instead of its own launch: the tests use it to assert which path ran. */
 long mtn_ln_epilogue_groups(void);
-/* Sublayers (since the library was loaded) whose fused forward kernel took its rows pre-scaled from the producer and applied
- * LayerNorm by linearity (mtn_mha_args.xa): the tests use it to assert which path ran. */
-long mtn_ln_linear_members(void);
 int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
 int mtn_sublayer_group_bwd(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream);
 

@@ -58,14 +58,8 @@ struct FhMember {
     mtn_dropout drop;  // FFN hidden dropout | attention-probability dropout
     bf16_t* o;         // attention output [rows, d]
     float* lse;        // {row max, 1 / row sum} per (b, head, query)
-    // LayerNorm by linearity (round 4, include/mtn_hip.h MTN_LN_FWD_EMIT): the producer of x left xa = bf16(x * a_2) and the rows'
-    // {sum, sum of squares} per 32 columns; with the fold vectors u | c of the Linear (lnf: u[lnK] then c[lnK]) the workgroup takes
-    // its rows as xa by LDS-DMA — no fp32 rows through registers, no normalisation pass — and its projections come out as
-    // rstd (W xa - mean u) + c.  Every slice writes ITS 64 columns of xn (saved for the parameter gradients).  NULL = off.
-    const bf16_t* xa;
-    const float* xstats;
-    const float* lnf;
-    int lnK;
+    // (LayerNorm FORWARD by linearity — pre-scaled bf16 rows + producer-side statistics — lived here in round 4: measured, no net gain,
+    //  removed in round 5: profiles/r04_k_ln_forward_by_linearity.txt)
     // a member may be a PART of a sublayer (samples b_off .. of it; every pointer above already points at the part's first row):
     // dropout indices are those of the whole sublayer (the backward kernels regenerate the masks from them).  See fh_plan: two unit sizes.
     int b_off;
@@ -116,8 +110,7 @@ __host__ __device__ inline int fh_pad_rows(int kind, int mk) { return kind == FH
 #endif
 
 // NP = 64-column weight blocks per workgroup (3: q|k|v or 192 FFN columns; 1: q only), MT = row tiles (16 rows).
-// LIN: the launch has members that take LayerNorm by linearity (opt-in, MTN_LN_LIN=1); the default kernels are compiled without that path
-template <int NP, int MT, bool LIN>
+template <int NP, int MT>
 __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, const int slice, const int rb, unsigned char* smem) {
     constexpr int NG = (MT * 4 + 7) / 8;           // row groups (4 rows) a wave normalises at most
     constexpr int NT = NP * MT;                    // accumulator tiles per wave
@@ -137,7 +130,6 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     const int qa = M.mask_sq ? a : 1;
     const int mask_bytes = ffn ? 0 : nsamp * qa * m;   // the mask image always exists (all ones without a mask): no branch per score
     const bool late_v = kind == FH_CROSS_READY && M.late_v != 0;
-    const bool lin = LIN ? M.xa != nullptr : false;      // LayerNorm by linearity: rows arrive as bf16(x * a_2), statistics from the producer's partials
     const FhLds L = fh_lds_map(MT, raw, key_rows, fh_pad_rows(kind, mk), mask_bytes, ffn ? NP : 0, late_v);
     unsigned char* xn_s = smem + L.xn;
     unsigned char* xm_s = smem + L.xm;
@@ -154,10 +146,8 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     // ~180 ns whatever the other waves do (about a dozen loads in flight per wave), so the memory phase is bounded by the EIGHT waves'
     // memory-level parallelism, not by the CU's pipe, and every wave still does "its loads, then its rows" one after the other.
     // (4) LayerNorm gains: threads 0..127 a_2, 128..255 b_2 (one float4 each) -> LDS
-    // (lin: only the 64 gains / biases of this slice's xn columns are needed: threads 0..15 a_2, 16..31 b_2)
     float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!lin) { if (tid < 256) gv = *(const float4*)((tid < 128 ? M.ln_a : M.ln_b - FH_D) + tid * 4); }
-    else if (tid < 32) gv = *(const float4*)((tid < 16 ? M.ln_a : M.ln_b - 64) + slice * 64 + tid * 4);
+    if (tid < 256) gv = *(const float4*)((tid < 128 ? M.ln_a : M.ln_b - FH_D) + tid * 4);
     // weight blocks: block p covers output columns ncol[p] .. +63 of the Linear; this wave: columns 16*wc .. +15, contraction
     // steps 8*kh .. +7
     int ncol[NP];
@@ -168,16 +158,14 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         else { ncol[p] = p * FH_D + slice * FH_DK; act[p] = (p == 0) || (p < 3 && kind != FH_CROSS_READY); }
     }
     // biases of the workgroup's 64 * NP output columns -> LDS (behind the gains)
-    float bias_v = 0.f, u_v = 0.f;
+    float bias_v = 0.f;
     if (tid < 64 * NP) {
         const int p_ = tid >> 6;
         bool on = false;
         int nc = 0;
 #pragma unroll
         for (int p = 0; p < NP; ++p) if (p == p_) { on = act[p] || (ffn && ncol[p] + (tid & 63) < M.ncols); nc = ncol[p]; }
-        const bool lnb = lin && (ffn || p_ == 0 || kind == FH_SELF);           // a block that sees LayerNorm(x): bias -> c = b + W b_2
-        if (on) bias_v = lnb ? M.lnf[M.lnK + nc + (tid & 63)] : M.bias[nc + (tid & 63)];
-        if (on && lnb) u_v = M.lnf[nc + (tid & 63)];
+        if (on) bias_v = M.bias[nc + (tid & 63)];
     }
     // (1) mask bytes of the block's samples
     // (wide form — the block's bytes start on a dword, a multiple of 8 of them, not shared between samples: thread t takes bytes
@@ -199,32 +187,13 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     // (3) x rows: row group rg = wave + 8i holds rows 4rg .. 4rg+3, one per 16-lane row; lane l15 reads columns 64j + 4*l15
     const float* __restrict__ xg = M.x + (size_t)row0 * FH_D;
     float4 xv[NG][8];
-    float4 st4[4];                                 // lin: eight of the row's 32 {sum, sum of squares} partials (row tid / 4, quarter tid % 4)
-    st4[0] = st4[1] = st4[2] = st4[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!lin) {
 #pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int r = 4 * (wave + 8 * i) + lg;
-            const bool ok = r < R;                     // (groups past the tile range have r >= MT*16 >= R)
+    for (int i = 0; i < NG; ++i) {
+        const int r = 4 * (wave + 8 * i) + lg;
+        const bool ok = r < R;                         // (groups past the tile range have r >= MT*16 >= R)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                xv[i][j] = ok ? *(const float4*)(xg + (size_t)r * FH_D + 64 * j + 4 * l15) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NG; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((tid >> 2) < R) {
-            const float4* sp = (const float4*)(M.xstats + ((size_t)(row0 + (tid >> 2)) * 32 + (tid & 3) * 8) * 2);
-            st4[0] = sp[0]; st4[1] = sp[1]; st4[2] = sp[2]; st4[3] = sp[3];
-        }
-        // the rows themselves: xa [row][512] bf16 -> the xn image by LDS-DMA (one wave-instruction = one 1 KiB row, chunk lane ^ (r & 15))
-        const fh_rsrc_t rsx = fh_make_rsrc(M.xa + (size_t)row0 * FH_D, (unsigned)(R * FH_ROWB));
-        for (int r = wave; r < MT * 16; r += 8) {
-            const unsigned voff = r < R ? (unsigned)r * FH_ROWB + (unsigned)((lane ^ (r & 15)) << 4) : 0x80000000u;
-            fh_dma16(rsx, (unsigned)(size_t)(xn_s + r * FH_ROWB), voff);
-        }
+        for (int j = 0; j < 8; ++j)
+            xv[i][j] = ok ? *(const float4*)(xg + (size_t)r * FH_D + 64 * j + 4 * l15) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     FH_STAMP(14);                                  // x rows issued
     // (2) LDS-DMA (inline asm: fused_common.h): rows of an un-projected memory (x attends an auto-encoder stream, mtn.py:215), or
@@ -306,12 +275,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             if (idx < mask_bytes) mk_s[idx] = mkb[i];
         }
     }
-    // lin: floats [0, 64) a_2 and [64, 128) b_2 of the slice's xn columns, [128, 128 + 64 NP) u, [512, 592) row means, [592, 672) 1 / (std + eps)
-    if (!lin) { if (tid < 256) *(float4*)(smem + L.gains + tid * 16) = gv; }
-    else {
-        if (tid < 32) *(float4*)(smem + L.gains + tid * 16) = gv;
-        if (tid < 64 * NP) *(float*)(smem + L.gains + 512 + tid * 4) = u_v;
-    }
+    if (tid < 256) *(float4*)(smem + L.gains + tid * 16) = gv;
     if (tid < 64 * NP) *(float*)(smem + L.gains + 4096 + tid * 4) = bias_v;
     FH_STAMP(2);                                   // masks, gains and biases have landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -334,31 +298,12 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
 
     // ---- LayerNorm (mtn.py:111-114): 16 lanes per row, 32 elements per lane; row -> bf16 -> LDS image
     const bool save = slice == 0;
-    if (lin) {
-        // statistics from the producer's partials: the row's four threads hold four {sum, sum of squares} pairs each
-        float S = ((st4[0].x + st4[0].z) + (st4[1].x + st4[1].z)) + ((st4[2].x + st4[2].z) + (st4[3].x + st4[3].z));
-        float Q = ((st4[0].y + st4[0].w) + (st4[1].y + st4[1].w)) + ((st4[2].y + st4[2].w) + (st4[3].y + st4[3].w));
-        S += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S), 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
-        Q += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Q), 0xB1, 0xf, 0xf, false));
-        S += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S), 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
-        Q += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Q), 0x4E, 0xf, 0xf, false));
-        const int r = tid >> 2;
-        if ((tid & 3) == 0 && r < MT * 16) {                   // (rows past R: mean = rstd = 0, their projections come out as c: finite)
-            const float mean = S * (1.0f / (float)FH_D);
-            const float var = fmaxf(Q - S * mean, 0.f) * (1.0f / (float)(FH_D - 1));       // unbiased (mtn.py:112: x.std(-1))
-            const float rstd = r < R ? 1.0f / (sqrtf(var) + M.eps) : 0.f;
-            *(float*)(smem + L.gains + 2048 + r * 4) = r < R ? mean : 0.f;
-            *(float*)(smem + L.gains + 2048 + 320 + r * 4) = rstd;
-            if (save && r < R) { M.mean[row0 + r] = mean; M.rstd[row0 + r] = rstd; }
-        }
-    }
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
 #ifndef FH_NO_INTERLEAVE
         if (i > 0 && i < NP) { __builtin_amdgcn_sched_barrier(0); issue_block(i); __builtin_amdgcn_sched_barrier(0); }
         if (i == 1 && kind == FH_CROSS_READY) issue_kv_dma();
 #endif
-        if (lin) continue;
         if (wave + 8 * i >= MT * 4) continue;
         const int r = 4 * (wave + 8 * i) + lg;
         float s = 0.f;
@@ -405,7 +350,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     }
     FH_STAMP(4);                                   // LayerNorm done
 #ifdef FH_NO_INTERLEAVE
-    if (raw || kind == FH_CROSS_READY || lin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA images have landed
+    if (raw || kind == FH_CROSS_READY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA images have landed
     __syncthreads();
 #else
     // Everything OLDER than the weight blocks has landed — the x rows, the LDS-DMA images — once at most the 8 NP weight loads (every
@@ -420,28 +365,6 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
 #endif
     FH_STAMP(5);
     if (G.stop == 1) return;
-    if (lin) {
-        // xn = rstd (xa - mean a_2) + b_2 for THIS slice's 64 columns of the rows (8 chunks of 16 bytes per row): what the parameter
-        // gradients of the projections read in backward — the eight slices of a row block write the whole row between them
-        const float* a2s = (const float*)(smem + L.gains);
-        const float* mean_s = (const float*)(smem + L.gains + 2048);
-        for (int idx = tid; idx < R * 8; idx += FH_THREADS) {
-            const int r = idx >> 3, k = idx & 7, chunk = slice * 8 + k;
-            const uint4 v = *(const uint4*)(xn_s + r * FH_ROWB + ((chunk ^ (r & 15)) << 4));
-            const float mu = mean_s[r], rs = mean_s[80 + r];
-            const float4 ga0 = *(const float4*)(a2s + k * 8), ga1 = *(const float4*)(a2s + k * 8 + 4);
-            const float4 gb0 = *(const float4*)(a2s + 64 + k * 8), gb1 = *(const float4*)(a2s + 64 + k * 8 + 4);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            const float ga[8] = {ga0.x, ga0.y, ga0.z, ga0.w, ga1.x, ga1.y, ga1.z, ga1.w}, gb[8] = {gb0.x, gb0.y, gb0.z, gb0.w, gb1.x, gb1.y, gb1.z, gb1.w};
-            uint32_t o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
-                o[e] = fh_pack2(rs * (lo - mu * ga[2 * e]) + gb[2 * e], rs * (hi - mu * ga[2 * e + 1]) + gb[2 * e + 1]);
-            }
-            *(uint4*)(M.xn + (size_t)(row0 + r) * FH_D + slice * 64 + k * 8) = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-    }
 
     // weight fragments into operand order (lane 16c + r takes the 16 bytes lane 4r + c loaded): step by step INSIDE the projection loops,
     // so that a step's MFMAs only wait for that step's fragments
@@ -547,19 +470,11 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         const int col = ncol[p] + 16 * wc + 4 * lg;             // column of the Linear's output
         unsigned char* img = p == 0 ? qi_s : (p == 1 ? ki_s : vi_s);          // (p == 3 exists for FFN members only)
         const float4 bvp = *(const float4*)(smem + L.gains + 4096 + (p * 64 + 16 * wc + 4 * lg) * 4);
-        const bool lnb = lin && (ffn || p == 0 || kind == FH_SELF);               // W LN(x) + b = rstd (W xa - mean u) + c  (bvp holds c)
-        float4 uvp = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lnb) uvp = *(const float4*)(smem + L.gains + 512 + (p * 64 + 16 * wc + 4 * lg) * 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if (((p * MT + mt) & 1) != kh) continue;
             const int r = mt * 16 + l15;
             float v[4] = {acc[p][mt][0] + bvp.x, acc[p][mt][1] + bvp.y, acc[p][mt][2] + bvp.z, acc[p][mt][3] + bvp.w};
-            if (lnb) {
-                const float mu = *(const float*)(smem + L.gains + 2048 + r * 4), rs = *(const float*)(smem + L.gains + 2048 + 320 + r * 4);
-                v[0] = rs * (acc[p][mt][0] - mu * uvp.x) + bvp.x; v[1] = rs * (acc[p][mt][1] - mu * uvp.y) + bvp.y;
-                v[2] = rs * (acc[p][mt][2] - mu * uvp.z) + bvp.z; v[3] = rs * (acc[p][mt][3] - mu * uvp.w) + bvp.w;
-            }
             if (ffn) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -775,7 +690,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
 #endif
 }
 
-template <int NP, bool LIN = false>
+template <int NP>
 __global__ __launch_bounds__(FH_THREADS) void fused_head_fwd_kernel(const FhGroup G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef FH_TIMELINE
@@ -801,12 +716,12 @@ __global__ __launch_bounds__(FH_THREADS) void fused_head_fwd_kernel(const FhGrou
 #endif
     if (rb * M.rows_per_wg >= M.rows) return;                  // padding workgroup (row-block count rounded up to the map's grid)
     if constexpr (NP == 4) {                       // 4 weight blocks: 128 VGPRs of fragments -> at most 64 rows (two row groups per wave)
-        if (M.mt <= 2) fh_body<NP, 2, LIN>(G, M, slice, rb, smem);
-        else fh_body<NP, 4, LIN>(G, M, slice, rb, smem);
+        if (M.mt <= 2) fh_body<NP, 2>(G, M, slice, rb, smem);
+        else fh_body<NP, 4>(G, M, slice, rb, smem);
     } else {
-        if (M.mt <= 2) fh_body<NP, 2, LIN>(G, M, slice, rb, smem);
-        else if (M.mt == 3) fh_body<NP, 3, LIN>(G, M, slice, rb, smem);
-        else fh_body<NP, 5, LIN>(G, M, slice, rb, smem);
+        if (M.mt <= 2) fh_body<NP, 2>(G, M, slice, rb, smem);
+        else if (M.mt == 3) fh_body<NP, 3>(G, M, slice, rb, smem);
+        else fh_body<NP, 5>(G, M, slice, rb, smem);
     }
 }
 
@@ -825,8 +740,6 @@ static bool fh_env_off() {
 int fh_is_enabled() { return fh_env_off() ? 0 : 1; }
 
 static constexpr int FH_LDS_MAX = 160 * 1024;
-// LayerNorm forward by linearity is opt-in (MTN_LN_LIN=1): measured in round 4, the producers' epilogues cost what the fused kernels gain
-static bool fh_lin_on() { const char* e = MTN_ENV("MTN_LN_LIN"); return e && e[0] == '1'; }
 // row tiles a workgroup may have: {2, 3, 5} in the 1- and 3-block kernels, {2, 4} in the 4-block kernel
 static const int fh_mt_sets[2][3] = {{2, 3, 5}, {2, 4, 4}};
 
@@ -935,9 +848,6 @@ static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn
         M.out = (bf16_t*)a.qkv + r0 * ldo; M.ld_out = ldo; M.kv = a.kv ? (bf16_t*)a.kv + rm0 * 2 * FH_D : nullptr;
         M.mask = a.mask ? a.mask + (size_t)s0 * a.mask_sb : nullptr; M.mask_sb = a.mask_sb; M.mask_sq = a.mask_sq; M.drop = a.drop_attn;
         M.o = (bf16_t*)a.o + r0 * FH_D; M.lse = a.lse ? a.lse + 2 * (size_t)s0 * (FH_D / FH_DK) * a.a : nullptr;
-        if (a.xa && a.x_stats && a.ln_fold && fh_lin_on()) {
-            M.xa = (const bf16_t*)a.xa + r0 * FH_D; M.xstats = a.x_stats + r0 * 64; M.lnf = a.ln_fold; M.lnK = a.self_attn ? 3 * FH_D : FH_D;
-        }
         G.wg_start[n] = wgs;
         const int nrb = (Bp + pl.blk - 1) / pl.blk;
         fh_pick_xcd_map(M, nrb, (double)M.rows * FH_D * 4, (M.kind == FH_CROSS_READY ? 1.0 : 3.0) * FH_D * FH_D * 2);
@@ -965,7 +875,6 @@ static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn
         M.w = (const bf16_t*)a.w1; M.bias = a.b1;
         M.xn = (bf16_t*)a.xn; M.mean = a.mean; M.rstd = a.rstd;
         M.out = (bf16_t*)a.hid; M.ld_out = a.d_ff; M.drop = a.drop_hidden;
-        if (a.xa && a.x_stats && a.ln_fold && M.nslice == 8 && fh_lin_on()) { M.xa = (const bf16_t*)a.xa; M.xstats = a.x_stats; M.lnf = a.ln_fold; M.lnK = a.d_ff; }
         G.wg_start[n] = wgs;
         int nrb = (a.rows + M.rows_per_wg - 1) / M.rows_per_wg;
         while ((nrb * M.nslice) % 8 != 0) ++nrb;          // padding row blocks (their workgroups leave at once): members start on XCD 0
@@ -989,34 +898,22 @@ int fh_group_eligible(int dtype, int n_mha, const mtn_mha_args* mha, int n_ffn, 
     return fh_plan(n_mha, mha, n_ffn, ffn, P) ? 1 : 0;
 }
 
-template <int NP, bool LIN> static int fh_launch_lin(const FhGroup& G, int wgs, size_t lds, hipStream_t s) {
+template <int NP> static int fh_launch(const FhGroup& G, int wgs, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)fused_head_fwd_kernel<NP, LIN>, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)fused_head_fwd_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_MAX) != hipSuccess) {
             mtn_set_error("fused_head_fwd_kernel: cannot raise the dynamic LDS limit");
             return MTN_ERR_LAUNCH;
         }
         attr = true;
     }
-    hipLaunchKernelGGL((fused_head_fwd_kernel<NP, LIN>), dim3(wgs), dim3(FH_THREADS), lds, s, G);
-#ifdef MTN_DBG_TWICE      // development probe: every launch issued twice — the second finds all of its operands in the L2s (tools/twice_probe.py)
-    hipLaunchKernelGGL((fused_head_fwd_kernel<NP, LIN>), dim3(wgs), dim3(FH_THREADS), lds, s, G);
-#endif
+    hipLaunchKernelGGL((fused_head_fwd_kernel<NP>), dim3(wgs), dim3(FH_THREADS), lds, s, G);
     return MTN_OK;
 }
-template <int NP> static int fh_launch(const FhGroup& G, int wgs, size_t lds, hipStream_t s) {
-    bool any_lin = false;
-    for (int i = 0; i < G.count; ++i) any_lin = any_lin || G.m[i].xa != nullptr;
-    return any_lin ? fh_launch_lin<NP, true>(G, wgs, lds, s) : fh_launch_lin<NP, false>(G, wgs, lds, s);
-}
-
-static long g_lin_members = 0;                // members launched with LayerNorm by linearity since the library was loaded (tests)
-extern "C" long mtn_ln_linear_members(void) { return g_lin_members; }
 
 int fh_group_fwd_stage1(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn_args* ffn, void* stream) {
     FhLaunch P;
     MTN_CHECK_ARG(fh_plan(n_mha, mha, n_ffn, ffn, P), "group outside the fused kernel's tiling");
-    for (int i = 0; i < P.G.count; ++i) g_lin_members += P.G.m[i].xa != nullptr;
     hipStream_t s = (hipStream_t)stream;
     const int rc = P.np == 4 ? fh_launch<4>(P.G, P.wgs, P.lds, s) : (P.np == 3 ? fh_launch<3>(P.G, P.wgs, P.lds, s) : fh_launch<1>(P.G, P.wgs, P.lds, s));
     if (rc != MTN_OK) return rc;

@@ -290,7 +290,6 @@ struct LnEpiSlot {
     float* dx;
     void* dx_lp;
     float* colpart;
-    void* ya;
     mtn_dropout dx_lp_drop;
     float gate_inv_scale, eps;
 };
@@ -808,11 +807,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
                 for (int j = 0; j < TN; ++j) {
                     const int col = col0 + wc * (BN / WC) + j * 16 + lg * 4;
                     const int cc = col < N ? col : 0;
-                    if (E.mode == MTN_LN_FWD_EMIT) emit_u[j] = *(const float4*)(E.a2 + cc);          // the consuming LayerNorm's gains
-                    else {
-                        emit_u[j] = *(const float4*)(E.fold + cc);
-                        emit_c[j] = *(const float4*)(E.fold + N + cc);
-                    }
+                    emit_u[j] = *(const float4*)(E.fold + cc);
+                    emit_c[j] = *(const float4*)(E.fold + N + cc);
                 }
             }
         }
@@ -952,37 +948,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
                 return;
             }
             float p1[TM], p2[TM];
-            if (lne_mode == MTN_LN_FWD_EMIT) {
-                // the ordinary epilogue (y = x + dropout(...) in fp32), y * a2 in the compute dtype for the next sublayer's fused kernel, and the
-                // row's {sum y, sum y^2} per 32-column block for its LayerNorm statistics
-                static_assert(BN / WC == 16 && TN == 1, "a wave owns one 16-column block of the tile's rows");
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    p1[i] = p2[i] = 0.f;
-                    const int row = row0 + wr * (BM / WR) + i * 16 + l15;
-                    if (row >= M) continue;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int col = col0 + wc * (BN / WC) + j * 16 + lg * 4;
-                        if (col >= N) continue;
-                        float v[4];
-                        epilogue4<T>(P, ds, vec_ok && col + 3 < N, row, col, N, acc[i][j], nullptr, nullptr, v, nullptr, pre_on && col + 3 < N, pre_b[j], pre_r[i][j], pre_g[i][j]);
-                        p1[i] += (v[0] + v[1]) + (v[2] + v[3]);
-                        p2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                        store_lp4<T>((T*)E.ya + (size_t)row * N + col, make_float4(v[0] * emit_u[j].x, v[1] * emit_u[j].y, v[2] * emit_u[j].z, v[3] * emit_u[j].w));
-                    }
-                }
-                // one pair per row and 16-column block — this wave's own columns: no exchange with the other waves, the stores leave
-                // with the tile's other stores (an LDS round + barrier here put a second store generation at the kernel's tail)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float s1 = fh_cross_sum(p1[i]), s2 = fh_cross_sum(p2[i]);
-                    const int row = row0 + wr * (BM / WR) + i * 16 + l15;
-                    if (lg == 0 && row < M && col0 + wc * (BN / WC) < N)
-                        ((float2*)E.part)[(size_t)row * (N / 16) + (col0 + wc * (BN / WC)) / 16] = make_float2(s1, s2);
-                }
-                return;
-            }
             // MTN_LN_EMIT: the ordinary epilogue, and the two dot products of the stored values on the way
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -2112,17 +2077,14 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
         grp.p[i].ln = nullptr;
         if (p.ln && p.ln->mode != 0) {
             const mtn_ln_epilogue& e = *p.ln;
-            MTN_CHECK_ARG(dtype == MTN_BF16 && !p.a_trans && !p.adam && (p.b_trans || e.mode == MTN_LN_FWD_EMIT), "LayerNorm epilogue: bf16; dX = dY W problems (backward modes) or a forward Linear (MTN_LN_FWD_EMIT)");
+            MTN_CHECK_ARG(dtype == MTN_BF16 && !p.a_trans && !p.adam && p.b_trans, "LayerNorm epilogue: bf16, dX = dY W problems");
             MTN_CHECK_ARG(n_lne < LNE_MAX_SLOTS, "LayerNorm epilogue: too many problems with one in this launch");
             MTN_CHECK_ARG(e.part, "LayerNorm epilogue: null row-sum partial buffer");
             LnEpiSlot& sl = lne.s[n_lne];
             sl.mode = e.mode; sl.np = e.np; sl.fold = e.fold; sl.part = e.part;
             sl.x = e.x; sl.a2 = e.a2; sl.mean = e.mean; sl.rstd = e.rstd; sl.dres = e.dres; sl.dx = e.dx; sl.dx_lp = e.dx_lp;
-            sl.colpart = e.colpart; sl.dx_lp_drop = e.dx_lp_drop; sl.gate_inv_scale = e.gate_inv_scale; sl.eps = e.eps; sl.ya = e.ya;
-            if (e.mode == MTN_LN_FWD_EMIT) {
-                MTN_CHECK_ARG(e.a2 && e.ya && p.N % 32 == 0 && p.out_f32 && ((((uintptr_t)e.a2) | ((uintptr_t)e.ya) | ((uintptr_t)e.part)) & 15) == 0,
-                              "LayerNorm epilogue (forward emit): gains, a compute-dtype ya, N % 32 == 0, an fp32 output");
-            } else if (e.mode == MTN_LN_EMIT) {
+            sl.colpart = e.colpart; sl.dx_lp_drop = e.dx_lp_drop; sl.gate_inv_scale = e.gate_inv_scale; sl.eps = e.eps;
+            if (e.mode == MTN_LN_EMIT) {
                 MTN_CHECK_ARG(e.fold && p.N % 64 == 0 && p.out_lp && (((uintptr_t)e.fold) & 15) == 0, "LayerNorm epilogue (emit): fold vectors, N % 64 == 0, a compute-dtype output");
                 lne_emit = true;
             } else {

@@ -193,32 +193,21 @@ extern "C" int mtn_sublayer_group_fwd(int dtype, int n_mha, const mtn_mha_args* 
         for (int i = 0; i < n_mha; ++i) attn_args_of(&mha[i], dtype, &t[i]);
         RUN(mtn_attention_fwd_group(dtype, n_mha, t, stream));
     }
-    // 4. output projection / FFN second Linear, + bias + dropout + residual (mtn.py:267, 280, 127); with ya / y_stats / next_ln_a
-    //    also y * (the next LayerNorm's gains) in the compute dtype and the rows' LayerNorm-statistics partials (MTN_LN_FWD_EMIT)
+    // 4. output projection / FFN second Linear, + bias + dropout + residual (mtn.py:267, 280, 127)
     {
         mtn_gemm_problem p[2 * MTN_SUBLAYER_MAX_GROUP];
-        mtn_ln_epilogue le[2 * MTN_SUBLAYER_MAX_GROUP];
         int n = 0;
-        auto fwd_emit = [&](mtn_gemm_problem& q, void* ya, float* y_stats, const float* next_ln_a) {
-            if (!(dtype == MTN_BF16 && ya && y_stats && next_ln_a && q.N % 16 == 0)) return;
-            mtn_ln_epilogue& e = le[n];
-            memset(&e, 0, sizeof(e));
-            e.mode = MTN_LN_FWD_EMIT; e.a2 = next_ln_a; e.ya = ya; e.part = y_stats;
-            q.ln = &e;
-        };
         for (int i = 0; i < n_mha; ++i) {
             const mtn_mha_args* a = &mha[i];
             const int d = a->d, rows = a->B * a->a;
             p[n] = gemm_init(a->o, d, a->w_o, d, rows, d, d, 0, 0);
             p[n].bias = a->b_o; p[n].drop = a->drop_out; p[n].residual = a->x; p[n].ldr = d; p[n].out_f32 = a->y; p[n].ldc = d;
-            fwd_emit(p[n], a->ya, a->y_stats, a->next_ln_a);
             ++n;
         }
         for (int i = 0; i < n_ffn; ++i) {
             const mtn_ffn_args* a = &ffn[i];
             p[n] = gemm_init(a->hid, a->d_ff, a->w2, a->d_ff, a->rows, a->d, a->d_ff, 0, 0);
             p[n].bias = a->b2; p[n].drop = a->drop_out; p[n].residual = a->x; p[n].ldr = a->d; p[n].out_f32 = a->y; p[n].out_lp = a->y_lp; p[n].ldc = a->d;
-            fwd_emit(p[n], a->ya, a->y_stats, a->next_ln_a);
             ++n;
         }
         RUN(mtn_gemm(dtype, n, p, stream));

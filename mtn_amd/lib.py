@@ -29,8 +29,7 @@ class AdamFuse(C.Structure):
 class LnEpilogue(C.Structure):
     _fields_ = [("mode", C.c_int), ("fold", C.c_void_p), ("gate_inv_scale", C.c_float), ("part", C.c_void_p), ("np", C.c_int),
                 ("x", C.c_void_p), ("a2", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("dres", C.c_void_p),
-                ("eps", C.c_float), ("dx", C.c_void_p), ("dx_lp", C.c_void_p), ("dx_lp_drop", Dropout), ("colpart", C.c_void_p),
-                ("ya", C.c_void_p)]
+                ("eps", C.c_float), ("dx", C.c_void_p), ("dx_lp", C.c_void_p), ("dx_lp_drop", Dropout), ("colpart", C.c_void_p)]
 
 
 class LnFoldDesc(C.Structure):
@@ -71,8 +70,7 @@ class MhaArgs(C.Structure):
                 ("d_w_qkv", C.c_void_p), ("d_b_qkv", C.c_void_p), ("d_w_o", C.c_void_p), ("d_b_o", C.c_void_p),
                 ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int),
                 ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout), ("kv_ready", C.c_int),
-                ("dmem_lp", C.c_void_p), ("dmem_lp_drop", Dropout), ("ln_fold", C.c_void_p),
-                ("xa", C.c_void_p), ("x_stats", C.c_void_p), ("ya", C.c_void_p), ("y_stats", C.c_void_p), ("next_ln_a", C.c_void_p)]
+                ("dmem_lp", C.c_void_p), ("dmem_lp_drop", Dropout), ("ln_fold", C.c_void_p)]
 
 
 class FfnArgs(C.Structure):
@@ -87,8 +85,7 @@ class FfnArgs(C.Structure):
                 ("d_w2", C.c_void_p), ("d_b2", C.c_void_p),
                 ("ws_lp", C.c_void_p), ("ws_f32", C.c_void_p), ("defer_param_grads", C.c_int),
                 ("dyl_ready", C.c_void_p), ("next_dyl", C.c_void_p), ("next_drop", Dropout), ("y_lp", C.c_void_p),
-                ("ln_fold", C.c_void_p), ("xa", C.c_void_p), ("x_stats", C.c_void_p), ("ya", C.c_void_p), ("y_stats", C.c_void_p),
-                ("next_ln_a", C.c_void_p)]
+                ("ln_fold", C.c_void_p)]
 
 
 class LossHeadArgs(C.Structure):
@@ -206,7 +203,6 @@ SYMBOLS = {
     "mtn_fused_enable": (C.c_int, [C.c_int]),
     "mtn_fused_counters": (C.c_int, [C.POINTER(C.c_long)]),
     "mtn_ln_epilogue_groups": (C.c_long, []),
-    "mtn_ln_linear_members": (C.c_long, []),
     "mtn_ln_fold": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "mtn_sublayer_group_fwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),
     "mtn_sublayer_group_bwd": (C.c_int, [C.c_int, C.c_int, C.POINTER(MhaArgs), C.c_int, C.POINTER(FfnArgs), _P]),

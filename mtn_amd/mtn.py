@@ -36,13 +36,6 @@ ATTN_DROPOUT_DEFAULT = 0.1   # mtn.py:339 builds MultiHeadedAttention(h, d_model
 _HANDOFF = os.environ.get("MTN_NO_HANDOFF") != "1"
 
 
-def _ln_lin_on() -> bool:
-    """LayerNorm FORWARD by linearity (producer-side statistics + pre-scaled bf16 rows, include/mtn_hip.h MTN_LN_FWD_EMIT): built and
-    measured in round 4, OFF by default — the fused kernels gain 58 us per cfg2 step, the producers' epilogues pay 71 (DESIGN.md §11,
-    profiles/r04_k_ln_forward_by_linearity.txt).  MTN_LN_LIN=1 turns it on (read per call: the tests flip it)."""
-    return os.environ.get("MTN_LN_LIN") == "1"
-
-
 # ------------------------------------------------------------------------------------------ leaf modules
 class LayerNorm(nn.Module):
     """a_2 * (x - mean) / (std_unbiased + eps) + b_2  (mtn.py:103-114) on the HIP kernel."""
@@ -239,16 +232,8 @@ class DecoderLayer(nn.Module):
         attended as un-projected memory later (the auto-encoder streams, mtn.py:215): they also leave in the compute dtype."""
         members, tensors = [], []
         for it in items:
-            sc, mod, mem, mask, inp = it[:5]
-            nxt = it[5] if len(it) > 5 else None          # the SublayerConnection that will read this member's output (or None)
-            mb = sc.member(mod, mem, mask)
-            # LayerNorm forward by linearity (include/mtn_hip.h, MTN_LN_FWD_EMIT): the member's output-projection GEMM leaves
-            # y * (the reader's LayerNorm gains) in the compute dtype and the rows' statistics partials; the reader finds them on y
-            if nxt is not None and mb.cfg.lp_dtype == torch.bfloat16 and inp.size(-1) == 512 and _ln_lin_on():
-                mb.next_ln_a = nxt.norm.a_2
-            xa = getattr(inp, "_mtn_xa", None)
-            if xa is not None and xa[0] is sc.norm.a_2 and mb.cfg.ln_fold is not None:
-                mb.xa = xa
+            sc, mod, mem, mask, inp = it[:5]      # (a sixth element names the next reader of the output: LayerNorm FORWARD by linearity used
+            mb = sc.member(mod, mem, mask)        #  it — measured in round 4, no net gain, removed in round 5: profiles/r04_k_ln_forward_by_linearity.txt)
             mb.want_lp = raw_memory_outputs and mb.kind == "ffn"
             kv = getattr(sc, "_kv_ready", None)        # K|V of a constant memory projected ahead of the layer loop
             if kv is not None and mb.kind == "mha" and mem is not None and kv.size(0) == mem.size(0) * mem.size(1):
@@ -268,8 +253,6 @@ class DecoderLayer(nn.Module):
                 outs[pos]._mtn_next = members[k].holder
             if members[k].out_lp is not None:
                 outs[pos]._mtn_lp = members[k].out_lp
-            if members[k].out_xa is not None:
-                outs[pos]._mtn_xa = members[k].out_xa
         return res
 
     def _plan(self, cap_memory, cap_mask, his_memory, his_mask, q_memory, q_mask, tgt_mask, vid_fts, vid_mask, ae_features):
@@ -1058,7 +1041,7 @@ class EncoderDecoder(nn.Module):
 
         def cut(t):
             u = t.detach().requires_grad_()
-            for attr in ("_mtn_lp", "_mtn_next", "_mtn_xa"):      # compute-dtype copy; gradient hand-off to the producer across the cut; pre-scaled rows + statistics
+            for attr in ("_mtn_lp", "_mtn_next"):      # compute-dtype copy; gradient hand-off to the producer across the cut
                 if hasattr(t, attr):
                     setattr(u, attr, getattr(t, attr))
             return u

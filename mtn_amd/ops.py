@@ -683,32 +683,12 @@ class GroupMember:
     kv_ready: Optional[torch.Tensor] = None     # K|V of a constant memory, projected ahead of the layer loop (project_memories)
     want_lp: bool = False                       # 'ffn': also write the output in the compute dtype (-> out_lp): it is attended as raw memory
     out_lp: Optional[torch.Tensor] = None
-    # LayerNorm forward by linearity (include/mtn_hip.h MTN_LN_FWD_EMIT).  next_ln_a: gains of the LayerNorm that will read this member's
-    # output -> the output GEMM also writes out_xa = (those gains, y * gains in the compute dtype, statistics partials); xa: the same triple
-    # found on this member's INPUT (written by its producer for THIS member's LayerNorm)
-    next_ln_a: Optional[torch.Tensor] = None
-    xa: Optional[tuple] = None
-    out_xa: Optional[tuple] = None
 
 
 class SublayerGroupFn(torch.autograd.Function):
     """Independent sublayers of one DecoderLayer executed in lockstep (one grouped launch per stage, see csrc/sublayer.hip).
     apply(members, x_0, mem_0, x_1, mem_1, ...) -> (y_0, y_1, ...); mem_i is None for self-attention / FFN members.
     Parameter gradients go straight to cfg.grads (flat gradient buffer) through cfg.queue (always deferred)."""
-
-    @staticmethod
-    def _lin_io(A, mb, y, lp):
-        """LayerNorm forward by linearity: hand the member its input's pre-scaled rows + statistics (mb.xa) and have its output GEMM
-        write the same for whoever reads y next (mb.next_ln_a)."""
-        if mb.xa is not None:
-            A.xa, A.x_stats = mb.xa[1].data_ptr(), mb.xa[2].data_ptr()
-        d = y.size(-1)
-        if mb.next_ln_a is not None and lp == torch.bfloat16 and d % 32 == 0:
-            rows = y.numel() // d
-            ya = torch.empty(rows, d, device=y.device, dtype=lp)
-            stats = torch.empty(rows, d // 16, 2, device=y.device, dtype=torch.float32)
-            A.ya, A.y_stats, A.next_ln_a = ya.data_ptr(), stats.data_ptr(), mb.next_ln_a.data_ptr()
-            mb.out_xa = (mb.next_ln_a, ya, stats)
 
     @staticmethod
     def forward(ctx, members, *tensors):
@@ -767,7 +747,6 @@ class SublayerGroupFn(torch.autograd.Function):
                 A.y, A.xn, A.mean, A.rstd = y.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr()
                 A.qkv, A.kv, A.o, A.lse = qkv.data_ptr(), L.ptr(kv), o.data_ptr(), lse.data_ptr()
                 A.ln_fold = L.ptr(cfg.ln_fold)
-                SublayerGroupFn._lin_io(A, mb, y, lp)
                 need_dmem = (not self_attn) and mem_t.requires_grad
                 gacc = None
                 if need_dmem:          # a memory serves every layer: its gradient is accumulated in place by the dmem GEMMs
@@ -795,7 +774,6 @@ class SublayerGroupFn(torch.autograd.Function):
                 A.w1_t, A.w2_t = L.ptr(cfg.w1_lpT), L.ptr(cfg.w2_lpT)
                 A.y, A.xn, A.mean, A.rstd, A.hid = y.data_ptr(), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), hid.data_ptr()
                 A.ln_fold = L.ptr(cfg.ln_fold)
-                SublayerGroupFn._lin_io(A, mb, y, lp)
                 if mb.want_lp and lp != torch.float32:
                     mb.out_lp = torch.empty(y.shape, device=dev, dtype=lp)
                     A.y_lp = mb.out_lp.data_ptr()
