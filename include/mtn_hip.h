@@ -597,9 +597,10 @@ int mtn_measure_hbm_peak(const void* src, void* dst, long bytes, void* stream, d
  * hypotheses, the per-token pass of `beam_search_decode` / `greedy_decode` (data_utils.py:197-208: `model.decode` + final LayerNorm)
  * in its cached form: the newest position of every hypothesis through N layers x (self-attention over the prefix cache, cross-attentions
  * over hoisted K|V, feed-forward), walking `stages` (a DEVICE array, built once per dialogue shape) with a grid barrier between stages.
- * bf16 weights.  `grid` workgroups must all be resident (<= 256: one per CU).  Buffers: x [W][d] fp32, q / o [W][d] and hid [W][d_ff]
- * bf16 scratch; out_lp [W][d] bf16 = final LayerNorm output (the generator's operand); sync: 2 unsigned (the library zeroes sync[0]
- * before the launch; sync[1] != 0 afterwards = a barrier timed out and the results are invalid).
+ * bf16 weights.  `grid` workgroups must all be resident (<= 256: one per CU).  Stages hand values over as 8-byte {data, tag} granules
+ * (no grid barrier): xg / qg / og / hg are the granule buffers (zeroed ONCE by the caller); out_lp [W][d] bf16 = final LayerNorm
+ * output (the generator's operand); sync: 2 unsigned, zeroed once: sync[0] = launch generation (advanced by the kernel), sync[1] != 0 =
+ * a poll timed out and the results are invalid.  W x d <= 4096.
  * ------------------------------------------------------------------------------------------ */
 #define MTN_DEC_EMBED 0     /* x = lut[token] * emb_scale + pe[pos] */
 #define MTN_DEC_SELF_QKV 1  /* q | k | v = LayerNorm(x) W^T + b (N = 3d): q -> scratch, k | v -> cache row (hypothesis, pos) */
@@ -621,7 +622,8 @@ typedef struct {
 } mtn_decode_stage;
 typedef struct {
     int W, d, h, L, n_stages, d_ff;
-    float* x; void* q; void* o; void* hid; void* out_lp;
+    void* xg; void* qg; void* og; void* hg;   /* granule buffers (8 bytes {data, tag} each), zeroed once: [W][d], [W][3d/2], [W][d/2], [W][d_ff/2] */
+    void* out_lp;
     const long* tokens;         /* [W] newest token of every hypothesis */
     const float* lut; float emb_scale; const float* pe;     /* target embedding table [V][d], sqrt(d), positional encodings [>= L][d] */
     const int* pos;             /* device scalar: the position being decoded (0-based) */

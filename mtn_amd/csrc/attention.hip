@@ -720,7 +720,7 @@ extern "C" int mtn_attention_fwd_group(int dtype, int count, const mtn_attn_args
     }
     hipStream_t s = (hipStream_t)stream;
     {   // MFMA path: every member has the same head size in {16,32,64,128} and 8-byte aligned rows
-        bool ok = MTN_ENV("MTN_ATTN_VALU") == nullptr;
+        bool ok = true;
         const int dk = args[0].dk;
         int gym = 0;
         for (int i = 0; i < count; ++i) {
@@ -734,7 +734,6 @@ extern "C" int mtn_attention_fwd_group(int dtype, int count, const mtn_attn_args
             for (int i = 0; i < count; ++i) { const int t = (args[i].m + MK - 1) / MK; nw = t > nw ? t : nw; wgs += args[i].B * args[i].h * gym; }
             // 8 waves (one or two tiles each) when the launch leaves most of the chip idle anyway (small batch x long memory)
             nw = nw <= 2 ? nw : ((nw > 4 && wgs <= 256) ? 8 : 4);
-            if (const char* f = MTN_ENV("MTN_ATTN_FWD_NW")) nw = atoi(f);
             int rc = (dtype == MTN_BF16) ? dispatch_fwd_mfma<bf16_t>(dk, G, gridm, nw, s) : dispatch_fwd_mfma<float>(dk, G, gridm, nw, s);
             if (rc == MTN_OK) { MTN_CHECK_LAUNCH(); return MTN_OK; }
         }
@@ -771,7 +770,7 @@ extern "C" int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args
     hipStream_t s = (hipStream_t)stream;
     {   // MFMA path: same supported head size everywhere; query rows in passes of 32 (a pass takes the members that still
         // have rows left; passes after the first add their dK / dV to the stored sums)
-        bool ok = MTN_ENV("MTN_ATTN_VALU") == nullptr;
+        bool ok = true;
         const int dk = args[0].dk;
         int amax = 0;
         for (int i = 0; i < count; ++i) {
@@ -803,7 +802,6 @@ extern "C" int mtn_attention_bwd_group(int dtype, int count, const mtn_attn_args
                 // 2 waves up to 8 key tiles: a 226-register wave leaves room for 2 per SIMD, and a group's one-tile members
                 // (one live wave each) then share the CU with the long member instead of waiting for a second round
                 nw = nw <= 1 ? 1 : (nw <= 8 ? 2 : ((wgs <= 256) ? 8 : 4));
-                if (const char* f = MTN_ENV("MTN_ATTN_BWD_NW")) nw = atoi(f);
                 const dim3 pgrid(px, 1, P.count);
                 rc = (dtype == MTN_BF16) ? dispatch_bwd_mfma<bf16_t>(dk, P, pgrid, nw, s) : dispatch_bwd_mfma<float>(dk, P, pgrid, nw, s);
                 if (rc != MTN_OK && q0 > 0) return rc;          // (a first-pass refusal falls through to the VALU kernel)

@@ -8,8 +8,12 @@
 // Rounds 1-4 ran this on the training launches: two launches per sublayer, ~90 dependent launches of 6-10 us per step for 72 MB of
 // weights (0.95 % of the HBM roofline).
 //
-// Here the whole pass is one grid of G <= 256 resident workgroups that walks a device-resident list of STAGES; between two stages a grid
-// barrier (one agent-scope counter, relaxed polling) replaces the launch boundary:
+// Here the whole pass is one grid of G <= 256 resident workgroups that walks a device-resident list of STAGES.  There is NO barrier between
+// stages: every value a stage hands to the next travels as an 8-byte GRANULE {data, tag} written by ONE agent-scope (sc1, write-through)
+// store, tag = (launch generation << 8 | producing stage); a consumer polls exactly the granules it needs until every tag matches
+// (MI355X_MICROARCH.md, hand-off rows R2 / handoff-1to1: the data IS the flag — no drain, no flag store, no separate load afterwards).
+// The first version synchronised with a grid-wide counter barrier per stage and was no faster than the launches it replaced (8.2 us per
+// stage: 3 us of barrier + 0.8-2.8 us to load the operands afterwards + 1.2 us of late bias loads; profiles/r05_decode_timeline_barrier.txt).
 //   * "slice" stages (q|k|v projection of the self-attention, output projections, both feed-forward Linears): every workgroup owns
 //     ceil(N / G) output features of the Linear — its rows of the weight matrix are read from HBM exactly once per step, by one CU, as
 //     MFMA B-fragments straight into registers, and they are REQUESTED BEFORE the workgroup waits at the barrier in front of the stage
@@ -17,10 +21,11 @@
 //   * "unit" stages (attention): workgroup (hypothesis j, head h) projects q_h = LN(x_j) W_q,h itself (its 64 rows of W_q likewise
 //     prefetched), attends the memory's hoisted K|V head rows (constant per dialogue: L2-resident after the first step) or the self
 //     cache, and publishes its 64 output columns.
-// Activations cross workgroups through small global buffers written with agent-scope (sc1, write-through) stores and read back with
-// agent-scope loads after the barrier (MI355X_MICROARCH.md, inter-workgroup visibility: the per-XCD L2s are not coherent, sc1 accesses
-// are); read-only operands (weights, hoisted K|V, masks) use plain loads.  Every spin is bounded (a timeout sets sync[1] and the step's
-// results are garbage — the host raises); the counter is zeroed by a memset node in front of every launch.
+// Granule buffers: xg [W][d] (fp32 residual stream), qg [W][3d/2] (q | k | v of the newest row, bf16 pairs), og [W][d/2] (attention output),
+// hg [W][d_ff/2] (FFN hidden).  A workgroup keeps ITS columns of the residual stream in LDS across stages (the slices of the three
+// N = d Linears coincide).  Read-only operands (weights, hoisted K|V, masks, the cache rows of earlier steps) use plain loads.  Every
+// poll is bounded (a timeout sets sync[1]: the step's results are garbage and the host raises).  The generation lives in sync[0]: read
+// by every workgroup at entry, advanced by workgroup 0 at the end — nothing to zero between launches (hipGraph replay safe).
 // Arithmetic mirrors the training kernels: LayerNorm statistics, softmax and accumulators fp32; LayerNorm output, q, probabilities'
 // operands, attention output and the FFN hidden rounded to bf16 where those kernels store bf16.
 #include "common.h"
@@ -48,33 +53,61 @@ struct DecKernelArgs {
     const mtn_decode_stage* stages;
 };
 
-// ---- grid barrier: every payload store of this workgroup is an agent-scope (write-through) store; drain them, then one arrival
-__device__ __forceinline__ void dec_grid_sync(unsigned* sync, const unsigned target) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (ld_ag32(sync) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 21)) { __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never hang the chip
+// ---- granules
+__device__ __forceinline__ void dec_pub(const dec_rsrc_t r, const unsigned index, const unsigned data, const unsigned tag) { st8(r, index * 8, (u64)data | ((u64)tag << 32)); }
+__device__ __forceinline__ unsigned dec_pack2(const float a, const float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); }
+// Poll `count` granules starting at `first` of buffer r until all carry `tag`; granule first + i goes to sink(i, data).  All 256 threads,
+// 8 granules per thread per pass (2 048 per round); a round is repeated until every thread's tags match.
+template <typename SINK>
+__device__ __forceinline__ bool dec_poll(const dec_rsrc_t r, const unsigned first, const int count, const unsigned tag, unsigned* sync, SINK sink) {
+    const int tid = threadIdx.x;
+    for (int base = 0; base < count; base += DEC_THREADS * 8) {
+        u64 v[8];
+        for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = base + k * DEC_THREADS + tid;
+                if (i < count) { v[k] = ld8(r, (first + i) * 8); ok = ok && (unsigned)(v[k] >> 32) == tag; }
+            }
+            if (__syncthreads_and(ok)) break;
+            if (spins > (1u << 20)) {                            // never hang the chip
+                if (tid == 0) __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+            if ((spins & 3) == 3) __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + k * DEC_THREADS + tid;
+            if (i < count) sink(i, (unsigned)v[k]);
         }
     }
-    __syncthreads();
+    return true;
 }
 
 // ---- LayerNorm of one row by one wave (mtn.py:111-114: unbiased std, eps added to std): lane holds 4 consecutive floats per 256 columns;
 // the result goes out as bf16 through `put(column, four values)` (an LDS image, or global memory for the final norm)
+// the gains / biases of a lane's columns (asked for before the row has arrived)
+struct DecLnGains { float4 a[4], b[4]; };
+__device__ __forceinline__ void dec_ln_gains(DecLnGains& g, const float* __restrict__ a2, const float* __restrict__ b2, const int d, const int lane) {
+    const int nv = (d + 255) >> 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        const bool ok = i < nv && c < d;
+        g.a[i] = ok ? *(const float4*)(a2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        g.b[i] = ok ? *(const float4*)(b2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 template <typename PUT>
-__device__ __forceinline__ void dec_ln_row(const dec_rsrc_t rx, const unsigned row_off, const float* __restrict__ a2, const float* __restrict__ b2,
-                                           const float eps, const int d, const int lane, PUT put) {
+__device__ __forceinline__ void dec_ln_row(const float* xrow /* LDS, fp32 [d] */, const DecLnGains& g, const float eps, const int d, const int lane, PUT put) {
     float4 v[4];                                   // d <= 1024
     const int nv = (d + 255) >> 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = (lane + 64 * i) * 4;
-        if (i < nv && c < d) { const uint4 q = ld16(rx, row_off + c * 4); v[i] = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)); }
-        else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = (i < nv && c < d) ? *(const float4*)(xrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float s = 0.f;
 #pragma unroll
@@ -92,7 +125,7 @@ __device__ __forceinline__ void dec_ln_row(const dec_rsrc_t rx, const unsigned r
     for (int i = 0; i < 4; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (i < nv && c < d) {
-            const float4 ga = *(const float4*)(a2 + c), gb = *(const float4*)(b2 + c);
+            const float4 ga = g.a[i], gb = g.b[i];
             put(c, make_float4(ga.x * (v[i].x - mean) * inv + gb.x, ga.y * (v[i].y - mean) * inv + gb.y, ga.z * (v[i].z - mean) * inv + gb.z, ga.w * (v[i].w - mean) * inv + gb.w));
         }
     }
@@ -157,11 +190,13 @@ __device__ __forceinline__ f32x4_t dec_w_mma(const DecWRegs& R, const DecWPlan& 
 // LDS layout (bytes)
 #define DEC_ACT_OFF 0                 /* activations image: W x (K * 2 + 16), K <= 4096: 8 x 8208 = 65 664 */
 #define DEC_RED_OFF 66048             /* partial tiles: 4 waves x 16 features x 8 rows fp32 = 2 048 */
-#define DEC_Q_OFF 68096               /* unit stages: q (fp32, <= 128) */
-#define DEC_SC_OFF 68608              /* scores / probabilities: <= 1024 keys fp32 */
-#define DEC_PART_OFF 72704            /* PV partials: (256 / (dk / 4)) key parts x dk columns fp32 = 4 096 bytes */
-#define DEC_MISC_OFF 76800            /* reductions: 16 floats */
-#define DEC_LDS 76928
+#define DEC_Q_OFF 68096               /* unit stages: q (fp32, <= 128) + the newest row's k and v of this head (self-attention): 3 x 128 floats */
+#define DEC_SC_OFF 69632              /* scores / probabilities: <= 1024 keys fp32 */
+#define DEC_PART_OFF 73728            /* PV partials: (256 / (dk / 4)) key parts x dk columns fp32 = 4 096 bytes */
+#define DEC_MISC_OFF 77824            /* reductions: 16 floats */
+#define DEC_XS_OFF 77952              /* this workgroup's columns of the residual stream: W x 64 fp32 = 2 048 */
+#define DEC_XF_OFF 80000              /* the residual rows a stage normalises: W x d fp32 <= 8 x 1024 x 4 = 32 768 */
+#define DEC_LDS 112768
 
 __device__ __forceinline__ float dec_block_max(float v, float* red, const int tid) {
     // wave max by swizzles, then across the four waves through LDS
@@ -186,34 +221,50 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
     const int G = gridDim.x, wg = blockIdx.x;
     const int W = A.W, d = A.d, dk = d / A.h, dff = A.d_ff;
     const int pos = *A.pos;
-    const dec_rsrc_t rX = dec_rsrc(A.x, (unsigned)W * d * 4);          // [W][d] fp32 residual stream
-    const dec_rsrc_t rQ = dec_rsrc(A.q, (unsigned)W * d * 2);          // [W][d] bf16
-    const dec_rsrc_t rO = dec_rsrc(A.o, (unsigned)W * d * 2);
-    const dec_rsrc_t rH = dec_rsrc(A.hid, (unsigned)W * dff * 2);      // [W][d_ff] bf16
+    const unsigned gen = (A.sync[0] + 1u) << 8;                          // this launch's generation (advanced by workgroup 0 at the end)
+    const dec_rsrc_t rX = dec_rsrc(A.xg, (unsigned)W * d * 8);          // [W][d] granules: fp32 residual stream
+    const dec_rsrc_t rQ = dec_rsrc(A.qg, (unsigned)W * 3 * d * 4);      // [W][3d/2] granules: q | k | v of the newest row, bf16 pairs
+    const dec_rsrc_t rO = dec_rsrc(A.og, (unsigned)W * d * 4);          // [W][d/2]
+    const dec_rsrc_t rH = dec_rsrc(A.hg, (unsigned)W * dff * 4);        // [W][d_ff/2]
     unsigned char* act = smem + DEC_ACT_OFF;
     float* red = (float*)(smem + DEC_RED_OFF);
     float* qs = (float*)(smem + DEC_Q_OFF);
     float* sc = (float*)(smem + DEC_SC_OFF);
     float* part = (float*)(smem + DEC_PART_OFF);
     float* misc = (float*)(smem + DEC_MISC_OFF);
+    float* xs = (float*)(smem + DEC_XS_OFF);                             // [W][per_x]: this workgroup's columns of x
+    float* xf = (float*)(smem + DEC_XF_OFF);                             // [W][d]
     const float scale = rsqrtf((float)dk);
-    unsigned epoch = 0;
-    u64* dbg = (A.dbg && wg == 0 && tid == 0) ? (u64*)A.dbg : nullptr;       // per stage: after the barrier / operands ready / computed / stores issued
+    const int per_x = ((d + G - 1) / G + 3) / 4 * 4;                     // the slice of every N = d stage (embed, output projections, FFN-2)
+    const int x0 = min(d, wg * per_x), x1 = min(d, x0 + per_x);
+    unsigned last_x_tag = 0;
+    u64* dbg = (A.dbg && wg == 0 && tid == 0) ? (u64*)A.dbg : nullptr;       // per stage: entered / operands arrived / computed / published
 
     DecWRegs R;
     DecWPlan plan;
+    DecLnGains lng;
+    float4 bpre[2];                                                       // the biases of this thread's epilogue quads
     int n0 = 0, n1 = 0;
-    // what the stage's weight prefetch needs is a function of the stage descriptor and the workgroup's place alone
+    // everything a stage can ask for BEFORE its operands exist: the workgroup's weight rows, LayerNorm gains, biases
     auto prefetch = [&](const mtn_decode_stage& S) {
         plan.tile = -1; n0 = n1 = 0;
-        if (S.kind == MTN_DEC_SELF_QKV || S.kind == MTN_DEC_OUT || S.kind == MTN_DEC_FFN1 || S.kind == MTN_DEC_FFN2) {
-            const int per = ((S.N + G - 1) / G + 3) / 4 * 4;       // a multiple of 4 features: outputs leave as 8-byte stores of four bf16
+        const bool slice = S.kind == MTN_DEC_SELF_QKV || S.kind == MTN_DEC_OUT || S.kind == MTN_DEC_FFN1 || S.kind == MTN_DEC_FFN2;
+        if (slice) {
+            const int per = ((S.N + G - 1) / G + 3) / 4 * 4;       // a multiple of 4 features: outputs leave as pairs of granules
             n0 = min(S.N, wg * per); n1 = min(S.N, n0 + per);
             if (n1 > n0) { plan = dec_w_plan(n1 - n0, S.K, wave); dec_w_issue(R, plan, (const bf16_t*)S.w, n0, n1, S.K, lane); }
+            const int S4 = (n1 - n0) >> 2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = tid + u * DEC_THREADS;
+                bpre[u] = i < S4 * W ? *(const float4*)(S.bias + n0 + (i % S4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         } else if (S.kind == MTN_DEC_CROSS && wg < W * A.h) {
             n0 = (wg % A.h) * dk; n1 = n0 + dk;
             plan = dec_w_plan(dk, S.K, wave); dec_w_issue(R, plan, (const bf16_t*)S.w, n0, n1, S.K, lane);
+            bpre[0].x = tid < dk ? S.bias[n0 + tid] : 0.f;
         }
+        if (S.kind == MTN_DEC_SELF_QKV || S.kind == MTN_DEC_FFN1 || S.kind == MTN_DEC_CROSS || S.kind == MTN_DEC_FINAL) dec_ln_gains(lng, S.ln_a, S.ln_b, d, lane);
     };
     // the four waves' partial tiles -> LDS; then thread (feature, row) sums them in a fixed order.  red[wave][feature 0..15][row 0..7]
     auto spill = [&](const f32x4_t& acc) {
@@ -233,143 +284,171 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
     const int n_stages = A.n_stages;
     mtn_decode_stage S = KA.stages[0];
     prefetch(S);
-    for (int si = 0; si < n_stages; ++si) {
-        if (si > 0) { ++epoch; dec_grid_sync(A.sync, epoch * (unsigned)G); }
+    bool alive = true;
+    for (int si = 0; si < n_stages && alive; ++si) {
+        const unsigned tag = gen | (unsigned)(si + 1);
         if (dbg) dbg[si * 4 + 0] = wall_clock64();
         const int K = S.K, pitch = K * 2 + 16;
         switch (S.kind) {
-        case MTN_DEC_EMBED: {          // x = lut[token] * sqrt(d) + PE[pos]   (mtn.py:289, 308; eval: no dropout): column quads dealt to the workgroups
-            const int per = ((d / 4 + G - 1) / G);
-            const int c0 = wg * per, c1 = min(d / 4, c0 + per);
-            for (int i = tid; i < W * (c1 - c0); i += DEC_THREADS) {
-                const int j = i / (c1 - c0), c = 4 * (c0 + i % (c1 - c0));
-                const float4 e = *(const float4*)(A.lut + (size_t)A.tokens[j] * d + c), pe = *(const float4*)(A.pe + (size_t)pos * d + c);
-                st16(rX, ((unsigned)j * d + c) * 4, make_uint4(__float_as_uint(e.x * A.emb_scale + pe.x), __float_as_uint(e.y * A.emb_scale + pe.y),
-                                                               __float_as_uint(e.z * A.emb_scale + pe.z), __float_as_uint(e.w * A.emb_scale + pe.w)));
+        case MTN_DEC_EMBED: {          // x = lut[token] * sqrt(d) + PE[pos]   (mtn.py:289, 308; eval: no dropout): this workgroup's columns
+            const int nx = x1 - x0;
+            for (int i = tid; i < W * nx; i += DEC_THREADS) {
+                const int j = i / nx, c = x0 + i % nx;
+                const float y = A.lut[(size_t)A.tokens[j] * d + c] * A.emb_scale + A.pe[(size_t)pos * d + c];
+                xs[j * per_x + (c - x0)] = y;
+                dec_pub(rX, (unsigned)j * d + c, __float_as_uint(y), tag);
             }
+            last_x_tag = tag;
         } break;
         case MTN_DEC_SELF_QKV: case MTN_DEC_FFN1: {    // LayerNorm(x) of every row -> act; features n0..n1 of the Linear
+            alive = dec_poll(rX, 0, W * d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+            __syncthreads();
+            if (dbg) dbg[si * 4 + 1] = wall_clock64();
             for (int j = wave; j < W; j += 4) {
                 bf16_t* row = (bf16_t*)(act + (size_t)j * pitch);
-                dec_ln_row(rX, (unsigned)j * d * 4, S.ln_a, S.ln_b, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
+                dec_ln_row(xf + (size_t)j * d, lng, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
             }
             __syncthreads();
-            if (dbg) dbg[si * 4 + 1] = wall_clock64();
             f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, W, lane);
             spill(acc);
             if (dbg) dbg[si * 4 + 2] = wall_clock64();
-            const int Sn = n1 - n0, S4 = Sn >> 2;                          // (slices are multiples of 4 features: one 8-byte store of four bf16)
-            const dec_rsrc_t rC = dec_rsrc(S.cache, (unsigned)W * A.L * 2 * d * 2);
-            for (int i = tid; i < S4 * W; i += DEC_THREADS) {
-                const int f = (i % S4) * 4, r = i / S4, n = n0 + f;
-                float4 y;
-                y.x = gather(Sn, f, r) + S.bias[n]; y.y = gather(Sn, f + 1, r) + S.bias[n + 1];
-                y.z = gather(Sn, f + 2, r) + S.bias[n + 2]; y.w = gather(Sn, f + 3, r) + S.bias[n + 3];
-                if (S.kind == MTN_DEC_FFN1) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); st8(rH, ((unsigned)r * S.N + n) * 2, dec_pack4(y)); }
-                else if (n < d) st8(rQ, ((unsigned)r * d + n) * 2, dec_pack4(y));
-                else st8(rC, (((unsigned)r * A.L + pos) * (2 * d) + (n - d)) * 2, dec_pack4(y));         // k | v of the new row into the prefix cache
-            }
-        } break;
-        case MTN_DEC_OUT: case MTN_DEC_FFN2: {         // act = attention output (OUT) | FFN hidden (FFN2), bf16 [W][K]; + bias + residual -> x
-            const dec_rsrc_t rS = S.kind == MTN_DEC_OUT ? rO : rH;
-            const int K8 = K / 8;
-            for (int i = tid; i < W * K8; i += DEC_THREADS) {
-                const int j = i / K8, c = i % K8;
-                *(uint4*)(act + (size_t)j * pitch + c * 16) = ld16(rS, ((unsigned)j * K + c * 8) * 2);
-            }
-            const int Sn = n1 - n0, S4 = Sn >> 2;
-            // the residual quads this thread will add: asked for now, beside the operand rows
-            uint4 xr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = tid + u * DEC_THREADS;
-                if (i < S4 * W) xr[u] = ld16(rX, ((unsigned)(i / S4) * d + n0 + (i % S4) * 4) * 4);
-            }
-            __syncthreads();
-            if (dbg) dbg[si * 4 + 1] = wall_clock64();
-            f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, W, lane);
-            spill(acc);
-            if (dbg) dbg[si * 4 + 2] = wall_clock64();
+            const int Sn = n1 - n0, S4 = Sn >> 2;                          // (slices are multiples of 4 features: two granules of a bf16 pair each)
+            const dec_rsrc_t rD = S.kind == MTN_DEC_FFN1 ? rH : rQ;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int i = tid + u * DEC_THREADS;
                 if (i < S4 * W) {
                     const int f = (i % S4) * 4, r = i / S4, n = n0 + f;
-                    const float y0 = gather(Sn, f, r) + S.bias[n] + __uint_as_float(xr[u].x), y1 = gather(Sn, f + 1, r) + S.bias[n + 1] + __uint_as_float(xr[u].y);
-                    const float y2 = gather(Sn, f + 2, r) + S.bias[n + 2] + __uint_as_float(xr[u].z), y3 = gather(Sn, f + 3, r) + S.bias[n + 3] + __uint_as_float(xr[u].w);
-                    st16(rX, ((unsigned)r * d + n) * 4, make_uint4(__float_as_uint(y0), __float_as_uint(y1), __float_as_uint(y2), __float_as_uint(y3)));
+                    float y0 = gather(Sn, f, r) + bpre[u].x, y1 = gather(Sn, f + 1, r) + bpre[u].y, y2 = gather(Sn, f + 2, r) + bpre[u].z, y3 = gather(Sn, f + 3, r) + bpre[u].w;
+                    if (S.kind == MTN_DEC_FFN1) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
+                    const unsigned g0 = ((unsigned)r * S.N + n) >> 1;
+                    dec_pub(rD, g0, dec_pack2(y0, y1), tag);
+                    dec_pub(rD, g0 + 1, dec_pack2(y2, y3), tag);
                 }
             }
+        } break;
+        case MTN_DEC_OUT: case MTN_DEC_FFN2: {         // act = attention output (OUT) | FFN hidden (FFN2), bf16 pairs [W][K/2]; + bias + residual -> x
+            const dec_rsrc_t rS = S.kind == MTN_DEC_OUT ? rO : rH;
+            const int K2 = K >> 1;
+            alive = dec_poll(rS, 0, W * K2, gen | (unsigned)si, A.sync, [&](int i, unsigned v) { *(unsigned*)(act + (size_t)(i / K2) * pitch + (i % K2) * 4) = v; });
+            __syncthreads();
+            if (dbg) dbg[si * 4 + 1] = wall_clock64();
+            f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, W, lane);
+            spill(acc);
+            if (dbg) dbg[si * 4 + 2] = wall_clock64();
+            const int Sn = n1 - n0, S4 = Sn >> 2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = tid + u * DEC_THREADS;
+                if (i < S4 * W) {
+                    const int f = (i % S4) * 4, r = i / S4, n = n0 + f;
+                    float* xr = xs + r * per_x + f;                          // (n0 == x0: the N = d slices coincide)
+                    const float b4[4] = {bpre[u].x, bpre[u].y, bpre[u].z, bpre[u].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float y = gather(Sn, f + k, r) + b4[k] + xr[k];
+                        xr[k] = y;
+                        dec_pub(rX, (unsigned)r * d + n + k, __float_as_uint(y), tag);
+                    }
+                }
+            }
+            last_x_tag = tag;
         } break;
         case MTN_DEC_CROSS: case MTN_DEC_SELF_ATT: {
             if (wg >= W * A.h) break;
             const int j = wg / A.h, hd = wg % A.h;
             const bool self = S.kind == MTN_DEC_SELF_ATT;
             const int m = self ? pos + 1 : S.m;
-            const dec_rsrc_t rC = dec_rsrc(S.cache, self ? (unsigned)W * A.L * 2 * d * 2 : 0u);
-            // this thread's first key row (one key per thread, 16-byte pieces): requested before q is ready.  Cross: hoisted K|V rows
-            // [j * m + t][2d] (read-only, plain loads); self: cache row of position t of THIS hypothesis' prefix = slot anc[j][t]
-            // (agent-scope loads: the newest row was written by other workgroups one stage ago)
-            uint4 kr[16];                                        // dk <= 128: 16 pieces of 8 bf16
             const int npc = dk / 8;
-            {
-                const int t = tid;
-                if (t < m) {
-                    if (self) {
-                        const unsigned off = (((unsigned)A.anc[j * A.L + t] * A.L + t) * (2 * d) + hd * dk) * 2;
+            const int c4 = tid % (dk / 4), qt = tid / (dk / 4), nq = DEC_THREADS / (dk / 4);
+            // read-only operands of the attention, requested before x has arrived: this thread's key row (one key per thread, 16-byte pieces),
+            // its mask byte, and its V quads of the first 8 * nq keys.  Cross: hoisted K|V rows [j * m + t][2d]; self: cache rows of positions
+            // < pos of THIS hypothesis' prefix (slot anc[j][t]: written by earlier launches) — the newest row arrives as granules
+            uint4 kr[16];
+            u64 vq[8];
+            unsigned char mb = 1;
+            auto krow_of = [&](int t) -> const uint4* {
+                return self ? (const uint4*)((const bf16_t*)S.cache + ((size_t)A.anc[j * A.L + t] * A.L + t) * (2 * d) + hd * dk)
+                            : (const uint4*)((const bf16_t*)S.kv + ((size_t)j * S.m + t) * (2 * d) + hd * dk);
+            };
+            const int m_old = self ? pos : m;                            // keys whose rows are in memory already
+            if (tid < m_old) {
+                const uint4* kp = krow_of(tid);
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = ld16(rC, off + c * 16);
-                    } else {
-                        const uint4* krow = (const uint4*)((const bf16_t*)S.kv + ((size_t)j * S.m + t) * (2 * d) + hd * dk);
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = krow[c];
-                    }
-                }
+                for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = kp[c];
+                if (!self && S.mask) mb = S.mask[(size_t)j * S.mask_stride + tid];
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = qt + u * nq;
+                vq[u] = t < m_old ? ((const u64*)((const bf16_t*)krow_of(t) + d))[c4] : 0;
+            }
+            float* knew = qs + 128; float* vnew = qs + 256;               // self: the newest row's k and v of this head
             if (!self) {
                 // q_h = LayerNorm(x_j) W_q,h^T + b_q,h  (the head's dk rows of W_q: prefetched), rounded to bf16 as the training kernels store q
-                if (wave == 0) dec_ln_row(rX, (unsigned)j * d * 4, S.ln_a, S.ln_b, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)((bf16_t*)act + c) = dec_pack4(y); });
+                alive = dec_poll(rX, (unsigned)j * d, d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
                 __syncthreads();
                 if (dbg) dbg[si * 4 + 1] = wall_clock64();
+                if (wave == 0) dec_ln_row(xf, lng, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)((bf16_t*)act + c) = dec_pack4(y); });
+                __syncthreads();
                 f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, 1, lane);
                 spill(acc);
-                if (tid < dk) qs[tid] = bf16_to_f32(f32_to_bf16(gather(dk, tid, 0) + S.bias[n0 + tid]));
+                if (tid < dk) qs[tid] = bf16_to_f32(f32_to_bf16(gather(dk, tid, 0) + bpre[0].x));
             } else {
-                if (tid < dk / 4) {
-                    const u64 q4 = ld8(rQ, ((unsigned)j * d + hd * dk + tid * 4) * 2);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) qs[4 * tid + k] = bf16_to_f32((bf16_t)(q4 >> (16 * k)));
-                }
-                if (dbg) dbg[si * 4 + 1] = wall_clock64();
+                // q_h, and k_h | v_h of the newest row, arrive as the projection stage's granules (gathered below)
             }
             __syncthreads();
+            if (self) {
+                // three ranges of dk / 2 granules: q at column hd*dk, k at d + hd*dk, v at 2d + hd*dk of row j
+                const int hp = dk / 2;
+                for (unsigned spins = 0;; ++spins) {
+                    bool ok = true;
+                    u64 g = 0;
+                    if (tid < 3 * hp) {
+                        const int which = tid / hp, i = tid % hp;
+                        g = ld8(rQ, (((unsigned)j * 3 * d + which * d + hd * dk) / 2 + i) * 8);
+                        ok = (unsigned)(g >> 32) == (gen | (unsigned)si);
+                    }
+                    if (__syncthreads_and(ok)) {
+                        if (tid < 3 * hp) {
+                            const int which = tid / hp, i = tid % hp;
+                            float* dst = which == 0 ? qs : (which == 1 ? knew : vnew);
+                            dst[2 * i] = __uint_as_float(((unsigned)g) << 16); dst[2 * i + 1] = __uint_as_float(((unsigned)g) & 0xffff0000u);
+                            if (which) ((unsigned*)((bf16_t*)S.cache + ((size_t)j * A.L + pos) * (2 * d) + (which - 1) * d + hd * dk))[i] = (unsigned)g;   // into the prefix cache, for the steps to come
+                        }
+                        break;
+                    }
+                    if (spins > (1u << 20)) { if (tid == 0) __hip_atomic_store(A.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); alive = false; break; }
+                }
+                __syncthreads();
+                if (dbg) dbg[si * 4 + 1] = wall_clock64();
+            }
             float mx = -3.0e38f;
             for (int t = tid; t < m; t += DEC_THREADS) {
-                if (t >= DEC_THREADS) {                              // keys beyond the first 256: loaded here
-                    if (self) {
-                        const unsigned off = (((unsigned)A.anc[j * A.L + t] * A.L + t) * (2 * d) + hd * dk) * 2;
+                float s_ = 0.f;
+                if (self && t == pos) {
+                    for (int c = 0; c < dk; ++c) s_ += qs[c] * knew[c];
+                } else {
+                    if (t >= DEC_THREADS) {                              // keys beyond the first 256: loaded here
+                        const uint4* kp = krow_of(t);
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = ld16(rC, off + c * 16);
-                    } else {
-                        const uint4* krow = (const uint4*)((const bf16_t*)S.kv + ((size_t)j * S.m + t) * (2 * d) + hd * dk);
+                        for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = kp[c];
+                        mb = (!self && S.mask) ? S.mask[(size_t)j * S.mask_stride + t] : 1;
+                    }
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = krow[c];
+                    for (int c = 0; c < 16; ++c) {
+                        if (c < npc) {
+                            const unsigned w4[4] = {kr[c].x, kr[c].y, kr[c].z, kr[c].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                s_ += qs[c * 8 + 2 * e] * __uint_as_float(w4[e] << 16) + qs[c * 8 + 2 * e + 1] * __uint_as_float(w4[e] & 0xffff0000u);
+                        }
                     }
                 }
-                float s = 0.f;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (c < npc) {
-                        const unsigned w4[4] = {kr[c].x, kr[c].y, kr[c].z, kr[c].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            s += qs[c * 8 + 2 * e] * __uint_as_float(w4[e] << 16) + qs[c * 8 + 2 * e + 1] * __uint_as_float(w4[e] & 0xffff0000u);
-                    }
-                }
-                s *= scale;
-                if (!self && S.mask && S.mask[(size_t)j * S.mask_stride + t] == 0) s = -1.0e9f;      // masked_fill(mask == 0, -1e9), mtn.py:226
-                sc[t] = s;
-                mx = fmaxf(mx, s);
+                s_ *= scale;
+                if (mb == 0) s_ = -1.0e9f;                               // masked_fill(mask == 0, -1e9), mtn.py:226
+                sc[t] = s_;
+                mx = fmaxf(mx, s_);
             }
             mx = dec_block_max(mx, misc, tid);
             float sum = 0.f;
@@ -377,50 +456,51 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
             sum = dec_block_sum(sum, misc, tid);
             const float inv = 1.0f / sum;
             // o[c] = sum_t P[t] V[t][c], P rounded to bf16 (the training kernels feed P to the MFMA in bf16): thread = (four columns, key part)
-            const int c4 = tid % (dk / 4), qt = tid / (dk / 4), nq = DEC_THREADS / (dk / 4);
             float o[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int t0 = qt; t0 < m; t0 += 4 * nq) {               // four keys' V quads in flight per round trip
-                u64 v4[4];
+            for (int u = 0; u * nq + qt < m; ++u) {
+                const int t = qt + u * nq;
+                const float pr = bf16_to_f32(f32_to_bf16(sc[t] * inv));
+                if (self && t == pos) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + u * nq;
-                    v4[u] = 0;
-                    if (t < m) {
-                        if (self) v4[u] = ld8(rC, (((unsigned)A.anc[j * A.L + t] * A.L + t) * (2 * d) + d + hd * dk + c4 * 4) * 2);
-                        else v4[u] = ((const u64*)((const bf16_t*)S.kv + ((size_t)j * S.m + t) * (2 * d) + d + hd * dk))[c4];
-                    }
-                }
+                    for (int k = 0; k < 4; ++k) o[k] += pr * vnew[c4 * 4 + k];
+                } else {
+                    u64 v4 = 0;
+                    if (u < 8) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + u * nq;
-                    if (t < m) {
-                        const float p = bf16_to_f32(f32_to_bf16(sc[t] * inv));
+                        for (int q = 0; q < 8; ++q) if (q == u) v4 = vq[q];
+                    } else v4 = ((const u64*)((const bf16_t*)krow_of(t) + d))[c4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] += p * bf16_to_f32((bf16_t)(v4[u] >> (16 * k)));
-                    }
+                    for (int k = 0; k < 4; ++k) o[k] += pr * bf16_to_f32((bf16_t)(v4 >> (16 * k)));
                 }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) part[qt * dk + c4 * 4 + k] = o[k];
             __syncthreads();
             if (dbg) dbg[si * 4 + 2] = wall_clock64();
-            if (tid < dk / 4) {
-                float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int q = 0; q < nq; ++q) { y.x += part[q * dk + tid * 4]; y.y += part[q * dk + tid * 4 + 1]; y.z += part[q * dk + tid * 4 + 2]; y.w += part[q * dk + tid * 4 + 3]; }
-                st8(rO, ((unsigned)j * d + hd * dk + tid * 4) * 2, dec_pack4(y));
+            if (tid < dk / 2) {
+                float y0 = 0.f, y1 = 0.f;
+                for (int q = 0; q < nq; ++q) { y0 += part[q * dk + tid * 2]; y1 += part[q * dk + tid * 2 + 1]; }
+                dec_pub(rO, ((unsigned)j * d + hd * dk) / 2 + tid, dec_pack2(y0, y1), tag);
             }
         } break;
         case MTN_DEC_FINAL: {          // the decoder's final LayerNorm (mtn.py:161) -> the generator's bf16 operand (read by the NEXT kernel: plain stores)
-            if (wg < W && wave == 0) {
-                bf16_t* row = (bf16_t*)A.out_lp + (size_t)wg * d;
-                dec_ln_row(rX, (unsigned)wg * d * 4, S.ln_a, S.ln_b, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
+            if (wg < W) {
+                alive = dec_poll(rX, (unsigned)wg * d, d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+                __syncthreads();
+                if (wave == 0) {
+                    bf16_t* row = (bf16_t*)A.out_lp + (size_t)wg * d;
+                    dec_ln_row(xf, lng, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
+                }
             }
         } break;
         default: break;
         }
         if (dbg) dbg[si * 4 + 3] = wall_clock64();
+        __syncthreads();                                                    // (LDS images are reused by the next stage)
         if (si + 1 < n_stages) { S = KA.stages[si + 1]; prefetch(S); }
     }
+    // workgroup 0 has seen the last stage's x of every producer: every workgroup has read the generation long ago
+    if (wg == 0 && tid == 0) A.sync[0] = gen >> 8;
 }
 
 extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage* stages_device, int grid, void* stream) {
@@ -430,7 +510,8 @@ extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage*
     MTN_CHECK_ARG(a->h >= 1 && a->d % a->h == 0 && (a->d / a->h == 32 || a->d / a->h == 64 || a->d / a->h == 128), "head size 32, 64 or 128");
     MTN_CHECK_ARG(a->n_stages >= 1 && a->L >= 1 && a->L <= 1024, "bad stage count / maximum length");
     MTN_CHECK_ARG(grid >= a->W * a->h && grid <= 256, "grid: at least one workgroup per (hypothesis, head), at most one per CU");
-    MTN_CHECK_ARG(a->x && a->q && a->o && a->hid && a->out_lp && a->tokens && a->lut && a->pe && a->pos && a->anc && a->sync, "null buffer");
+    MTN_CHECK_ARG(a->xg && a->qg && a->og && a->hg && a->out_lp && a->tokens && a->lut && a->pe && a->pos && a->anc && a->sync, "null buffer");
+    MTN_CHECK_ARG(a->W * a->d <= 4096 && a->n_stages <= 250, "W x d_model <= 4096; at most 250 stages");
     MTN_CHECK_ARG(a->d_ff >= a->d && a->d_ff <= 4096 && a->d_ff % 32 == 0, "d_ff: a multiple of 32, at most 4096");
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
@@ -441,7 +522,6 @@ extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage*
         }
         attr = true;
     }
-    if (hipMemsetAsync(a->sync, 0, 4, s) != hipSuccess) { mtn_set_error("mtn_decode_step: memset failed"); return MTN_ERR_LAUNCH; }   // the arrival counter (sync[1], the timeout flag, is sticky)
     DecKernelArgs KA;
     KA.a = *a;
     KA.stages = stages_device;

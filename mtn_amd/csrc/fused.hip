@@ -733,7 +733,7 @@ extern "C" int mtn_fused_enable(int on) {
     return prev;
 }
 static bool fh_env_off() {
-    if (fh_enabled < 0) { const char* e = getenv("MTN_FUSED"); fh_enabled = (e && e[0] == '0') ? 0 : 1; }
+    if (fh_enabled < 0) fh_enabled = 1;          // (mtn_fused_enable() switches the fused launches off / on: A/B measurements, tests)
     return fh_enabled == 0;
 }
 
@@ -828,7 +828,7 @@ static bool fh_plan(int n_mha, const mtn_mha_args* mha, int n_ffn, const mtn_ffn
         M.kind = a.self_attn ? FH_SELF : (a.kv_ready ? FH_CROSS_READY : FH_CROSS_RAW);
         M.a = a.a; M.m = mm; M.blk = pl.blk; M.mt = pl.mt; M.late_v = pl.late_v;
         {   // key ranges per (sample, 16 query rows): all 8 waves of a workgroup that holds few pairs and a long memory
-            static const bool ksplit = [] { const char* e = getenv("MTN_FH_KSPLIT"); return !(e && e[0] == '0'); }();
+            const bool ksplit = true;
             const int npairs = pl.blk * ((a.a + 15) / 16), chunks = (M.m + 63) / 64;
             int nks = 1;
             if (ksplit && npairs <= 4 && chunks >= 4 && !a.self_attn && a.kv_ready) {     // (long memories projected ahead of the layer loop)

@@ -645,7 +645,7 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
     P.wide = false;
     for (int i = 0; i < n_mha; ++i) {
         const mtn_mha_args& A = mha[i];
-        static const int max_a = [] { const char* e = getenv("MTN_FB_MAX_A"); return e ? atoi(e) : 64; }();       // (A/B: 32 = round 2's limit)
+        const int max_a = 64;                     // (round 2's limit was 32: +12 % target tokens/s on AVSD-length answers, profiles/r03_i_ragged_corpus_ab.txt)
         if (A.d != FH_D || A.h != FH_D / FH_DK || !A.w_o_t || A.a > max_a || A.a < 1) return false;
         const bool self = A.self_attn != 0;
         const int m = self ? A.a : A.m, qa = A.mask_sq ? A.a : 1;
@@ -669,7 +669,7 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
             if (((A.B + b - 1) / b) * (FH_D / FH_DK) <= budget) break;
         }
         if (!blk) return false;
-        static const int ring_min = [] { const char* e = getenv("MTN_FB_RING_MIN"); return e ? atoi(e) : 192; }();
+        const int ring_min = 192;
         if (blk == 1 && !ring && !self && m >= ring_min && A.a <= 64) {
             // one sample per workgroup anyway (two would not fit): take the ring form, where BOTH four-wave teams work on the sample
             const int need = fb_lds_map(mt, m, qa * m, true).total;

@@ -1500,13 +1500,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tt_dma128_table_kernel(const TTHe
     else { tn_ = idx / Q.tiles_m; tm_ = idx - tn_ * Q.tiles_m; }
     AdamCoef coef;
     if (hdr->any) coef = adam_coef(hdr->state, hdr->grad_scale, hdr->beta1, hdr->beta2, hdr->eps);
-#ifdef MTN_TT_ABLATION
-    // measurement build (tools/tt_ablation.sh): bit 1 = no contraction (the optimiser epilogue alone, zero gradients), bit 2 = no epilogue
-    if (hdr->plain_tile_order & 2) P.K = 0;
-    if (hdr->plain_tile_order & 4) { S.p = nullptr; P.out_f32 = nullptr; }
-    if (hdr->plain_tile_order & 8) S.lpT = nullptr;              // no transposed compute-dtype copy
-    if (hdr->plain_tile_order & 16) S.lp = nullptr;              // no compute-dtype copy
-#endif
     BiasAdam bz{nullptr, nullptr, nullptr, nullptr};
     if (Q.bias_off >= 0) { bz.p = hdr->fp + Q.bias_off; bz.m = hdr->fm + Q.bias_off; bz.v = hdr->fv + Q.bias_off; bz.lp = hdr->flp ? hdr->flp + Q.bias_off : nullptr; }
     tt128_tile(P, S, hdr->lds_epilogue != 0, coef, tm_ * 128, tn_ * 128, smem, bz);
@@ -1844,7 +1837,7 @@ static int launch_dma_any(const GemmGroup& grp, int tiles, bool btr, hipStream_t
 // tile_start[] for a given tile shape; returns the total
 static int retile(GemmGroup& grp, int bm, int bn, bool xcd2d = false) {
     int tiles = 0;
-    const bool on = xcd2d && !grp.plain_tile_order && !(MTN_ENV("MTN_GEMM_XCD2D") && MTN_ENV("MTN_GEMM_XCD2D")[0] == '0');
+    const bool on = xcd2d && !grp.plain_tile_order;
     for (int i = 0; i < grp.count; ++i) {
         grp.tile_start[i] = tiles;
         const int tm = (grp.p[i].M + bm - 1) / bm, tn = (grp.p[i].N + bn - 1) / bn;
@@ -1921,10 +1914,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
                 const int tiles = retile(g2, 128, 128);
                 g_variant = V_DMA128X; g_variant_tiles = tiles;
                 if (lne) hipLaunchKernelGGL((gemm_dma128x_kernel<true, 16, true>), dim3(tiles), dim3(1024), G8_LDS + LNE_LDS_EXTRA, s, g2, *lne);
-                else if (MTN_ENV("MTN_GEMM_128X_NW8") != nullptr) {
-                    if (bt) hipLaunchKernelGGL((gemm_dma128x_kernel<true, 8>), dim3(tiles), dim3(512), G8_LDS, s, g2, NoLn{});
-                    else hipLaunchKernelGGL((gemm_dma128x_kernel<false, 8>), dim3(tiles), dim3(512), G8_LDS, s, g2, NoLn{});
-                } else {
+                else {                 // (sixteen waves: +0.5 % against eight, round 3)
                     if (bt) hipLaunchKernelGGL((gemm_dma128x_kernel<true, 16>), dim3(tiles), dim3(1024), G8_LDS, s, g2, NoLn{});
                     else hipLaunchKernelGGL((gemm_dma128x_kernel<false, 16>), dim3(tiles), dim3(1024), G8_LDS, s, g2, NoLn{});
                 }
@@ -1935,7 +1925,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
     }
     // B stored contraction-major ([K][N], b_trans = 1: dX = dY W with W as the forward pass keeps it): same kernel, the B tile is
     // brought as [k][columns] and its fragments come out of the transposing LDS read — bf16 only, N and ldb multiples of 8
-    bool btr_ok = bt && sizeof(T) == 2 && MTN_ENV("MTN_GEMM_NT_REG") == nullptr;
+    bool btr_ok = bt && sizeof(T) == 2;
     for (int i = 0; i < grp.count && btr_ok; ++i)
         btr_ok = grp.p[i].N % 8 == 0 && grp.p[i].ldb % 8 == 0 && (long)grp.p[i].K * grp.p[i].ldb * 2 < (1L << 31);
     if (lne && !(!at && dma_ok && (!bt || btr_ok))) {
@@ -1964,24 +1954,22 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
         }
         double c64 = (double)((t64 + 255) / 256) * (b64 / t64);
         // 257..512 tiles of 64x64 run in ONE round on half-size stages (two workgroups per CU, like the 32x32 tiles: x0.75)
-        if (t64 > 256 && t64 <= 512 && MTN_ENV("MTN_GEMM_NO_HALF") == nullptr && !(MTN_ENV("MTN_GEMM_C64H") && MTN_ENV("MTN_GEMM_C64H")[0] == '0')) c64 = 0.75 * b64 / 256.0;   // +0.3 % cfg2, +0.5 % at 64 samples (profiles/r03_o_c64h_ab.txt)
+        if (t64 > 256 && t64 <= 512) c64 = 0.75 * b64 / 256.0;   // +0.3 % cfg2, +0.5 % at 64 samples (profiles/r03_o_c64h_ab.txt)
         double c32 = 0.75 * b32 / 256.0;
         if (c32 < wg32max) c32 = wg32max;
         // half-size stages (256 B of contraction per row) double the resident workgroups: taken when the launch would
         // otherwise need a second round (64x64: one workgroup per CU at 128 KiB; 32x32: two at 64 KiB)
-        const bool half_ok = MTN_ENV("MTN_GEMM_NO_HALF") == nullptr;
+        const bool half_ok = true;
         const bool half_force = MTN_ENV("MTN_GEMM_FORCE_HALF") != nullptr;      // tests
         {   // eight waves pull a 64 x 64 workgroup's bytes faster than four did when the 0.75 above was fitted: the 64 x 64 cost is
             // weighted 0.8 (sweep in profiles/r03_ac_c64_scale_sweep.txt: cfg2 +0.3 %, batch 64 +2.1 % against 1.0; 0.5 loses)
-            const char* sc = MTN_ENV("MTN_GEMM_C64_SCALE");
-            c64 *= sc ? atof(sc) : 0.8;
+            c64 *= 0.8;
         }
         // (a ring of four half-size stages for long contractions was measured at -0.8 % on the cfg2 step, profiles/r03_x_deep_ring_ab.txt: not kept)
         if (f == 64 || (!f && c64 <= c32)) {
             const int t = retile(g2, 64, 64, true);
             if (half_force || (half_ok && t > 256)) {
-                if (lne || (MTN_ENV("MTN_GEMM_NW4") == nullptr && MTN_ENV("MTN_GEMM_NW4H") == nullptr)) return launch_dma_any<T, 64, 64, 256, 2, 8>(g2, t, bt, s, lne);
-                return launch_dma_any<T, 64, 64, 256>(g2, t, bt, s);
+                return launch_dma_any<T, 64, 64, 256, 2, 8>(g2, t, bt, s, lne);       // (eight waves: four were the rounds 1-2 form)
             }
             if constexpr (sizeof(T) == 2) {
                 // sixteen waves (a 4 x 4 grid of 16 x 16 wave tiles): cfg2 step +0.6 %, batch 64 +0.4 % against eight (profiles/r04_s_nw16_ab.txt).
@@ -1990,8 +1978,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
                 const int m16 = n16 ? atoi(n16) : 3;
                 if (((m16 & 1) && !lne) || ((m16 & 2) && lne)) return launch_dma_any<T, 64, 64, 512, 2, 16>(g2, t, bt, s, lne);
             }
-            if (lne || MTN_ENV("MTN_GEMM_NW4") == nullptr) return launch_dma_any<T, 64, 64, 512, 2, 8>(g2, t, bt, s, lne);     // eight waves: see the kernel
-            return launch_dma_any<T, 64, 64, 512>(g2, t, bt, s);
+            return launch_dma_any<T, 64, 64, 512, 2, 8>(g2, t, bt, s, lne);     // eight waves: see the kernel
         }
         if (f == 3264) return launch_dma_any<T, 32, 64, 512>(g2, retile(g2, 32, 64, true), bt, s);
         const int t = retile(g2, 32, 32, true);
@@ -2000,11 +1987,11 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
     } else if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, s, grp, NoAdam{});
     else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, s, grp, NoAdam{});
     else if (at && bt) {
-        bool ttd = (sizeof(T) == 2) && MTN_ENV("MTN_GEMM_TT_REG") == nullptr;      // LDS-DMA + transposing LDS reads (bf16)
+        bool ttd = sizeof(T) == 2;      // LDS-DMA + transposing LDS reads (bf16)
         for (int i = 0; i < grp.count; ++i)
             ttd = ttd && grp.p[i].M % 8 == 0 && grp.p[i].N % 8 == 0 && (long)grp.p[i].K * grp.p[i].lda * 2 < (1L << 31) &&
                   (long)grp.p[i].K * grp.p[i].ldb * 2 < (1L << 31);
-        bool ttb = ttd && MTN_ENV("MTN_GEMM_TT64") == nullptr;                    // 128x128 tiles when every problem fills them
+        bool ttb = ttd;                    // 128x128 tiles when every problem fills them
         int t128 = 0;
         for (int i = 0; i < grp.count; ++i) {
             ttb = ttb && grp.p[i].M >= 128 && grp.p[i].N >= 128;
@@ -2023,7 +2010,7 @@ static int launch_gemm(const GemmGroup& grp, const AdamGroup& adam, int total_ti
                 const int tiles = retile(g2, 128, 128);
                 g_variant = V_TT_DMA128; g_variant_tiles = tiles;
                 AdamGroup a2 = adam;
-                a2.lds_epilogue = adam.any && MTN_ENV("MTN_ADAM_EPILOGUE_DIRECT") == nullptr;
+                a2.lds_epilogue = adam.any;
                 for (int i = 0; i < grp.count; ++i) {
                     const AdamSlot& sl = adam.a[i];
                     if (!sl.p) continue;
@@ -2055,7 +2042,7 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     int n_lne = 0;
     bool lne_emit = false;
     grp.count = count;
-    grp.plain_tile_order = MTN_ENV("MTN_GEMM_PLAIN_TILES") != nullptr;
+    grp.plain_tile_order = 0;
     grp.epi_pre = !(MTN_ENV("MTN_GEMM_EPI_PRE") && MTN_ENV("MTN_GEMM_EPI_PRE")[0] == '0');
     int tiles = 0;
     const int align = (dtype == MTN_BF16) ? 8 : 4;
@@ -2117,11 +2104,10 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     // LDS-DMA path: row-major operands below 2 GiB, no row-sum side output, and a grid that fits the chip in about two
     // rounds (128 KiB of LDS = one workgroup per CU): large grids are throughput-bound and do better on the
     // register-staged kernel at 5 workgroups per CU.
-    const char* dmax = MTN_ENV("MTN_GEMM_DMA_MAX_TILES");
     // (b_trans = 1: the register-staged <N,T> fallback is 1.5x slower than <N,N> — 33.7 vs 21.7 us on the memories' dX launch,
     //  the LDS-DMA kernel with half stages 24.2: tools/nt_gemm_probe.py — so the LDS-DMA kernel keeps those too)
     // (a launch with a LayerNorm epilogue stays on the LDS-DMA kernels whatever its grid: the epilogue lives there)
-    bool dma_ok = !problems[0].rowsum_out && (n_lne > 0 || tiles <= (dmax ? atoi(dmax) : (problems[0].b_trans && !problems[0].a_trans ? 4096 : 640)));
+    bool dma_ok = !problems[0].rowsum_out && (n_lne > 0 || tiles <= (problems[0].b_trans && !problems[0].a_trans ? 4096 : 640));
     const long esz = (dtype == MTN_BF16) ? 2 : 4;
     for (int i = 0; i < count; ++i) {
         const mtn_gemm_problem& p = problems[i];
@@ -2129,7 +2115,7 @@ extern "C" int mtn_gemm(int dtype, int count, const mtn_gemm_problem* problems, 
     }
     // many large problems with the short contraction K = 512 (the memories' K|V projections for all layers): csrc/gemm_k512.hip
     int rc = 1, k512_tiles = 0;
-    static const int k512_min = [] { const char* e = getenv("MTN_GEMM_K512_MIN_TILES"); return e ? atoi(e) : 512; }();
+    const int k512_min = 512;
     const int took = (dtype == MTN_BF16 && k512_min > 0 && !n_lne) ? gemm_k512_try(count, problems, k512_min, s, &k512_tiles) : 0;
     if (took < 0) { mtn_set_error("gemm_k512_kernel: launch failed"); return MTN_ERR_LAUNCH; }
     if (took == 1) { g_variant = V_K512; g_variant_tiles = k512_tiles; rc = MTN_OK; }
@@ -2233,7 +2219,7 @@ extern "C" int mtn_gemm_tt_table_aux(int dtype, int count, const mtn_gemm_proble
     H->tilemap_off = sizeof(TTHeader) + (long)count * sizeof(TTProblem);
     TTProblem* Q = (TTProblem*)(sl->host + H->problems_off);
     uint32_t* map = (uint32_t*)(sl->host + H->tilemap_off);
-    bool lds_ok = MTN_ENV("MTN_ADAM_EPILOGUE_DIRECT") == nullptr;
+    bool lds_ok = true;
     if (aux) {
         H->n_front = n_front; H->n_ln_units = n_ln_units; H->n_chunks = n_chunks;
         H->fp = aux->p; H->fg = aux->g; H->fm = aux->m; H->fv = aux->v; H->flp = (bf16_t*)aux->lp;
@@ -2288,16 +2274,8 @@ extern "C" int mtn_gemm_tt_table_aux(int dtype, int count, const mtn_gemm_proble
     // traffic per launch for 0.44 GB of operands).  Here every problem is given to ONE XCD: grid index i holds a tile of the
     // queue of XCD i % 8; problems are dealt to the queues longest-processing-time-first on an estimate of their cost
     // (tiles x (contraction rows + the epilogue's bytes in row equivalents)), which balances the queues to within one problem.
-    if (MTN_ENV("MTN_TT_TABLE_SPREAD") != nullptr) {
-        H->plain_tile_order = MTN_ENV("MTN_GEMM_PLAIN_TILES") != nullptr;
-        int pos = 0;
-        for (int i = 0; i < count; ++i)
-            for (int k = 0; k < Q[i].tiles_m * Q[i].tiles_n; ++k) map[pos++] = ((uint32_t)i << 12) | (uint32_t)k;
-    } else {
+    {
         H->plain_tile_order = 1;                                          // inside a problem: plain order, one L2 sees them all
-#ifdef MTN_TT_ABLATION
-        if (const char* e = MTN_ENV("MTN_TT_ABLATE")) H->plain_tile_order |= atoi(e) & 30;
-#endif
         std::vector<int> order(count);
         std::vector<double> cost(count);
         for (int i = 0; i < count; ++i) {
@@ -2330,21 +2308,14 @@ extern "C" int mtn_gemm_tt_table_aux(int dtype, int count, const mtn_gemm_proble
         }
     }
     if (n_front > 0) {
-        // Where the optimiser units sit in the grid (a multiple of 8 of them, so that a dW tile keeps its grid index mod 8 and with it its
-        // XCD).  Measured, same box, cfg2 step (profiles/r05_d_tail_head_ab.txt): ALL AT THE FRONT 3.559 -> 3.529 ms (the first resident dW
-        // tiles are in their contraction phase and leave HBM idle); dealt in between the dW tiles, eight behind every `gap` tiles: +-0 (they
-        // compete with the tiles' streaming phases); all at the end: -14 us.  MTN_TT_AUX_GAP = n > 0 selects the dealt form (A/B).
+        // The optimiser units sit at the FRONT of the grid (a multiple of 8 of them, so that a dW tile keeps its grid index mod 8 and with it
+        // its XCD).  Measured, same box, cfg2 step (profiles/r05_d_tail_head_ab.txt): all at the front 3.559 -> 3.529 ms (the first
+        // resident dW tiles are in their contraction phase and leave HBM idle); dealt in between the dW tiles +-0 (they compete with
+        // the tiles' streaming phases); all at the end -14 us.
         std::vector<uint32_t> dmap(map, map + tiles);
-        long gap = 0;
-        if (const char* ge = MTN_ENV("MTN_TT_AUX_GAP")) { const long v = atol(ge) / 8 * 8; if (v >= 0) gap = v; }
-        long pos = 0, di = 0, au = 0;
-        if (gap == 0) while (au < n_front) map[pos++] = 0x80000000u | (uint32_t)au++;
-        while (di < tiles) {
-            const long take = gap == 0 ? tiles - di : (tiles - di < gap ? tiles - di : gap);
-            for (long k = 0; k < take; ++k) map[pos++] = dmap[di++];
-            for (int k = 0; k < 8 && au < n_front; ++k) map[pos++] = 0x80000000u | (uint32_t)au++;
-        }
-        while (au < n_front) map[pos++] = 0x80000000u | (uint32_t)au++;
+        long pos = 0;
+        for (long au = 0; au < n_front; ++au) map[pos++] = 0x80000000u | (uint32_t)au;
+        for (long di = 0; di < tiles; ++di) map[pos++] = dmap[di];
     }
     static bool attr_set = false;
     if (!attr_set) {

@@ -481,7 +481,7 @@ int gemm_k512_try(int count, const mtn_gemm_problem* p, int min_tiles, hipStream
         return 1;
     }
     // wide tiles (128 x 256) when every problem's N fills them: half the LDS reads per FLOP (MTN_K512_WIDE=0: 128 x 128 tiles)
-    bool wide = !(MTN_ENV("MTN_K512_WIDE") && MTN_ENV("MTN_K512_WIDE")[0] == '0');
+    bool wide = true;
     for (int i = 0; i < count; ++i) wide = wide && (p[i].N % 256) == 0;
     if (wide) {
         static bool attr_w = false;

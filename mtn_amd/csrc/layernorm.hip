@@ -168,7 +168,7 @@ extern "C" int mtn_layernorm_fwd_group(int dtype, int count, const mtn_ln_fwd_de
     hipStream_t s = (hipStream_t)stream;
     int dmax = 0;
     for (int i = 0; i < count; ++i) dmax = descs[i].d > dmax ? descs[i].d : dmax;
-    if (dmax <= 512 && MTN_ENV("MTN_LN_FWD_GENERIC") == nullptr) {
+    if (dmax <= 512) {
         if (dtype == MTN_BF16) hipLaunchKernelGGL((ln_fwd_small_kernel<bf16_t, 2>), dim3(blocks), dim3(256), 0, s, grp);
         else hipLaunchKernelGGL((ln_fwd_small_kernel<float, 2>), dim3(blocks), dim3(256), 0, s, grp);
     } else if (dtype == MTN_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, grp);
@@ -537,10 +537,7 @@ extern "C" int mtn_layernorm_bwd_group(int count, const mtn_ln_bwd_desc* descs, 
     }
     for (int i = count; i <= MTN_LN_MAX_GROUP; ++i) grp.block_start[i] = blocks;
     const size_t lds = any_partial ? sizeof(float) * 8 * (size_t)dmax : 0;
-    if (dmax <= 512 && MTN_ENV("MTN_LN_BWD_GENERIC") == nullptr) {
-        if (MTN_ENV("MTN_LN_BWD_4W") != nullptr) hipLaunchKernelGGL((ln_bwd_small_kernel<2, 4>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, grp);
-        else hipLaunchKernelGGL((ln_bwd_small_kernel<2, 8>), dim3(blocks), dim3(512), 2 * lds, (hipStream_t)stream, grp);
-    }
+    if (dmax <= 512) hipLaunchKernelGGL((ln_bwd_small_kernel<2, 8>), dim3(blocks), dim3(512), 2 * lds, (hipStream_t)stream, grp);
     else hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, grp);
     MTN_CHECK_LAUNCH();
     return MTN_OK;

@@ -271,7 +271,7 @@ class MegaDecodeSession(DecodeSession):
         except AttributeError:
             return False
         W = batch.query.size(0) * width
-        if model.compute_dtype != torch.bfloat16 or W > MegaDecodeSession.MAX_W or d not in (128, 256, 512, 1024) or d % h or d // h not in (32, 64, 128):
+        if model.compute_dtype != torch.bfloat16 or W > MegaDecodeSession.MAX_W or W * d > 4096 or d not in (128, 256, 512, 1024) or d % h or d // h not in (32, 64, 128):
             return False
         if dff > 4096 or dff % 32 or max_len > 1024 or model.auto_encoder_ft not in ("query", "caption", "summary"):
             return False
@@ -291,10 +291,11 @@ class MegaDecodeSession(DecodeSession):
         lp = torch.bfloat16
         self._W = W
         self._mcache = torch.zeros(nl, W, Lm, 2 * d, device=dev, dtype=lp)
-        self._x = torch.zeros(W, d, device=dev, dtype=torch.float32)
-        self._q = torch.zeros(W, d, device=dev, dtype=lp)
-        self._o = torch.zeros(W, d, device=dev, dtype=lp)
-        self._hid = torch.zeros(W, dff, device=dev, dtype=lp)
+        # granule buffers (8 bytes {data, tag}): residual stream, q|k|v of the newest row, attention output, FFN hidden — zeroed once
+        self._x = torch.zeros(W, d, device=dev, dtype=torch.int64)
+        self._q = torch.zeros(W, 3 * d // 2, device=dev, dtype=torch.int64)
+        self._o = torch.zeros(W, d // 2, device=dev, dtype=torch.int64)
+        self._hid = torch.zeros(W, dff // 2, device=dev, dtype=torch.int64)
         self._out_lp = torch.zeros(W, d, device=dev, dtype=lp)
         self._sync = torch.zeros(2, device=dev, dtype=torch.int32)
         # what the host changes every step, in ONE pinned block -> ONE copy: [W newest tokens (int64) | position (int32, padded) | anc (W x L int32)]
@@ -316,7 +317,7 @@ class MegaDecodeSession(DecodeSession):
         a.W, a.d, a.h, a.L, a.n_stages, a.d_ff = W, d, h, Lm, self._n_stages, dff
         self._dbg = torch.zeros(4 * self._n_stages, device=dev, dtype=torch.int64) if os.environ.get("MTN_DECODE_TIMELINE") == "1" else None
         a.dbg = self._dbg.data_ptr() if self._dbg is not None else None
-        a.x, a.q, a.o, a.hid, a.out_lp = self._x.data_ptr(), self._q.data_ptr(), self._o.data_ptr(), self._hid.data_ptr(), self._out_lp.data_ptr()
+        a.xg, a.qg, a.og, a.hg, a.out_lp = self._x.data_ptr(), self._q.data_ptr(), self._o.data_ptr(), self._hid.data_ptr(), self._out_lp.data_ptr()
         a.tokens = self._devblk.data_ptr()
         a.lut, a.emb_scale, a.pe = emb.lut.weight.data_ptr(), float(d) ** 0.5, pe.pe.data_ptr()
         a.pos, a.anc, a.sync = self._devblk.data_ptr() + self._off_pos, self._devblk.data_ptr() + self._off_anc, self._sync.data_ptr()

@@ -176,7 +176,7 @@ class ShardedOptimizerSync:
         if self.lp_fn is None or self.update_lp is None:
             return False
         lp = self.lp_fn()
-        return lp is not None and lp.dtype != torch.float32 and os.environ.get("MTN_DP_LP_GATHER", "1") != "0"
+        return lp is not None and lp.dtype != torch.float32
 
     def gather(self, buf: torch.Tensor):
         """Make a per-element buffer complete on every rank — the Adam moments, and (compute-dtype gather) the fp32 master

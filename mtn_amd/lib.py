@@ -139,8 +139,8 @@ class DecodeStage(C.Structure):
 
 
 class DecodeArgs(C.Structure):
-    _fields_ = [("W", C.c_int), ("d", C.c_int), ("h", C.c_int), ("L", C.c_int), ("n_stages", C.c_int), ("d_ff", C.c_int), ("x", C.c_void_p), ("q", C.c_void_p),
-                ("o", C.c_void_p), ("hid", C.c_void_p), ("out_lp", C.c_void_p), ("tokens", C.c_void_p), ("lut", C.c_void_p),
+    _fields_ = [("W", C.c_int), ("d", C.c_int), ("h", C.c_int), ("L", C.c_int), ("n_stages", C.c_int), ("d_ff", C.c_int), ("xg", C.c_void_p), ("qg", C.c_void_p),
+                ("og", C.c_void_p), ("hg", C.c_void_p), ("out_lp", C.c_void_p), ("tokens", C.c_void_p), ("lut", C.c_void_p),
                 ("emb_scale", C.c_float), ("pe", C.c_void_p), ("pos", C.c_void_p), ("anc", C.c_void_p), ("sync", C.c_void_p), ("dbg", C.c_void_p)]
 
 

@@ -33,7 +33,7 @@ from . import ops
 ATTN_DROPOUT_DEFAULT = 0.1   # mtn.py:339 builds MultiHeadedAttention(h, d_model) without forwarding `dropout`
 
 
-_HANDOFF = os.environ.get("MTN_NO_HANDOFF") != "1"
+_HANDOFF = True       # gradient hand-off along a chain: the consumer's backward writes the producer's masked compute-dtype dy (no cast launches)
 
 
 # ------------------------------------------------------------------------------------------ leaf modules
@@ -508,7 +508,6 @@ class Generator(nn.Module):
 
 # ------------------------------------------------------------------------------------------ top level
 # which transposed weight copies (besides W_o^T) the flat layout keeps: see EncoderDecoder._flatten
-KEEP_WT_DEFAULT = ""
 
 
 class EncoderDecoder(nn.Module):
@@ -540,7 +539,7 @@ class EncoderDecoder(nn.Module):
         self._queue = ops.ParamGradQueue()     # dW/db/LN-parameter work batched at the end of backward
         self.lockstep = True                   # independent sublayers of a layer share launches (ops.SublayerGroupFn)
         self.fused_embed = True                # Embeddings + PositionalEncoding + Encoder LayerNorm in one grouped launch
-        self.hoist_kv = os.environ.get("MTN_NO_KV_HOIST") != "1"   # K|V of the constant memories projected ahead of the layer loop
+        self.hoist_kv = True                   # K|V of the constant memories projected ahead of the layer loop
         self._embed_calls = 0
         self._ln_fold_stale = True
         self._ln_fold_buf = self._ln_fold_table = None
@@ -629,9 +628,8 @@ class EncoderDecoder(nn.Module):
         # reads W_o^T rows, csrc/fused_bwd.hip): every other dX = dY W runs on the LDS-DMA GEMM with W as it lies (b_trans = 1:
         # [k][n] tiles + transposing LDS reads, csrc/gemm.hip), so the optimiser epilogue writes no transposed copy for them —
         # those scattered 128-byte runs were 16 % of the launch for 7 % of its bytes (profiles/r03_tt_ablation.txt).
-        # MTN_KEEP_WT=qkv,w1,w2,gen (or "all") keeps the named ones (A/B).
-        keep_env = os.environ.get("MTN_KEEP_WT", KEEP_WT_DEFAULT)
-        keep = {"qkv", "w1", "w2", "gen"} if keep_env in ("all", "1") else {k for k in keep_env.split(",") if k}
+        # (rounds 1-2 kept one for every 2-D weight; the A/B switch is gone with round 5: profiles/r03_m_keep_wt_ab.txt)
+        keep = set()
         tdescs = []
         fusable = []         # ... of those, the weights whose gradient is ONE deferred GEMM (optimiser epilogue)
         optional = set()     # ... offsets of fusable weights that may legitimately get no deferred GEMM in a step

@@ -19,8 +19,8 @@ from . import lib as L
 
 
 # ------------------------------------------------------------------------------------------ helpers
-_XACC = os.environ.get("MTN_NO_XACC") != "1"
-_HANDOFF_MEM = os.environ.get("MTN_NO_MEM_HANDOFF") != "1"     # a memory's final gradient also leaves its last dmem GEMM as the producer's masked dy
+_XACC = True          # a tensor with several consumers collects its gradients in one buffer (no autograd add)
+_HANDOFF_MEM = True   # a memory's final gradient also leaves its last dmem GEMM as the producer's masked dy
 
 
 def _drop(p: float, salt: int, seed: Optional[torch.Tensor]) -> L.Dropout:
@@ -148,9 +148,9 @@ class ParamGradQueue:
         gradient is one of the launch's problems (updated by the tile that sums it), and every other range of the flat buffers no dW
         epilogue covers — the embedding tables, whose gradient the scatter launch above has completed — as <= 4096-element chunks.
         Nothing is left behind the launch: FusedAdam.step_rest() then only refreshes transposed copies.  Returns (aux, keep-alive)
-        or None (MTN_TT_AUX=0, or a gradient that does not live in the model's flat buffer)."""
+        or None (a gradient that does not live in the model's flat buffer)."""
         A = self.adam
-        if A is None or os.environ.get("MTN_TT_AUX") == "0" or not A.get("n_flat"):
+        if A is None or not A.get("n_flat"):
             return None
         g0, n_flat = A["grad"], A["n_flat"]
         inside = lambda ptr, n: ptr is not None and g0 <= ptr and ptr + 4 * n <= g0 + 4 * n_flat and (ptr - g0) % 4 == 0
@@ -243,7 +243,7 @@ class ParamGradQueue:
         adam_keep = self._attach_adam() if self.adam is not None else None      # noqa: F841 (descriptors live until the launches)
         # a grouped launch lasts as long as its longest contraction: keep the long ones (memories: K = B*m rows) together
         self.gemm.sort(key=lambda p: -p.K)
-        if os.environ.get("MTN_TT_TABLE") != "0" and self.dtype == L.MTN_BF16:
+        if self.dtype == L.MTN_BF16:
             # ALL parameter-gradient problems in one launch of 128x128 tiles (csrc/gemm.hip, table form), long and short
             # contractions side by side: no launch boundaries or partial rounds (296 vs 430 us at cfg2), and with the optimiser
             # epilogue the tiles' streaming phases overlap other tiles' contractions.  Without the epilogue only when the

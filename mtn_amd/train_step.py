@@ -24,7 +24,7 @@ from .data_utils import FusedAdam, LabelSmoothing, NoamOpt, SimpleLossCompute
 # with hipErrorStreamCaptureInvalidated (seen on hardware: tools/dp_rccl_probe.py, round 3).  Only this thread's calls matter here:
 # the kernels come from this thread and from autograd's device thread, both onto the capturing stream.
 CAPTURE_MODE = os.environ.get("MTN_CAPTURE_MODE", "thread_local")
-_CUT_GACC = os.environ.get("MTN_DP_CUT_GACC", "1") != "0"      # gradients across a layer cut meet in the memory-gradient buffer (no autograd add)
+_CUT_GACC = True      # gradients across a layer cut meet in the memory-gradient buffer (no autograd add)
 
 
 class TrainStep:

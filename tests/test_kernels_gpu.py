@@ -342,38 +342,6 @@ def test_attention_dropout_statistics_and_consistency(dev):
             dv_col = dv[b, :dk, hh * dk]                       # dV[j, c] = Pdrop[0, j] * go[0, c]
             assert torch.allclose(dv_col, p_row0, rtol=1e-4, atol=1e-7)
 
-
-@pytest.mark.parametrize("dtype", DTYPES)
-def test_gemm_tt_128_tile_group(dev, dtype):
-    """Parameter-gradient layout (both operands contraction-major) on the 128x128-tile kernel: grouped, ragged output
-    sizes (not multiples of 128), ragged contraction, row sums = bias gradients."""
-    import os
-    from mtn_amd import lib as L, ops
-    os.environ["MTN_GEMM_TT128"] = "1"
-    L.reload_env()
-    g = torch.Generator().manual_seed(9)
-    probs, checks = [], []
-    for (M, N, K) in [(512, 512, 640), (1536, 512, 100), (200, 136, 333), (3000, 512, 64)]:
-        a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
-        A, B = a.t().contiguous().to(dev, dtype), b.t().contiguous().to(dev, dtype)
-        out = torch.full((M, N), float("nan"), device=dev)
-        rs = torch.full((M,), float("nan"), device=dev)
-        p = _gemm_problem(L, A, B, M, N, K, 1, 1, M, N)
-        p.out_f32, p.ldc, p.rowsum_out = out.data_ptr(), N, rs.data_ptr()
-        probs.append(p)
-        ar, br = lp_round(a, dtype).double(), lp_round(b, dtype).double()
-        checks.append((out, rs, ar @ br.t(), ar.sum(1), (A, B)))
-    try:
-        ops.gemm(L.dtype_code(dtype), probs)
-        torch.cuda.synchronize()
-    finally:
-        del os.environ["MTN_GEMM_TT128"]
-        L.reload_env()
-    for out, rs, ref, rsum, _keep in checks:
-        assert relmax(out, ref) < 1e-4
-        assert relmax(rs, rsum) < 1e-4
-
-
 def test_gemm_tt_dma_128_tile_group(dev):
     """bf16 parameter-gradient GEMMs on the 128x128-tile LDS-DMA kernel (transposing LDS reads): grouped, ragged output sizes,
     ragged contraction (not a multiple of the 64-row stage), row sums = bias gradients."""
@@ -574,8 +542,7 @@ def test_gemm_k512_many_large_problems(dev, persistent):
         assert bool((out[:, N:].float() == 7.0).all())             # nothing written past the problem's columns
 
 
-@pytest.mark.parametrize("force", ["", "MTN_GEMM_TILE=64", "MTN_GEMM_TILE=32", "MTN_GEMM_TILE=64,MTN_GEMM_FORCE_HALF=1", "MTN_GEMM_TILE=32,MTN_GEMM_FORCE_HALF=1",
-                                   "MTN_GEMM_TILE=64,MTN_GEMM_DEEP=1", "MTN_GEMM_TILE=32,MTN_GEMM_DEEP=1"])
+@pytest.mark.parametrize("force", ["", "MTN_GEMM_TILE=64", "MTN_GEMM_TILE=32", "MTN_GEMM_TILE=64,MTN_GEMM_FORCE_HALF=1", "MTN_GEMM_TILE=32,MTN_GEMM_FORCE_HALF=1"])
 def test_gemm_contraction_major_b_on_lds_dma(dev, force):
     """dX = dY W with W as the forward pass keeps it (b_trans = 1: B stored [K][N]) on gemm_dma_kernel's [k][n]-tile variant
     (transposing LDS reads): every tile / stage size, ragged M, N (multiples of 8) and K (tails inside a stage and across
