@@ -30,7 +30,11 @@
 // operands, attention output and the FFN hidden rounded to bf16 where those kernels store bf16.
 #include "common.h"
 
-#define DEC_THREADS 256
+#define DEC_MAX_NW 16
+// Waves per workgroup.  Measured on the 6-layer model, one step (profiles/r05_decode_timeline_*): 4 waves 790 us, 8 waves 602 us, 16 waves
+// 747 us — sixteen waves have 128 registers each and the attention stage then spills 82 of them; eight fit (219) and halve the time a stage
+// spends ISSUING its prefetch.
+#define DEC_NW_USED 8
 #define DEC_MAX_W 8
 
 typedef unsigned long long u64;
@@ -56,17 +60,17 @@ struct DecKernelArgs {
 // ---- granules
 __device__ __forceinline__ void dec_pub(const dec_rsrc_t r, const unsigned index, const unsigned data, const unsigned tag) { st8(r, index * 8, (u64)data | ((u64)tag << 32)); }
 __device__ __forceinline__ unsigned dec_pack2(const float a, const float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); }
-// Poll `count` granules starting at `first` of buffer r until all carry `tag`; granule first + i goes to sink(i, data).  All 256 threads,
-// 8 granules per thread per pass (2 048 per round); a round is repeated until every thread's tags match.
-template <typename SINK>
+// Poll `count` granules starting at `first` of buffer r until all carry `tag`; granule first + i goes to sink(i, data).  All threads,
+// 4 granules per thread per pass; a round is repeated until every thread's tags match.
+template <int DEC_THREADS, typename SINK>
 __device__ __forceinline__ bool dec_poll(const dec_rsrc_t r, const unsigned first, const int count, const unsigned tag, unsigned* sync, SINK sink) {
     const int tid = threadIdx.x;
-    for (int base = 0; base < count; base += DEC_THREADS * 8) {
-        u64 v[8];
+    for (int base = 0; base < count; base += DEC_THREADS * 4) {
+        u64 v[4];
         for (unsigned spins = 0;; ++spins) {
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 const int i = base + k * DEC_THREADS + tid;
                 if (i < count) { v[k] = ld8(r, (first + i) * 8); ok = ok && (unsigned)(v[k] >> 32) == tag; }
             }
@@ -78,7 +82,7 @@ __device__ __forceinline__ bool dec_poll(const dec_rsrc_t r, const unsigned firs
             if ((spins & 3) == 3) __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 4; ++k) {
             const int i = base + k * DEC_THREADS + tid;
             if (i < count) sink(i, (unsigned)v[k]);
         }
@@ -88,20 +92,8 @@ __device__ __forceinline__ bool dec_poll(const dec_rsrc_t r, const unsigned firs
 
 // ---- LayerNorm of one row by one wave (mtn.py:111-114: unbiased std, eps added to std): lane holds 4 consecutive floats per 256 columns;
 // the result goes out as bf16 through `put(column, four values)` (an LDS image, or global memory for the final norm)
-// the gains / biases of a lane's columns (asked for before the row has arrived)
-struct DecLnGains { float4 a[4], b[4]; };
-__device__ __forceinline__ void dec_ln_gains(DecLnGains& g, const float* __restrict__ a2, const float* __restrict__ b2, const int d, const int lane) {
-    const int nv = (d + 255) >> 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        const bool ok = i < nv && c < d;
-        g.a[i] = ok ? *(const float4*)(a2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        g.b[i] = ok ? *(const float4*)(b2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
 template <typename PUT>
-__device__ __forceinline__ void dec_ln_row(const float* xrow /* LDS, fp32 [d] */, const DecLnGains& g, const float eps, const int d, const int lane, PUT put) {
+__device__ __forceinline__ void dec_ln_row(const float* xrow /* LDS, fp32 [d] */, const float* gains /* LDS: a_2 [d] then b_2 [d] */, const float eps, const int d, const int lane, PUT put) {
     float4 v[4];                                   // d <= 1024
     const int nv = (d + 255) >> 8;
 #pragma unroll
@@ -125,7 +117,7 @@ __device__ __forceinline__ void dec_ln_row(const float* xrow /* LDS, fp32 [d] */
     for (int i = 0; i < 4; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (i < nv && c < d) {
-            const float4 ga = g.a[i], gb = g.b[i];
+            const float4 ga = *(const float4*)(gains + c), gb = *(const float4*)(gains + d + c);
             put(c, make_float4(ga.x * (v[i].x - mean) * inv + gb.x, ga.y * (v[i].y - mean) * inv + gb.y, ga.z * (v[i].z - mean) * inv + gb.z, ga.w * (v[i].w - mean) * inv + gb.w));
         }
     }
@@ -135,41 +127,46 @@ __device__ __forceinline__ u64 dec_pack4(const float4 y) {
 }
 
 // ---- the weight side of a small-M Linear on MFMA: out[row r < W][feature n] = sum_k act[r][k] w[n][k]
-// A wave owns ONE 16-feature tile and a contiguous range of 32-element contraction steps of it: with T = ceil(S / 16) tiles of the
-// workgroup's S features, T >= 3 -> wave w takes tile w whole; T = 2 -> two waves per tile, half the contraction each; T = 1 -> four
-// quarters.  The B fragments (lane: feature n0 + lane % 16, elements k0 + (lane / 16) * 8 ..+7: 16 contiguous bytes of a weight row) of
-// the wave's first 16 steps are loaded into registers by dec_w_issue() — before the barrier; further steps (not at the shapes of the
-// benchmark) are loaded in the loop.
-struct DecWPlan { int tile, k_lo, k_hi; };       // this wave's tile (-1: none) and contraction steps [k_lo, k_hi)
+// The workgroup's S <= 64 features are T = ceil(S / 16) tiles of 16; its NW waves are dealt wpt = NW / T' to a tile (T' = T rounded up to
+// a power of two) and split that tile's K / 32 contraction steps evenly.  A CU accepts a wave's loads at a fixed rate (one 1 KiB load per
+// ~180 ns and wave: DESIGN.md §10), so the weight slice is requested NW / 4 times faster than by the first, four-wave version of this
+// kernel, which spent 2-3 us per stage just issuing its prefetch (profiles/r05_decode_timeline_granules_v1.txt).  The B fragments (lane:
+// feature n0 + lane % 16, elements k0 + (lane / 16) * 8 ..+7: 16 contiguous bytes of a weight row) of the wave's first 64 / NW steps are loaded
+// into registers by dec_w_issue() — before the stage's operands exist; further steps (not at the benchmark's shapes) in the loop.
+struct DecWPlan { int tile, k_lo, k_hi, wpt; };       // this wave's tile (-1: none), contraction steps [k_lo, k_hi), waves per tile
+template <int DEC_NW>
 __device__ __forceinline__ DecWPlan dec_w_plan(const int S, const int K, const int wave) {
     const int T = (S + 15) >> 4, KS = K >> 5;
     DecWPlan p;
-    if (T >= 3) { p.tile = wave < T ? wave : -1; p.k_lo = 0; p.k_hi = KS; }
-    else if (T == 2) { p.tile = wave >> 1; const int half = (KS + 1) >> 1; p.k_lo = (wave & 1) * half; p.k_hi = min(KS, p.k_lo + half); }
-    else { p.tile = 0; const int q = (KS + 3) >> 2; p.k_lo = wave * q; p.k_hi = min(KS, p.k_lo + q); }
-    if (p.k_lo >= p.k_hi) p.tile = -1;
+    p.wpt = T <= 1 ? DEC_NW : (T == 2 ? DEC_NW / 2 : DEC_NW / 4);
+    p.tile = wave / p.wpt;
+    const int sub = wave % p.wpt, q = (KS + p.wpt - 1) / p.wpt;
+    p.k_lo = sub * q; p.k_hi = min(KS, p.k_lo + q);
+    if (p.tile >= T || p.k_lo >= p.k_hi) p.tile = -1;
     return p;
 }
-struct DecWRegs { uint4 w[16]; };
-__device__ __forceinline__ void dec_w_issue(DecWRegs& R, const DecWPlan& p, const bf16_t* __restrict__ w, const int n0, const int n1, const int K, const int lane) {
+template <int NR> struct DecWRegs { uint4 w[NR]; };
+template <int NR>
+__device__ __forceinline__ void dec_w_issue(DecWRegs<NR>& R, const DecWPlan& p, const bf16_t* __restrict__ w, const int n0, const int n1, const int K, const int lane) {
     const int n = n0 + p.tile * 16 + (lane & 15);
     const bool ok = p.tile >= 0 && n < n1;
     const bf16_t* row = w + (size_t)(ok ? n : n0) * K + (lane >> 4) * 8;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int ks = p.k_lo + i;
         R.w[i] = (ok && ks < p.k_hi) ? *(const uint4*)(row + ks * 32) : make_uint4(0, 0, 0, 0);
     }
 }
 // act: LDS image [W rows][K] bf16 with row pitch `pitch` bytes (K * 2 + 16: the W rows a ds_read_b128 touches sit in different banks)
-__device__ __forceinline__ f32x4_t dec_w_mma(const DecWRegs& R, const DecWPlan& p, const bf16_t* __restrict__ w, const int n0, const int n1, const int K,
+template <int NR>
+__device__ __forceinline__ f32x4_t dec_w_mma(const DecWRegs<NR>& R, const DecWPlan& p, const bf16_t* __restrict__ w, const int n0, const int n1, const int K,
                                              const unsigned char* act, const int pitch, const int W, const int lane) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     if (p.tile < 0) return acc;
     const int r = lane & 15;
     const unsigned char* arow = act + (size_t)(r < W ? r : 0) * pitch + (lane >> 4) * 16;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int ks = p.k_lo + i;
         if (ks < p.k_hi) {                                      // (wave-uniform)
             uint4 a = *(const uint4*)(arow + ks * 64);
@@ -178,7 +175,7 @@ __device__ __forceinline__ f32x4_t dec_w_mma(const DecWRegs& R, const DecWPlan& 
         }
     }
     const int n = n0 + p.tile * 16 + r;
-    for (int ks = p.k_lo + 16; ks < p.k_hi; ++ks) {             // beyond the prefetched steps
+    for (int ks = p.k_lo + NR; ks < p.k_hi; ++ks) {              // beyond the prefetched steps (d_ff = 4096 only)
         const uint4 b = n < n1 ? *(const uint4*)(w + (size_t)n * K + ks * 32 + (lane >> 4) * 8) : make_uint4(0, 0, 0, 0);
         uint4 a = *(const uint4*)(arow + ks * 64);
         if (r >= W) a = make_uint4(0, 0, 0, 0);
@@ -189,32 +186,44 @@ __device__ __forceinline__ f32x4_t dec_w_mma(const DecWRegs& R, const DecWPlan& 
 
 // LDS layout (bytes)
 #define DEC_ACT_OFF 0                 /* activations image: W x (K * 2 + 16), K <= 4096: 8 x 8208 = 65 664 */
-#define DEC_RED_OFF 66048             /* partial tiles: 4 waves x 16 features x 8 rows fp32 = 2 048 */
-#define DEC_Q_OFF 68096               /* unit stages: q (fp32, <= 128) + the newest row's k and v of this head (self-attention): 3 x 128 floats */
-#define DEC_SC_OFF 69632              /* scores / probabilities: <= 1024 keys fp32 */
-#define DEC_PART_OFF 73728            /* PV partials: (256 / (dk / 4)) key parts x dk columns fp32 = 4 096 bytes */
-#define DEC_MISC_OFF 77824            /* reductions: 16 floats */
-#define DEC_XS_OFF 77952              /* this workgroup's columns of the residual stream: W x 64 fp32 = 2 048 */
-#define DEC_XF_OFF 80000              /* the residual rows a stage normalises: W x d fp32 <= 8 x 1024 x 4 = 32 768 */
-#define DEC_LDS 112768
+#define DEC_RED_OFF 66048             /* partial tiles: <= 16 waves x 16 features x 8 rows fp32 = 8 192 */
+#define DEC_Q_OFF 74240               /* unit stages: q (fp32, <= 128) + the newest row's k and v of this head (self-attention): 3 x 128 floats */
+#define DEC_SC_OFF 75776              /* scores / probabilities: <= 1024 keys fp32; afterwards the second level of the PV reduction */
+#define DEC_PART_OFF 79872            /* PV partials: (threads / (dk / 4)) key parts x dk columns fp32 <= 16 384 */
+#define DEC_MISC_OFF 96256            /* block reductions: 32 floats */
+#define DEC_XS_OFF 96512              /* this workgroup's columns of the residual stream: W x 64 fp32 = 2 048 */
+#define DEC_XF_OFF 98560              /* the residual rows a stage normalises: W x d fp32 <= 8 x 1024 x 4 = 32 768 */
+#define DEC_GAIN_OFF 131328           /* LayerNorm a_2 | b_2 of the stage: 2 x 1024 floats */
+#define DEC_STG_OFF 139520            /* the stage list: <= 160 descriptors of 104 bytes */
+#define DEC_MAX_STAGES 160
+#define DEC_LDS (DEC_STG_OFF + DEC_MAX_STAGES * 104)
 
+// block reductions over the workgroup's waves: distinct LDS slots for the maximum (0..15) and the sum (16..31), one barrier each — the slots
+// are not touched again before the stage's closing barrier
+template <int DEC_NW>
 __device__ __forceinline__ float dec_block_max(float v, float* red, const int tid) {
-    // wave max by swizzles, then across the four waves through LDS
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < DEC_NW; ++i) r = fmaxf(r, red[i]);
+    return r;
 }
+template <int DEC_NW>
 __device__ __forceinline__ float dec_block_sum(float v, float* red, const int tid) {
     v = fh_cross_sum(fh_row16_sum(v));
+    if ((tid & 63) == 0) red[16 + (tid >> 6)] = v;
     __syncthreads();
-    if ((tid & 63) == 0) red[4 + (tid >> 6)] = v;
-    __syncthreads();
-    return (red[4] + red[5]) + (red[6] + red[7]);
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < DEC_NW; ++i) r += red[16 + i];
+    return r;
 }
 
-__global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKernelArgs KA) {
+template <int DEC_NW>
+__global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKernelArgs KA) {
+    constexpr int DEC_THREADS = DEC_NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mtn_decode_args& A = KA.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -234,16 +243,17 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
     float* misc = (float*)(smem + DEC_MISC_OFF);
     float* xs = (float*)(smem + DEC_XS_OFF);                             // [W][per_x]: this workgroup's columns of x
     float* xf = (float*)(smem + DEC_XF_OFF);                             // [W][d]
+    float* gains = (float*)(smem + DEC_GAIN_OFF);                        // a_2 [d] | b_2 [d]
     const float scale = rsqrtf((float)dk);
     const int per_x = ((d + G - 1) / G + 3) / 4 * 4;                     // the slice of every N = d stage (embed, output projections, FFN-2)
     const int x0 = min(d, wg * per_x), x1 = min(d, x0 + per_x);
     unsigned last_x_tag = 0;
     u64* dbg = (A.dbg && wg == 0 && tid == 0) ? (u64*)A.dbg : nullptr;       // per stage: entered / operands arrived / computed / published
 
-    DecWRegs R;
+    DecWRegs<64 / DEC_NW> R;                                            // 4 prefetched steps per wave on sixteen waves, 8 on eight
     DecWPlan plan;
-    DecLnGains lng;
-    float4 bpre[2];                                                       // the biases of this thread's epilogue quads
+    float4 gpre = make_float4(0.f, 0.f, 0.f, 0.f);                       // this thread's quad of the stage's LayerNorm a_2 | b_2
+    float4 bpre = make_float4(0.f, 0.f, 0.f, 0.f);                       // the biases of this thread's epilogue quad
     int n0 = 0, n1 = 0;
     // everything a stage can ask for BEFORE its operands exist: the workgroup's weight rows, LayerNorm gains, biases
     auto prefetch = [&](const mtn_decode_stage& S) {
@@ -252,21 +262,21 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
         if (slice) {
             const int per = ((S.N + G - 1) / G + 3) / 4 * 4;       // a multiple of 4 features: outputs leave as pairs of granules
             n0 = min(S.N, wg * per); n1 = min(S.N, n0 + per);
-            if (n1 > n0) { plan = dec_w_plan(n1 - n0, S.K, wave); dec_w_issue(R, plan, (const bf16_t*)S.w, n0, n1, S.K, lane); }
+            if (n1 > n0) { plan = dec_w_plan<DEC_NW>(n1 - n0, S.K, wave); dec_w_issue(R, plan, (const bf16_t*)S.w, n0, n1, S.K, lane); }
             const int S4 = (n1 - n0) >> 2;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = tid + u * DEC_THREADS;
-                bpre[u] = i < S4 * W ? *(const float4*)(S.bias + n0 + (i % S4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            bpre = tid < S4 * W ? *(const float4*)(S.bias + n0 + (tid % S4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         } else if (S.kind == MTN_DEC_CROSS && wg < W * A.h) {
             n0 = (wg % A.h) * dk; n1 = n0 + dk;
-            plan = dec_w_plan(dk, S.K, wave); dec_w_issue(R, plan, (const bf16_t*)S.w, n0, n1, S.K, lane);
-            bpre[0].x = tid < dk ? S.bias[n0 + tid] : 0.f;
+            plan = dec_w_plan<DEC_NW>(dk, S.K, wave); dec_w_issue(R, plan, (const bf16_t*)S.w, n0, n1, S.K, lane);
+            bpre.x = tid < dk ? S.bias[n0 + tid] : 0.f;
         }
-        if (S.kind == MTN_DEC_SELF_QKV || S.kind == MTN_DEC_FFN1 || S.kind == MTN_DEC_CROSS || S.kind == MTN_DEC_FINAL) dec_ln_gains(lng, S.ln_a, S.ln_b, d, lane);
+        if (S.kind == MTN_DEC_SELF_QKV || S.kind == MTN_DEC_FFN1 || S.kind == MTN_DEC_CROSS || S.kind == MTN_DEC_FINAL) {
+            const int q4 = d >> 2;
+            if (tid < 2 * q4) gpre = tid < q4 ? ((const float4*)S.ln_a)[tid] : ((const float4*)S.ln_b)[tid - q4];
+        }
     };
-    // the four waves' partial tiles -> LDS; then thread (feature, row) sums them in a fixed order.  red[wave][feature 0..15][row 0..7]
+    auto gains_to_lds = [&]() { if (tid < (d >> 1)) ((float4*)gains)[tid] = gpre; };       // (before the barrier that follows a poll)
+    // the waves' partial tiles -> LDS; then thread (feature, row) sums a tile's partials in a fixed order.  red[wave][feature 0..15][row 0..7]
     auto spill = [&](const f32x4_t& acc) {
         if ((lane >> 4) < 2) {                                  // rows 0..7 (an idle wave's accumulators are zero)
 #pragma unroll
@@ -276,13 +286,38 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
     };
     auto gather = [&](const int S_, const int f, const int r) -> float {       // feature f in [0, S_), row r
         const int T = (S_ + 15) >> 4, t = f >> 4, c = f & 15;
-        if (T >= 3) return red[(t * 16 + c) * 8 + r];
-        if (T == 2) return red[((2 * t) * 16 + c) * 8 + r] + red[((2 * t + 1) * 16 + c) * 8 + r];
-        return (red[(0 * 16 + c) * 8 + r] + red[(1 * 16 + c) * 8 + r]) + (red[(2 * 16 + c) * 8 + r] + red[(3 * 16 + c) * 8 + r]);
+        const int wpt = T <= 1 ? DEC_NW : (T == 2 ? DEC_NW / 2 : DEC_NW / 4);
+        const float* p = red + ((t * wpt) * 16 + c) * 8 + r;
+        if (wpt == 2) return p[0] + p[128];
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < wpt; i += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s4[k] += p[(i + k) * 128];
+        }
+        return (s4[0] + s4[1]) + (s4[2] + s4[3]);
     };
 
+    // the stage list -> LDS once (a descriptor read from memory at every stage entry cost 1-2 us of scalar-cache miss in front of the
+    // prefetch that needs its fields: profiles/r05_decode_timeline_granules_v1.txt, column "barrier")
     const int n_stages = A.n_stages;
-    mtn_decode_stage S = KA.stages[0];
+    mtn_decode_stage* stg = (mtn_decode_stage*)(smem + DEC_STG_OFF);
+    {
+        const unsigned* src = (const unsigned*)KA.stages;
+        unsigned* dst = (unsigned*)stg;
+        const int nw32 = n_stages * (int)(sizeof(mtn_decode_stage) / 4);
+        for (int i = tid; i < nw32; i += DEC_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    // a descriptor is wave-uniform: pulled out of LDS into scalar registers (26 VGPRs otherwise)
+    auto stage_of = [&](const int i) {
+        mtn_decode_stage D;
+        const unsigned* src = (const unsigned*)(stg + i);
+        unsigned* dst = (unsigned*)&D;
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(mtn_decode_stage) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
+        return D;
+    };
+    mtn_decode_stage S = stage_of(0);
     prefetch(S);
     bool alive = true;
     for (int si = 0; si < n_stages && alive; ++si) {
@@ -301,12 +336,13 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
             last_x_tag = tag;
         } break;
         case MTN_DEC_SELF_QKV: case MTN_DEC_FFN1: {    // LayerNorm(x) of every row -> act; features n0..n1 of the Linear
-            alive = dec_poll(rX, 0, W * d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+            alive = dec_poll<DEC_THREADS>(rX, 0, W * d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+            gains_to_lds();
             __syncthreads();
             if (dbg) dbg[si * 4 + 1] = wall_clock64();
-            for (int j = wave; j < W; j += 4) {
-                bf16_t* row = (bf16_t*)(act + (size_t)j * pitch);
-                dec_ln_row(xf + (size_t)j * d, lng, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
+            if (wave < W) {                                                  // one row per wave
+                bf16_t* row = (bf16_t*)(act + (size_t)wave * pitch);
+                dec_ln_row(xf + (size_t)wave * d, gains, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
             }
             __syncthreads();
             f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, W, lane);
@@ -314,42 +350,34 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
             if (dbg) dbg[si * 4 + 2] = wall_clock64();
             const int Sn = n1 - n0, S4 = Sn >> 2;                          // (slices are multiples of 4 features: two granules of a bf16 pair each)
             const dec_rsrc_t rD = S.kind == MTN_DEC_FFN1 ? rH : rQ;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = tid + u * DEC_THREADS;
-                if (i < S4 * W) {
-                    const int f = (i % S4) * 4, r = i / S4, n = n0 + f;
-                    float y0 = gather(Sn, f, r) + bpre[u].x, y1 = gather(Sn, f + 1, r) + bpre[u].y, y2 = gather(Sn, f + 2, r) + bpre[u].z, y3 = gather(Sn, f + 3, r) + bpre[u].w;
-                    if (S.kind == MTN_DEC_FFN1) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
-                    const unsigned g0 = ((unsigned)r * S.N + n) >> 1;
-                    dec_pub(rD, g0, dec_pack2(y0, y1), tag);
-                    dec_pub(rD, g0 + 1, dec_pack2(y2, y3), tag);
-                }
+            if (tid < S4 * W) {
+                const int f = (tid % S4) * 4, r = tid / S4, n = n0 + f;
+                float y0 = gather(Sn, f, r) + bpre.x, y1 = gather(Sn, f + 1, r) + bpre.y, y2 = gather(Sn, f + 2, r) + bpre.z, y3 = gather(Sn, f + 3, r) + bpre.w;
+                if (S.kind == MTN_DEC_FFN1) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
+                const unsigned g0 = ((unsigned)r * S.N + n) >> 1;
+                dec_pub(rD, g0, dec_pack2(y0, y1), tag);
+                dec_pub(rD, g0 + 1, dec_pack2(y2, y3), tag);
             }
         } break;
         case MTN_DEC_OUT: case MTN_DEC_FFN2: {         // act = attention output (OUT) | FFN hidden (FFN2), bf16 pairs [W][K/2]; + bias + residual -> x
             const dec_rsrc_t rS = S.kind == MTN_DEC_OUT ? rO : rH;
             const int K2 = K >> 1;
-            alive = dec_poll(rS, 0, W * K2, gen | (unsigned)si, A.sync, [&](int i, unsigned v) { *(unsigned*)(act + (size_t)(i / K2) * pitch + (i % K2) * 4) = v; });
+            alive = dec_poll<DEC_THREADS>(rS, 0, W * K2, gen | (unsigned)si, A.sync, [&](int i, unsigned v) { *(unsigned*)(act + (size_t)(i / K2) * pitch + (i % K2) * 4) = v; });
             __syncthreads();
             if (dbg) dbg[si * 4 + 1] = wall_clock64();
             f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, W, lane);
             spill(acc);
             if (dbg) dbg[si * 4 + 2] = wall_clock64();
             const int Sn = n1 - n0, S4 = Sn >> 2;
+            if (tid < S4 * W) {
+                const int f = (tid % S4) * 4, r = tid / S4, n = n0 + f;
+                float* xr = xs + r * per_x + f;                              // (n0 == x0: the N = d slices coincide)
+                const float b4[4] = {bpre.x, bpre.y, bpre.z, bpre.w};
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int i = tid + u * DEC_THREADS;
-                if (i < S4 * W) {
-                    const int f = (i % S4) * 4, r = i / S4, n = n0 + f;
-                    float* xr = xs + r * per_x + f;                          // (n0 == x0: the N = d slices coincide)
-                    const float b4[4] = {bpre[u].x, bpre[u].y, bpre[u].z, bpre[u].w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float y = gather(Sn, f + k, r) + b4[k] + xr[k];
-                        xr[k] = y;
-                        dec_pub(rX, (unsigned)r * d + n + k, __float_as_uint(y), tag);
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    const float y = gather(Sn, f + k, r) + b4[k] + xr[k];
+                    xr[k] = y;
+                    dec_pub(rX, (unsigned)r * d + n + k, __float_as_uint(y), tag);
                 }
             }
             last_x_tag = tag;
@@ -361,39 +389,41 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
             const int m = self ? pos + 1 : S.m;
             const int npc = dk / 8;
             const int c4 = tid % (dk / 4), qt = tid / (dk / 4), nq = DEC_THREADS / (dk / 4);
-            // read-only operands of the attention, requested before x has arrived: this thread's key row (one key per thread, 16-byte pieces),
-            // its mask byte, and its V quads of the first 8 * nq keys.  Cross: hoisted K|V rows [j * m + t][2d]; self: cache rows of positions
+            // read-only operands of the attention, requested before x has arrived: this thread's HALF of a key row (two threads per key, 16-byte
+            // pieces), its mask byte, and its V quads of the first 4 * nq keys.  Cross: hoisted K|V rows [j * m + t][2d]; self: cache rows of positions
             // < pos of THIS hypothesis' prefix (slot anc[j][t]: written by earlier launches) — the newest row arrives as granules
-            uint4 kr[16];
-            u64 vq[8];
+            uint4 kr[4];                                                  // (dk <= 64: half a row is <= 4 pieces)
+            u64 vq[4];
+            const int kt = tid >> 1, kh = tid & 1, nph = npc >> 1;        // this thread's key, its half, pieces per half
             unsigned char mb = 1;
             auto krow_of = [&](int t) -> const uint4* {
                 return self ? (const uint4*)((const bf16_t*)S.cache + ((size_t)A.anc[j * A.L + t] * A.L + t) * (2 * d) + hd * dk)
                             : (const uint4*)((const bf16_t*)S.kv + ((size_t)j * S.m + t) * (2 * d) + hd * dk);
             };
             const int m_old = self ? pos : m;                            // keys whose rows are in memory already
-            if (tid < m_old) {
-                const uint4* kp = krow_of(tid);
+            if (kt < m_old) {
+                const uint4* kp = krow_of(kt) + kh * nph;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = kp[c];
-                if (!self && S.mask) mb = S.mask[(size_t)j * S.mask_stride + tid];
+                for (int c = 0; c < 4; ++c) if (c < nph) kr[c] = kp[c];
+                if (!self && S.mask) mb = S.mask[(size_t)j * S.mask_stride + kt];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int t = qt + u * nq;
                 vq[u] = t < m_old ? ((const u64*)((const bf16_t*)krow_of(t) + d))[c4] : 0;
             }
             float* knew = qs + 128; float* vnew = qs + 256;               // self: the newest row's k and v of this head
             if (!self) {
                 // q_h = LayerNorm(x_j) W_q,h^T + b_q,h  (the head's dk rows of W_q: prefetched), rounded to bf16 as the training kernels store q
-                alive = dec_poll(rX, (unsigned)j * d, d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+                alive = dec_poll<DEC_THREADS>(rX, (unsigned)j * d, d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+                gains_to_lds();
                 __syncthreads();
                 if (dbg) dbg[si * 4 + 1] = wall_clock64();
-                if (wave == 0) dec_ln_row(xf, lng, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)((bf16_t*)act + c) = dec_pack4(y); });
+                if (wave == 0) dec_ln_row(xf, gains, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)((bf16_t*)act + c) = dec_pack4(y); });
                 __syncthreads();
                 f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, 1, lane);
                 spill(acc);
-                if (tid < dk) qs[tid] = bf16_to_f32(f32_to_bf16(gather(dk, tid, 0) + bpre[0].x));
+                if (tid < dk) qs[tid] = bf16_to_f32(f32_to_bf16(gather(dk, tid, 0) + bpre.x));
             } else {
                 // q_h, and k_h | v_h of the newest row, arrive as the projection stage's granules (gathered below)
             }
@@ -424,36 +454,41 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
                 if (dbg) dbg[si * 4 + 1] = wall_clock64();
             }
             float mx = -3.0e38f;
-            for (int t = tid; t < m; t += DEC_THREADS) {
+            for (int t = kt; t < (m + DEC_THREADS / 2 - 1) / (DEC_THREADS / 2) * (DEC_THREADS / 2); t += DEC_THREADS / 2) {       // (every pair runs the same trip count: the shuffle below)
                 float s_ = 0.f;
-                if (self && t == pos) {
-                    for (int c = 0; c < dk; ++c) s_ += qs[c] * knew[c];
-                } else {
-                    if (t >= DEC_THREADS) {                              // keys beyond the first 256: loaded here
-                        const uint4* kp = krow_of(t);
+                const bool live = t < m;
+                if (live && self && t == pos) {
+                    for (int c = 0; c < dk / 2; ++c) s_ += qs[kh * (dk / 2) + c] * knew[kh * (dk / 2) + c];
+                } else if (live) {
+                    if (t >= DEC_THREADS / 2) {                          // keys beyond the first pass: loaded here
+                        const uint4* kp = krow_of(t) + kh * nph;
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) if (c < npc) kr[c] = kp[c];
+                        for (int c = 0; c < 4; ++c) if (c < nph) kr[c] = kp[c];
                         mb = (!self && S.mask) ? S.mask[(size_t)j * S.mask_stride + t] : 1;
                     }
+                    const float* qh = qs + kh * (dk / 2);
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        if (c < npc) {
+                    for (int c = 0; c < 4; ++c) {
+                        if (c < nph) {
                             const unsigned w4[4] = {kr[c].x, kr[c].y, kr[c].z, kr[c].w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                s_ += qs[c * 8 + 2 * e] * __uint_as_float(w4[e] << 16) + qs[c * 8 + 2 * e + 1] * __uint_as_float(w4[e] & 0xffff0000u);
+                                s_ += qh[c * 8 + 2 * e] * __uint_as_float(w4[e] << 16) + qh[c * 8 + 2 * e + 1] * __uint_as_float(w4[e] & 0xffff0000u);
                         }
                     }
                 }
-                s_ *= scale;
-                if (mb == 0) s_ = -1.0e9f;                               // masked_fill(mask == 0, -1e9), mtn.py:226
-                sc[t] = s_;
-                mx = fmaxf(mx, s_);
+                s_ += __shfl_xor(s_, 1);                                 // the two halves (same order in both lanes)
+                if (live) {
+                    s_ *= scale;
+                    if (mb == 0) s_ = -1.0e9f;                           // masked_fill(mask == 0, -1e9), mtn.py:226
+                    if (kh == 0) sc[t] = s_;
+                    mx = fmaxf(mx, s_);
+                }
             }
-            mx = dec_block_max(mx, misc, tid);
+            mx = dec_block_max<DEC_NW>(mx, misc, tid);
             float sum = 0.f;
             for (int t = tid; t < m; t += DEC_THREADS) { const float e = __expf(sc[t] - mx); sc[t] = e; sum += e; }
-            sum = dec_block_sum(sum, misc, tid);
+            sum = dec_block_sum<DEC_NW>(sum, misc, tid);
             const float inv = 1.0f / sum;
             // o[c] = sum_t P[t] V[t][c], P rounded to bf16 (the training kernels feed P to the MFMA in bf16): thread = (four columns, key part)
             float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -465,9 +500,9 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
                     for (int k = 0; k < 4; ++k) o[k] += pr * vnew[c4 * 4 + k];
                 } else {
                     u64 v4 = 0;
-                    if (u < 8) {
+                    if (u < 4) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) if (q == u) v4 = vq[q];
+                        for (int q = 0; q < 4; ++q) if (q == u) v4 = vq[q];
                     } else v4 = ((const u64*)((const bf16_t*)krow_of(t) + d))[c4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[k] += pr * bf16_to_f32((bf16_t)(v4 >> (16 * k)));
@@ -476,20 +511,28 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
 #pragma unroll
             for (int k = 0; k < 4; ++k) part[qt * dk + c4 * 4 + k] = o[k];
             __syncthreads();
-            if (dbg) dbg[si * 4 + 2] = wall_clock64();
-            if (tid < dk / 2) {
-                float y0 = 0.f, y1 = 0.f;
-                for (int q = 0; q < nq; ++q) { y0 += part[q * dk + tid * 2]; y1 += part[q * dk + tid * 2 + 1]; }
-                dec_pub(rO, ((unsigned)j * d + hd * dk) / 2 + tid, dec_pack2(y0, y1), tag);
+            {   // two levels, fixed order: thread (group g of threads / dk, column c) sums the key parts g, g + G1, ..; then dk / 2 threads the groups
+                const int G1 = DEC_THREADS / dk, g = tid / dk, c = tid % dk;
+                float y = 0.f;
+                for (int q = g; q < nq; q += G1) y += part[q * dk + c];
+                sc[g * dk + c] = y;                                        // (the probabilities are dead: every PV loop is behind the barrier)
+                __syncthreads();
+                if (dbg) dbg[si * 4 + 2] = wall_clock64();
+                if (tid < dk / 2) {
+                    float y0 = 0.f, y1 = 0.f;
+                    for (int q = 0; q < G1; ++q) { y0 += sc[q * dk + tid * 2]; y1 += sc[q * dk + tid * 2 + 1]; }
+                    dec_pub(rO, ((unsigned)j * d + hd * dk) / 2 + tid, dec_pack2(y0, y1), tag);
+                }
             }
         } break;
         case MTN_DEC_FINAL: {          // the decoder's final LayerNorm (mtn.py:161) -> the generator's bf16 operand (read by the NEXT kernel: plain stores)
             if (wg < W) {
-                alive = dec_poll(rX, (unsigned)wg * d, d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+                alive = dec_poll<DEC_THREADS>(rX, (unsigned)wg * d, d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+                gains_to_lds();
                 __syncthreads();
                 if (wave == 0) {
                     bf16_t* row = (bf16_t*)A.out_lp + (size_t)wg * d;
-                    dec_ln_row(xf, lng, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
+                    dec_ln_row(xf, gains, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
                 }
             }
         } break;
@@ -497,7 +540,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_step_kernel(const DecKerne
         }
         if (dbg) dbg[si * 4 + 3] = wall_clock64();
         __syncthreads();                                                    // (LDS images are reused by the next stage)
-        if (si + 1 < n_stages) { S = KA.stages[si + 1]; prefetch(S); }
+        if (si + 1 < n_stages) { S = stage_of(si + 1); prefetch(S); }
     }
     // workgroup 0 has seen the last stage's x of every producer: every workgroup has read the generation long ago
     if (wg == 0 && tid == 0) A.sync[0] = gen >> 8;
@@ -507,16 +550,16 @@ extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage*
     MTN_CHECK_ARG(a && stages_device, "null arguments");
     MTN_CHECK_ARG(a->W >= 1 && a->W <= DEC_MAX_W, "1 .. 8 hypotheses per launch");
     MTN_CHECK_ARG(a->d >= 128 && a->d <= 1024 && (a->d == 128 || a->d == 256 || a->d == 512 || a->d == 1024), "d_model in {128, 256, 512, 1024}");
-    MTN_CHECK_ARG(a->h >= 1 && a->d % a->h == 0 && (a->d / a->h == 32 || a->d / a->h == 64 || a->d / a->h == 128), "head size 32, 64 or 128");
+    MTN_CHECK_ARG(a->h >= 1 && a->d % a->h == 0 && (a->d / a->h == 32 || a->d / a->h == 64), "head size 32 or 64");
     MTN_CHECK_ARG(a->n_stages >= 1 && a->L >= 1 && a->L <= 1024, "bad stage count / maximum length");
     MTN_CHECK_ARG(grid >= a->W * a->h && grid <= 256, "grid: at least one workgroup per (hypothesis, head), at most one per CU");
     MTN_CHECK_ARG(a->xg && a->qg && a->og && a->hg && a->out_lp && a->tokens && a->lut && a->pe && a->pos && a->anc && a->sync, "null buffer");
-    MTN_CHECK_ARG(a->W * a->d <= 4096 && a->n_stages <= 250, "W x d_model <= 4096; at most 250 stages");
+    MTN_CHECK_ARG(a->W * a->d <= 4096 && a->n_stages <= DEC_MAX_STAGES, "W x d_model <= 4096; at most 160 stages");
     MTN_CHECK_ARG(a->d_ff >= a->d && a->d_ff <= 4096 && a->d_ff % 32 == 0, "d_ff: a multiple of 32, at most 4096");
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)decode_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)decode_step_kernel<DEC_NW_USED>, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS) != hipSuccess) {
             mtn_set_error("mtn_decode_step: cannot opt into %d bytes of LDS", DEC_LDS);
             return MTN_ERR_LAUNCH;
         }
@@ -525,7 +568,7 @@ extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage*
     DecKernelArgs KA;
     KA.a = *a;
     KA.stages = stages_device;
-    hipLaunchKernelGGL(decode_step_kernel, dim3(grid), dim3(DEC_THREADS), DEC_LDS, s, KA);
+    hipLaunchKernelGGL(decode_step_kernel<DEC_NW_USED>, dim3(grid), dim3(DEC_NW_USED * 64), DEC_LDS, s, KA);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }

@@ -271,7 +271,7 @@ class MegaDecodeSession(DecodeSession):
         except AttributeError:
             return False
         W = batch.query.size(0) * width
-        if model.compute_dtype != torch.bfloat16 or W > MegaDecodeSession.MAX_W or W * d > 4096 or d not in (128, 256, 512, 1024) or d % h or d // h not in (32, 64, 128):
+        if model.compute_dtype != torch.bfloat16 or W > MegaDecodeSession.MAX_W or W * d > 4096 or d not in (128, 256, 512, 1024) or d % h or d // h not in (32, 64):
             return False
         if dff > 4096 or dff % 32 or max_len > 1024 or model.auto_encoder_ft not in ("query", "caption", "summary"):
             return False
@@ -310,6 +310,7 @@ class MegaDecodeSession(DecodeSession):
         self._h_anc = hb[self._off_anc:].view(np.int32).reshape(W, Lm)
         self._h_anc[:] = np.arange(W, dtype=np.int32)[:, None]
         self._prev = None
+        self._top_host = None
         self._grid = max(W * h, -(-max(dff, 3 * d) // 64))
         self._build_stages(L, d, h, dff)
         emb, pe = model.tgt_embed[0], model.tgt_embed[1]
@@ -378,11 +379,22 @@ class MegaDecodeSession(DecodeSession):
         import ctypes as C
         from . import lib as L
         m = self.model
+        # the step's host inputs and (with device-side selection) its host outputs travel INSIDE the pass — copy nodes of the captured graph —
+        # so a generated token costs the host one replay and one stream synchronisation
+        self._devblk.copy_(self._host, non_blocking=True)
         L.check(L.load().mtn_decode_step(C.byref(self._args), self._stages_dev.data_ptr(), self._grid, L.stream_ptr()))
         g = m.generator._fused
         self.logp = ops.generator_log_probs(self._out_lp, g["w_lp"], g["bias"])          # (W, V) fp32 log-probabilities (mtn.py:68-69)
         if self.select is not None:
             self.top = ops.topk_rows(self.logp, min(self.select[0], self.logp.size(1)), self.select[1])
+            if self._top_host is None:
+                self._top_host = torch.empty(self.top.shape, dtype=self.top.dtype).pin_memory()
+            self._top_host.copy_(self.top, non_blocking=True)
+
+    def top_host(self):
+        """The rows' heads of the last step on the host (a pinned block the pass itself filled)."""
+        torch.cuda.current_stream().synchronize()
+        return self._top_host.numpy()
 
     def check(self):
         """Raises if a grid barrier of any step since the session was built timed out (the results would be garbage)."""
@@ -408,7 +420,6 @@ class MegaDecodeSession(DecodeSession):
                 self._h_anc[j, l - 1] = j
         self._prev = [[list(p) for p in prefixes] for prefixes in prefix_lists]
         self._h_pos[0] = l - 1
-        self._devblk.copy_(self._host, non_blocking=True)
         with torch.no_grad():
             if not self.use_graph:
                 self._pass_mega()
@@ -523,7 +534,7 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
         logps = sess.step_many([bm.prefixes() for bm in beams])
         if sess.top is not None:
             # device-side selection inside the pass (csrc/select.hip): only the heads of the rows travel, in one copy
-            full = sess.top.cpu().numpy().astype("float64")
+            full = (sess.top_host() if isinstance(sess, MegaDecodeSession) else sess.top.cpu().numpy()).astype("float64")
             live = [r for d, lp in enumerate(logps) for r in range(d * sess.width, d * sess.width + lp.size(0))]
             packed = full[live]
             kk = (packed.shape[1] - 1) // 2
