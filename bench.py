@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--windows", type=int, default=4, help="extra timed windows of --steps steps after the one `value` comes from")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (batch-64 figure, one-rank RCCL "
                     "schedule and decode figures at N=1, exchange-free single-rank figure at N>1)")
+    ap.add_argument("--pmc-calibration", action="store_true", help="after the timed steps, one whole-buffer mtn_adam_step over a scratch "
+                    "buffer of 2^24 elements: a launch of exactly known HBM traffic (16 B read + 14 B written per element) for "
+                    "tools/pmc_summary.py to calibrate the WRITE_SIZE counter on (the fused step itself no longer has one)")
     ap.add_argument("--dp-one-rank-probe", action="store_true", help=argparse.SUPPRESS)     # child process of the N = 1 secondary measurement
     ap.add_argument("--no-record", action="store_true", help="development probe: allows MTN_DP_EMULATE_WORLD (a rank updates 1/N of "
                     "every slice as in an N-GPU job — WRONG parameters, timing only); the line is then marked \"record\": false")
@@ -803,6 +806,15 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(model, cfg, B, args.cpu_steps)
             except Exception as e:  # pragma: no cover
                 line["cpu_baseline"] = {"error": str(e)}
+    if args.pmc_calibration and rank == 0:
+        from mtn_amd import lib as L
+        n = 1 << 24
+        p_, g_, m_, v_ = (torch.full((n,), x, device=dev) for x in (0.5, 1e-3, 0.0, 0.0))
+        lp_ = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+        st_ = torch.tensor([1.0, 1e-3, 0.1, 0.02, 0, 0, 0, 0], device=dev)           # step, lr, 1 - beta1^t, 1 - beta2^t
+        L.check(L.load().mtn_adam_step(L.dtype_code(torch.bfloat16), n, p_.data_ptr(), g_.data_ptr(), m_.data_ptr(), v_.data_ptr(),
+                                       lp_.data_ptr(), st_.data_ptr(), None, 0.9, 0.98, 1e-9, L.stream_ptr()))
+        torch.cuda.synchronize()
     # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would surface after our line at
     # exit: flush every rank's C buffers first, so that the JSON line is the last thing the job prints
     import ctypes
