@@ -162,6 +162,8 @@ class ShardedOptimizerSync:
             force = os.environ.get("MTN_FORCE_DIST") == "1"
         self.collective = self.world > 1 or (dist.is_initialized() and bool(force))
         self.side = None
+        self._stamp, self._stamps = None, False      # (timeline measurement: the stream the gathers' ends are stamped on)
+        self._pending_gather = None
         self._works = []
         self.slices = set()             # every (lo, hi) this object split into shards (for gather())
         self.lp_slices = set()          # ... of them, the matrix ranges whose foreign fp32 masters are stale (gathered in the compute dtype)
@@ -247,6 +249,28 @@ class ShardedOptimizerSync:
                 e.record()
                 tl[name] = e
 
+        def gather():
+            # what the other ranks need of this shard: its bf16 copy | its fp32 master
+            buf = self.lp_fn() if lp_gather else flat
+            mine = []
+            if self.native:
+                mine.append(dist.all_gather_into_tensor(buf[lo:tail], buf[own:own + per], group=self.group, async_op=True))
+                self.calls["all_gather"] += 1
+            else:
+                for r in range(self.world):
+                    mine.append(dist.broadcast(buf[lo + r * per: lo + (r + 1) * per], src=r, group=self.group, async_op=True))
+                    self.calls["broadcast"] += 1
+            self._works += mine
+            if tl is not None:                     # measurement only: a THIRD stream waits for the gather so that its end can be stamped
+                tl["bytes_gathered"] = buf.element_size() * (tail - lo)
+                if self._stamp is None:
+                    self._stamp = torch.cuda.Stream()
+                with torch.cuda.stream(self._stamp):
+                    for w in mine:
+                        w.wait()
+                    mark("gathered")
+                self._stamps = True
+
         def chain():
             mark("ready")                          # (side stream: behind everything the compute stream had queued = the slice's gradients)
             for w in works:
@@ -257,34 +281,39 @@ class ShardedOptimizerSync:
             if tail < hi:
                 upd(tail, hi - tail)               # replicated: identical inputs -> identical results on every rank
             mark("updated")
-            if per > 0:
-                buf = self.lp_fn() if lp_gather else flat          # what the other ranks need of this shard: its bf16 copy | its fp32 master
-                mine = []
-                if self.native:
-                    mine.append(dist.all_gather_into_tensor(buf[lo:tail], buf[own:own + per], group=self.group, async_op=True))
-                    self.calls["all_gather"] += 1
-                else:
-                    for r in range(self.world):
-                        mine.append(dist.broadcast(buf[lo + r * per: lo + (r + 1) * per], src=r, group=self.group, async_op=True))
-                        self.calls["broadcast"] += 1
-                self._works += mine
-                if tl is not None:                 # measurement only: the side stream waits for the gather so that its end can be stamped
-                    tl["bytes_gathered"] = buf.element_size() * (tail - lo)
-                    for w in mine:
-                        w.wait()
-                    mark("gathered")
 
+        # Issue order on the collective stream: this slice's reduce-scatter went out above; the PREVIOUS slice's all-gather — which waits
+        # for that slice's Adam — goes out only now, behind it.  Issued in program order (gather k, then reduce-scatter k+1) the
+        # reduce-scatter of the next slice would sit behind a collective that waits for an optimiser pass, and the whole exchange
+        # would run as one serial chain: reduce -> update -> gather -> reduce -> ... (profiles/r05_dp_timeline_serial.txt)
+        self._flush_gather()
         if cuda:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 chain()
         else:
             chain()
+        if per > 0:
+            self._pending_gather = gather
+
+    def _flush_gather(self):
+        g, self._pending_gather = self._pending_gather, None
+        if g is None:
+            return
+        if self.side is not None:
+            with torch.cuda.stream(self.side):     # the collective waits for what the side stream has queued: that slice's update
+                g()
+        else:
+            g()
 
     def finish(self):
         """The current stream waits for every chain issued since the last finish()."""
+        self._flush_gather()
         for w in self._works:
             w.wait()
         self._works = []
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+        if self._stamps:
+            torch.cuda.current_stream().wait_stream(self._stamp)
+            self._stamps = False

@@ -33,7 +33,9 @@ def one_step(rows):
     adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] or "adam_chunks_kernel" in r["Kernel_Name"]]
     if len(adam) < 3:                  # a step ends with the table launch (tools/prof_breakdown.py)
         adam = [i for i, r in enumerate(rows) if "gemm_tt_dma128_table_kernel" in r["Kernel_Name"]]
-    cands = [rows[adam[i] + 1: adam[i + 1] + 1] for i in range(max(0, len(adam) - 4), len(adam) - 1)]
+    cands = [rows[adam[i] + 1: adam[i + 1] + 1] for i in range(len(adam) - 1)]
+    # whole train steps only (bench.py's per-kernel census replays just the GEMM launches, and ends in the table launch too)
+    cands = [c for c in cands if any("fused_head_fwd" in r["Kernel_Name"] for r in c) and any("fused_head_bwd" in r["Kernel_Name"] for r in c)]
     return min(cands, key=len)          # a replayed graph step (bench.py's eager census pass has extra kernels)
 
 

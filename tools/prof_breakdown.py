@@ -7,9 +7,10 @@ adam = [i for i,r in enumerate(rows) if 'adam_kernel' in r[0] or 'adam_chunks_ke
 if len(adam) < 3:
     # round 5: the rest of the optimiser rides in the table launch (no adam_chunks launch behind it): a step ends with the table launch
     adam = [i for i,r in enumerate(rows) if 'gemm_tt_dma128_table_kernel' in r[0]]
-# the last few optimiser-to-optimiser intervals; the shortest one is a replayed graph step (bench.py's eager census pass, which
-# also ends in an optimiser kernel, is longer)
-cands = [rows[adam[i]+1:adam[i+1]+1] for i in range(max(0, len(adam)-5), len(adam)-1)]
+# optimiser-to-optimiser intervals that are whole train steps (bench.py's per-kernel census replays only the GEMM launches, and
+# those passes end in the table launch too); the shortest one is a replayed graph step (the eager census pass is longer)
+cands = [rows[adam[i]+1:adam[i+1]+1] for i in range(len(adam)-1)]
+cands = [c for c in cands if any('fused_head_fwd' in r[0] for r in c) and any('fused_head_bwd' in r[0] for r in c)][-6:]
 step = min(cands, key=lambda st: st[-1][2] - st[0][1])
 t0, t1 = step[0][1], step[-1][2]
 iv = sorted((r[1], r[2]) for r in step)
