@@ -431,12 +431,14 @@ def exchange_timeline(step, ref_ms):
     tl, step.sharded.timeline = step.sharded.timeline, None
     us = lambda e: round(e_start.elapsed_time(e) * 1e3, 1)
     slices = [{"flat_range": [t["lo"], t["hi"]], "MB_reduced": round(t["bytes_reduced"] / 1e6, 1), "MB_gathered": round(t["bytes_gathered"] / 1e6, 1),
-               **{k + "_us": us(t[k]) for k in ("ready", "reduced", "updated", "gathered") if k in t}} for t in tl if "lo" in t]
+               **{k + "_us": us(t[k]) for k in ("ready", "reduced", "update_begins", "updated", "gathered") if k in t}} for t in tl if "lo" in t]
     chain_end = [us(t["chain_end"]) for t in tl if "chain_end" in t]
-    return {"what": "this rank, one step: offsets from the step's start (HIP events on the stream the exchange chain runs on): a slice's gradients "
-                    "ready (its segment graph done) -> reduce-scatter done -> Adam on the shard done -> all-gather done; compute_chain_end = the last "
-                    "segment graph finished, step_end = the exchange drained and the copies refreshed.  exposed = step_end - compute_chain_end; the "
-                    "chain's stretch under the exchange = compute_chain_end / the exchange-free single-rank step of the same batch (optimiser inside its dW launch)",
+    return {"what": "this rank, one step, offsets from the step's start (HIP events): a slice's gradients ready (its segment graph done, "
+                    "reduce-scatter issued) -> reduce-scatter done (stamped on a separate stream) -> the compute stream, one segment later, "
+                    "begins Adam on the shard -> done, all-gather issued -> all-gather done (stamped); compute_chain_end = the last segment "
+                    "graph finished, step_end = the exchange drained and the copies refreshed.  exposed = step_end - compute_chain_end (the "
+                    "last slices' update + gather); the chain's stretch = compute_chain_end / the exchange-free single-rank step of the "
+                    "same batch (optimiser inside its dW launch): it contains the shard updates of all but the last slices",
             "slices": slices, "compute_chain_end_us": chain_end[0] if chain_end else None, "step_end_us": us(e_end),
             "exposed_exchange_us": round(us(e_end) - chain_end[0], 1) if chain_end else None,
             "chain_stretch_vs_single_rank_step": round(chain_end[0] / (ref_ms * 1e3), 3) if (chain_end and ref_ms) else None}
@@ -457,12 +459,23 @@ def dp_schedule_one_rank(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--dp-one-rank-probe", "--steps", str(args.steps), "--workload", args.workload,
            "--dtype", args.dtype, "--dropout", str(args.dropout)] + (["--no-graph"] if args.no_graph else []) + \
           (["--batch-per-gpu", str(args.batch_per_gpu)] if args.batch_per_gpu else [])
-    try:
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    def child(env, extra=()):
+        out = subprocess.run(cmd + list(extra), env=env, capture_output=True, text=True, timeout=240)
         for ln in reversed(out.stdout.strip().splitlines()):
             if ln.startswith("{"):
                 return json.loads(ln)
         return {"error": (out.stderr or out.stdout)[-400:]}
+
+    try:
+        res = child(env)
+        # the same schedule with the update of a rank of 8: Adam on 1/8 of every slice (the parameters come out WRONG: a timing probe,
+        # `--no-record`); the one-rank collectives move nothing, so this is a rank's own cost in an 8-GPU job without any link time
+        r8 = child(dict(env, MTN_DP_EMULATE_WORLD="8"), ("--no-record",))
+        if "ms_per_step" in r8 and "ms_per_step" in res:
+            res["ms_per_step_update_of_a_rank_of_8"] = r8["ms_per_step"]
+            res["update_of_a_rank_of_8_what"] = ("same probe, Adam on 1/8 of every slice as on a rank of an 8-GPU job (results wrong: timing only); "
+                                                 "collectives still one-rank: no link time in it")
+        return res
     except Exception as e:  # pragma: no cover
         return {"error": f"{type(e).__name__}: {e}"}
 
@@ -474,6 +487,8 @@ def dp_one_rank_probe(args):
     from mtn_amd.synthetic import CONFIGS, synthetic_batch
     from mtn_amd.train_step import TrainStep
     dp.init_distributed(force=True)
+    dp.ALLOW_EMULATION = bool(args.no_record)
+    emulating = args.no_record and os.environ.get("MTN_DP_EMULATE_WORLD", "1") not in ("", "0", "1")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     lib.load()
@@ -504,12 +519,12 @@ def dp_one_rank_probe(args):
     sh = st.sharded
     out = {"ms_per_step": round(ms, 4), "samples_per_s": round(B / ms * 1e3, 1), "rccl_ranks": dist.get_world_size(), "dist_backend": dist.get_backend(),
            "schedule": ("layer-segmented backward (N+3 hipGraphs), " if st.overlap else "two-graph schedule, ") +
-                       ("reduce-scatter -> Adam on the shard -> all-gather per slice" if sh is not None else "all-reduce per slice + full Adam"),
+                       ("reduce-scatter -> Adam on the shard (compute stream, one segment later) -> all-gather, per slice" if sh is not None else "all-reduce per slice + full Adam"),
            "collectives_issued": dict(sh.calls) if sh is not None else {}, "slices_per_step": len(st._slices()), "batch_per_gpu": B,
            "what": "the step of a data-parallel rank on this one GPU in a fresh process, every collective through a one-rank RCCL group "
                    "(shard = the whole slice): the schedule's cost without peers (segmentation, the separate optimiser pass, RCCL "
                    "calls); same batch as `value`"}
-    if sh is not None:                       # the same schedule with the collectives skipped: what the RCCL calls themselves cost
+    if sh is not None and not emulating:     # the same schedule with the collectives skipped: what the RCCL calls themselves cost
         st2 = TrainStep(model, batch, cfg["vocab"], pad=1, warmup=4000, grad_sync=sync, use_graph=not args.no_graph)
         st2.sharded.collective = False
         out["ms_per_step_collectives_skipped"] = round(timed(st2), 4)

@@ -130,9 +130,9 @@ class ShardedOptimizerSync:
     instead of  all-reduce -> the full Adam pass on every rank.  The bytes on the links are those of the all-reduce (a ring
     all-reduce IS a reduce-scatter followed by an all-gather), but every rank streams 38 B/param of optimiser state for 1/N of
     the parameters instead of all of them, and the replicas are identical by construction (every element is summed and updated
-    exactly once, then copied).  With the layer-segmented backward (train_step.TrainStep) slice k's three stages run on the
-    communication / side streams while the compute stream is already in the backward of layer k-1; only the last slice's
-    chain is exposed.  After the last slice, ``finish()`` waits and the caller refreshes the compute-dtype copies (cast +
+    exactly once, then copied).  With the layer-segmented backward (train_step.TrainStep) slice k's reduce-scatter runs on the
+    collective stream while the compute stream is in the backward of layer k-1; its shard update follows THAT segment on the
+    compute stream and its all-gather runs under layer k-2 (see reduce_update); only the last slice's chain is exposed.  After the last slice, ``finish()`` waits and the caller refreshes the compute-dtype copies (cast +
     transposes of everything: 10 B/param, local).
 
     ``update(off, n)`` applies the optimiser to flat elements [off, off+n) (HIP: mtn_adam_step on the sub-buffers; the CPU
@@ -156,20 +156,19 @@ class ShardedOptimizerSync:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.native = dist.is_initialized() and dist.get_backend(group) == "nccl"
         # A one-rank RCCL group (MTN_FORCE_DIST=1 on a 1-GPU box) takes the SAME collective chain as N ranks — in-place
-        # reduce_scatter_tensor / all_gather_into_tensor, side stream, finish() — with per = the whole slice and own = lo, so
+        # reduce_scatter_tensor / all_gather_into_tensor, pipelined update, finish() — with per = the whole slice and own = lo, so
         # that the code an N-GPU job executes has run (and is tested bit for bit against the fused one-rank step) before it.
         if force is None:
             force = os.environ.get("MTN_FORCE_DIST") == "1"
         self.collective = self.world > 1 or (dist.is_initialized() and bool(force))
-        self.side = None
-        self._stamp, self._stamps = None, False      # (timeline measurement: the stream the gathers' ends are stamped on)
-        self._pending_gather = None
+        self._stamp, self._stamps = None, False      # (timeline measurement: the stream the collectives' ends are stamped on)
+        self._pending = None                         # the previous slice's wait -> update -> gather, issued behind the next segment
         self._works = []
         self.slices = set()             # every (lo, hi) this object split into shards (for gather())
         self.lp_slices = set()          # ... of them, the matrix ranges whose foreign fp32 masters are stale (gathered in the compute dtype)
         self.masters_stale = False      # a step ran the compute-dtype gather since the last gather() of the fp32 masters
         # measurement (bench.py secondary.exchange.timeline): when a list, every reduce_update() appends HIP events of its chain —
-        # gradient slice ready / reduced / shard updated / gathered — recorded on the side stream the chain runs on
+        # gradient slice ready / reduced / update begins / shard updated / gathered (compute stream; collectives' ends on a stamp stream)
         self.timeline = None
         self.calls = {"reduce_scatter": 0, "all_reduce": 0, "all_gather": 0, "broadcast": 0}   # collectives issued (tests, bench line)
 
@@ -211,8 +210,6 @@ class ShardedOptimizerSync:
             self.masters_stale = self.world > 1
         per, own, tail = self.split(lo, shard_hi)
         cuda = grad.is_cuda
-        if cuda and self.side is None:
-            self.side = torch.cuda.Stream()
         upd = self.update_lp if lp_gather else self.update
         if not self.collective:
             # one rank, no process group: the plain update.  MTN_DP_EMULATE_WORLD (update 1/emu of the slice, as a rank of an
@@ -225,6 +222,31 @@ class ShardedOptimizerSync:
             n = hi - lo
             upd(lo, n if emu <= 1 else max(4, (n // (emu * 4)) * 4))
             return
+        emu = 1
+        if self.world == 1 and ALLOW_EMULATION:             # timing probe (`bench.py --no-record`): the update of a rank of `emu`, see above
+            emu = int(os.environ.get("MTN_DP_EMULATE_WORLD", "1"))
+        tl = None
+        if self.timeline is not None and cuda:
+            tl = {"lo": lo, "hi": hi, "bytes_reduced": 4 * (tail - lo) if per > 0 else 0, "bytes_gathered": 0}
+            self.timeline.append(tl)
+
+        def mark(name):
+            if tl is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                tl[name] = e
+
+        def stamp(ws, name):               # measurement only: a separate stream waits for the collectives so that their END can be stamped
+            if tl is not None:
+                if self._stamp is None:
+                    self._stamp = torch.cuda.Stream()
+                with torch.cuda.stream(self._stamp):
+                    for w in ws:
+                        w.wait()
+                    mark(name)
+                self._stamps = True
+
+        mark("ready")                          # the slice's gradients: everything the compute stream has queued so far
         works = []
         if per > 0:
             if self.native:
@@ -237,83 +259,54 @@ class ShardedOptimizerSync:
         if tail < hi:                                      # the replicated remainder: < 4 * world matrix elements (+ the slice's vectors)
             works.append(dist.all_reduce(grad[tail:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.calls["all_reduce"] += 1
+        stamp(works, "reduced")
 
-        tl = None
-        if self.timeline is not None and cuda:
-            tl = {"lo": lo, "hi": hi, "bytes_reduced": 4 * (tail - lo) if per > 0 else 0, "bytes_gathered": 0}
-            self.timeline.append(tl)
-
-        def mark(name):
-            if tl is not None:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()
-                tl[name] = e
-
-        def gather():
-            # what the other ranks need of this shard: its bf16 copy | its fp32 master
-            buf = self.lp_fn() if lp_gather else flat
-            mine = []
-            if self.native:
-                mine.append(dist.all_gather_into_tensor(buf[lo:tail], buf[own:own + per], group=self.group, async_op=True))
-                self.calls["all_gather"] += 1
-            else:
-                for r in range(self.world):
-                    mine.append(dist.broadcast(buf[lo + r * per: lo + (r + 1) * per], src=r, group=self.group, async_op=True))
-                    self.calls["broadcast"] += 1
-            self._works += mine
-            if tl is not None:                     # measurement only: a THIRD stream waits for the gather so that its end can be stamped
-                tl["bytes_gathered"] = buf.element_size() * (tail - lo)
-                if self._stamp is None:
-                    self._stamp = torch.cuda.Stream()
-                with torch.cuda.stream(self._stamp):
-                    for w in mine:
-                        w.wait()
-                    mark("gathered")
-                self._stamps = True
-
-        def chain():
-            mark("ready")                          # (side stream: behind everything the compute stream had queued = the slice's gradients)
+        def complete():
             for w in works:
-                w.wait()                           # the current (side) stream waits; the host does not
-            mark("reduced")
+                w.wait()                           # the compute stream waits (the host does not): by now a whole segment was queued behind the reduce-scatter
+            mark("update_begins")
             if per > 0:
-                upd(own, per)
+                upd(own, per if emu <= 1 else max(4, (per // (emu * 4)) * 4))
             if tail < hi:
                 upd(tail, hi - tail)               # replicated: identical inputs -> identical results on every rank
             mark("updated")
+            if per > 0:
+                buf = self.lp_fn() if lp_gather else flat          # what the other ranks need of this shard: its bf16 copy | its fp32 master
+                mine = []
+                if self.native:
+                    mine.append(dist.all_gather_into_tensor(buf[lo:tail], buf[own:own + per], group=self.group, async_op=True))
+                    self.calls["all_gather"] += 1
+                else:
+                    for r in range(self.world):
+                        mine.append(dist.broadcast(buf[lo + r * per: lo + (r + 1) * per], src=r, group=self.group, async_op=True))
+                        self.calls["broadcast"] += 1
+                self._works += mine
+                if tl is not None:
+                    tl["bytes_gathered"] = buf.element_size() * (tail - lo)
+                stamp(mine, "gathered")
 
-        # Issue order on the collective stream: this slice's reduce-scatter went out above; the PREVIOUS slice's all-gather — which waits
-        # for that slice's Adam — goes out only now, behind it.  Issued in program order (gather k, then reduce-scatter k+1) the
-        # reduce-scatter of the next slice would sit behind a collective that waits for an optimiser pass, and the whole exchange
-        # would run as one serial chain: reduce -> update -> gather -> reduce -> ... (profiles/r05_dp_timeline_serial.txt)
-        self._flush_gather()
-        if cuda:
-            self.side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
-                chain()
-        else:
-            chain()
-        if per > 0:
-            self._pending_gather = gather
+        # The schedule, ONE compute stream + the collective stream:
+        #     segment k | reduce-scatter k issued | segment k+1 | reduce-scatter k+1 issued | wait RS k, Adam on shard k, all-gather k issued | ...
+        # The update of slice k runs on the COMPUTE stream, after the next segment: by then its reduce-scatter has had a whole segment
+        # (~0.4 ms) to finish, so the wait is free; the shard is 1/N of the slice (9 us of Adam at N = 8), and nothing hops between
+        # streams on the critical path.  Rounds 2-4 ran the update on a side stream under the next segment: on one rank, where the
+        # "shard" is the whole slice, the two HBM-bound streams stretched each other by more than the update's own length and every
+        # stream hop cost 60-100 us (profiles/r05_dp_timeline_serial.txt: 4.61 ms; serialised by rocprofv3 the same launches took 3.94).
+        # Collective-stream order: RS 0, RS 1, AG 0, RS 2, AG 1, ...: a reduce-scatter never queues behind a gather that waits for an update.
+        self._complete_pending()
+        self._pending = complete
 
-    def _flush_gather(self):
-        g, self._pending_gather = self._pending_gather, None
-        if g is None:
-            return
-        if self.side is not None:
-            with torch.cuda.stream(self.side):     # the collective waits for what the side stream has queued: that slice's update
-                g()
-        else:
-            g()
+    def _complete_pending(self):
+        c, self._pending = self._pending, None
+        if c is not None:
+            c()
 
     def finish(self):
         """The current stream waits for every chain issued since the last finish()."""
-        self._flush_gather()
+        self._complete_pending()
         for w in self._works:
             w.wait()
         self._works = []
-        if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
         if self._stamps:
             torch.cuda.current_stream().wait_stream(self._stamp)
             self._stamps = False
