@@ -357,10 +357,16 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     // wave issues exactly that many, and they are its youngest loads) are still in flight; the normalised rows are in LDS once the
     // LDS counter is down.  No vmcnt(0) here (__syncthreads has one): the last weight block has only just been asked for, and the
     // projections below start on the fragments that have landed (counted waits by the compiler, fragment by fragment).
+    // (The count assumes what the compiler emits today.  MTN_SAFE_WAITS builds the same kernels with full waits —
+    // libmtn_hip_safewaits.so, mtn_amd/build.py — and tests/test_counted_waits_gpu.py compares the two libraries bit for bit.)
     static_assert(NP == 1 || NP == 3 || NP == 4, "the counted wait below spells 8 * NP out");
+#ifdef MTN_SAFE_WAITS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
     if constexpr (NP == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
 #endif
     FH_STAMP(5);

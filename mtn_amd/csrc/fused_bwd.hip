@@ -269,6 +269,10 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     // ================================================================ on chip from here
     // LDS-DMA images and weight fragments have landed once at most the FH_MASKB + 4 NQB + 1 loads issued behind them fly
     static_assert(FH_MASKB == 8 && (NQB == 1 || NQB == 2), "the counted waits below spell the number of younger loads out");
+    // (MTN_SAFE_WAITS: the full-wait build the counted one is compared with bit for bit, tests/test_counted_waits_gpu.py)
+#ifdef MTN_SAFE_WAITS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     if (mask_wide) {                                            // 2 (mask dwords) + 4 NQB (statistics) + 1 (fold value)
         if constexpr (NQB == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
@@ -276,6 +280,7 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
         if constexpr (NQB == 1) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
     }
+#endif
     __builtin_amdgcn_s_barrier();
     FB_STAMP(2);
     if (stop == 1) return;
@@ -430,8 +435,12 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                 if ((it & 1) == 0) {
                     // key block it / 2 has landed in its slot: the only younger vector-memory operations of this wave are the 4 LDS-DMA
                     // instructions of the next block (loads return in order), if there is one
+#ifdef MTN_SAFE_WAITS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
                     if ((it / 2 + 1) * FB_RING_KEYS < mk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                     __builtin_amdgcn_s_barrier();          // (raw barriers in this loop: __syncthreads() would drain the refill DMA in flight)
                 }
                 jimg = ((j0 / FB_RING_KEYS) & 1) * FB_RING_KEYS + (j0 & (FB_RING_KEYS - 1));

@@ -84,7 +84,9 @@ extern "C" int mtn_topk_rows(const float* x, int rows, int V, long ldx, int k, i
 // ---------------------------------------------------------------- Generator: log-softmax of the logit rows (mtn.py:68-69)
 // out[row][c] = x[row][c] - (max + log sum exp(x - max)); one 256-thread workgroup per row, the row read twice (it sits in L2: a
 // decode step has beam x dialogues rows of |V| floats).  In place when out == x.
-__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int V, long ldx, float* __restrict__ out, long ldo) {
+// (x and out may be the same buffer — the generator calls it in place —, so neither pointer is __restrict__: a thread reads the
+// elements it later writes, in that order)
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* x, int V, long ldx, float* out, long ldo) {
     __shared__ float red[4];
     const float* xr = x + (size_t)blockIdx.x * ldx;
     float* orow = out + (size_t)blockIdx.x * ldo;

@@ -498,9 +498,14 @@ class Generator(nn.Module):
 
     def forward(self, x):                      # mtn.py:68-69
         f = self._fused
-        if f is not None and x.is_cuda and not torch.is_grad_enabled() and f["w_lp"].device == x.device and x.size(-1) % 8 == 0:
-            # inference (decode, validation): the library's GEMM + row log-softmax (ops.generator_log_probs) — no vendor BLAS /
-            # softmax kernels in a decode step.  The composed form below stays for callers that differentiate through it.
+        differentiated = torch.is_grad_enabled() and (x.requires_grad or self.proj.weight.requires_grad)
+        if f is not None and x.is_cuda and not self.training and not differentiated and f["w_lp"].device == x.device and x.size(-1) % 8 == 0:
+            # inference — eval() mode and nothing to differentiate (decode, validation): the library's GEMM + row log-softmax
+            # (ops.generator_log_probs), no vendor BLAS / softmax kernels in a decode step.  NUMERICS: x and the weight enter the GEMM in
+            # the compute dtype (bf16: 8 mantissa bits; fp32 accumulation, fp32 log-softmax), where the reference's generator is fp32
+            # throughout — log-probabilities differ by ~1e-3 relative (tests/test_decode_gpu.py pins the bound).  The path depends on
+            # the module's MODE, not on the grad mode alone: train() always takes the composed fp32 form below, and so does a caller
+            # that differentiates through an eval() module.
             f["prepare"]()                     # the compute-dtype weight copy follows the fp32 master (load_state_dict, torch optimisers)
             return ops.generator_log_probs(x, f["w_lp"], f["bias"])
         return F.log_softmax(self.proj(x), dim=-1)
