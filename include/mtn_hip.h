@@ -596,8 +596,10 @@ int mtn_measure_hbm_peak(const void* src, void* dst, long bytes, void* stream, d
  * One decode step of the target stream as ONE persistent launch (round 5, version 112; csrc/decode.hip).  Replaces, for W <= 8 live
  * hypotheses, the per-token pass of `beam_search_decode` / `greedy_decode` (data_utils.py:197-208: `model.decode` + final LayerNorm)
  * in its cached form: the newest position of every hypothesis through N layers x (self-attention over the prefix cache, cross-attentions
- * over hoisted K|V, feed-forward), walking `stages` (a DEVICE array, built once per dialogue shape) with a grid barrier between stages.
- * bf16 weights.  `grid` workgroups must all be resident (<= 256: one per CU).  Stages hand values over as 8-byte {data, tag} granules
+ * over hoisted K|V, feed-forward), walking `stages` (a DEVICE array, built once per dialogue shape; stage 0 = MTN_DEC_EMBED, last = MTN_DEC_FINAL).
+ * bf16 weights.  `grid` (<= 256: one per CU, all resident) is the most workgroups the launch may use: W x h attention units + d / 16
+ * writers of the residual stream + up to 128 for the wide projections — three classes, so that consecutive stages run on different
+ * workgroups and each class prefetches its next stage while the others work.  Stages hand values over as 8-byte {data, tag} granules
  * (no grid barrier): xg / qg / og / hg are the granule buffers (zeroed ONCE by the caller); out_lp [W][d] bf16 = final LayerNorm
  * output (the generator's operand); sync: 2 unsigned, zeroed once: sync[0] = launch generation (advanced by the kernel), sync[1] != 0 =
  * a poll timed out and the results are invalid.  W x d <= 4096.
@@ -629,8 +631,8 @@ typedef struct {
     const int* pos;             /* device scalar: the position being decoded (0-based) */
     const int* anc;             /* [W][L] cache slot that holds position t of hypothesis j's prefix (anc[j][pos] = j) */
     unsigned* sync;
-    void* dbg;                  /* NULL, or 4 x n_stages uint64: workgroup 0's 100 MHz wall-clock stamps per stage (behind the barrier / operands
-                                   ready / computed / stores issued) — tools/decode_timeline.py */
+    void* dbg;                  /* NULL, or 4 x n_stages uint64: 100 MHz wall-clock stamps per stage of the first workgroup of the stage's class
+                                   (entered / operands arrived / computed / stores issued) — tools/decode_timeline.py */
 } mtn_decode_args;
 int mtn_decode_step(const mtn_decode_args* args /* host */, const mtn_decode_stage* stages_device, int grid, void* stream);
 /* The library's development / test switches (MTN_GEMM_*, MTN_ATTN_*, MTN_LN_*, MTN_EMBED_DETERMINISTIC, ...) are read from the

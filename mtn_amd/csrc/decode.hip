@@ -55,6 +55,7 @@ __device__ __forceinline__ unsigned ld_ag32(const unsigned* p) { return __hip_at
 struct DecKernelArgs {
     mtn_decode_args a;
     const mtn_decode_stage* stages;
+    int n_xw, n_mid;            // workgroup classes: [0, n_xw) write x, [n_xw, n_xw + n_mid) the wide projections, the last W * h the attention units
 };
 
 // ---- granules
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mtn_decode_args& A = KA.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = gridDim.x, wg = blockIdx.x;
+    const int wg = blockIdx.x;
     const int W = A.W, d = A.d, dk = d / A.h, dff = A.d_ff;
     const int pos = *A.pos;
     const unsigned gen = (A.sync[0] + 1u) << 8;                          // this launch's generation (advanced by workgroup 0 at the end)
@@ -245,10 +246,20 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
     float* xf = (float*)(smem + DEC_XF_OFF);                             // [W][d]
     float* gains = (float*)(smem + DEC_GAIN_OFF);                        // a_2 [d] | b_2 [d]
     const float scale = rsqrtf((float)dk);
-    const int per_x = ((d + G - 1) / G + 3) / 4 * 4;                     // the slice of every N = d stage (embed, output projections, FFN-2)
-    const int x0 = min(d, wg * per_x), x1 = min(d, x0 + per_x);
-    unsigned last_x_tag = 0;
-    u64* dbg = (A.dbg && wg == 0 && tid == 0) ? (u64*)A.dbg : nullptr;       // per stage: entered / operands arrived / computed / published
+    // Three CLASSES of workgroups, so that consecutive stages never run on the same workgroups (the stage order is wide -> unit -> x ->
+    // unit -> x ... -> wide -> x): while one class works, the next class has already asked for its weights / K | V rows and sits in its
+    // poll.  On one shared set of workgroups (the first versions) every stage paid its 1.6-2.1 us of prefetch ISSUE on the critical
+    // path (profiles/r05_decode_timeline_8waves.txt).
+    //   class 0  "x writers"  EMBED, OUT, FFN2 (N = d): each keeps ITS columns of the residual stream in LDS across the whole step
+    //   class 1  "wide"       SELF_QKV (N = 3d), FFN1 (N = d_ff)
+    //   class 2  "units"      CROSS, SELF_ATT: (hypothesis, head); FINAL: one row each
+    const int n_xw = KA.n_xw, n_mid = KA.n_mid;
+    const int cls = wg < n_xw ? 0 : (wg < n_xw + n_mid ? 1 : 2);
+    const int idx = cls == 0 ? wg : (cls == 1 ? wg - n_xw : wg - n_xw - n_mid);
+    const int csize = cls == 0 ? n_xw : (cls == 1 ? n_mid : W * A.h);
+    const int per_x = ((d + n_xw - 1) / n_xw + 3) / 4 * 4;               // the slice of every N = d stage
+    const int x0 = min(d, idx * per_x), x1 = min(d, x0 + per_x);         // (class 0)
+    u64* dbg = (A.dbg && idx == 0 && tid == 0) ? (u64*)A.dbg : nullptr;       // per stage (first workgroup of the stage's class): entered / operands arrived / computed / published
 
     DecWRegs<64 / DEC_NW> R;                                            // 4 prefetched steps per wave on sixteen waves, 8 on eight
     DecWPlan plan;
@@ -260,13 +271,13 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
         plan.tile = -1; n0 = n1 = 0;
         const bool slice = S.kind == MTN_DEC_SELF_QKV || S.kind == MTN_DEC_OUT || S.kind == MTN_DEC_FFN1 || S.kind == MTN_DEC_FFN2;
         if (slice) {
-            const int per = ((S.N + G - 1) / G + 3) / 4 * 4;       // a multiple of 4 features: outputs leave as pairs of granules
-            n0 = min(S.N, wg * per); n1 = min(S.N, n0 + per);
+            const int per = ((S.N + csize - 1) / csize + 3) / 4 * 4;       // a multiple of 4 features: outputs leave as pairs of granules
+            n0 = min(S.N, idx * per); n1 = min(S.N, n0 + per);
             if (n1 > n0) { plan = dec_w_plan<DEC_NW>(n1 - n0, S.K, wave); dec_w_issue(R, plan, (const bf16_t*)S.w, n0, n1, S.K, lane); }
             const int S4 = (n1 - n0) >> 2;
             bpre = tid < S4 * W ? *(const float4*)(S.bias + n0 + (tid % S4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        } else if (S.kind == MTN_DEC_CROSS && wg < W * A.h) {
-            n0 = (wg % A.h) * dk; n1 = n0 + dk;
+        } else if (S.kind == MTN_DEC_CROSS) {
+            n0 = (idx % A.h) * dk; n1 = n0 + dk;
             plan = dec_w_plan<DEC_NW>(dk, S.K, wave); dec_w_issue(R, plan, (const bf16_t*)S.w, n0, n1, S.K, lane);
             bpre.x = tid < dk ? S.bias[n0 + tid] : 0.f;
         }
@@ -317,14 +328,29 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
         for (int k = 0; k < (int)(sizeof(mtn_decode_stage) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
         return D;
     };
-    mtn_decode_stage S = stage_of(0);
-    prefetch(S);
+    auto kind_of = [&](const int i) -> int { return __builtin_amdgcn_readfirstlane(*(const int*)(stg + i)); };
+    auto class_of = [](const int kind) -> int {
+        return (kind == MTN_DEC_EMBED || kind == MTN_DEC_OUT || kind == MTN_DEC_FFN2) ? 0 : ((kind == MTN_DEC_SELF_QKV || kind == MTN_DEC_FFN1) ? 1 : 2);
+    };
+    auto next_mine = [&](int i) -> int {                                  // this class's next stage behind stage i
+        for (++i; i < n_stages && class_of(kind_of(i)) != cls; ++i) {}
+        return i;
+    };
+    auto x_tag_before = [&](int i) -> unsigned {                          // the tag of the residual stream a stage reads: its latest writer
+        for (--i; i > 0 && class_of(kind_of(i)) != 0; --i) {}
+        return gen | (unsigned)(i + 1);
+    };
+    int si = next_mine(-1);
+    mtn_decode_stage S;
+    if (si < n_stages) { S = stage_of(si); prefetch(S); }
     bool alive = true;
-    for (int si = 0; si < n_stages && alive; ++si) {
+    while (si < n_stages && alive) {
         const unsigned tag = gen | (unsigned)(si + 1);
         if (dbg) dbg[si * 4 + 0] = wall_clock64();
         const int K = S.K, pitch = K * 2 + 16;
-        switch (S.kind) {
+        // a workgroup without a share of this stage must not even poll: nothing orders it against the stages to come
+        const bool share = S.kind == MTN_DEC_EMBED ? x1 > x0 : (cls == 2 ? true : n1 > n0);
+        if (share) switch (S.kind) {
         case MTN_DEC_EMBED: {          // x = lut[token] * sqrt(d) + PE[pos]   (mtn.py:289, 308; eval: no dropout): this workgroup's columns
             const int nx = x1 - x0;
             for (int i = tid; i < W * nx; i += DEC_THREADS) {
@@ -333,10 +359,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
                 xs[j * per_x + (c - x0)] = y;
                 dec_pub(rX, (unsigned)j * d + c, __float_as_uint(y), tag);
             }
-            last_x_tag = tag;
         } break;
         case MTN_DEC_SELF_QKV: case MTN_DEC_FFN1: {    // LayerNorm(x) of every row -> act; features n0..n1 of the Linear
-            alive = dec_poll<DEC_THREADS>(rX, 0, W * d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+            alive = dec_poll<DEC_THREADS>(rX, 0, W * d, x_tag_before(si), A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
             gains_to_lds();
             __syncthreads();
             if (dbg) dbg[si * 4 + 1] = wall_clock64();
@@ -380,11 +405,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
                     dec_pub(rX, (unsigned)r * d + n + k, __float_as_uint(y), tag);
                 }
             }
-            last_x_tag = tag;
         } break;
         case MTN_DEC_CROSS: case MTN_DEC_SELF_ATT: {
-            if (wg >= W * A.h) break;
-            const int j = wg / A.h, hd = wg % A.h;
+            const int j = idx / A.h, hd = idx % A.h;
             const bool self = S.kind == MTN_DEC_SELF_ATT;
             const int m = self ? pos + 1 : S.m;
             const int npc = dk / 8;
@@ -415,7 +438,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
             float* knew = qs + 128; float* vnew = qs + 256;               // self: the newest row's k and v of this head
             if (!self) {
                 // q_h = LayerNorm(x_j) W_q,h^T + b_q,h  (the head's dk rows of W_q: prefetched), rounded to bf16 as the training kernels store q
-                alive = dec_poll<DEC_THREADS>(rX, (unsigned)j * d, d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+                alive = dec_poll<DEC_THREADS>(rX, (unsigned)j * d, d, x_tag_before(si), A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
                 gains_to_lds();
                 __syncthreads();
                 if (dbg) dbg[si * 4 + 1] = wall_clock64();
@@ -526,12 +549,12 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
             }
         } break;
         case MTN_DEC_FINAL: {          // the decoder's final LayerNorm (mtn.py:161) -> the generator's bf16 operand (read by the NEXT kernel: plain stores)
-            if (wg < W) {
-                alive = dec_poll<DEC_THREADS>(rX, (unsigned)wg * d, d, last_x_tag, A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
+            if (idx < W) {
+                alive = dec_poll<DEC_THREADS>(rX, (unsigned)idx * d, d, x_tag_before(si), A.sync, [&](int i, unsigned v) { xf[i] = __uint_as_float(v); });
                 gains_to_lds();
                 __syncthreads();
                 if (wave == 0) {
-                    bf16_t* row = (bf16_t*)A.out_lp + (size_t)wg * d;
+                    bf16_t* row = (bf16_t*)A.out_lp + (size_t)idx * d;
                     dec_ln_row(xf, gains, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
                 }
             }
@@ -540,10 +563,12 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
         }
         if (dbg) dbg[si * 4 + 3] = wall_clock64();
         __syncthreads();                                                    // (LDS images are reused by the next stage)
-        if (si + 1 < n_stages) { S = stage_of(si + 1); prefetch(S); }
+        const bool last = S.kind == MTN_DEC_FINAL && idx == 0;
+        si = next_mine(si);
+        if (si < n_stages) { S = stage_of(si); prefetch(S); }
+        // the unit that normalised row 0 has seen the last x of every producer: every workgroup read the generation long ago
+        if (last && tid == 0) A.sync[0] = gen >> 8;
     }
-    // workgroup 0 has seen the last stage's x of every producer: every workgroup has read the generation long ago
-    if (wg == 0 && tid == 0) A.sync[0] = gen >> 8;
 }
 
 extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage* stages_device, int grid, void* stream) {
@@ -552,7 +577,9 @@ extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage*
     MTN_CHECK_ARG(a->d >= 128 && a->d <= 1024 && (a->d == 128 || a->d == 256 || a->d == 512 || a->d == 1024), "d_model in {128, 256, 512, 1024}");
     MTN_CHECK_ARG(a->h >= 1 && a->d % a->h == 0 && (a->d / a->h == 32 || a->d / a->h == 64), "head size 32 or 64");
     MTN_CHECK_ARG(a->n_stages >= 1 && a->L >= 1 && a->L <= 1024, "bad stage count / maximum length");
-    MTN_CHECK_ARG(grid >= a->W * a->h && grid <= 256, "grid: at least one workgroup per (hypothesis, head), at most one per CU");
+    const int n_unit = a->W * a->h, n_xw = a->d / 16;
+    const int n_mid = (grid - n_unit - n_xw) < 128 ? (grid - n_unit - n_xw) : 128;
+    MTN_CHECK_ARG(grid <= 256 && n_unit <= 64 && n_mid >= 16, "grid: at most one workgroup per CU; W x heads <= 64 attention units + d / 16 + >= 16 more workgroups must fit");
     MTN_CHECK_ARG(a->xg && a->qg && a->og && a->hg && a->out_lp && a->tokens && a->lut && a->pe && a->pos && a->anc && a->sync, "null buffer");
     MTN_CHECK_ARG(a->W * a->d <= 4096 && a->n_stages <= DEC_MAX_STAGES, "W x d_model <= 4096; at most 160 stages");
     MTN_CHECK_ARG(a->d_ff >= a->d && a->d_ff <= 4096 && a->d_ff % 32 == 0, "d_ff: a multiple of 32, at most 4096");
@@ -568,7 +595,8 @@ extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage*
     DecKernelArgs KA;
     KA.a = *a;
     KA.stages = stages_device;
-    hipLaunchKernelGGL(decode_step_kernel<DEC_NW_USED>, dim3(grid), dim3(DEC_NW_USED * 64), DEC_LDS, s, KA);
+    KA.n_xw = n_xw; KA.n_mid = n_mid;
+    hipLaunchKernelGGL(decode_step_kernel<DEC_NW_USED>, dim3(n_xw + n_mid + n_unit), dim3(DEC_NW_USED * 64), DEC_LDS, s, KA);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }

@@ -277,8 +277,7 @@ class MegaDecodeSession(DecodeSession):
             return False
         if max(batch.his.size(1), batch.cap.size(1), batch.query.size(1)) > 1024:
             return False
-        grid = max(W * h, -(-max(dff, 3 * d) // 64))
-        return grid <= 256 and all(len(l.sublayer) == 5 + 4 * len(l.auto_encoder_attn) for l in model.decoder.layers)
+        return W * h <= 64 and all(len(l.sublayer) == 5 + 4 * len(l.auto_encoder_attn) for l in model.decoder.layers)
 
     def __init__(self, model, batch, max_len, width, pad=1, use_graph=True, select=None):
         super().__init__(model, batch, max_len, width, pad=pad, use_graph=use_graph, kv_cache=False, select=select)
@@ -311,7 +310,7 @@ class MegaDecodeSession(DecodeSession):
         self._h_anc[:] = np.arange(W, dtype=np.int32)[:, None]
         self._prev = None
         self._top_host = None
-        self._grid = max(W * h, -(-max(dff, 3 * d) // 64))
+        self._grid = 256             # the most the launch may use (one workgroup per CU); the library deals them to its three classes
         self._build_stages(L, d, h, dff)
         emb, pe = model.tgt_embed[0], model.tgt_embed[1]
         a = L.DecodeArgs()
