@@ -58,6 +58,15 @@ struct DecKernelArgs {
     int n_xw, n_mid;            // workgroup classes: [0, n_xw) write x, [n_xw, n_xw + n_mid) the wide projections, the last W * h the attention units
 };
 
+// maximum over the 16 lanes of a DPP row (every lane gets it)
+__device__ __forceinline__ float dec_row16_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));     // quad_perm [1,0,3,2]
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));     // quad_perm [2,3,0,1]
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));    // row_half_mirror
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false)));    // row_mirror
+    return v;
+}
+
 // ---- granules
 __device__ __forceinline__ void dec_pub(const dec_rsrc_t r, const unsigned index, const unsigned data, const unsigned tag) { st8(r, index * 8, (u64)data | ((u64)tag << 32)); }
 __device__ __forceinline__ unsigned dec_pack2(const float a, const float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); }
@@ -191,36 +200,13 @@ __device__ __forceinline__ f32x4_t dec_w_mma(const DecWRegs<NR>& R, const DecWPl
 #define DEC_Q_OFF 74240               /* unit stages: q (fp32, <= 128) + the newest row's k and v of this head (self-attention): 3 x 128 floats */
 #define DEC_SC_OFF 75776              /* scores / probabilities: <= 1024 keys fp32; afterwards the second level of the PV reduction */
 #define DEC_PART_OFF 79872            /* PV partials: (threads / (dk / 4)) key parts x dk columns fp32 <= 16 384 */
-#define DEC_MISC_OFF 96256            /* block reductions: 32 floats */
+#define DEC_MISC_OFF 96256            /* the waves' (max, sum) pairs of the softmax: 32 floats */
 #define DEC_XS_OFF 96512              /* this workgroup's columns of the residual stream: W x 64 fp32 = 2 048 */
 #define DEC_XF_OFF 98560              /* the residual rows a stage normalises: W x d fp32 <= 8 x 1024 x 4 = 32 768 */
 #define DEC_GAIN_OFF 131328           /* LayerNorm a_2 | b_2 of the stage: 2 x 1024 floats */
 #define DEC_STG_OFF 139520            /* the stage list: <= 160 descriptors of 104 bytes */
 #define DEC_MAX_STAGES 160
 #define DEC_LDS (DEC_STG_OFF + DEC_MAX_STAGES * 104)
-
-// block reductions over the workgroup's waves: distinct LDS slots for the maximum (0..15) and the sum (16..31), one barrier each — the slots
-// are not touched again before the stage's closing barrier
-template <int DEC_NW>
-__device__ __forceinline__ float dec_block_max(float v, float* red, const int tid) {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    float r = red[0];
-#pragma unroll
-    for (int i = 1; i < DEC_NW; ++i) r = fmaxf(r, red[i]);
-    return r;
-}
-template <int DEC_NW>
-__device__ __forceinline__ float dec_block_sum(float v, float* red, const int tid) {
-    v = fh_cross_sum(fh_row16_sum(v));
-    if ((tid & 63) == 0) red[16 + (tid >> 6)] = v;
-    __syncthreads();
-    float r = 0.f;
-#pragma unroll
-    for (int i = 0; i < DEC_NW; ++i) r += red[16 + i];
-    return r;
-}
 
 template <int DEC_NW>
 __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKernelArgs KA) {
@@ -274,8 +260,11 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
             const int per = ((S.N + csize - 1) / csize + 3) / 4 * 4;       // a multiple of 4 features: outputs leave as pairs of granules
             n0 = min(S.N, idx * per); n1 = min(S.N, n0 + per);
             if (n1 > n0) { plan = dec_w_plan<DEC_NW>(n1 - n0, S.K, wave); dec_w_issue(R, plan, (const bf16_t*)S.w, n0, n1, S.K, lane); }
-            const int S4 = (n1 - n0) >> 2;
-            bpre = tid < S4 * W ? *(const float4*)(S.bias + n0 + (tid % S4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // epilogue work items: one thread per (feature, row) where the stage writes x (one fp32 granule each), per (feature pair, row)
+            // where it writes bf16 pairs — as many threads as there are granules, each with its bias in a register
+            const int Sn = n1 - n0;
+            if (S.kind == MTN_DEC_OUT || S.kind == MTN_DEC_FFN2) bpre.x = (Sn > 0 && tid < Sn * W) ? S.bias[n0 + tid % Sn] : 0.f;
+            else if (Sn > 0 && tid < (Sn >> 1) * W) { const float2 b2 = *(const float2*)(S.bias + n0 + 2 * (tid % (Sn >> 1))); bpre.x = b2.x; bpre.y = b2.y; }
         } else if (S.kind == MTN_DEC_CROSS) {
             n0 = (idx % A.h) * dk; n1 = n0 + dk;
             plan = dec_w_plan<DEC_NW>(dk, S.K, wave); dec_w_issue(R, plan, (const bf16_t*)S.w, n0, n1, S.K, lane);
@@ -373,15 +362,13 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
             f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, W, lane);
             spill(acc);
             if (dbg) dbg[si * 4 + 2] = wall_clock64();
-            const int Sn = n1 - n0, S4 = Sn >> 2;                          // (slices are multiples of 4 features: two granules of a bf16 pair each)
+            const int Sn = n1 - n0, S2 = Sn >> 1;                          // (slices are multiples of 4 features)
             const dec_rsrc_t rD = S.kind == MTN_DEC_FFN1 ? rH : rQ;
-            if (tid < S4 * W) {
-                const int f = (tid % S4) * 4, r = tid / S4, n = n0 + f;
-                float y0 = gather(Sn, f, r) + bpre.x, y1 = gather(Sn, f + 1, r) + bpre.y, y2 = gather(Sn, f + 2, r) + bpre.z, y3 = gather(Sn, f + 3, r) + bpre.w;
-                if (S.kind == MTN_DEC_FFN1) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
-                const unsigned g0 = ((unsigned)r * S.N + n) >> 1;
-                dec_pub(rD, g0, dec_pack2(y0, y1), tag);
-                dec_pub(rD, g0 + 1, dec_pack2(y2, y3), tag);
+            if (tid < S2 * W) {                                              // thread = (feature pair, row): one granule
+                const int f = (tid % S2) * 2, r = tid / S2;
+                float y0 = gather(Sn, f, r) + bpre.x, y1 = gather(Sn, f + 1, r) + bpre.y;
+                if (S.kind == MTN_DEC_FFN1) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+                dec_pub(rD, ((unsigned)r * S.N + n0 + f) >> 1, dec_pack2(y0, y1), tag);
             }
         } break;
         case MTN_DEC_OUT: case MTN_DEC_FFN2: {         // act = attention output (OUT) | FFN hidden (FFN2), bf16 pairs [W][K/2]; + bias + residual -> x
@@ -393,17 +380,13 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
             f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, W, lane);
             spill(acc);
             if (dbg) dbg[si * 4 + 2] = wall_clock64();
-            const int Sn = n1 - n0, S4 = Sn >> 2;
-            if (tid < S4 * W) {
-                const int f = (tid % S4) * 4, r = tid / S4, n = n0 + f;
+            const int Sn = n1 - n0;
+            if (tid < Sn * W) {                                              // thread = (feature, row): one granule
+                const int f = tid % Sn, r = tid / Sn;
                 float* xr = xs + r * per_x + f;                              // (n0 == x0: the N = d slices coincide)
-                const float b4[4] = {bpre.x, bpre.y, bpre.z, bpre.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float y = gather(Sn, f + k, r) + b4[k] + xr[k];
-                    xr[k] = y;
-                    dec_pub(rX, (unsigned)r * d + n + k, __float_as_uint(y), tag);
-                }
+                const float y = gather(Sn, f, r) + bpre.x + *xr;
+                *xr = y;
+                dec_pub(rX, (unsigned)r * d + n0 + f, __float_as_uint(y), tag);
             }
         } break;
         case MTN_DEC_CROSS: case MTN_DEC_SELF_ATT: {
@@ -442,6 +425,8 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
                 gains_to_lds();
                 __syncthreads();
                 if (dbg) dbg[si * 4 + 1] = wall_clock64();
+                // (one wave normalises: every wave doing it into a copy of its own saves the barrier but doubles the instruction streams per SIMD —
+                // measured +0.5 us per stage)
                 if (wave == 0) dec_ln_row(xf, gains, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)((bf16_t*)act + c) = dec_pack4(y); });
                 __syncthreads();
                 f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, 1, lane);
@@ -476,7 +461,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
                 __syncthreads();
                 if (dbg) dbg[si * 4 + 1] = wall_clock64();
             }
-            float mx = -3.0e38f;
+            float mx = -3.0e38f, sum = 0.f;
             for (int t = kt; t < (m + DEC_THREADS / 2 - 1) / (DEC_THREADS / 2) * (DEC_THREADS / 2); t += DEC_THREADS / 2) {       // (every pair runs the same trip count: the shuffle below)
                 float s_ = 0.f;
                 const bool live = t < m;
@@ -500,24 +485,37 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
                         }
                     }
                 }
-                s_ += __shfl_xor(s_, 1);                                 // the two halves (same order in both lanes)
-                if (live) {
+                s_ += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s_), 0xB1, 0xf, 0xf, false));     // the other half (lane ^ 1)
+                if (live && kh == 0) {                                   // (one lane of the pair carries the key into the reduction)
                     s_ *= scale;
                     if (mb == 0) s_ = -1.0e9f;                           // masked_fill(mask == 0, -1e9), mtn.py:226
-                    if (kh == 0) sc[t] = s_;
-                    mx = fmaxf(mx, s_);
+                    sc[t] = s_;
+                    const float M = fmaxf(mx, s_);
+                    sum = sum * __expf(mx - M) + __expf(s_ - M);
+                    mx = M;
                 }
             }
-            mx = dec_block_max<DEC_NW>(mx, misc, tid);
-            float sum = 0.f;
-            for (int t = tid; t < m; t += DEC_THREADS) { const float e = __expf(sc[t] - mx); sc[t] = e; sum += e; }
-            sum = dec_block_sum<DEC_NW>(sum, misc, tid);
+            // row maximum and sum of exponentials behind ONE workgroup barrier: a thread's (max, sum) pair is rescaled to the wave's maximum
+            // (one exponential), the wave's pair to the row's (eight independent exponentials) — no chain of dependent ones
+            {
+                const float wm = fh_cross_max(dec_row16_max(mx));
+                sum *= __expf(mx - wm);
+                sum = fh_cross_sum(fh_row16_sum(sum));
+                if (lane == 0) { misc[wave] = wm; misc[16 + wave] = sum; }
+            }
+            __syncthreads();                                             // (also: every score is in LDS)
+            mx = misc[0];
+#pragma unroll
+            for (int w_ = 1; w_ < DEC_NW; ++w_) mx = fmaxf(mx, misc[w_]);
+            sum = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < DEC_NW; ++w_) sum += misc[16 + w_] * __expf(misc[w_] - mx);
             const float inv = 1.0f / sum;
             // o[c] = sum_t P[t] V[t][c], P rounded to bf16 (the training kernels feed P to the MFMA in bf16): thread = (four columns, key part)
             float o[4] = {0.f, 0.f, 0.f, 0.f};
             for (int u = 0; u * nq + qt < m; ++u) {
                 const int t = qt + u * nq;
-                const float pr = bf16_to_f32(f32_to_bf16(sc[t] * inv));
+                const float pr = bf16_to_f32(f32_to_bf16(__expf(sc[t] - mx) * inv));
                 if (self && t == pos) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[k] += pr * vnew[c4 * 4 + k];
@@ -531,21 +529,23 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
                     for (int k = 0; k < 4; ++k) o[k] += pr * bf16_to_f32((bf16_t)(v4 >> (16 * k)));
                 }
             }
+            // the key parts a wave holds (64 / (dk / 4) of them) by shuffles, the waves' sums through LDS in wave order
 #pragma unroll
-            for (int k = 0; k < 4; ++k) part[qt * dk + c4 * 4 + k] = o[k];
+            for (int k = 0; k < 4; ++k) {                                  // (DPP / permlane, not ds_bpermute: lanes with equal lane % (dk / 4))
+                if (dk == 32) o[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o[k]), 0x128, 0xf, 0xf, false));    // row_ror:8
+                o[k] = fh_cross_sum(o[k]);
+            }
+            if (lane < dk / 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) part[wave * dk + c4 * 4 + k] = o[k];
+            }
             __syncthreads();
-            {   // two levels, fixed order: thread (group g of threads / dk, column c) sums the key parts g, g + G1, ..; then dk / 2 threads the groups
-                const int G1 = DEC_THREADS / dk, g = tid / dk, c = tid % dk;
-                float y = 0.f;
-                for (int q = g; q < nq; q += G1) y += part[q * dk + c];
-                sc[g * dk + c] = y;                                        // (the probabilities are dead: every PV loop is behind the barrier)
-                __syncthreads();
-                if (dbg) dbg[si * 4 + 2] = wall_clock64();
-                if (tid < dk / 2) {
-                    float y0 = 0.f, y1 = 0.f;
-                    for (int q = 0; q < G1; ++q) { y0 += sc[q * dk + tid * 2]; y1 += sc[q * dk + tid * 2 + 1]; }
-                    dec_pub(rO, ((unsigned)j * d + hd * dk) / 2 + tid, dec_pack2(y0, y1), tag);
-                }
+            if (dbg) dbg[si * 4 + 2] = wall_clock64();
+            if (tid < dk / 2) {
+                float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+                for (int w_ = 0; w_ < DEC_NW; ++w_) { y0 += part[w_ * dk + tid * 2]; y1 += part[w_ * dk + tid * 2 + 1]; }
+                dec_pub(rO, ((unsigned)j * d + hd * dk) / 2 + tid, dec_pack2(y0, y1), tag);
             }
         } break;
         case MTN_DEC_FINAL: {          // the decoder's final LayerNorm (mtn.py:161) -> the generator's bf16 operand (read by the NEXT kernel: plain stores)
