@@ -72,6 +72,8 @@ __device__ __forceinline__ void dec_pub(const dec_rsrc_t r, const unsigned index
 __device__ __forceinline__ unsigned dec_pack2(const float a, const float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); }
 // Poll `count` granules starting at `first` of buffer r until all carry `tag`; granule first + i goes to sink(i, data).  All threads,
 // 4 granules per thread per pass; a round is repeated until every thread's tags match.
+// (Two probes in flight half a round trip apart — to notice the arrival after 0.5-1.0 instead of 0.5-1.5 round trips — were measured and
+// LOSE: the hand-offs took 0.35-0.4 us LONGER, profiles/r05_decode_poll_two_probes.txt; one probe at a time it stays.)
 template <int DEC_THREADS, typename SINK>
 __device__ __forceinline__ bool dec_poll(const dec_rsrc_t r, const unsigned first, const int count, const unsigned tag, unsigned* sync, SINK sink) {
     const int tid = threadIdx.x;

@@ -51,6 +51,9 @@ class DecodeSession:
         ops.prepare_masks(self.trg_mask)
         self.logp = None
         self._graph = None
+        self._static = None                   # load(): a private copy of the dialogue's inputs that a captured encoder-side pass reads
+        self._load_graph = None
+        self._loads = 0
         self.load(batch)
         if self.kv_cache:
             # Prefix K/V cache of the target self-attention (the reference recomputes the whole prefix for every hypothesis and
@@ -77,13 +80,57 @@ class DecodeSession:
     def load(self, batch):
         """Encoder side + the N x F auto-encoder chains of a new dialogue (target-independent: once per dialogue).  A batch of
         D dialogues is decoded side by side: every per-dialogue tensor is repeated `width` times along the batch dimension
-        (rows d*width .. d*width+width-1 belong to dialogue d)."""
-        model, width, b = self.model, self.width, batch
-        self.D = D = b.query.size(0)
+        (rows d*width .. d*width+width-1 belong to dialogue d).
+        The pass is ~100 small launches, host-bound when issued one by one (2-3 ms per dialogue — a fifth of a 20-token beam search):
+        from the third dialogue of a shape on, the inputs are copied into a private static Batch and the whole pass is ONE graph replay."""
+        model = self.model
         if model.training:                       # (nn.Module.eval() walks every submodule: ~1 ms of Python per dialogue)
             model.eval()
         model.prepare()
+        self._loads += 1
+        if not (self.use_graph and batch.query.is_cuda) or self._loads == 1:
+            return self._load_body(batch)
+        self._stage(batch)
+        if self._load_graph is None:
+            if self._loads == 2:
+                return self._load_body(self._static)       # warm-up on the static inputs (and this dialogue's results)
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._load_body(self._static)
+                self._load_graph = g
+            except Exception as e:                          # never lose a decode to the faster path
+                import logging
+                logging.getLogger("mtn_amd").warning("decode: capturing the encoder-side pass failed (%s); it stays eager", e)
+                self._load_graph = False
+                torch.cuda.synchronize()
+                return self._load_body(self._static)
+        if self._load_graph is False:
+            return self._load_body(self._static)
+        self._load_graph.replay()
+
+    def _stage(self, b):
+        """Copy a dialogue's inputs into the session's static Batch (created from the first one staged)."""
+        import copy
+        tensors = lambda x: [x.query, x.query_mask, x.his, x.his_mask, x.cap, x.cap_mask] + list(x.fts) + list(x.fts_mask)
+        if self._static is None:
+            st = copy.copy(b)
+            st.query, st.query_mask, st.his, st.his_mask, st.cap, st.cap_mask = (t.clone() for t in (b.query, b.query_mask, b.his, b.his_mask, b.cap, b.cap_mask))
+            st.fts, st.fts_mask = [t.clone() for t in b.fts], [t.clone() for t in b.fts_mask]
+            self._static = st
+            return
+        for dst, src in zip(tensors(self._static), tensors(b)):
+            dst.copy_(src)
+
+    def _load_body(self, batch):
+        model, width, b = self.model, self.width, batch
+        self.D = D = b.query.size(0)
         lp = model.compute_dtype
+        if b is self._static:                    # its masks' kernel images exist from the warm-up: refresh them (part of the captured pass)
+            for mk in [b.query_mask, b.his_mask, b.cap_mask] + list(b.fts_mask):
+                if getattr(mk, "_mtn_u8", None) is not None:
+                    mk._mtn_u8.copy_(mk)
         with torch.no_grad():
             q, v, cp, hs, ae = model.encode(b.query, b.query_mask, b.his, b.his_mask, b.cap, b.cap_mask, b.fts, b.fts_mask)
             ops.prepare_masks(b.his_mask, b.cap_mask, b.query_mask, b.fts_mask)
@@ -400,6 +447,36 @@ class MegaDecodeSession(DecodeSession):
         if int(self._sync[1].item()) != 0:
             raise RuntimeError("mtn_decode_step: a grid barrier timed out (not every workgroup of the launch was resident?)")
 
+    def step_extend(self, l: int, slots, tokens, parents):
+        """One step given the live hypotheses directly: hypothesis in row ``slots[i]`` ends in ``tokens[i]`` (its l-th token) and extends
+        the hypothesis that sat in row ``parents[i]`` at the previous step (ignored at l = 1).  What step_many() derives from prefix
+        lists, without building or searching them: the beam search below knows every candidate's parent."""
+        if l > 1:
+            self._h_anc[slots, :l - 1] = self._h_anc[parents, :l - 1]          # (the right-hand side is gathered into a copy first)
+        self._h_anc[slots, l - 1] = slots
+        self._h_tok[:] = self.pad
+        self._h_tok[slots] = tokens
+        self._h_pos[0] = l - 1
+        self._prev = None
+        self._run()
+
+    def _run(self):
+        with torch.no_grad():
+            if not self.use_graph:
+                self._pass_mega()
+            else:
+                if self._graph is None:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        self._pass_mega()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._pass_mega()
+                self._graph.replay()
+
     def step_many(self, prefix_lists):
         if len(prefix_lists) != self.D:
             raise ValueError("one prefix list per dialogue of the session")
@@ -419,21 +496,7 @@ class MegaDecodeSession(DecodeSession):
                 self._h_anc[j, l - 1] = j
         self._prev = [[list(p) for p in prefixes] for prefixes in prefix_lists]
         self._h_pos[0] = l - 1
-        with torch.no_grad():
-            if not self.use_graph:
-                self._pass_mega()
-            else:
-                if self._graph is None:
-                    side = torch.cuda.Stream()
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        self._pass_mega()
-                    torch.cuda.current_stream().wait_stream(side)
-                    torch.cuda.synchronize()
-                    self._graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self._graph):
-                        self._pass_mega()
-                self._graph.replay()
+        self._run()
         return [self.logp[d_ * W:d_ * W + len(p)] for d_, p in enumerate(prefix_lists)]
 
 
@@ -470,6 +533,7 @@ class _Beam:
     def __init__(self, start_symbol, unk_symbol, end_symbol, beam, penalty, min_len):
         self.unk, self.eos, self.beam, self.penalty, self.min_len = unk_symbol, end_symbol, beam, penalty, min_len
         self.hyps = [([], 0.0, [start_symbol])]
+        self.parents = [0]                        # per hypothesis: the index (in the previous step's list) of the one it extends
         self.best, self.done = None, []
 
     def prefixes(self):
@@ -480,7 +544,7 @@ class _Beam:
         carries each row's k = beam+2 best entries in descending order: at most `beam` candidates per hypothesis can enter the
         new beam and at most two (<unk>, <eos>) are skipped, so the rest of the vocabulary is never looked at."""
         import numpy as np
-        new, argmin = [], 0
+        new, par, argmin = [], [], 0
         for h, (out, lp, st) in enumerate(self.hyps):
             if top is None:
                 lp_vec = (logp[h] + lp).astype("float32")
@@ -501,14 +565,16 @@ class _Beam:
                 if len(new) == self.beam:
                     if new[argmin][1] < s:
                         new[argmin] = (out + [o], s, st + [o])
+                        par[argmin] = h
                         argmin = min(range(len(new)), key=lambda i: new[i][1])
                     else:
                         break
                 else:
                     new.append((out + [o], s, st + [o]))
+                    par.append(h)
                     if len(new) == self.beam:
                         argmin = min(range(len(new)), key=lambda i: new[i][1])
-        self.hyps = new
+        self.hyps, self.parents = new, par
 
     def result(self, nbest):
         if self.done:
@@ -529,12 +595,23 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
     sel = (k + 1, end_symbol) if k + 1 <= SELECT_MAX_K else None
     sess = _session(model, batch, max_len, beam, pad_symbol, use_graph, kv_cache, select=sel, mega=auto)
     beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
+    mega = isinstance(sess, MegaDecodeSession)
     for l in range(max_len):
-        logps = sess.step_many([bm.prefixes() for bm in beams])
+        if mega:
+            # the persistent step takes (row, newest token, parent row) of every live hypothesis: no prefix lists are built or searched
+            Wd = sess.width
+            live = [d * Wd + i for d, bm in enumerate(beams) for i in range(len(bm.hyps))]
+            sess.step_extend(l + 1, live, [h[2][-1] for bm in beams for h in bm.hyps],
+                             [d * Wd + p for d, bm in enumerate(beams) for p in bm.parents])
+            logps = [sess.logp[d * Wd:d * Wd + len(bm.hyps)] for d, bm in enumerate(beams)] if sess.top is None else None
+            counts = [len(bm.hyps) for bm in beams]
+        else:
+            logps = sess.step_many([bm.prefixes() for bm in beams])
+            counts = [lp.size(0) for lp in logps]
+            live = [r for d, n in enumerate(counts) for r in range(d * sess.width, d * sess.width + n)]
         if sess.top is not None:
             # device-side selection inside the pass (csrc/select.hip): only the heads of the rows travel, in one copy
-            full = (sess.top_host() if isinstance(sess, MegaDecodeSession) else sess.top.cpu().numpy()).astype("float64")
-            live = [r for d, lp in enumerate(logps) for r in range(d * sess.width, d * sess.width + lp.size(0))]
+            full = (sess.top_host() if mega else sess.top.cpu().numpy()).astype("float64")
             packed = full[live]
             kk = (packed.shape[1] - 1) // 2
             allp = None
@@ -547,10 +624,9 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
         # exact ties inside a row's head would make the visiting order depend on the selection algorithm: the reference's
         # order (argsort, data_utils.py:219) is then taken from the full row
         tie = bool((vals[:, 1:] == vals[:, :-1]).any())
-        host = (allp if allp is not None else torch.cat(logps, 0)).double().cpu().numpy() if tie else None
+        host = (allp if allp is not None else sess.logp[live]).double().cpu().numpy() if tie else None
         o = 0
-        for bm, lp in zip(beams, logps):
-            n = lp.size(0)
+        for bm, n in zip(beams, counts):
             if tie:
                 bm.advance(host[o:o + n], l)
             else:

@@ -283,3 +283,32 @@ def test_persistent_decode_beam_search_equals_launch_pass(dev):
     assert len(n1) == len(n0) == int(g["beam.n"])
     assert abs(best1 - best0) < 1e-2 * max(1.0, abs(best0))
     assert abs(best1 - float(g["beam.best"])) < 1e-2 * max(1.0, abs(float(g["beam.best"])))
+
+
+def test_captured_encoder_side_pass_equals_eager_over_several_dialogues(dev):
+    """A session reused for further dialogues of a shape stages their inputs into a static Batch and replays ONE graph for the encoder-side
+    pass (DecodeSession.load) from the third dialogue on.  Five different dialogues through one session (eager, staged eager, captured,
+    replayed, replayed) against each dialogue through a fresh session: identical n-best lists and scores — and the caller's tensors untouched."""
+    from mtn_amd import decode as D
+    from mtn_amd import make_model
+    from mtn_amd.synthetic import CONFIGS, synthetic_batch
+    cfg = dict(CONFIGS["cfg2"])
+    torch.manual_seed(0)
+    model = make_model(cfg["vocab"], cfg["vocab"], N=2, d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"], dropout=0.1,
+                       ft_sizes=cfg["ft_sizes"], diff_encoder=True, auto_encoder_ft="query", compute_dtype=torch.bfloat16).to(dev).eval()
+    bs = [synthetic_batch(cfg["vocab"], 1, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=200 + i, ragged=True)
+          for i in range(5)]
+    keep = [b.query.clone() for b in bs]
+    D._SESSIONS.clear()
+    reused = [D.beam_search_decode(model, b, 12, 2, 0, 3, 1, beam=4) for b in bs]
+    sess = [s[0] for s in D._SESSIONS.values()]
+    assert len(sess) == 1 and sess[0]._load_graph not in (None, False), "the encoder-side pass was not captured"
+    fresh = []
+    for b in bs:
+        D._SESSIONS.clear()
+        fresh.append(D.beam_search_decode(model, b, 12, 2, 0, 3, 1, beam=4))
+    D._SESSIONS.clear()
+    for (n1, b1), (n0, b0) in zip(reused, fresh):
+        assert [h[0] for h in n1] == [h[0] for h in n0]
+        assert b1 == b0 and [h[1] for h in n1] == [h[1] for h in n0]
+    assert all(torch.equal(b.query, k) for b, k in zip(bs, keep))
