@@ -216,8 +216,9 @@ def decode_measure(model, cfg, dev, beam=4, max_len=20, dialogues=4, batch_dialo
         wbytes += model._flat_lp.element_size() * model.generator.proj.weight.numel()
         step_ms = out["beam"]["ms_per_step"]
         out["roofline"] = {"bound": "hbm", "what": "weights one decode step streams (target-stream sublayers + generator, compute dtype) / measured "
-                                                   "time per step of the one-dialogue beam search; the step is a chain of ~90 dependent launches over 80 rows, so it sits "
-                                                   "far below the stream rate (launch-latency-bound), which is why dialogues are batched (beam_batched)",
+                                                   "time per step of the one-dialogue beam search.  For <= 8 live hypotheses the step is ONE persistent launch (csrc/decode.hip) whose "
+                                                   "92 stages are a chain of all-to-all hand-offs (each >= one fabric round trip): it is bound by that chain's latency, far below the "
+                                                   "stream rate — which is why dialogues are batched where throughput matters (beam_batched: the launch path, 8 x beam rows per weight pass)",
                            "weight_bytes_per_step": int(wbytes), "achieved": round(wbytes / (step_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": round(wbytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)}
         if "beam_batched" in out:

@@ -14,13 +14,15 @@
 // (MI355X_MICROARCH.md, hand-off rows R2 / handoff-1to1: the data IS the flag — no drain, no flag store, no separate load afterwards).
 // The first version synchronised with a grid-wide counter barrier per stage and was no faster than the launches it replaced (8.2 us per
 // stage: 3 us of barrier + 0.8-2.8 us to load the operands afterwards + 1.2 us of late bias loads; profiles/r05_decode_timeline_barrier.txt).
-//   * "slice" stages (q|k|v projection of the self-attention, output projections, both feed-forward Linears): every workgroup owns
-//     ceil(N / G) output features of the Linear — its rows of the weight matrix are read from HBM exactly once per step, by one CU, as
-//     MFMA B-fragments straight into registers, and they are REQUESTED BEFORE the workgroup waits at the barrier in front of the stage
-//     (weights do not depend on the previous stage), so the weight stream hides under the synchronisation;
+//   * "slice" stages (q|k|v projection of the self-attention, output projections, both feed-forward Linears): every workgroup of the stage's
+//     CLASS owns ceil(N / class size) output features of the Linear — its rows of the weight matrix are read from HBM exactly once per step,
+//     by one CU, as MFMA B-fragments straight into registers, and they are REQUESTED BEFORE the workgroup starts polling for the stage's
+//     operands (weights do not depend on the previous stage);
 //   * "unit" stages (attention): workgroup (hypothesis j, head h) projects q_h = LN(x_j) W_q,h itself (its 64 rows of W_q likewise
 //     prefetched), attends the memory's hoisted K|V head rows (constant per dialogue: L2-resident after the first step) or the self
 //     cache, and publishes its 64 output columns.
+// Three classes of workgroups — x writers (EMBED, OUT, FFN2), wide (q|k|v, FFN1), units — so that consecutive stages never share
+// workgroups: while one class works the next has issued its prefetch and sits in its poll (the kernel body explains the ordering argument).
 // Granule buffers: xg [W][d] (fp32 residual stream), qg [W][3d/2] (q | k | v of the newest row, bf16 pairs), og [W][d/2] (attention output),
 // hg [W][d_ff/2] (FFN hidden).  A workgroup keeps ITS columns of the residual stream in LDS across stages (the slices of the three
 // N = d Linears coincide).  Read-only operands (weights, hoisted K|V, masks, the cache rows of earlier steps) use plain loads.  Every
