@@ -559,6 +559,23 @@ int mtn_assemble_features(int count, const mtn_assemble_features_desc* descs /* 
  * 1 <= k <= 16, V < 2^24.
  * ------------------------------------------------------------------------------------------ */
 int mtn_topk_rows(const float* x, int rows, int V, long ldx, int k, int extra_col, float* out, void* stream);
+/* One step of the beam search's hypothesis bookkeeping on the device (round 5, version 112; data_utils.py:209-240 — the loop body behind
+ * `model.decode`): from the rows' heads left by mtn_topk_rows (k_top values, k_top columns, the <eos> column's value per live hypothesis)
+ * build the new beam exactly as the reference does (hypotheses in order, candidates in descending log-probability, <unk> / <eos>
+ * skipped, the worst member replaced while a candidate beats it), WRITE what the next mtn_decode_step reads (newest tokens, ancestor
+ * table, position) and LOG the step for the host: log_* are [L][dialogues * width] (log_n_*: [L][dialogues]); log_done holds
+ * lp + logp[<eos>] + penalty * (length + 1) of every hypothesis alive at a step >= min_len.  flags[0] is raised when a row's head holds
+ * an exact tie (the reference's order then comes from the full row: re-run that search on the host path).  width <= 16.
+ * State (zeroed / initialised by the caller per search): lp [dialogues * width] doubles, n_live / step [dialogues]. */
+typedef struct {
+    int dialogues, width, L, k_top, k, beam, unk, eos, pad, min_len;
+    double penalty;
+    const float* top;           /* [dialogues * width][2 * k_top + 1] */
+    long* tokens; int* pos; int* anc;             /* as mtn_decode_args */
+    double* lp; int* n_live; int* step; int* flags;
+    int* log_parent; int* log_tok; double* log_score; double* log_done; int* log_n_old; int* log_n_new;
+} mtn_beam_args;
+int mtn_beam_advance(const mtn_beam_args* args /* host */, void* stream);
 /* Generator (mtn.py:62-69) at inference: out[row][c] = x[row][c] - logsumexp(x[row][0..V-1]) over logit rows x [rows, V] (row
  * strides ldx / ldo; out may be x).  The logits themselves are one mtn_gemm (x W^T + b, fp32 out). */
 int mtn_log_softmax_rows(const float* x, int rows, int V, long ldx, float* out, long ldo, void* stream);

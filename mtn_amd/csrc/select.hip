@@ -81,6 +81,86 @@ extern "C" int mtn_topk_rows(const float* x, int rows, int V, long ldx, int k, i
     return MTN_OK;
 }
 
+// ---------------------------------------------------------------- the beam search's hypothesis bookkeeping, one step (data_utils.py:209-240)
+// What the reference does on the host after every `model.decode`: for every live hypothesis h (in order) — record the finished
+// hypothesis `out_h + <eos>` with score lp_h + logp[eos] + penalty * (len + 1) once the length allows it, then walk h's candidates in
+// descending log-probability, skip <unk> / <eos>, fill the new beam, and once it is full replace its WORST member (first minimum) while a
+// candidate beats it, stopping at the first that does not.  Here as one tiny launch per step (one workgroup per dialogue, thread 0 walks
+// the <= beam x k candidates), reading the rows' heads left by topk_rows_kernel, so that a whole search runs as ONE captured graph with
+// no host in the loop: it writes what the next decode step needs (newest tokens, ancestor table, position) and LOGS the step (parents,
+// tokens, scores, finished scores) for the host to rebuild the n-best lists from afterwards.  Arithmetic as on the host: scores are float32
+// values held as doubles — sums in double, the candidate's score rounded to float32 (numpy's astype), the finished score kept in double.
+// A tie inside a row's head raises `flags[0]`: the visiting order would then depend on the selection algorithm, and the caller re-runs the
+// search on the host path, which takes the reference's order from the full row.
+struct BeamArgs { mtn_beam_args a; };
+__global__ __launch_bounds__(64) void beam_advance_kernel(const BeamArgs BA) {
+    const mtn_beam_args& A = BA.a;
+    __shared__ int s_anc[16 * 64];                             // the parents' ancestor rows (<= 16 hypotheses x <= 1024 positions in chunks of 64)
+    __shared__ int s_parent[16], s_n;
+    const int d = blockIdx.x, tid = threadIdx.x, Wd = A.width, base = d * Wd, k1 = A.k_top, cols = 2 * k1 + 1;
+    const int l = A.step[d];                                     // tokens generated so far = index of this step
+    if (tid == 0) {
+        const int n = A.n_live[d];
+        int np[16], nt[16]; double ns[16];
+        int cnt = 0, argmin = 0, tie = 0;
+        A.log_n_old[l * gridDim.x + d] = n;
+        for (int h = 0; h < n; ++h) {
+            const float* row = A.top + (size_t)(base + h) * cols;
+            const double lp = A.lp[base + h];
+            for (int i = 0; i + 1 < k1; ++i) tie |= row[i] == row[i + 1];
+            if (l >= A.min_len) A.log_done[(size_t)l * gridDim.x * Wd + base + h] = (double)(float)((double)row[2 * k1] + lp) + A.penalty * (double)(l + 1);
+            for (int i = 0; i < A.k; ++i) {
+                const int o = (int)row[k1 + i];
+                if (o == A.unk || o == A.eos) continue;
+                const double sc = (double)(float)((double)row[i] + lp);
+                if (cnt == A.beam) {
+                    if (ns[argmin] < sc) {
+                        np[argmin] = h; nt[argmin] = o; ns[argmin] = sc;
+                        argmin = 0;
+                        for (int q = 1; q < cnt; ++q) if (ns[q] < ns[argmin]) argmin = q;
+                    } else break;
+                } else {
+                    np[cnt] = h; nt[cnt] = o; ns[cnt] = sc; ++cnt;
+                    if (cnt == A.beam) { argmin = 0; for (int q = 1; q < cnt; ++q) if (ns[q] < ns[argmin]) argmin = q; }
+                }
+            }
+        }
+        for (int i = 0; i < Wd; ++i) {
+            const size_t at = (size_t)l * gridDim.x * Wd + base + i;
+            A.tokens[base + i] = i < cnt ? (long)nt[i] : (long)A.pad;
+            if (i < cnt) { A.lp[base + i] = ns[i]; A.log_parent[at] = np[i]; A.log_tok[at] = nt[i]; A.log_score[at] = ns[i]; s_parent[i] = np[i]; }
+        }
+        A.log_n_new[l * gridDim.x + d] = cnt;
+        A.n_live[d] = cnt;
+        A.step[d] = l + 1;
+        if (tie) A.flags[0] = 1;
+        if (d == 0) *A.pos = l + 1;                             // (read by the NEXT decode step only)
+        s_n = cnt;
+    }
+    __syncthreads();
+    // ancestor table: row i takes its parent's slots for positions 0..l and its own slot for position l + 1 (all reads before any write)
+    const int cnt = s_n, npos = l + 1;
+    for (int c0 = 0; c0 < npos; c0 += 64) {
+        const int t = c0 + tid;
+        for (int i = 0; i < cnt; ++i) if (t < npos) s_anc[i * 64 + tid] = A.anc[(size_t)(base + s_parent[i]) * A.L + t];
+        __syncthreads();
+        for (int i = 0; i < cnt; ++i) if (t < npos) A.anc[(size_t)(base + i) * A.L + t] = s_anc[i * 64 + tid];
+        __syncthreads();
+    }
+    if (tid < cnt && npos < A.L) A.anc[(size_t)(base + tid) * A.L + npos] = base + tid;
+}
+
+extern "C" int mtn_beam_advance(const mtn_beam_args* a, void* stream) {
+    MTN_CHECK_ARG(a && a->top && a->tokens && a->pos && a->anc && a->lp && a->n_live && a->step && a->flags, "null buffer");
+    MTN_CHECK_ARG(a->log_parent && a->log_tok && a->log_score && a->log_done && a->log_n_old && a->log_n_new, "null log buffer");
+    MTN_CHECK_ARG(a->dialogues >= 1 && a->width >= 1 && a->width <= 16 && a->beam >= 1 && a->beam <= a->width, "1 <= beam <= width <= 16");
+    MTN_CHECK_ARG(a->k >= 1 && a->k <= a->k_top && a->k_top <= SEL_MAX_K && a->L >= 1, "1 <= k <= k_top <= 16");
+    BeamArgs BA; BA.a = *a;
+    hipLaunchKernelGGL(beam_advance_kernel, dim3(a->dialogues), dim3(64), 0, (hipStream_t)stream, BA);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}
+
 // ---------------------------------------------------------------- Generator: log-softmax of the logit rows (mtn.py:68-69)
 // out[row][c] = x[row][c] - (max + log sum exp(x - max)); one 256-thread workgroup per row, the row read twice (it sits in L2: a
 // decode step has beam x dialogues rows of |V| floats).  In place when out == x.

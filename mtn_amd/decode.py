@@ -442,6 +442,110 @@ class MegaDecodeSession(DecodeSession):
         torch.cuda.current_stream().synchronize()
         return self._top_host.numpy()
 
+    def search(self, beam, k, start, unk, eos, penalty, min_len, nbest):
+        log = self._search_log(beam, k, start, unk, eos, penalty, min_len, eos)
+        if log is None:
+            return None
+        par, tok, n_old, n_new, score, done_sc, flags = log
+        results = []
+        for d_ in range(self.D):
+            base = d_ * self.width
+            outs, done = [[]], []
+            for l in range(self.max_len):
+                if l >= min_len:
+                    done += [(outs[h], float(done_sc[l, base + h])) for h in range(int(n_old[l, d_]))]
+                outs = [outs[int(par[l, base + i])] + [int(tok[l, base + i])] for i in range(int(n_new[l, d_]))]
+            if done:
+                results.append((sorted(done, key=lambda h: -h[1])[:nbest], max(h[1] for h in done)))
+            else:
+                results.append(([([], 0)], None))
+        return results
+
+    def greedy(self, start):
+        """argmax decoding of the session's (one) dialogue as one graph replay: a beam of one that skips nothing and finishes nothing
+        (mtn_beam_advance with beam = k = 1, no <unk> / <eos>).  Returns the max_len - 1 generated tokens, or None (tie / not applicable)."""
+        log = self._search_log(1, 1, start, -1, -1, 0.0, self.max_len + 1, self.select[1] if self.select is not None else 0)
+        return None if log is None else [int(t) for t in log[1][:self.max_len - 1, 0]]
+
+    def _search_log(self, beam, k, start, unk, eos, penalty, min_len, extra_col):
+        """A whole beam search (data_utils.py:188-242) for every dialogue of the session as ONE graph replay: max_len x [persistent decode
+        step, generator, row heads (csrc/select.hip topk_rows), hypothesis bookkeeping on the device (mtn_beam_advance)], the step log
+        copied to a pinned block at the end.  The host synchronises once per search and rebuilds the n-best lists from the log.
+        Returns None when a row's head held an exact tie (the reference's visiting order then comes from the full row: the caller runs the
+        search step by step) or when the device-side selection does not apply."""
+        import ctypes as C
+        import numpy as np
+        from . import lib as L
+        k_top = k + 1
+        if self.select is None or self.select[0] != k_top or self.select[1] != extra_col or beam > self.width or k_top > SELECT_MAX_K or not self.use_graph:
+            return None
+        W, D, Lm = self._W, self.D, self.max_len
+        key = (beam, k, start, unk, eos, float(penalty), min_len)
+        if getattr(self, "_search_key", None) != key:
+            dev = self._x.device
+            # device state of the search [lp (W doubles) | n_live (D) | step (D) | flags (2)] and its initial image
+            nst = 8 * W + 4 * (2 * D + 2)
+            self._bstate = torch.zeros(nst, device=dev, dtype=torch.uint8)
+            init = np.zeros(nst, dtype=np.uint8)
+            init[8 * W:8 * W + 4 * D].view(np.int32)[:] = 1
+            self._bstate_init = torch.from_numpy(init).pin_memory()
+            blk = np.zeros(self._host.numel(), dtype=np.uint8)               # [tokens | pos | anc] before the first step: <sos> in every dialogue's row 0
+            tok = blk[:8 * W].view(np.int64)
+            tok[:] = self.pad
+            tok[::self.width] = start
+            blk[self._off_anc:].view(np.int32).reshape(W, Lm)[:] = np.arange(W, dtype=np.int32)[:, None]
+            self._blk_init = torch.from_numpy(blk).pin_memory()
+            # the step log: [parent | tok (int32 L x W each) | n_old | n_new (int32 L x D each) | score | done (double L x W each) | flags (2 x int32)]
+            o_par, o_tok = 0, 4 * Lm * W
+            o_nold, o_nnew = 8 * Lm * W, 8 * Lm * W + 4 * Lm * D
+            o_sc = (8 * Lm * W + 8 * Lm * D + 7) // 8 * 8
+            o_done = o_sc + 8 * Lm * W
+            o_flags = o_done + 8 * Lm * W
+            self._log = torch.zeros(o_flags + 8, device=dev, dtype=torch.uint8)
+            self._log_host = torch.zeros(o_flags + 8, dtype=torch.uint8).pin_memory()
+            hb = self._log_host.numpy()
+            self._log_views = (hb[o_par:o_tok].view(np.int32).reshape(Lm, W), hb[o_tok:o_nold].view(np.int32).reshape(Lm, W),
+                               hb[o_nold:o_nnew].view(np.int32).reshape(Lm, D), hb[o_nnew:o_nnew + 4 * Lm * D].view(np.int32).reshape(Lm, D),
+                               hb[o_sc:o_done].view(np.float64).reshape(Lm, W), hb[o_done:o_flags].view(np.float64).reshape(Lm, W),
+                               hb[o_flags:o_flags + 8].view(np.int32))
+            a = L.BeamArgs()
+            a.dialogues, a.width, a.L, a.k_top, a.k, a.beam, a.unk, a.eos, a.pad, a.min_len = D, self.width, Lm, k_top, k, beam, unk, eos, self.pad, min_len
+            a.penalty = float(penalty)
+            p0, s0, l0 = self._devblk.data_ptr(), self._bstate.data_ptr(), self._log.data_ptr()
+            a.tokens, a.pos, a.anc = p0, p0 + self._off_pos, p0 + self._off_anc
+            a.lp, a.n_live, a.step, a.flags = s0, s0 + 8 * W, s0 + 8 * W + 4 * D, l0 + o_flags
+            a.log_parent, a.log_tok, a.log_n_old, a.log_n_new, a.log_score, a.log_done = l0 + o_par, l0 + o_tok, l0 + o_nold, l0 + o_nnew, l0 + o_sc, l0 + o_done
+            self._beam_args = a
+
+            def body():
+                self._devblk.copy_(self._blk_init, non_blocking=True)
+                self._bstate.copy_(self._bstate_init, non_blocking=True)
+                self._log[o_flags:].zero_()
+                g = self.model.generator._fused
+                for _ in range(Lm):
+                    L.check(L.load().mtn_decode_step(C.byref(self._args), self._stages_dev.data_ptr(), self._grid, L.stream_ptr()))
+                    logp = ops.generator_log_probs(self._out_lp, g["w_lp"], g["bias"])
+                    top = ops.topk_rows(logp, k_top, extra_col)
+                    a.top = top.data_ptr()
+                    L.check(L.load().mtn_beam_advance(C.byref(a), L.stream_ptr()))
+                self._log_host.copy_(self._log, non_blocking=True)
+
+            with torch.no_grad():
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    body()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                self._search_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._search_graph):
+                    body()
+            self._search_key = key
+        self._search_graph.replay()
+        self._prev = None
+        torch.cuda.current_stream().synchronize()
+        return None if self._log_views[6][0] else self._log_views
+
     def check(self):
         """Raises if a grid barrier of any step since the session was built timed out (the results would be garbage)."""
         if int(self._sync[1].item()) != 0:
@@ -594,8 +698,14 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
     # device-side candidate selection (csrc/select.hip) holds at most SELECT_MAX_K entries per row: wider beams keep torch.topk
     sel = (k + 1, end_symbol) if k + 1 <= SELECT_MAX_K else None
     sess = _session(model, batch, max_len, beam, pad_symbol, use_graph, kv_cache, select=sel, mega=auto)
-    beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
     mega = isinstance(sess, MegaDecodeSession)
+    if mega and sel is not None:
+        # the whole search as one graph replay, hypothesis bookkeeping on the device; None = a tie somewhere: step by step below
+        res = sess.search(beam, k, start_symbol, unk_symbol, end_symbol, penalty, min_len, nbest)
+        if res is not None:
+            sess.check()
+            return res
+    beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
     for l in range(max_len):
         if mega:
             # the persistent step takes (row, newest token, parent row) of every live hypothesis: no prefix lists are built or searched
@@ -651,8 +761,22 @@ def beam_search_decode(model, batch, max_len, start_symbol, unk_symbol, end_symb
 def greedy_decode(model, batch, max_len, start_symbol, pad_symbol=1, use_graph=True, kv_cache=None):
     """data_utils.py:159-186 (the reference's own greedy_decode cannot run: it calls decode() with the wrong arity, SURVEY
     §8c) — pinned to: argmax of the generator's log-probabilities at every step, (1, max_len) tokens incl. <sos>."""
-    sess = _session(model, batch, max_len, 1, pad_symbol, use_graph, max_len > KV_CACHE_FROM if kv_cache is None else kv_cache, mega=kv_cache is None)
+    auto = kv_cache is None
+    sess = _session(model, batch, max_len, 1, pad_symbol, use_graph, max_len > KV_CACHE_FROM if kv_cache is None else kv_cache,
+                    select=(2, 0) if auto else None, mega=auto)
     ys = [start_symbol]
+    if isinstance(sess, MegaDecodeSession) and sess.select is not None:
+        toks = sess.greedy(start_symbol)                   # the whole decode as one graph replay (None: a tie in some row's head)
+        if toks is None:
+            # step by step: the row's head (largest log-probability, its column) arrives in a pinned block — one replay and one
+            # stream synchronisation per token, no argmax launch, no .item()
+            for l in range(1, max_len):
+                sess.step_extend(l, [0], [ys[-1]], [0])
+                ys.append(int(sess.top_host()[0, 2]))
+        else:
+            ys += toks
+        sess.check()
+        return torch.tensor([ys], dtype=batch.query.dtype, device=batch.query.device)
     for _ in range(max_len - 1):
         nxt = int(sess.step([ys]).argmax(dim=-1)[0])
         ys.append(nxt)

@@ -147,6 +147,14 @@ class DecodeArgs(C.Structure):
 DEC_EMBED, DEC_SELF_QKV, DEC_SELF_ATT, DEC_OUT, DEC_CROSS, DEC_FFN1, DEC_FFN2, DEC_FINAL = range(8)
 
 
+class BeamArgs(C.Structure):
+    _fields_ = [("dialogues", C.c_int), ("width", C.c_int), ("L", C.c_int), ("k_top", C.c_int), ("k", C.c_int), ("beam", C.c_int), ("unk", C.c_int),
+                ("eos", C.c_int), ("pad", C.c_int), ("min_len", C.c_int), ("penalty", C.c_double), ("top", C.c_void_p), ("tokens", C.c_void_p),
+                ("pos", C.c_void_p), ("anc", C.c_void_p), ("lp", C.c_void_p), ("n_live", C.c_void_p), ("step", C.c_void_p), ("flags", C.c_void_p),
+                ("log_parent", C.c_void_p), ("log_tok", C.c_void_p), ("log_score", C.c_void_p), ("log_done", C.c_void_p), ("log_n_old", C.c_void_p),
+                ("log_n_new", C.c_void_p)]
+
+
 class LnFinalizeDesc(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("nparts", C.c_int), ("d", C.c_int), ("da2", C.c_void_p), ("db2", C.c_void_p)]
 
@@ -192,6 +200,7 @@ SYMBOLS = {
     "mtn_gemm": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
     "mtn_gemm_tt_table": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
     "mtn_decode_step": (C.c_int, [C.POINTER(DecodeArgs), _P, C.c_int, _P]),
+    "mtn_beam_advance": (C.c_int, [C.POINTER(BeamArgs), _P]),
     "mtn_gemm_tt_table_aux": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), C.POINTER(TtAux), _P]),
     "mtn_layernorm_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mtn_layernorm_fwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(LnFwdDesc), _P]),

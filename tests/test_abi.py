@@ -31,14 +31,14 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_c(tmp_path):
     lib = _lib_or_build()
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "mtn_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mtn_dropout),'
+    src.write_text('#include <stdio.h>\n#include "mtn_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mtn_dropout),'
                    ' sizeof(mtn_gemm_problem), sizeof(mtn_attn_args), sizeof(mtn_mha_args), sizeof(mtn_ffn_args), sizeof(mtn_ln_epilogue),'
-                   ' sizeof(mtn_ln_fold_desc), sizeof(mtn_transpose_desc), sizeof(mtn_tt_ln_unit), sizeof(mtn_tt_aux));return 0;}\n')
+                   ' sizeof(mtn_ln_fold_desc), sizeof(mtn_transpose_desc), sizeof(mtn_tt_ln_unit), sizeof(mtn_tt_aux), sizeof(mtn_decode_stage), sizeof(mtn_decode_args), sizeof(mtn_beam_args));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     mine = [ctypes.sizeof(c) for c in (lib.Dropout, lib.GemmProblem, lib.AttnArgs, lib.MhaArgs, lib.FfnArgs, lib.LnEpilogue, lib.LnFoldDesc, lib.TransposeDesc,
-                                       lib.TtLnUnit, lib.TtAux)]
+                                       lib.TtLnUnit, lib.TtAux, lib.DecodeStage, lib.DecodeArgs, lib.BeamArgs)]
     assert sizes == mine
 
 

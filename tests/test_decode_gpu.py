@@ -312,3 +312,56 @@ def test_captured_encoder_side_pass_equals_eager_over_several_dialogues(dev):
         assert [h[0] for h in n1] == [h[0] for h in n0]
         assert b1 == b0 and [h[1] for h in n1] == [h[1] for h in n0]
     assert all(torch.equal(b.query, k) for b, k in zip(bs, keep))
+
+
+@pytest.mark.parametrize("D_,beam", [(1, 4), (1, 5), (2, 4), (1, 8)])
+def test_device_side_beam_bookkeeping_equals_host_loop_exactly(dev, D_, beam, monkeypatch):
+    """The whole search as one graph replay (mtn_beam_advance keeps the hypotheses on the device) against the same session driven step by
+    step from the host (the reference's bookkeeping, data_utils.py:209-240, in Python): the per-step kernels are the same, so the n-best
+    lists, every score and the best score must be EQUAL — penalty, min_len and the <unk> / <eos> skips included."""
+    from mtn_amd import decode as D
+    from mtn_amd import make_model
+    from mtn_amd.synthetic import CONFIGS, synthetic_batch
+    cfg = dict(CONFIGS["cfg2"])
+    torch.manual_seed(1)
+    model = make_model(cfg["vocab"], cfg["vocab"], N=2, d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"], dropout=0.1,
+                       ft_sizes=cfg["ft_sizes"], diff_encoder=True, auto_encoder_ft="query", compute_dtype=torch.bfloat16).to(dev).eval()
+    for seed, (penalty, min_len) in enumerate([(1.0, 1), (0.3, 3), (2.0, 0)]):
+        b = synthetic_batch(cfg["vocab"], D_, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=300 + seed, ragged=True)
+        D._SESSIONS.clear()
+        dev_res = D.beam_search_decode_many(model, b, 14, 2, 0, 3, 1, beam=beam, penalty=penalty, nbest=5, min_len=min_len)
+        sess = [s[0] for s in D._SESSIONS.values()]
+        assert len(sess) == 1 and isinstance(sess[0], D.MegaDecodeSession) and getattr(sess[0], "_search_key", None) is not None, "the device-side search did not run"
+        with monkeypatch.context() as mp:
+            mp.setattr(D.MegaDecodeSession, "search", lambda self, *a, **k: None)
+            host_res = D.beam_search_decode_many(model, b, 14, 2, 0, 3, 1, beam=beam, penalty=penalty, nbest=5, min_len=min_len)
+        assert dev_res == host_res
+    D._SESSIONS.clear()
+
+
+def test_device_side_greedy_equals_host_loop(dev, monkeypatch):
+    """greedy_decode as one graph replay (a beam of one on the device) against the same session stepped from the host: same tokens."""
+    from mtn_amd import decode as D
+    from mtn_amd import make_model
+    from mtn_amd.synthetic import CONFIGS, synthetic_batch
+    cfg = dict(CONFIGS["cfg2"])
+    torch.manual_seed(2)
+    model = make_model(cfg["vocab"], cfg["vocab"], N=2, d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"], dropout=0.1,
+                       ft_sizes=cfg["ft_sizes"], diff_encoder=True, auto_encoder_ft="query", compute_dtype=torch.bfloat16).to(dev).eval()
+    b = synthetic_batch(cfg["vocab"], 1, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=400, ragged=True)
+    D._SESSIONS.clear()
+    a = D.greedy_decode(model, b, 16, 2)
+    sess = [s[0] for s in D._SESSIONS.values()]
+    assert isinstance(sess[0], D.MegaDecodeSession) and getattr(sess[0], "_search_key", None) is not None
+    with monkeypatch.context() as mp:
+        mp.setattr(D.MegaDecodeSession, "greedy", lambda self, *a, **k: None)
+        h = D.greedy_decode(model, b, 16, 2)
+    os.environ["MTN_DECODE_MEGA"] = "0"
+    try:
+        D._SESSIONS.clear()
+        launch = D.greedy_decode(model, b, 16, 2)
+    finally:
+        del os.environ["MTN_DECODE_MEGA"]
+        D._SESSIONS.clear()
+    assert torch.equal(a, h) and a.shape == (1, 16)
+    assert (a == launch).float().mean() > 0.8          # (the launch path's log-probabilities differ in the last bf16 bits: an argmax may flip)

@@ -1,0 +1,7 @@
+set -x
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout 900 python -m pytest tests/test_decode_gpu.py -q --tb=short -x 2>&1 | tail -25 > gpurun_out/r05_z_pytest_decode.txt
+cat gpurun_out/r05_z_pytest_decode.txt
+timeout 300 python bench_decode.py --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/r05_z_bench_decode.txt
+cut -c1-700 gpurun_out/r05_z_bench_decode.txt
