@@ -256,7 +256,7 @@ def hbm_peak_measured(dev):
 def gemm_census_roofline(step, peak_tflops):
     """Live roofline of the step's dominant kernel family, the grouped MFMA GEMMs.  One eager pass of the step's
     forward+backward is recorded by the library's launch census (include/mtn_hip.h: mtn_census_*), then EVERY recorded GEMM
-    launch is re-issued in step order between its own pair of HIP events on the launch stream (5 passes): duration per launch, algorithmic
+    launch is re-issued in step order between its own pair of HIP events on the launch stream (median of 5 passes): duration per launch, algorithmic
     FLOPs (2*M*N*K) and algorithmic bytes (operands once + outputs once) per launch, aggregated per kernel.  The dominant
     kernel is the one with the largest summed duration; its average duration is what rocprofv3 --stats reports for the
     same kernel name (profiles/)."""
@@ -274,10 +274,10 @@ def gemm_census_roofline(step, peak_tflops):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # every launch is timed IN STEP ORDER (launch i runs right after launch i-1, as in the step, so its operands are as cold as
     # in the step — re-issuing one launch back-to-back keeps its weights in L2/Infinity Cache and reads ~15 % too fast), one event
-    # pair per launch, averaged over `reps` passes over the whole sequence
+    # pair per launch, the median of `reps` passes over the whole sequence
     reps = 5
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-    tot = [0.0] * n
+    samples = [[] for _ in range(n)]
     for rep in range(reps + 1):
         for i in range(n):
             evs[i][0].record(st)
@@ -286,19 +286,22 @@ def gemm_census_roofline(step, peak_tflops):
         torch.cuda.synchronize()
         if rep:                                  # first pass = warm-up
             for i in range(n):
-                tot[i] += evs[i][0].elapsed_time(evs[i][1]) * 1e3
+                samples[i].append(evs[i][0].elapsed_time(evs[i][1]) * 1e3)
+    # the MEDIAN over the passes: an event pair brackets a host-side launch call, and a host hiccup between the first record and the launch
+    # (seen once: 30 ms inside one pair, which made a 24 us kernel the "dominant" one) is idle time, not kernel time
+    tot = [sorted(x)[len(x) // 2] * reps for x in samples]
     # an event pair costs a few microseconds of marker hand-over that a kernel between the records only partly hides: time the
     # whole sequence once more between ONE pair (overhead amortised over all launches) and take the per-pair overhead as the
     # difference, so that the per-launch durations add up to the measured duration of the sequence
-    seq = 0.0
+    seqs = []
     for rep in range(reps):
         evs[0][0].record(st)
         for i in range(n):
             L.check(lib.mtn_census_replay(i, 1, st.cuda_stream))
         evs[0][1].record(st)
         torch.cuda.synchronize()
-        seq += evs[0][0].elapsed_time(evs[0][1]) * 1e3
-    seq /= reps
+        seqs.append(evs[0][0].elapsed_time(evs[0][1]) * 1e3)
+    seq = sorted(seqs)[len(seqs) // 2]
     overhead = max((sum(tot) / reps - seq) / n, 0.0)
     per = {}
     for i in range(n):
@@ -787,7 +790,7 @@ def main():
             roof["what"] = ("dominant kernel of the step (largest summed duration): algorithmic bytes (operands once + per weight the "
                             "optimiser epilogue's 26 B: p, m, v read and written, the bf16 copy written; + 2 B for the W_o matrices' transposed copy) or FLOPs per launch / HIP-event "
                             "duration per launch, averaged over all of its launches in one step (library launch census, each "
-                            "launch replayed in step order, one HIP-event pair each, 5 passes); traffic = HBM bytes per launch from the "
+                            "launch replayed in step order, one HIP-event pair each, median of 5 passes); traffic = HBM bytes per launch from the "
                             "committed rocprofv3 PMC passes")
             roof["traffic_source"] = pmc_source()
             if roof["traffic_source"] and roof["traffic_source"].get("stale"):
