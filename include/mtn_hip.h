@@ -618,7 +618,7 @@ int mtn_measure_hbm_peak(const void* src, void* dst, long bytes, void* stream, d
  * writers of the residual stream + up to 128 for the wide projections — three classes, so that consecutive stages run on different
  * workgroups and each class prefetches its next stage while the others work.  Stages hand values over as 8-byte {data, tag} granules
  * (no grid barrier): xg / qg / og / hg are the granule buffers (zeroed ONCE by the caller); out_lp [W][d] bf16 = final LayerNorm
- * output (the generator's operand); sync: 2 unsigned, zeroed once: sync[0] = launch generation (advanced by the kernel), sync[1] != 0 =
+ * output (the generator's operand); sync: 4 unsigned, zeroed once: sync[0] = launch generation (advanced by the kernel), sync[2] = its check-in counter, sync[1] != 0 =
  * a poll timed out and the results are invalid.  W x d <= 4096.
  * ------------------------------------------------------------------------------------------ */
 #define MTN_DEC_EMBED 0     /* x = lut[token] * emb_scale + pe[pos] */

@@ -26,8 +26,8 @@
 // Granule buffers: xg [W][d] (fp32 residual stream), qg [W][3d/2] (q | k | v of the newest row, bf16 pairs), og [W][d/2] (attention output),
 // hg [W][d_ff/2] (FFN hidden).  A workgroup keeps ITS columns of the residual stream in LDS across stages (the slices of the three
 // N = d Linears coincide).  Read-only operands (weights, hoisted K|V, masks, the cache rows of earlier steps) use plain loads.  Every
-// poll is bounded (a timeout sets sync[1]: the step's results are garbage and the host raises).  The generation lives in sync[0]: read
-// by every workgroup at entry, advanced by workgroup 0 at the end — nothing to zero between launches (hipGraph replay safe).
+// poll is bounded (a timeout sets sync[1]: the step's results are garbage and the host raises).  The generation lives in sync[0] (sync[2] counts the workgroups that have read it): read
+// by every workgroup at entry, advanced at the end by the unit that finishes row 0 — nothing to zero between launches (hipGraph replay safe).
 // Arithmetic mirrors the training kernels: LayerNorm statistics, softmax and accumulators fp32; LayerNorm output, q, probabilities'
 // operands, attention output and the FFN hidden rounded to bf16 where those kernels store bf16.
 #include "common.h"
@@ -221,7 +221,10 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
     const int wg = blockIdx.x;
     const int W = A.W, d = A.d, dk = d / A.h, dff = A.d_ff;
     const int pos = *A.pos;
-    const unsigned gen = (A.sync[0] + 1u) << 8;                          // this launch's generation (advanced by workgroup 0 at the end)
+    unsigned gen0 = __hip_atomic_load(A.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" : "+v"(gen0));                                        // (the value has ARRIVED before the check-in below is issued)
+    const unsigned gen = (gen0 + 1u) << 8;                               // this launch's generation (advanced at the end, once EVERY workgroup has read it)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(A.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // checked in
     const dec_rsrc_t rX = dec_rsrc(A.xg, (unsigned)W * d * 8);          // [W][d] granules: fp32 residual stream
     const dec_rsrc_t rQ = dec_rsrc(A.qg, (unsigned)W * 3 * d * 4);      // [W][3d/2] granules: q | k | v of the newest row, bf16 pairs
     const dec_rsrc_t rO = dec_rsrc(A.og, (unsigned)W * d * 4);          // [W][d/2]
@@ -571,7 +574,12 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
         si = next_mine(si);
         if (si < n_stages) { S = stage_of(si); prefetch(S); }
         // the unit that normalised row 0 has seen the last x of every producer: every workgroup read the generation long ago
-        if (last && tid == 0) A.sync[0] = gen >> 8;
+        if (last && tid == 0) {
+            // (a workgroup dispatched late must not find the next generation: wait for all check-ins — normally long complete)
+            for (unsigned spins = 0; __hip_atomic_load(A.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && spins < (1u << 22); ++spins) __builtin_amdgcn_s_sleep(2);
+            __hip_atomic_store(A.sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.sync, gen >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -343,7 +343,7 @@ class MegaDecodeSession(DecodeSession):
         self._o = torch.zeros(W, d // 2, device=dev, dtype=torch.int64)
         self._hid = torch.zeros(W, dff // 2, device=dev, dtype=torch.int64)
         self._out_lp = torch.zeros(W, d, device=dev, dtype=lp)
-        self._sync = torch.zeros(2, device=dev, dtype=torch.int32)
+        self._sync = torch.zeros(4, device=dev, dtype=torch.int32)
         # what the host changes every step, in ONE pinned block -> ONE copy: [W newest tokens (int64) | position (int32, padded) | anc (W x L int32)]
         self._off_pos, self._off_anc = 8 * W, 8 * W + 8
         nbytes = self._off_anc + 4 * W * Lm
