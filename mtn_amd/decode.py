@@ -324,7 +324,8 @@ class MegaDecodeSession(DecodeSession):
             return False
         if max(batch.his.size(1), batch.cap.size(1), batch.query.size(1)) > 1024:
             return False
-        return W * h <= 64 and all(len(l.sublayer) == 5 + 4 * len(l.auto_encoder_attn) for l in model.decoder.layers)
+        n_stages = 2 + sum(3 + 2 * (3 + len(l.auto_encoder_attn)) + 2 for l in model.decoder.layers)       # csrc/decode.hip DEC_MAX_STAGES
+        return W * h <= 64 and n_stages <= 160 and all(len(l.sublayer) == 5 + 4 * len(l.auto_encoder_attn) for l in model.decoder.layers)
 
     def __init__(self, model, batch, max_len, width, pad=1, use_graph=True, select=None):
         super().__init__(model, batch, max_len, width, pad=pad, use_graph=use_graph, kv_cache=False, select=select)
