@@ -193,6 +193,24 @@ def decode_measure(model, cfg, dev, beam=4, max_len=20, dialogues=4, batch_dialo
         torch.cuda.synchronize()
         t_g = time.perf_counter() - t0
         out["greedy"] = {"tokens_per_s": round(dialogues * (max_len - 1) / t_g, 1), "ms_per_step": round(1e3 * t_g / dialogues / (max_len - 1), 3)}
+        # two dialogues side by side = 2 x beam rows: the widest search the persistent decode-step kernel takes (<= 8 hypotheses)
+        try:
+            pairs = [synthetic_batch(cfg["vocab"], 2, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev,
+                                     seed=200 + i, ragged=False) for i in range(max(2, dialogues // 2))]
+            two = lambda b: beam_search_decode_many(model, b, max_len, SOS, UNK, EOS, PAD, beam=beam, nbest=beam, use_graph=use_graph)
+            for i in range(3):
+                two(pairs[i % len(pairs)])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for b in pairs:
+                two(b)
+            torch.cuda.synchronize()
+            t_two = time.perf_counter() - t0
+            out["beam_two_side_by_side"] = {"hypothesis_tokens_per_s": round(2 * len(pairs) * live / t_two, 1), "dialogues_per_s": round(2 * len(pairs) / t_two, 2),
+                                            "ms_per_step": round(1e3 * t_two / len(pairs) / max_len, 3),
+                                            "what": "two dialogues per search on the persistent decode-step kernel (8 hypothesis rows per launch)"}
+        except Exception as e:  # pragma: no cover
+            out["beam_two_side_by_side"] = {"error": f"{type(e).__name__}: {e}"}
         if batch_dialogues > 0:
             D = batch_dialogues
             big = synthetic_batch(cfg["vocab"], D, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=300, ragged=True)

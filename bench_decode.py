@@ -55,7 +55,8 @@ def main():
         return beam_search_decode(model, b, args.max_len, SOS, UNK, EOS, PAD, beam=args.beam, nbest=args.beam, kv_cache=KV,
                                   use_graph=not args.no_graph)
 
-    run_beam(batches[0])                                   # warm-up (allocator, first graph capture)
+    for i in range(3):                                     # warm-up: allocator, the search graph, and (third dialogue of a shape) the capture
+        run_beam(batches[i % len(batches)])                # of the per-dialogue encoder-side pass: the steady state is timed
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for b in batches:
@@ -65,7 +66,8 @@ def main():
     live = 1 + (args.max_len - 1) * args.beam              # step 0 extends <sos> only, later steps `beam` hypotheses
     tok_beam = args.dialogues * live / t_beam
 
-    greedy_decode(model, batches[0], args.max_len, SOS, PAD, use_graph=not args.no_graph, kv_cache=KV)
+    for i in range(3):
+        greedy_decode(model, batches[i % len(batches)], args.max_len, SOS, PAD, use_graph=not args.no_graph, kv_cache=KV)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for b in batches:
@@ -82,6 +84,20 @@ def main():
                      "ms_per_step": round(1e3 * t_beam / args.dialogues / args.max_len, 3)},
             "greedy": {"tokens_per_s": round(args.dialogues * (args.max_len - 1) / t_greedy, 1),
                        "ms_per_step": round(1e3 * t_greedy / args.dialogues / (args.max_len - 1), 3)}}
+    # two dialogues per search = 2 x beam rows: the widest search the persistent decode-step kernel takes (<= 8 hypotheses per launch)
+    pairs = [synthetic_batch(cfg["vocab"], 2, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=200 + i, ragged=False)
+             for i in range(max(2, args.dialogues // 2))]
+    two = lambda b: beam_search_decode_many(model, b, args.max_len, SOS, UNK, EOS, PAD, beam=args.beam, nbest=args.beam, use_graph=not args.no_graph, kv_cache=KV)
+    for i in range(3):
+        two(pairs[i % len(pairs)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in pairs:
+        two(b)
+    torch.cuda.synchronize()
+    t_two = time.perf_counter() - t0
+    line["beam_two_side_by_side"] = {"hypothesis_tokens_per_s": round(2 * len(pairs) * live / t_two, 1), "dialogues_per_s": round(2 * len(pairs) / t_two, 2),
+                                     "ms_per_step": round(1e3 * t_two / len(pairs) / args.max_len, 3)}
     if args.batch_dialogues > 0:
         D = args.batch_dialogues
         big = synthetic_batch(cfg["vocab"], D, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=300, ragged=True)
