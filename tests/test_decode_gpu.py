@@ -365,3 +365,17 @@ def test_device_side_greedy_equals_host_loop(dev, monkeypatch):
         D._SESSIONS.clear()
     assert torch.equal(a, h) and a.shape == (1, 16)
     assert (a == launch).float().mean() > 0.8          # (the launch path's log-probabilities differ in the last bf16 bits: an argmax may flip)
+
+
+@pytest.mark.parametrize("d,h,dff,width", [(1024, 16, 4096, 2), (256, 4, 1024, 6)])
+def test_persistent_decode_step_other_widths(dev, d, h, dff, width):
+    """The persistent decode step at the edges of its shape range: d_model 1024 with d_ff 4096 (contraction steps beyond the prefetched
+    fragments, the largest activation image), d_model 256 with four heads of 64 — against the launch-per-sublayer pass."""
+    from mtn_amd import make_model
+    from mtn_amd.synthetic import synthetic_batch
+    torch.manual_seed(3)
+    model = make_model(500, 500, N=2, d_model=d, d_ff=dff, h=h, dropout=0.1, ft_sizes=[64, 32], diff_encoder=True, auto_encoder_ft="query",
+                       compute_dtype=torch.bfloat16).to(dev).eval()
+    b = synthetic_batch(500, 1, 12, 40, 16, 10, [8, 8], [64, 32], device=dev, seed=11, ragged=True)
+    worst = _mega_vs_launch_pass(dev, model, b, width, 9, 6)
+    print(f"d_model {d}, {h} heads, d_ff {dff}, width {width}: worst relative log-probability difference {worst:.2e}")
