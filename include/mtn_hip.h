@@ -40,7 +40,9 @@ const char* mtn_last_error(void);
  * mtn_ffn_bwd_ws_f32_floats() return larger workspaces (multi-pass dK / dV sums; LayerNorm row-sum partials).
  * 111: mtn_transpose_desc gained `dst_off` (the transposed copies have a compact buffer of their own).
  * 112 (round 5): new entry points only (mtn_measure_mfma_peak_shapes, ...: see INTEGRATION.md); mtn_measure_mfma_peak now reports
- * the better of two MFMA shapes. */
+ * the better of two MFMA shapes.
+ * 113 (round 6): mtn_decode_args gained the trailing field `max_m`; mtn_decode_step takes W <= 16 rows, clamps `grid` to the device's
+ * compute-unit count and bounds its polls in time (see there). */
 int mtn_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -610,16 +612,20 @@ int mtn_measure_mfma_peak_shapes(int iters, float* scratch, void* stream, double
  * denominator bench.py reports beside the 8 TB/s spec for the HBM-bound parameter-gradient + optimiser launch. */
 int mtn_measure_hbm_peak(const void* src, void* dst, long bytes, void* stream, double* gbps);
 /* ------------------------------------------------------------------------------------------
- * One decode step of the target stream as ONE persistent launch (round 5, version 112; csrc/decode.hip).  Replaces, for W <= 8 live
+ * One decode step of the target stream as ONE persistent launch (round 5, version 112; W <= 16 and `max_m` since 113; csrc/decode.hip).  Replaces, for W <= 16 live
  * hypotheses, the per-token pass of `beam_search_decode` / `greedy_decode` (data_utils.py:197-208: `model.decode` + final LayerNorm)
  * in its cached form: the newest position of every hypothesis through N layers x (self-attention over the prefix cache, cross-attentions
  * over hoisted K|V, feed-forward), walking `stages` (a DEVICE array, built once per dialogue shape; stage 0 = MTN_DEC_EMBED, last = MTN_DEC_FINAL).
- * bf16 weights.  `grid` (<= 256: one per CU, all resident) is the most workgroups the launch may use: W x h attention units + d / 16
+ * bf16 weights.  `grid` (<= 256: one per CU, all resident; clamped to the device's compute-unit count, and the call is refused when the three
+ * classes do not fit) is the most workgroups the launch may use: W x h (<= 128) attention units + d / 16
  * writers of the residual stream + up to 128 for the wide projections — three classes, so that consecutive stages run on different
  * workgroups and each class prefetches its next stage while the others work.  Stages hand values over as 8-byte {data, tag} granules
  * (no grid barrier): xg / qg / og / hg are the granule buffers (zeroed ONCE by the caller); out_lp [W][d] bf16 = final LayerNorm
  * output (the generator's operand); sync: 4 unsigned, zeroed once: sync[0] = launch generation (advanced by the kernel), sync[2] = its check-in counter, sync[1] != 0 =
- * a poll timed out and the results are invalid.  W x d <= 4096.
+ * a poll timed out (50 ms, e.g. because another kernel held compute units and not every workgroup was resident) and the results are invalid:
+ * every later launch returns at once until the caller zeroes sync[1] and sync[2] and ADVANCES sync[0] by one (stale granules of the failed
+ * step must not match); mtn_amd/decode.py then re-runs the search on the launch-per-sublayer pass.
+ * W x d <= 8192 and W x (2 max(d, d_ff) + 16) <= 66048 (16 rows up to d_ff = 2048, 8 at d_ff = 4096).
  * ------------------------------------------------------------------------------------------ */
 #define MTN_DEC_EMBED 0     /* x = lut[token] * emb_scale + pe[pos] */
 #define MTN_DEC_SELF_QKV 1  /* q | k | v = LayerNorm(x) W^T + b (N = 3d): q -> scratch, k | v -> cache row (hypothesis, pos) */
@@ -650,8 +656,13 @@ typedef struct {
     unsigned* sync;
     void* dbg;                  /* NULL, or 4 x n_stages uint64: 100 MHz wall-clock stamps per stage of the first workgroup of the stage's class
                                    (entered / operands arrived / computed / stores issued) — tools/decode_timeline.py */
+    int max_m;                  /* (113) the longest memory (`m`) of any MTN_DEC_CROSS stage, <= 1024: the stage list lives in device memory,
+                                   so the host-side argument check needs it here */
 } mtn_decode_args;
 int mtn_decode_step(const mtn_decode_args* args /* host */, const mtn_decode_stage* stages_device, int grid, void* stream);
+/* Test support (113): `n_wg` one-wave workgroups that hold `lds_bytes` of LDS each for `usec` microseconds and do nothing — compute units
+ * taken away from whatever runs beside it.  tests/test_decode_gpu.py uses it to make mtn_decode_step's residency assumption fail. */
+int mtn_debug_hold_cus(int n_wg, int lds_bytes, int usec, void* stream);
 /* The library's development / test switches (MTN_GEMM_*, MTN_ATTN_*, MTN_LN_*, MTN_EMBED_DETERMINISTIC, ...) are read from the
  * environment once per call site and cached: a process that changes one after the library has used it calls this to make the
  * next launches re-read them.  Returns the new generation number. */

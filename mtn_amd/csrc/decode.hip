@@ -37,7 +37,14 @@
 // 747 us — sixteen waves have 128 registers each and the attention stage then spills 82 of them; eight fit (219) and halve the time a stage
 // spends ISSUING its prefetch.
 #define DEC_NW_USED 8
-#define DEC_MAX_W 8
+// Hypothesis rows per launch.  Every small-M Linear is a 16-row MFMA tile, so rows 9..16 ride in what used to be zero padding (round 6:
+// four dialogues x beam 4 in ONE launch).  What bounds W is LDS: the activation image W x (K * 2 + 16) bytes <= DEC_ACT_BYTES and the
+// normalised residual rows W x d fp32 <= 32 KiB — at d_ff = 4096 (d_model 1024) 8 rows, at the benchmark's d_ff = 2048 all 16.
+#define DEC_MAX_W 16
+#define DEC_ACT_BYTES 66048
+// a poll gives up after DEC_POLL_TICKS of the 100 MHz wall clock (50 ms: a whole step is ~0.5 ms) — or at once when another workgroup has
+// (sync[1] set): a launch that cannot have all its workgroups resident costs one timeout, not one per workgroup and stage
+#define DEC_POLL_TICKS 5000000ull
 
 typedef unsigned long long u64;
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
@@ -69,6 +76,16 @@ __device__ __forceinline__ float dec_row16_max(float v) {
     return v;
 }
 
+// Bounded polls (uniform over the workgroup: every thread reads the same words).  True = stop polling: this workgroup has waited
+// DEC_POLL_TICKS (it raises sync[1]), or another one already has.
+__device__ __forceinline__ bool dec_give_up(unsigned* sync, u64& t0) {
+    const u64 now = wall_clock64();
+    if (t0 == 0) { t0 = now; return false; }
+    const bool late = now - t0 > DEC_POLL_TICKS;
+    if (late && threadIdx.x == 0) __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __syncthreads_or(late || ld_ag32(sync + 1) != 0);
+}
+
 // ---- granules
 __device__ __forceinline__ void dec_pub(const dec_rsrc_t r, const unsigned index, const unsigned data, const unsigned tag) { st8(r, index * 8, (u64)data | ((u64)tag << 32)); }
 __device__ __forceinline__ unsigned dec_pack2(const float a, const float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); }
@@ -81,6 +98,7 @@ __device__ __forceinline__ bool dec_poll(const dec_rsrc_t r, const unsigned firs
     const int tid = threadIdx.x;
     for (int base = 0; base < count; base += DEC_THREADS * 4) {
         u64 v[4];
+        u64 t0 = 0;
         for (unsigned spins = 0;; ++spins) {
             bool ok = true;
 #pragma unroll
@@ -89,10 +107,7 @@ __device__ __forceinline__ bool dec_poll(const dec_rsrc_t r, const unsigned firs
                 if (i < count) { v[k] = ld8(r, (first + i) * 8); ok = ok && (unsigned)(v[k] >> 32) == tag; }
             }
             if (__syncthreads_and(ok)) break;
-            if (spins > (1u << 20)) {                            // never hang the chip
-                if (tid == 0) __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
+            if ((spins & 63) == 63 && dec_give_up(sync, t0)) return false;       // never hang the chip
             if ((spins & 3) == 3) __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
@@ -199,18 +214,21 @@ __device__ __forceinline__ f32x4_t dec_w_mma(const DecWRegs<NR>& R, const DecWPl
 }
 
 // LDS layout (bytes)
-#define DEC_ACT_OFF 0                 /* activations image: W x (K * 2 + 16), K <= 4096: 8 x 8208 = 65 664 */
-#define DEC_RED_OFF 66048             /* partial tiles: <= 16 waves x 16 features x 8 rows fp32 = 8 192 */
+#define DEC_ACT_OFF 0                 /* activations image: W x (K * 2 + 16) <= DEC_ACT_BYTES: 8 x 8208 (K = 4096) or 16 x 4112 (K = 2048) */
+#define DEC_RED_OFF 66048             /* partial tiles: 8 waves x 16 features x 16 rows fp32 = 8 192 */
 #define DEC_Q_OFF 74240               /* unit stages: q (fp32, <= 128) + the newest row's k and v of this head (self-attention): 3 x 128 floats */
 #define DEC_SC_OFF 75776              /* scores / probabilities: <= 1024 keys fp32; afterwards the second level of the PV reduction */
 #define DEC_PART_OFF 79872            /* PV partials: (threads / (dk / 4)) key parts x dk columns fp32 <= 16 384 */
 #define DEC_MISC_OFF 96256            /* the waves' (max, sum) pairs of the softmax: 32 floats */
-#define DEC_XS_OFF 96512              /* this workgroup's columns of the residual stream: W x 64 fp32 = 2 048 */
-#define DEC_XF_OFF 98560              /* the residual rows a stage normalises: W x d fp32 <= 8 x 1024 x 4 = 32 768 */
+#define DEC_XS_OFF 96512              /* this workgroup's columns of the residual stream: W x per_x (<= 32 columns) fp32 <= 2 048 */
+#define DEC_XF_OFF 98560              /* the residual rows a stage normalises: W x d fp32 <= 32 768 (W x d <= 8192) */
 #define DEC_GAIN_OFF 131328           /* LayerNorm a_2 | b_2 of the stage: 2 x 1024 floats */
-#define DEC_STG_OFF 139520            /* the stage list: <= 160 descriptors of 104 bytes */
+#define DEC_STG_OFF 139520            /* the stage list: <= 160 descriptors */
 #define DEC_MAX_STAGES 160
-#define DEC_LDS (DEC_STG_OFF + DEC_MAX_STAGES * 104)
+#define DEC_LDS (DEC_STG_OFF + DEC_MAX_STAGES * (int)sizeof(mtn_decode_stage))
+static_assert(DEC_LDS <= 160 * 1024, "decode_step_kernel: LDS image beyond the CU's 160 KiB");
+static_assert(DEC_NW_USED * 16 * 16 * 4 <= DEC_Q_OFF - DEC_RED_OFF, "decode_step_kernel: partial-tile area");
+
 
 template <int DEC_NW>
 __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKernelArgs KA) {
@@ -221,6 +239,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
     const int wg = blockIdx.x;
     const int W = A.W, d = A.d, dk = d / A.h, dff = A.d_ff;
     const int pos = *A.pos;
+    // a step of this session has timed out: its granules are garbage and nothing advanced the generation — every later launch of the
+    // (captured) search leaves at once; the host resets sync[] and re-runs the search on the launch-per-sublayer pass (decode.py)
+    if (ld_ag32(A.sync + 1) != 0) return;
     unsigned gen0 = __hip_atomic_load(A.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" : "+v"(gen0));                                        // (the value has ARRIVED before the check-in below is issued)
     const unsigned gen = (gen0 + 1u) << 8;                               // this launch's generation (advanced at the end, once EVERY workgroup has read it)
@@ -283,23 +304,20 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
         }
     };
     auto gains_to_lds = [&]() { if (tid < (d >> 1)) ((float4*)gains)[tid] = gpre; };       // (before the barrier that follows a poll)
-    // the waves' partial tiles -> LDS; then thread (feature, row) sums a tile's partials in a fixed order.  red[wave][feature 0..15][row 0..7]
+    // the waves' partial tiles -> LDS; then thread (feature, row) sums a tile's partials in a fixed order.  red[wave][feature 0..15][row 0..15]
     auto spill = [&](const f32x4_t& acc) {
-        if ((lane >> 4) < 2) {                                  // rows 0..7 (an idle wave's accumulators are zero)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) red[(wave * 16 + (lane & 15)) * 8 + (lane >> 4) * 4 + k] = acc[k];
-        }
+        *(f32x4_t*)(red + (wave * 16 + (lane & 15)) * 16 + (lane >> 4) * 4) = acc;       // rows (lane / 16) * 4 ..+3 (an idle wave's accumulators are zero)
         __syncthreads();
     };
     auto gather = [&](const int S_, const int f, const int r) -> float {       // feature f in [0, S_), row r
         const int T = (S_ + 15) >> 4, t = f >> 4, c = f & 15;
         const int wpt = T <= 1 ? DEC_NW : (T == 2 ? DEC_NW / 2 : DEC_NW / 4);
-        const float* p = red + ((t * wpt) * 16 + c) * 8 + r;
-        if (wpt == 2) return p[0] + p[128];
+        const float* p = red + ((t * wpt) * 16 + c) * 16 + r;
+        if (wpt == 2) return p[0] + p[256];
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < wpt; i += 4) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s4[k] += p[(i + k) * 128];
+            for (int k = 0; k < 4; ++k) s4[k] += p[(i + k) * 256];
         }
         return (s4[0] + s4[1]) + (s4[2] + s4[3]);
     };
@@ -361,9 +379,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
             gains_to_lds();
             __syncthreads();
             if (dbg) dbg[si * 4 + 1] = wall_clock64();
-            if (wave < W) {                                                  // one row per wave
-                bf16_t* row = (bf16_t*)(act + (size_t)wave * pitch);
-                dec_ln_row(xf + (size_t)wave * d, gains, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
+            for (int rw = wave; rw < W; rw += DEC_NW) {                      // one row per wave (two beyond 8 hypotheses)
+                bf16_t* row = (bf16_t*)(act + (size_t)rw * pitch);
+                dec_ln_row(xf + (size_t)rw * d, gains, S.ln_eps, d, lane, [&](int c, float4 y) { *(u64*)(row + c) = dec_pack4(y); });
             }
             __syncthreads();
             f32x4_t acc = dec_w_mma(R, plan, (const bf16_t*)S.w, n0, n1, K, act, pitch, W, lane);
@@ -446,6 +464,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
             if (self) {
                 // three ranges of dk / 2 granules: q at column hd*dk, k at d + hd*dk, v at 2d + hd*dk of row j
                 const int hp = dk / 2;
+                u64 t0 = 0;
                 for (unsigned spins = 0;; ++spins) {
                     bool ok = true;
                     u64 g = 0;
@@ -463,7 +482,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
                         }
                         break;
                     }
-                    if (spins > (1u << 20)) { if (tid == 0) __hip_atomic_store(A.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); alive = false; break; }
+                    if ((spins & 63) == 63 && dec_give_up(A.sync, t0)) { alive = false; break; }
                 }
                 __syncthreads();
                 if (dbg) dbg[si * 4 + 1] = wall_clock64();
@@ -585,16 +604,38 @@ __global__ __launch_bounds__(DEC_NW * 64) void decode_step_kernel(const DecKerne
 
 extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage* stages_device, int grid, void* stream) {
     MTN_CHECK_ARG(a && stages_device, "null arguments");
-    MTN_CHECK_ARG(a->W >= 1 && a->W <= DEC_MAX_W, "1 .. 8 hypotheses per launch");
+    MTN_CHECK_ARG(a->W >= 1 && a->W <= DEC_MAX_W, "1 .. 16 hypotheses per launch");
     MTN_CHECK_ARG(a->d >= 128 && a->d <= 1024 && (a->d == 128 || a->d == 256 || a->d == 512 || a->d == 1024), "d_model in {128, 256, 512, 1024}");
     MTN_CHECK_ARG(a->h >= 1 && a->d % a->h == 0 && (a->d / a->h == 32 || a->d / a->h == 64), "head size 32 or 64");
     MTN_CHECK_ARG(a->n_stages >= 1 && a->L >= 1 && a->L <= 1024, "bad stage count / maximum length");
+    MTN_CHECK_ARG(a->max_m >= 1 && a->max_m <= 1024, "max_m (the longest memory of any MTN_DEC_CROSS stage) must be 1 .. 1024: the score row lives in LDS");
+    MTN_CHECK_ARG(a->d_ff >= a->d && a->d_ff <= 4096 && a->d_ff % 32 == 0, "d_ff: a multiple of 32, at most 4096");
+    // Every workgroup of the launch must be RESIDENT at once (they poll each other's granules; ~150 KiB of LDS each = one per CU): the grid
+    // is clamped to the device's CU count, and a launch that does not fit is refused here instead of timing out on the device.
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) {
+            mtn_set_error("mtn_decode_step: cannot read the device's compute-unit count");
+            return MTN_ERR_LAUNCH;
+        }
+        n_cu = v;
+    }
+    if (grid > n_cu) grid = n_cu;
     const int n_unit = a->W * a->h, n_xw = a->d / 16;
     const int n_mid = (grid - n_unit - n_xw) < 128 ? (grid - n_unit - n_xw) : 128;
-    MTN_CHECK_ARG(grid <= 256 && n_unit <= 64 && n_mid >= 16, "grid: at most one workgroup per CU; W x heads <= 64 attention units + d / 16 + >= 16 more workgroups must fit");
+    MTN_CHECK_ARG(grid <= 256 && n_unit <= 128 && n_mid >= 16, "grid: at most one workgroup per CU (and per compute unit of THIS device); W x heads <= 128 attention units + d / 16 + >= 16 more workgroups must fit");
+    // a workgroup computes at most 64 output features of a Linear (four 16-feature MFMA tiles dealt to its waves; its epilogue has one
+    // thread per granule): the widest slices are those of the q|k|v projection and the first FFN Linear over the n_mid wide workgroups
+    const int widest = 3 * a->d > a->d_ff ? 3 * a->d : a->d_ff;
+    MTN_CHECK_ARG(((widest + n_mid - 1) / n_mid + 3) / 4 * 4 <= 64 && ((a->d + n_xw - 1) / n_xw + 3) / 4 * 4 <= 32, "a workgroup's slice of a Linear exceeds 64 (wide) / 32 (d_model) features: the grid is too small for this width");
+    {
+        const int per_w = ((widest + n_mid - 1) / n_mid + 3) / 4 * 4, per_x = ((a->d + n_xw - 1) / n_xw + 3) / 4 * 4;
+        MTN_CHECK_ARG((per_w / 2) * a->W <= DEC_NW_USED * 64 && per_x * a->W <= DEC_NW_USED * 64, "epilogue granules per workgroup exceed its threads");
+    }
     MTN_CHECK_ARG(a->xg && a->qg && a->og && a->hg && a->out_lp && a->tokens && a->lut && a->pe && a->pos && a->anc && a->sync, "null buffer");
-    MTN_CHECK_ARG(a->W * a->d <= 4096 && a->n_stages <= DEC_MAX_STAGES, "W x d_model <= 4096; at most 160 stages");
-    MTN_CHECK_ARG(a->d_ff >= a->d && a->d_ff <= 4096 && a->d_ff % 32 == 0, "d_ff: a multiple of 32, at most 4096");
+    const int kmax = a->d_ff > a->d ? a->d_ff : a->d;
+    MTN_CHECK_ARG(a->W * a->d <= 8192 && a->W * (kmax * 2 + 16) <= DEC_ACT_BYTES && a->n_stages <= DEC_MAX_STAGES, "W x d_model <= 8192, W x (2 max(d_model, d_ff) + 16) <= 66048 bytes of LDS, at most 160 stages");
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {
@@ -609,6 +650,26 @@ extern "C" int mtn_decode_step(const mtn_decode_args* a, const mtn_decode_stage*
     KA.stages = stages_device;
     KA.n_xw = n_xw; KA.n_mid = n_mid;
     hipLaunchKernelGGL(decode_step_kernel<DEC_NW_USED>, dim3(n_xw + n_mid + n_unit), dim3(DEC_NW_USED * 64), DEC_LDS, s, KA);
+    MTN_CHECK_LAUNCH();
+    return MTN_OK;
+}
+
+// ---- test support: `n_wg` workgroups that each hold `lds_bytes` of LDS (i.e. a share of a compute unit) for `usec` microseconds and do
+// nothing else.  tests/test_decode_gpu.py runs it on a second stream to make the persistent step's residency assumption FAIL on purpose.
+__global__ __launch_bounds__(64) void hold_cus_kernel(const unsigned long long ticks, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u64 t0 = wall_clock64();
+    unsigned acc = 0;
+    while (wall_clock64() - t0 < ticks) { acc += smem[(acc * 64 + threadIdx.x) & 1023]; __builtin_amdgcn_s_sleep(32); }
+    if (acc == 0xffffffffu && sink) *sink = acc;          // (keeps the LDS allocation alive)
+}
+extern "C" int mtn_debug_hold_cus(int n_wg, int lds_bytes, int usec, void* stream) {
+    MTN_CHECK_ARG(n_wg >= 1 && n_wg <= 4096 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && usec >= 1 && usec <= 2000000, "1..4096 workgroups, 1 KiB..160 KiB of LDS each, at most 2 s");
+    if (hipFuncSetAttribute((const void*)hold_cus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+        mtn_set_error("mtn_debug_hold_cus: cannot opt into %d bytes of LDS", lds_bytes);
+        return MTN_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(hold_cus_kernel, dim3(n_wg), dim3(64), lds_bytes, (hipStream_t)stream, (unsigned long long)usec * 100ull, (unsigned*)nullptr);
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }

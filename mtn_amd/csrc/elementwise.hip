@@ -14,7 +14,7 @@ void mtn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* mtn_last_error(void) { return g_err; }
-extern "C" int mtn_version(void) { return 112; }
+extern "C" int mtn_version(void) { return 113; }
 
 // ---------------------------------------------------------------- environment switches (common.h: MTN_ENV)
 // The library is entered from the caller's thread AND from autograd's device thread (backward), so a site's cache may be filled by

@@ -75,7 +75,7 @@ class DecodeSession:
     @staticmethod
     def signature(model, batch, max_len, width):
         return (id(model), model._flat.data_ptr() if model._flat is not None else 0, model.compute_dtype, width, max_len, tuple(batch.query.shape), tuple(batch.his.shape),
-                tuple(batch.cap.shape), tuple(tuple(f.shape) for f in batch.fts), str(batch.query.device))
+                tuple(batch.cap.shape), tuple(tuple(f.shape) for f in (batch.fts or [])), str(batch.query.device))
 
     def load(self, batch):
         """Encoder side + the N x F auto-encoder chains of a new dialogue (target-independent: once per dialogue).  A batch of
@@ -88,6 +88,12 @@ class DecodeSession:
             model.eval()
         model.prepare()
         self._loads += 1
+        # what a captured pass froze: the weights' flat buffers (prepare() re-creates them when parameters were replaced) and the set of
+        # hoisted projections — if either changed since the capture, the graph is stale: capture again
+        ver = (getattr(model, "_flat_version", None), len(getattr(model, "_kv_targets", None) or ()))
+        if getattr(self, "_load_ver", ver) != ver:
+            self._load_graph, self._loads = None, 2 if self._static is not None else 1
+        self._load_ver = ver
         if not (self.use_graph and batch.query.is_cuda) or self._loads == 1:
             return self._load_body(batch)
         self._stage(batch)
@@ -113,14 +119,18 @@ class DecodeSession:
     def _stage(self, b):
         """Copy a dialogue's inputs into the session's static Batch (created from the first one staged)."""
         import copy
-        tensors = lambda x: [x.query, x.query_mask, x.his, x.his_mask, x.cap, x.cap_mask] + list(x.fts) + list(x.fts_mask)
+        tensors = lambda x: [x.query, x.query_mask, x.his, x.his_mask, x.cap, x.cap_mask] + list(x.fts or []) + list(x.fts_mask or [])
         if self._static is None:
             st = copy.copy(b)
             st.query, st.query_mask, st.his, st.his_mask, st.cap, st.cap_mask = (t.clone() for t in (b.query, b.query_mask, b.his, b.his_mask, b.cap, b.cap_mask))
-            st.fts, st.fts_mask = [t.clone() for t in b.fts], [t.clone() for t in b.fts_mask]
+            st.fts, st.fts_mask = [t.clone() for t in (b.fts or [])], [t.clone() for t in (b.fts_mask or [])]
             self._static = st
             return
-        for dst, src in zip(tensors(self._static), tensors(b)):
+        mine, theirs = tensors(self._static), tensors(b)
+        # the captured pass is frozen to the first staged dialogue's shapes and dtypes: anything else must not be replayed into it
+        if len(mine) != len(theirs) or any(d_.shape != s_.shape or d_.dtype != s_.dtype for d_, s_ in zip(mine, theirs)):
+            raise ValueError("DecodeSession.load: this dialogue's tensors differ in shape / dtype from the session's (sessions are per shape: decode._session keys them)")
+        for dst, src in zip(mine, theirs):
             dst.copy_(src)
 
     def _load_body(self, batch):
@@ -299,13 +309,18 @@ class DecodeSession:
 
 class MegaDecodeSession(DecodeSession):
     """The per-token pass as ONE persistent launch (csrc/decode.hip, include/mtn_hip.h mtn_decode_step) + the generator's three small
-    launches, for sessions of at most 8 live hypotheses on a bf16 model: the newest position of every hypothesis walks a
+    launches, for sessions of at most 16 live hypotheses on a bf16 model (8 at d_ff = 4096): the newest position of every hypothesis walks a
     device-resident stage list (per layer: self-attention over its prefix cache, the cross-attentions over the K|V hoisted by load(),
     the feed-forward) with grid barriers instead of ~90 dependent launches.  The prefix cache is never copied when a beam step
     re-orders hypotheses: position t of hypothesis j's prefix is read from cache slot anc[j][t], a (W, L) int table the host updates
-    from the parents (the slot of row j at position l-1 is j itself).  Same search results as the launch-per-sublayer pass (tested)."""
+    from the parents (the slot of row j at position l-1 is j itself).  Same search results as the launch-per-sublayer pass (tested).
 
-    MAX_W = 8
+    The launch needs ALL its workgroups resident at once (they poll each other).  `supported()` refuses devices with fewer compute units than
+    the launch has workgroups; if a poll still times out (another kernel held compute units), `timed_out()` reports it, `recover()` makes the
+    session's device state consistent again, and the callers below re-run the search on the launch-per-sublayer pass (FALLBACKS counts them)."""
+
+    MAX_W = 16
+    FALLBACKS = 0          # searches re-run on the launch-per-sublayer pass after a poll timeout of the persistent step
 
     @staticmethod
     def supported(model, batch, max_len, width) -> bool:
@@ -318,14 +333,27 @@ class MegaDecodeSession(DecodeSession):
         except AttributeError:
             return False
         W = batch.query.size(0) * width
-        if model.compute_dtype != torch.bfloat16 or W > MegaDecodeSession.MAX_W or W * d > 4096 or d not in (128, 256, 512, 1024) or d % h or d // h not in (32, 64):
+        if model.compute_dtype != torch.bfloat16 or W > MegaDecodeSession.MAX_W or W * d > 8192 or d not in (128, 256, 512, 1024) or d % h or d // h not in (32, 64):
             return False
-        if dff > 4096 or dff % 32 or max_len > 1024 or model.auto_encoder_ft not in ("query", "caption", "summary"):
+        if dff > 4096 or dff < d or dff % 32 or max_len > 1024 or model.auto_encoder_ft not in ("query", "caption", "summary"):
             return False
-        if max(batch.his.size(1), batch.cap.size(1), batch.query.size(1)) > 1024:
+        if W * (2 * max(d, dff) + 16) > 66048:                      # csrc/decode.hip DEC_ACT_BYTES: the activation image of the widest Linear
+            return False
+        if max([batch.his.size(1), batch.cap.size(1), batch.query.size(1)] + [f.size(1) for f in (batch.fts or [])]) > 1024:
+            return False
+        # every workgroup of the launch must be resident at once, one per compute unit: W x h attention units + d / 16 writers of the
+        # residual stream + enough "wide" workgroups that a slice of the q|k|v / first FFN projection is at most 64 features
+        grid = MegaDecodeSession.grid_for(batch.query.device)
+        n_mid = min(128, grid - W * h - d // 16)
+        if W * h > 128 or n_mid < 16 or (-(-max(3 * d, dff) // n_mid) + 3) // 4 * 4 > 64:
             return False
         n_stages = 2 + sum(3 + 2 * (3 + len(l.auto_encoder_attn)) + 2 for l in model.decoder.layers)       # csrc/decode.hip DEC_MAX_STAGES
-        return W * h <= 64 and n_stages <= 160 and all(len(l.sublayer) == 5 + 4 * len(l.auto_encoder_attn) for l in model.decoder.layers)
+        return n_stages <= 160 and all(len(l.sublayer) == 5 + 4 * len(l.auto_encoder_attn) for l in model.decoder.layers)
+
+    @staticmethod
+    def grid_for(device) -> int:
+        """The most workgroups the persistent launch may use on this device: one per compute unit, at most 256."""
+        return min(256, int(torch.cuda.get_device_properties(device).multi_processor_count))
 
     def __init__(self, model, batch, max_len, width, pad=1, use_graph=True, select=None):
         super().__init__(model, batch, max_len, width, pad=pad, use_graph=use_graph, kv_cache=False, select=select)
@@ -358,11 +386,11 @@ class MegaDecodeSession(DecodeSession):
         self._h_anc[:] = np.arange(W, dtype=np.int32)[:, None]
         self._prev = None
         self._top_host = None
-        self._grid = 256             # the most the launch may use (one workgroup per CU); the library deals them to its three classes
+        self._grid = self.grid_for(dev)     # the most the launch may use (one workgroup per CU); the library deals them to its three classes
         self._build_stages(L, d, h, dff)
         emb, pe = model.tgt_embed[0], model.tgt_embed[1]
         a = L.DecodeArgs()
-        a.W, a.d, a.h, a.L, a.n_stages, a.d_ff = W, d, h, Lm, self._n_stages, dff
+        a.W, a.d, a.h, a.L, a.n_stages, a.d_ff, a.max_m = W, d, h, Lm, self._n_stages, dff, self._max_m
         self._dbg = torch.zeros(4 * self._n_stages, device=dev, dtype=torch.int64) if os.environ.get("MTN_DECODE_TIMELINE") == "1" else None
         a.dbg = self._dbg.data_ptr() if self._dbg is not None else None
         a.xg, a.qg, a.og, a.hg, a.out_lp = self._x.data_ptr(), self._q.data_ptr(), self._o.data_ptr(), self._hid.data_ptr(), self._out_lp.data_ptr()
@@ -383,6 +411,7 @@ class MegaDecodeSession(DecodeSession):
         cap_mask, his_mask, q_mask = self.masks
         kvmap = {id(sc): kv for sc, kv in self._kv_pairs}
         st = []
+        self._max_m = 1
 
         def stage(kind, **kw):
             s_ = L.DecodeStage()
@@ -410,6 +439,7 @@ class MegaDecodeSession(DecodeSession):
                 if kv is None or kv.dtype != torch.bfloat16:
                     raise ValueError("a memory's K|V were not hoisted")
                 mk = getattr(mask, "_mtn_u8", None)
+                self._max_m = max(self._max_m, int(mem.size(1)))
                 stage(L.DEC_CROSS, N=d, K=d, w=f["w_qkv_lp"].data_ptr(), bias=f["b_qkv"].data_ptr(), kv=kv.data_ptr(), m=mem.size(1),
                       mask=mk.data_ptr() if mk is not None else None, mask_stride=mem.size(1), **ln(sc))
                 stage(L.DEC_OUT, N=d, K=d, w=f["w_o_lp"].data_ptr(), bias=f["b_o"].data_ptr())
@@ -545,12 +575,28 @@ class MegaDecodeSession(DecodeSession):
         self._search_graph.replay()
         self._prev = None
         torch.cuda.current_stream().synchronize()
+        if self.timed_out():                 # the log is garbage: the caller sees timed_out() and falls back
+            return None
         return None if self._log_views[6][0] else self._log_views
 
+    def timed_out(self) -> bool:
+        """True if a poll of any step since the session was built (or last recovered) timed out: the results since then are garbage."""
+        return int(self._sync[1].item()) != 0
+
+    def recover(self):
+        """After a timeout: nothing advanced the launch generation and the granule buffers hold tags of the failed step.  Advance the
+        generation past it, clear the timeout flag and the check-in counter — the next launch starts clean."""
+        torch.cuda.synchronize()
+        gen = int(self._sync[0].item())
+        self._sync.copy_(torch.tensor([gen + 1, 0, 0, 0], dtype=torch.int32))
+        self._prev = None
+        torch.cuda.synchronize()
+
     def check(self):
-        """Raises if a grid barrier of any step since the session was built timed out (the results would be garbage)."""
-        if int(self._sync[1].item()) != 0:
-            raise RuntimeError("mtn_decode_step: a grid barrier timed out (not every workgroup of the launch was resident?)")
+        """Raises if a poll of any step since the session was built timed out (for callers that drive step() / step_extend() themselves;
+        beam_search_decode / greedy_decode fall back to the launch-per-sublayer pass instead)."""
+        if self.timed_out():
+            raise RuntimeError("mtn_decode_step: a poll timed out (not every workgroup of the launch was resident?)")
 
     def step_extend(self, l: int, slots, tokens, parents):
         """One step given the live hypotheses directly: hypothesis in row ``slots[i]`` ends in ``tokens[i]`` (its l-th token) and extends
@@ -692,9 +738,29 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
     """beam_search_decode for a Batch of D dialogues at once: the D x beam live hypotheses are the batch dimension of ONE
     target-stream pass per generated token (the pass is launch-latency-bound, so D dialogues cost little more than one).
     Returns a list of D (n-best list, best score) pairs, each equal to what the single-dialogue search returns."""
-    auto = kv_cache is None          # the caller leaves the pass to us: one persistent launch per token where it applies (<= 8 hypotheses, bf16)
+    auto = kv_cache is None          # the caller leaves the pass to us: one persistent launch per token where it applies (<= 16 hypotheses, bf16)
     if kv_cache is None:
         kv_cache = max_len > KV_CACHE_FROM
+    args = (model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam, penalty, nbest, min_len, use_graph, kv_cache)
+    res = _beam_search_many(*args, mega=auto)
+    if res is None:                  # a poll of the persistent step timed out (compute units held by another kernel): the launch-per-sublayer pass
+        res = _beam_search_many(*args, mega=False)
+    return res
+
+
+def _mega_failed(sess) -> bool:
+    """After a search on a persistent-step session: True (and the session is made consistent again) if one of its polls timed out."""
+    if not sess.timed_out():
+        return False
+    import logging
+    logging.getLogger("mtn_amd").warning("decode: the persistent step timed out (not every workgroup was resident); re-running on the launch-per-sublayer pass")
+    sess.recover()
+    MegaDecodeSession.FALLBACKS += 1
+    return True
+
+
+def _beam_search_many(model, batch, max_len, start_symbol, unk_symbol, end_symbol, pad_symbol, beam, penalty, nbest, min_len, use_graph, kv_cache, mega):
+    auto = mega
     k = beam + 2
     # device-side candidate selection (csrc/select.hip) holds at most SELECT_MAX_K entries per row: wider beams keep torch.topk
     sel = (k + 1, end_symbol) if k + 1 <= SELECT_MAX_K else None
@@ -703,8 +769,9 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
     if mega and sel is not None:
         # the whole search as one graph replay, hypothesis bookkeeping on the device; None = a tie somewhere: step by step below
         res = sess.search(beam, k, start_symbol, unk_symbol, end_symbol, penalty, min_len, nbest)
+        if _mega_failed(sess):
+            return None
         if res is not None:
-            sess.check()
             return res
     beams = [_Beam(start_symbol, unk_symbol, end_symbol, beam, penalty, min_len) for _ in range(sess.D)]
     for l in range(max_len):
@@ -743,8 +810,8 @@ def beam_search_decode_many(model, batch, max_len, start_symbol, unk_symbol, end
             else:
                 bm.advance(None, l, top=(vals[o:o + n, :k], idx[o:o + n, :k], eos[o:o + n]))
             o += n
-    if isinstance(sess, MegaDecodeSession):
-        sess.check()
+    if mega and _mega_failed(sess):
+        return None
     return [bm.result(nbest) for bm in beams]
 
 
@@ -763,6 +830,13 @@ def greedy_decode(model, batch, max_len, start_symbol, pad_symbol=1, use_graph=T
     """data_utils.py:159-186 (the reference's own greedy_decode cannot run: it calls decode() with the wrong arity, SURVEY
     §8c) — pinned to: argmax of the generator's log-probabilities at every step, (1, max_len) tokens incl. <sos>."""
     auto = kv_cache is None
+    ys = _greedy(model, batch, max_len, start_symbol, pad_symbol, use_graph, kv_cache, auto)
+    if ys is None:                   # the persistent step timed out: the launch-per-sublayer pass
+        ys = _greedy(model, batch, max_len, start_symbol, pad_symbol, use_graph, kv_cache, False)
+    return torch.tensor([ys], dtype=batch.query.dtype, device=batch.query.device)
+
+
+def _greedy(model, batch, max_len, start_symbol, pad_symbol, use_graph, kv_cache, auto):
     sess = _session(model, batch, max_len, 1, pad_symbol, use_graph, max_len > KV_CACHE_FROM if kv_cache is None else kv_cache,
                     select=(2, 0) if auto else None, mega=auto)
     ys = [start_symbol]
@@ -776,9 +850,8 @@ def greedy_decode(model, batch, max_len, start_symbol, pad_symbol=1, use_graph=T
                 ys.append(int(sess.top_host()[0, 2]))
         else:
             ys += toks
-        sess.check()
-        return torch.tensor([ys], dtype=batch.query.dtype, device=batch.query.device)
+        return None if _mega_failed(sess) else ys
     for _ in range(max_len - 1):
         nxt = int(sess.step([ys]).argmax(dim=-1)[0])
         ys.append(nxt)
-    return torch.tensor([ys], dtype=batch.query.dtype, device=batch.query.device)
+    return ys

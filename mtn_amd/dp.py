@@ -301,6 +301,19 @@ class ShardedOptimizerSync:
         if c is not None:
             c()
 
+    def abort(self):
+        """A step raised between reduce_update() and finish(): drop the deferred wait -> update -> gather of its last slice (it would
+        otherwise run at the NEXT step's first reduce_update(), against that step's gradients — possibly on this rank only) and let the
+        collectives already in flight complete."""
+        self._pending = None
+        for w in self._works:
+            try:
+                w.wait()
+            except Exception:
+                pass
+        self._works = []
+        self._stamps = False
+
     def finish(self):
         """The current stream waits for every chain issued since the last finish()."""
         self._complete_pending()

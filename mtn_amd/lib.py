@@ -141,7 +141,7 @@ class DecodeStage(C.Structure):
 class DecodeArgs(C.Structure):
     _fields_ = [("W", C.c_int), ("d", C.c_int), ("h", C.c_int), ("L", C.c_int), ("n_stages", C.c_int), ("d_ff", C.c_int), ("xg", C.c_void_p), ("qg", C.c_void_p),
                 ("og", C.c_void_p), ("hg", C.c_void_p), ("out_lp", C.c_void_p), ("tokens", C.c_void_p), ("lut", C.c_void_p),
-                ("emb_scale", C.c_float), ("pe", C.c_void_p), ("pos", C.c_void_p), ("anc", C.c_void_p), ("sync", C.c_void_p), ("dbg", C.c_void_p)]
+                ("emb_scale", C.c_float), ("pe", C.c_void_p), ("pos", C.c_void_p), ("anc", C.c_void_p), ("sync", C.c_void_p), ("dbg", C.c_void_p), ("max_m", C.c_int)]
 
 
 DEC_EMBED, DEC_SELF_QKV, DEC_SELF_ATT, DEC_OUT, DEC_CROSS, DEC_FFN1, DEC_FFN2, DEC_FINAL = range(8)
@@ -201,6 +201,7 @@ SYMBOLS = {
     "mtn_gemm_tt_table": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), _P]),
     "mtn_decode_step": (C.c_int, [C.POINTER(DecodeArgs), _P, C.c_int, _P]),
     "mtn_beam_advance": (C.c_int, [C.POINTER(BeamArgs), _P]),
+    "mtn_debug_hold_cus": (C.c_int, [C.c_int, C.c_int, C.c_int, _P]),
     "mtn_gemm_tt_table_aux": (C.c_int, [C.c_int, C.c_int, C.POINTER(GemmProblem), C.POINTER(TtAux), _P]),
     "mtn_layernorm_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mtn_layernorm_fwd_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(LnFwdDesc), _P]),

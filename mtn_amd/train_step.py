@@ -104,6 +104,8 @@ class TrainStep:
         m.zero_glue_grads()
         if m._queue is not None and (m._queue.gemm or m._queue.ln or m._queue._armed):
             m._queue.reset()               # left over from a step that raised: never mix it into this one
+        if getattr(self, "sharded", None) is not None and (self.sharded._pending is not None or self.sharded._works):
+            self.sharded.abort()           # ... nor its deferred shard update / gather
         if fuse:
             self.opt.begin_fused_step()
         try:
@@ -113,6 +115,8 @@ class TrainStep:
         except BaseException:
             if m._queue is not None:
                 m._queue.reset()
+            if getattr(self, "sharded", None) is not None:
+                self.sharded.abort()
             raise
         return loss.detach()
 
@@ -205,10 +209,18 @@ class TrainStep:
 
     def _run_segmented(self, runners):
         if self.sharded is not None:
+            if self.sharded._pending is not None or self.sharded._works:
+                self.sharded.abort()                    # left over from a step that raised between reduce_update() and finish()
             self.opt.begin_sharded_step()
-            for run, (lo, hi, mat_hi) in runners:
-                run()
-                self.sharded.reduce_update(lo, hi, mat_hi)
+            try:
+                for run, (lo, hi, mat_hi) in runners:
+                    run()
+                    self.sharded.reduce_update(lo, hi, mat_hi)
+            except BaseException:
+                self.sharded.abort()                    # never let this step's deferred shard update run against the next step's gradients
+                if self.model._queue is not None:
+                    self.model._queue.reset()
+                raise
             if self.sharded.timeline is not None and torch.cuda.is_available():
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()                              # the compute chain (every segment graph) ends here; what follows is exposed exchange

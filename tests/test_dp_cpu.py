@@ -101,7 +101,7 @@ def _ref_adam(p, g, m, v, lr, b1=0.9, b2=0.98, eps=1e-9, t=1):
     p.sub_(lr / (1 - b1 ** t) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps))
 
 
-def _sharded_worker(rank, world, port, out_dir):
+def _sharded_worker(rank, world, port, out_dir, raise_in_step=0):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from mtn_amd import dp
@@ -115,6 +115,15 @@ def _sharded_worker(rank, world, port, out_dir):
     for t in range(1, 4):
         grad = torch.randn(n, generator=torch.Generator().manual_seed(100 * t + rank))     # this rank's local gradient
         sh.update = lambda off, cnt, t=t: _ref_adam(flat[off:off + cnt], grad[off:off + cnt], m[off:off + cnt], v[off:off + cnt], 1e-2, t=t)
+        if t == raise_in_step:
+            # a step that raises between reduce_update() and finish(): its first slice's chain is issued, the deferred
+            # wait -> update -> gather is pending.  The error path calls abort(); the step is then run again from its gradients.
+            keep = grad.clone()
+            sh.reduce_update(cuts[-2], cuts[-1])
+            assert sh._pending is not None
+            sh.abort()
+            assert sh._pending is None and not sh._works
+            grad = keep                                     # (the reduce-scatter ran in place on the gradient buffer)
         for lo, hi in list(zip(cuts[:-1], cuts[1:]))[::-1]:
             sh.reduce_update(lo, hi)
         sh.finish()
@@ -125,12 +134,15 @@ def _sharded_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_optimizer_exchange_equals_allreduce_plus_full_update(tmp_path):
+@pytest.mark.parametrize("raise_in_step", [0, 2], ids=["clean", "one-step-aborted"])
+def test_sharded_optimizer_exchange_equals_allreduce_plus_full_update(tmp_path, raise_in_step):
     """dp.ShardedOptimizerSync (reduce-scatter -> update of the own shard -> all-gather, with a replicated tail) on two gloo
     ranks, three steps: the replicas are BIT-identical (parameters and, after gather(), both moments) and equal to one process
-    that sums the two gradients and updates everything."""
+    that sums the two gradients and updates everything.  Second case: step 2 "raises" after its first reduce_update() on both ranks,
+    abort() drops the deferred shard update, and the step is repeated — same results (without abort() the stale closure would run
+    at the repeated step's first reduce_update() and the slice would be updated twice)."""
     port = _free_port()
-    mp.start_processes(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_sharded_worker, args=(2, port, str(tmp_path), raise_in_step), nprocs=2, join=True, start_method="spawn")
     r0, r1 = torch.load(tmp_path / "sh0.pt"), torch.load(tmp_path / "sh1.pt")
     for k in ("flat", "m", "v"):
         assert torch.equal(r0[k], r1[k]), k
