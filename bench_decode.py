@@ -84,20 +84,26 @@ def main():
                      "ms_per_step": round(1e3 * t_beam / args.dialogues / args.max_len, 3)},
             "greedy": {"tokens_per_s": round(args.dialogues * (args.max_len - 1) / t_greedy, 1),
                        "ms_per_step": round(1e3 * t_greedy / args.dialogues / (args.max_len - 1), 3)}}
-    # two dialogues per search = 2 x beam rows: the widest search the persistent decode-step kernel takes (<= 8 hypotheses per launch)
-    pairs = [synthetic_batch(cfg["vocab"], 2, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=200 + i, ragged=False)
-             for i in range(max(2, args.dialogues // 2))]
-    two = lambda b: beam_search_decode_many(model, b, args.max_len, SOS, UNK, EOS, PAD, beam=args.beam, nbest=args.beam, use_graph=not args.no_graph, kv_cache=KV)
-    for i in range(3):
-        two(pairs[i % len(pairs)])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for b in pairs:
-        two(b)
-    torch.cuda.synchronize()
-    t_two = time.perf_counter() - t0
-    line["beam_two_side_by_side"] = {"hypothesis_tokens_per_s": round(2 * len(pairs) * live / t_two, 1), "dialogues_per_s": round(2 * len(pairs) / t_two, 2),
-                                     "ms_per_step": round(1e3 * t_two / len(pairs) / args.max_len, 3)}
+    # two / four dialogues per search = 8 / 16 hypothesis rows in the persistent decode-step kernel (16 = the rows of its MFMA tiles: the
+    # widest launch it takes; round 5 stopped at 8)
+    many_of = lambda b: beam_search_decode_many(model, b, args.max_len, SOS, UNK, EOS, PAD, beam=args.beam, nbest=args.beam, use_graph=not args.no_graph, kv_cache=KV)
+    for D_, key in ((2, "beam_two_side_by_side"), (4, "beam_four_side_by_side")):
+        if D_ * args.beam > 16:
+            continue
+        groups = [synthetic_batch(cfg["vocab"], D_, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=200 + 10 * D_ + i, ragged=False)
+                  for i in range(max(2, args.dialogues // D_))]
+        for i in range(3):
+            many_of(groups[i % len(groups)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in groups:
+            many_of(b)
+        torch.cuda.synchronize()
+        t_g = time.perf_counter() - t0
+        line[key] = {"hypothesis_tokens_per_s": round(D_ * len(groups) * live / t_g, 1), "dialogues_per_s": round(D_ * len(groups) / t_g, 2),
+                     "ms_per_step": round(1e3 * t_g / len(groups) / args.max_len, 3)}
+    from mtn_amd.decode import MegaDecodeSession
+    line["persistent_step_fallbacks"] = MegaDecodeSession.FALLBACKS          # searches re-run on the launch pass after a poll timeout: 0 expected
     if args.batch_dialogues > 0:
         D = args.batch_dialogues
         big = synthetic_batch(cfg["vocab"], D, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=300, ragged=True)

@@ -1,5 +1,6 @@
 """Where one decode step of the persistent launch (csrc/decode.hip) spends its time: workgroup 0's wall-clock stamps per stage
-(MTN_DECODE_TIMELINE=1: behind the barrier / operands ready / computed / stores issued), cfg5 shape (cfg2 model, beam 4)."""
+(MTN_DECODE_TIMELINE=1: behind the barrier / operands ready / computed / stores issued), cfg5 shape (cfg2 model, beam 4).
+    python tools/decode_timeline.py [dialogues side by side = 1]      (4 = the 16-row launch)"""
 import os, sys
 os.environ["MTN_DECODE_TIMELINE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,14 +12,17 @@ dev = torch.device("cuda:0")
 cfg = dict(CONFIGS["cfg2"]); torch.manual_seed(0)
 model = make_model(cfg["vocab"], cfg["vocab"], N=cfg["N"], d_model=cfg["d_model"], d_ff=cfg["d_ff"], h=cfg["h"], dropout=0.1,
                    ft_sizes=cfg["ft_sizes"], diff_encoder=True, auto_encoder_ft="query", compute_dtype=torch.bfloat16).to(dev).eval()
-b = synthetic_batch(cfg["vocab"], 1, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=100, ragged=False)
+D = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+b = synthetic_batch(cfg["vocab"], D, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=100, ragged=False)
 sess = MegaDecodeSession(model, b, 20, 4, pad=1, use_graph=False)
-prefixes = [[2]]
+plists = [[[2]] for _ in range(D)]
 for l in range(6):
-    lp = sess.step(prefixes)
-    top = lp.topk(4, dim=-1).indices.tolist()
-    nxt = [p + [int(t)] for p, tt in zip(prefixes, top) for t in tt][:4]
-    prefixes = nxt
+    lps = sess.step_many(plists)
+    nxt = []
+    for prefixes, lp in zip(plists, lps):
+        top = lp.topk(4, dim=-1).indices.tolist()
+        nxt.append([p + [int(t)] for p, tt in zip(prefixes, top) for t in tt][:4])
+    plists = nxt
 torch.cuda.synchronize()
 st = sess._dbg.view(-1, 4).cpu().numpy().astype("int64")
 names = ["EMBED", "SELF_QKV", "SELF_ATT", "OUT", "CROSS", "FFN1", "FFN2", "FINAL"]
@@ -28,6 +32,7 @@ raw = bytes(sess._stages_dev.cpu().numpy())
 kinds = [L.DecodeStage.from_buffer_copy(raw[i * C.sizeof(L.DecodeStage):(i + 1) * C.sizeof(L.DecodeStage)]).kind for i in range(sess._n_stages)]
 t0 = st[0, 0]
 agg = {}
+print(f"{D} dialogue(s) x beam 4 = {4 * D} hypothesis rows")
 print(f"step total (first stage start -> last stage stores issued): {(st[-1, 3] - t0) / 100:.1f} us over {len(kinds)} stages")
 for i, k in enumerate(kinds):
     prev_end = st[i - 1, 3] if i else st[0, 0]
