@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--pmc-calibration", action="store_true", help="after the timed steps, one whole-buffer mtn_adam_step over a scratch "
                     "buffer of 2^24 elements: a launch of exactly known HBM traffic (16 B read + 14 B written per element) for "
                     "tools/pmc_summary.py to calibrate the WRITE_SIZE counter on (the fused step itself no longer has one)")
+    ap.add_argument("--full-record", default=None, metavar="PATH", help="also write the VERBOSE record (every figure with its prose description, "
+                    "per-slice exchange timeline, full kernel tables) to PATH as JSON; the printed line is the terse form of it (README.md, "
+                    "\"Reading the bench line\")")
     ap.add_argument("--dp-one-rank-probe", action="store_true", help=argparse.SUPPRESS)     # child process of the N = 1 secondary measurement
     ap.add_argument("--no-record", action="store_true", help="development probe: allows MTN_DP_EMULATE_WORLD (a rank updates 1/N of "
                     "every slice as in an N-GPU job — WRONG parameters, timing only); the line is then marked \"record\": false")
@@ -193,24 +196,27 @@ def decode_measure(model, cfg, dev, beam=4, max_len=20, dialogues=4, batch_dialo
         torch.cuda.synchronize()
         t_g = time.perf_counter() - t0
         out["greedy"] = {"tokens_per_s": round(dialogues * (max_len - 1) / t_g, 1), "ms_per_step": round(1e3 * t_g / dialogues / (max_len - 1), 3)}
-        # two dialogues side by side = 2 x beam rows: the widest search the persistent decode-step kernel takes (<= 8 hypotheses)
-        try:
-            pairs = [synthetic_batch(cfg["vocab"], 2, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev,
-                                     seed=200 + i, ragged=False) for i in range(max(2, dialogues // 2))]
-            two = lambda b: beam_search_decode_many(model, b, max_len, SOS, UNK, EOS, PAD, beam=beam, nbest=beam, use_graph=use_graph)
-            for i in range(3):
-                two(pairs[i % len(pairs)])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for b in pairs:
-                two(b)
-            torch.cuda.synchronize()
-            t_two = time.perf_counter() - t0
-            out["beam_two_side_by_side"] = {"hypothesis_tokens_per_s": round(2 * len(pairs) * live / t_two, 1), "dialogues_per_s": round(2 * len(pairs) / t_two, 2),
-                                            "ms_per_step": round(1e3 * t_two / len(pairs) / max_len, 3),
-                                            "what": "two dialogues per search on the persistent decode-step kernel (8 hypothesis rows per launch)"}
-        except Exception as e:  # pragma: no cover
-            out["beam_two_side_by_side"] = {"error": f"{type(e).__name__}: {e}"}
+        # two / four dialogues side by side = 8 / 16 hypothesis rows in ONE persistent decode-step launch (16 = the rows of its MFMA tiles)
+        for D_, key in ((2, "beam_two_side_by_side"), (4, "beam_four_side_by_side")):
+            if D_ * beam > 16:
+                continue
+            try:
+                groups = [synthetic_batch(cfg["vocab"], D_, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev,
+                                          seed=200 + 10 * D_ + i, ragged=False) for i in range(max(2, dialogues // D_))]
+                many_of = lambda b: beam_search_decode_many(model, b, max_len, SOS, UNK, EOS, PAD, beam=beam, nbest=beam, use_graph=use_graph)
+                for i in range(3):
+                    many_of(groups[i % len(groups)])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for b in groups:
+                    many_of(b)
+                torch.cuda.synchronize()
+                t_g = time.perf_counter() - t0
+                out[key] = {"hypothesis_tokens_per_s": round(D_ * len(groups) * live / t_g, 1), "dialogues_per_s": round(D_ * len(groups) / t_g, 2),
+                            "ms_per_step": round(1e3 * t_g / len(groups) / max_len, 3),
+                            "what": f"{D_} dialogues per search on the persistent decode-step kernel ({D_ * beam} hypothesis rows per launch)"}
+            except Exception as e:  # pragma: no cover
+                out[key] = {"error": f"{type(e).__name__}: {e}"}
         if batch_dialogues > 0:
             D = batch_dialogues
             big = synthetic_batch(cfg["vocab"], D, cfg["Q"], cfg["H"], cfg["C"], cfg["T"], cfg["frames"], cfg["ft_sizes"], device=dev, seed=300, ragged=True)
@@ -236,11 +242,19 @@ def decode_measure(model, cfg, dev, beam=4, max_len=20, dialogues=4, batch_dialo
         wbytes += model._flat_lp.element_size() * model.generator.proj.weight.numel()
         step_ms = out["beam"]["ms_per_step"]
         out["roofline"] = {"bound": "hbm", "what": "weights one decode step streams (target-stream sublayers + generator, compute dtype) / measured "
-                                                   "time per step of the one-dialogue beam search.  For <= 8 live hypotheses the step is ONE persistent launch (csrc/decode.hip) whose "
+                                                   "time per step of the one-dialogue beam search.  For <= 16 live hypotheses the step is ONE persistent launch (csrc/decode.hip) whose "
                                                    "92 stages are a chain of all-to-all hand-offs (each >= one fabric round trip): it is bound by that chain's latency, far below the "
                                                    "stream rate — which is why dialogues are batched where throughput matters (beam_batched: the launch path, 8 x beam rows per weight pass)",
                            "weight_bytes_per_step": int(wbytes), "achieved": round(wbytes / (step_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": round(wbytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)}
+        widest = out.get("beam_four_side_by_side") or out.get("beam_two_side_by_side") or {}
+        if "ms_per_step" in widest:
+            rows = (4 if "beam_four_side_by_side" in out and "ms_per_step" in out["beam_four_side_by_side"] else 2) * beam
+            out["roofline"]["widest_persistent"] = {"hypothesis_rows_per_launch": rows, "achieved": round(wbytes / (widest["ms_per_step"] * 1e-3) / 1e9, 1),
+                                                    "frac": round(wbytes / (widest["ms_per_step"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                                                    "hypothesis_tokens_per_weight_pass": rows}
+        from mtn_amd.decode import MegaDecodeSession
+        out["persistent_step_fallbacks"] = MegaDecodeSession.FALLBACKS       # searches re-run on the launch pass after a poll timeout: 0 expected
         if "beam_batched" in out:
             bms = out["beam_batched"]["ms_per_step"]
             out["roofline"]["batched"] = {"dialogues_side_by_side": out["beam_batched"]["dialogues_side_by_side"],
@@ -564,6 +578,102 @@ def dp_one_rank_probe(args):
     dist.destroy_process_group()
 
 
+KERNEL_COLS = ["launches_per_step", "avg_us", "achieved_TFLOPs", "achieved_GBps_algorithmic", "avg_workgroups"]
+
+
+def _kernels_terse(table):
+    """{kernel: [launches, avg us, TFLOP/s, algorithmic GB/s, avg workgroups]} (columns: KERNEL_COLS), largest summed duration first"""
+    order = sorted(table, key=lambda k: -table[k]["total_us_per_step"])
+    return {k: [table[k][c] for c in KERNEL_COLS] for k in order}
+
+
+def terse_line(full):
+    """The one JSON line the driver records keeps only an 8 KB tail: this is the verbose record with the prose removed (it lives in
+    README.md, "Reading the bench line") and the tables packed, < 7 KB, the contract's keys first.  `--full-record PATH` writes the verbose form."""
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if (isinstance(d, dict) and len(ks) > 1) else (d.get(ks[0]) if isinstance(d, dict) else None))
+    keep = lambda d, ks: {k: d[k] for k in ks if isinstance(d, dict) and d.get(k) is not None}
+    line = {k: full[k] for k in ("metric", "value", "unit", "record", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data") if k in full}
+    cfg = full["config"]
+    line["config"] = keep(cfg, ["workload", "batch_per_gpu", "global_batch", "parallelism", "dropout", "attn_dropout", "hip_graph", "rccl_ranks",
+                                "dist_backend", "window_ms_per_step", "median_window_ms_per_step", "normalised_loss_last_step"])
+    r = full["roofline"]
+    roof = keep(r, ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_us_per_launch", "gflop_per_launch",
+                    "algorithmic_bytes_per_launch", "achieved_TFLOPs", "peak_measured", "frac_of_measured_peak", "peak_guide_copy", "frac_of_guide_copy", "error"])
+    ts = r.get("traffic_source") or {}
+    roof["traffic_source"] = {"file": ts.get("file"), "stale": ts.get("stale")}
+    if r.get("next_kernel"):
+        roof["next_kernel"] = keep(r["next_kernel"], ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_us_per_launch",
+                                                      "algorithmic_bytes_per_launch", "frac_of_measured_peak"])
+    st = r.get("step") or {}
+    roof["step"] = keep(st, ["achieved_TFLOPs", "frac", "frac_of_measured_peak", "gflop_per_sample", "hip_event_ms_per_step", "optimiser_bytes_per_step",
+                             "hbm_GB_per_step_pmc", "hbm_frac_of_8TBps"])
+    if st.get("mfma_peak_measured_by_shape"):
+        roof["step"]["mfma_peak_measured"] = {"16x16x32": st["mfma_peak_measured_by_shape"].get("v_mfma_f32_16x16x32_bf16"),
+                                              "32x32x16": st["mfma_peak_measured_by_shape"].get("v_mfma_f32_32x32x16_bf16")}
+    if r.get("all_gemm_kernels"):
+        roof["all_gemm_kernels"] = keep(r["all_gemm_kernels"], ["launches_per_step", "total_us_per_step", "gflop_per_step", "achieved_TFLOPs", "frac"])
+    if r.get("kernels"):
+        roof["kernel_cols"] = KERNEL_COLS
+        roof["kernels"] = _kernels_terse(r["kernels"])
+    line["roofline"] = roof
+    if "cpu_baseline" in full:
+        cb = dict(full["cpu_baseline"])
+        if isinstance(cb.get("value"), float):
+            cb["value"] = round(cb["value"], 2)
+        line["cpu_baseline"] = cb
+    # secondary figures LAST (the driver's record keeps the tail of the line): batch 64 first, then DP, sweep, cfg4, corpus loop, decode
+    sec = cfg.get("secondary") or {}
+    out = {}
+    b64 = sec.get("batch64_one_gpu")
+    if b64:
+        stp = g(b64, "roofline", "step") or {}
+        out["batch64_one_gpu"] = {**keep(b64, ["samples_per_s", "ms_per_step"]),
+                                  **{k: stp.get(k) for k in ("achieved_TFLOPs", "frac", "frac_of_measured_peak") if stp.get(k) is not None},
+                                  "dominant_kernel": g(b64, "roofline", "dominant_kernel"),
+                                  "all_gemm_kernels": keep(g(b64, "roofline", "all_gemm_kernels") or {}, ["launches_per_step", "total_us_per_step", "achieved_TFLOPs"]),
+                                  "kernels": _kernels_terse(g(b64, "roofline", "kernels") or {})}
+    dpr = sec.get("dp_schedule_one_rank")
+    if dpr:
+        out["dp_schedule_one_rank"] = {**keep(dpr, ["ms_per_step", "samples_per_s", "ms_per_step_collectives_skipped", "ms_per_step_update_of_a_rank_of_8",
+                                                    "rccl_ranks", "dist_backend", "slices_per_step", "collectives_issued", "error"]),
+                                       **keep(dpr.get("timeline") or {}, ["compute_chain_end_us", "step_end_us", "exposed_exchange_us"])}
+    if sec.get("batch_sweep"):
+        out["batch_sweep"] = {b: [v["samples_per_s"], v["ms_per_step"], v["step_TFLOPs"], v["frac_of_2.5PF"]] for b, v in sec["batch_sweep"]["batches"].items()}
+        out["batch_sweep_cols"] = ["samples_per_s", "ms_per_step", "step_TFLOPs", "frac_of_2.5PF"]
+    if sec.get("cfg4_long_context"):
+        out["cfg4_long_context"] = keep(sec["cfg4_long_context"], ["samples_per_s", "ms_per_step", "step_TFLOPs"])
+    if sec.get("corpus_loop"):
+        out["corpus_loop"] = keep(sec["corpus_loop"], ["samples_per_s", "target_tokens_per_s", "ms_per_step", "steps_timed", "padded_shapes_captured"])
+    dec = sec.get("decode")
+    if dec:
+        d_ = {k: keep(dec[k], ["hypothesis_tokens_per_s", "tokens_per_s", "dialogues_per_s", "ms_per_step", "dialogues_side_by_side", "error"])
+              for k in ("beam", "greedy", "beam_two_side_by_side", "beam_four_side_by_side", "beam_batched") if k in dec}
+        d_["roofline"] = keep(dec.get("roofline") or {}, ["bound", "weight_bytes_per_step", "achieved", "peak", "unit", "frac"])
+        if g(dec, "roofline", "widest_persistent"):
+            d_["roofline"]["widest_persistent"] = dec["roofline"]["widest_persistent"]
+        if g(dec, "roofline", "batched"):
+            d_["roofline"]["batched"] = keep(dec["roofline"]["batched"], ["achieved", "frac", "hypothesis_tokens_per_weight_pass"])
+        d_.update(keep(dec, ["beam_width", "max_len", "persistent_step_fallbacks"]))
+        if dec.get("cpu_baseline"):
+            d_["cpu_baseline"] = keep(dec["cpu_baseline"], ["value", "unit", "cores", "kind"])
+        out["decode"] = d_
+    for k in ("one_rank_no_exchange",):
+        if sec.get(k):
+            out[k] = keep(sec[k], ["samples_per_s", "ms_per_step"])
+    ex = sec.get("exchange")
+    if ex:
+        tl = ex.get("timeline") or {}
+        out["exchange"] = {**keep(ex, ["step_minus_one_rank_no_exchange_ms", "bytes_on_the_links_per_rank_per_step", "scheme", "collectives_per_step"]),
+                           "timeline": {**keep(tl, ["compute_chain_end_us", "step_end_us", "exposed_exchange_us", "chain_stretch_vs_single_rank_step"]),
+                                        "slices_us": [[sl.get(k + "_us") for k in ("ready", "reduced", "update_begins", "updated", "gathered")] for sl in tl.get("slices", [])],
+                                        "slices_cols": ["ready", "reduced", "update_begins", "updated", "gathered"]}}
+    if sec.get("error"):
+        out["error"] = sec["error"]
+    line["secondary"] = out
+    return line
+
+
 def main():
     args = parse()
     if args.dp_one_rank_probe:
@@ -862,7 +972,10 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        if args.full_record:
+            with open(args.full_record, "w") as f:
+                json.dump(line, f, indent=1)
+        print(json.dumps(terse_line(line), separators=(",", ":")), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

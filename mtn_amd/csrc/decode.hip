@@ -89,31 +89,39 @@ __device__ __forceinline__ bool dec_give_up(unsigned* sync, u64& t0) {
 // ---- granules
 __device__ __forceinline__ void dec_pub(const dec_rsrc_t r, const unsigned index, const unsigned data, const unsigned tag) { st8(r, index * 8, (u64)data | ((u64)tag << 32)); }
 __device__ __forceinline__ unsigned dec_pack2(const float a, const float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); }
-// Poll `count` granules starting at `first` of buffer r until all carry `tag`; granule first + i goes to sink(i, data).  All threads,
-// 4 granules per thread per pass; a round is repeated until every thread's tags match.
+// Poll `count` granules starting at `first` of buffer r until all carry `tag`; granule first + i goes to sink(i, data).  All threads;
+// a thread reads PAIRS of adjacent granules with 16-byte loads (8-byte accesses run at 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md),
+// DEC_PPT pairs per pass — every use has an even `first` and an even `count` — and a pass is repeated until every thread's tags match.
+// Round 5 read 4 single granules per thread and pass: with 16 hypothesis rows the FFN hidden (16 x 1024 granules) then took EIGHT dependent
+// passes of one fabric round trip each (profiles/r06_decode_timeline_4_vs_16_rows_before.txt: FFN2 5.5 -> 21 us per stage); now two.
 // (Two probes in flight half a round trip apart — to notice the arrival after 0.5-1.0 instead of 0.5-1.5 round trips — were measured and
 // LOSE: the hand-offs took 0.35-0.4 us LONGER, profiles/r05_decode_poll_two_probes.txt; one probe at a time it stays.)
+#define DEC_PPT 8
 template <int DEC_THREADS, typename SINK>
 __device__ __forceinline__ bool dec_poll(const dec_rsrc_t r, const unsigned first, const int count, const unsigned tag, unsigned* sync, SINK sink) {
     const int tid = threadIdx.x;
-    for (int base = 0; base < count; base += DEC_THREADS * 4) {
-        u64 v[4];
+    const int npairs = count >> 1;
+    for (int base = 0; base < npairs; base += DEC_THREADS * DEC_PPT) {
+        uint4 v[DEC_PPT];
         u64 t0 = 0;
+        const bool narrow = npairs - base <= DEC_THREADS * (DEC_PPT / 2);       // (uniform) half the loads suffice: the common case at <= 8 rows
         for (unsigned spins = 0;; ++spins) {
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < DEC_PPT; ++k) {
+                if (k >= DEC_PPT / 2 && narrow) break;
                 const int i = base + k * DEC_THREADS + tid;
-                if (i < count) { v[k] = ld8(r, (first + i) * 8); ok = ok && (unsigned)(v[k] >> 32) == tag; }
+                if (i < npairs) { v[k] = ld16(r, (first + 2 * i) * 8); ok = ok && v[k].y == tag && v[k].w == tag; }
             }
             if (__syncthreads_and(ok)) break;
             if ((spins & 63) == 63 && dec_give_up(sync, t0)) return false;       // never hang the chip
             if ((spins & 3) == 3) __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < DEC_PPT; ++k) {
+            if (k >= DEC_PPT / 2 && narrow) break;
             const int i = base + k * DEC_THREADS + tid;
-            if (i < count) sink(i, (unsigned)v[k]);
+            if (i < npairs) { sink(2 * i, v[k].x); sink(2 * i + 1, v[k].z); }
         }
     }
     return true;

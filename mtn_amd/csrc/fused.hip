@@ -103,10 +103,13 @@ static constexpr int FH_PART_FLOATS = 18;                   // a wave's attentio
 // image rows behind the keys that a 64-key chunk of the last sample may touch
 __host__ __device__ inline int fh_pad_rows(int kind, int mk) { return kind == FH_CROSS_READY ? ((mk + 63) & ~63) - mk : 64; }
 
+// The one development switch of this file: -DFH_TIMELINE (tools/fh_bench.hip) records wall-clock / shader-clock stamps per workgroup.
 #ifdef FH_TIMELINE
-#define FH_STAMP(k) do { if (tid == 0) G.dbg[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define FH_STAMP(k) do { if (threadIdx.x == 0) G.dbg[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define FH_STAMP_CLK(k) do { if (threadIdx.x == 0) G.dbg[(size_t)blockIdx.x * 16 + (k)] = clock64(); } while (0)
 #else
 #define FH_STAMP(k) do { } while (0)
+#define FH_STAMP_CLK(k) do { } while (0)
 #endif
 
 // NP = 64-column weight blocks per workgroup (3: q|k|v or 192 FFN columns; 1: q only), MT = row tiles (16 rows).
@@ -222,9 +225,6 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             if (!late_v) fh_dma16(rv, (unsigned)(size_t)(vi_s + i * 1024), vv);
         }
     };
-#ifdef FH_NO_INTERLEAVE
-    if (kind == FH_CROSS_READY) issue_kv_dma();
-#endif
     // (5) weight fragments.  The MFMA A-operand layout (lane 16c + r <-> row r, 16-byte chunk c of the 64-byte step) would make every
     // quad of adjacent lanes touch four different weight rows: the texture addresser then takes 64 cycles per wave-instruction
     // instead of 16.  So the loads are issued COALESCED — lane 4r + c reads (row r, chunk c): a quad = 64 contiguous bytes — and the
@@ -236,11 +236,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             if (act[p]) {
                 const bf16_t* wrow = M.w + (size_t)(ncol[p] + 16 * wc + (lane >> 2)) * FH_D + kh * 256 + (lane & 3) * 8;
 #pragma unroll
-#ifdef FH_W_NT      // development A/B: the weight slice as non-temporal loads (each workgroup reads its slice once)
-                for (int s = 0; s < 8; ++s) wf[p][s] = as_uint4(__builtin_nontemporal_load((const u32x4_t*)(wrow + s * 32)));
-#else
                 for (int s = 0; s < 8; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
-#endif
             } else {                                    // inactive block (q-only member in a 3-block launch, attention member in a 4-block one)
 #pragma unroll
                 for (int s = 0; s < 8; ++s) wf[p][s] = make_uint4(0, 0, 0, 0);
@@ -260,11 +256,6 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
             for (int s = 0; s < 8; ++s) wf[p][s] = *(const uint4*)(wrow + s * 32);
         }
     };
-#ifdef FH_SPLIT_ORDER
-    const bool w_first = wave < 4;                 // (experiment: waves 4-7 normalise first; wave w and w + 4 share a SIMD)
-#else
-    const bool w_first = true;
-#endif
     // masks, gains and biases -> LDS (they were asked for first: the x rows, the images and the weights may still fly)
     if (mask_wide) {
         if (8 * tid < mask_bytes) *(uint2*)(mk_s + 8 * tid) = make_uint2(mkw0, mkw1);
@@ -285,12 +276,7 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     // loads takes ~4 us during which the wave does nothing else, and the LayerNorm — 3.4 us of arithmetic on rows that landed long
     // before — only started behind them (profiles/r03_fh_order.txt).  Interleaved (round 4): block 0, row group 0, block 1, row
     // group 1, ...: the arithmetic runs while the queue drains.  -DFH_NO_INTERLEAVE: all blocks first, as before.
-#ifdef FH_NO_INTERLEAVE
-    if (w_first) issue_weights();
-#else
-    (void)w_first;
     issue_block(0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     FH_STAMP(13);                                  // first half of the waves: all loads issued
     const DropState ds = drop_init(M.drop);
@@ -300,10 +286,8 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     const bool save = slice == 0;
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-#ifndef FH_NO_INTERLEAVE
         if (i > 0 && i < NP) { __builtin_amdgcn_sched_barrier(0); issue_block(i); __builtin_amdgcn_sched_barrier(0); }
         if (i == 1 && kind == FH_CROSS_READY) issue_kv_dma();
-#endif
         if (wave + 8 * i >= MT * 4) continue;
         const int r = 4 * (wave + 8 * i) + lg;
         float s = 0.f;
@@ -333,13 +317,9 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-#ifdef FH_NO_INTERLEAVE
-    if (!w_first) issue_weights();
-#else
 #pragma unroll
     for (int p = NG > 1 ? NG : 1; p < NP; ++p) issue_block(p);          // the blocks that found no row group to precede
     if (NG == 1 && kind == FH_CROSS_READY) issue_kv_dma();
-#endif
     __builtin_amdgcn_sched_barrier(0);
     // zero padding behind the key images (a key chunk may run past the last key: its V rows must be finite)
     if (!ffn && kind != FH_CROSS_READY) {
@@ -349,10 +329,6 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         }
     }
     FH_STAMP(4);                                   // LayerNorm done
-#ifdef FH_NO_INTERLEAVE
-    if (raw || kind == FH_CROSS_READY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA images have landed
-    __syncthreads();
-#else
     // Everything OLDER than the weight blocks has landed — the x rows, the LDS-DMA images — once at most the 8 NP weight loads (every
     // wave issues exactly that many, and they are its youngest loads) are still in flight; the normalised rows are in LDS once the
     // LDS counter is down.  No vmcnt(0) here (__syncthreads has one): the last weight block has only just been asked for, and the
@@ -360,15 +336,10 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
     // (The count assumes what the compiler emits today.  MTN_SAFE_WAITS builds the same kernels with full waits —
     // libmtn_hip_safewaits.so, mtn_amd/build.py — and tests/test_counted_waits_gpu.py compares the two libraries bit for bit.)
     static_assert(NP == 1 || NP == 3 || NP == 4, "the counted wait below spells 8 * NP out");
-#ifdef MTN_SAFE_WAITS
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-    if constexpr (NP == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
-#endif
+    if constexpr (NP == 1) FH_WAIT_VM_LGKM0(8);
+    else if constexpr (NP == 3) FH_WAIT_VM_LGKM0(24);
+    else FH_WAIT_VM_LGKM0(32);
     __builtin_amdgcn_s_barrier();
-#endif
     FH_STAMP(5);
     if (G.stop == 1) return;
 
@@ -533,12 +504,8 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
 
     // ---- attention of this head, on chip.  Item = (sample, 16 query rows[, key range]), one wave each.
     FH_STAMP(8);
-#ifdef FH_NO_INTERLEAVE
-    if (late_v) {                                  // the V image's DMA (issued after the projections) has landed
-#else
     if (late_v || kind == FH_CROSS_READY) {        // ... and the K | V images asked for between the LayerNorm row groups: EXPLICITLY (the
                                                    // LDS-DMA is inline asm: the compiler may drop the vmcnt(0) of a __syncthreads as redundant)
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -691,21 +658,14 @@ __device__ __forceinline__ void fh_body(const FhGroup& G, const FhMember& M, con
         }
     }
     FH_STAMP(9);
-#ifdef FH_TIMELINE
-    if (tid == 0) G.dbg[(size_t)blockIdx.x * 16 + 11] = clock64();
-#endif
+    FH_STAMP_CLK(11);
 }
 
 template <int NP>
 __global__ __launch_bounds__(FH_THREADS) void fused_head_fwd_kernel(const FhGroup G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef FH_TIMELINE
-    const int tid = threadIdx.x;
-#endif
     FH_STAMP(0);
-#ifdef FH_TIMELINE
-    if (tid == 0) G.dbg[(size_t)blockIdx.x * 16 + 10] = clock64();
-#endif
+    FH_STAMP_CLK(10);
     int g = 0;
     while (g + 1 < G.count && (int)blockIdx.x >= G.wg_start[g + 1]) ++g;
     const FhMember& M = G.m[g];
@@ -717,9 +677,7 @@ __global__ __launch_bounds__(FH_THREADS) void fused_head_fwd_kernel(const FhGrou
     const int xcd = t & 7, j = t >> 3;
     const int hpg = M.nslice / M.hg;
     const int slice = (xcd % M.hg) * hpg + (j % hpg), rb = (j / hpg) * M.sg + (xcd / M.hg);
-#ifdef FH_TIMELINE
-    if (tid == 0) G.dbg[(size_t)blockIdx.x * 16 + 12] = wall_clock64() + (unsigned long long)(slice + rb) * 0;   // member found, first fields read
-#endif
+    FH_STAMP(12);                                  // member found, first fields read
     if (rb * M.rows_per_wg >= M.rows) return;                  // padding workgroup (row-block count rounded up to the map's grid)
     if constexpr (NP == 4) {                       // 4 weight blocks: 128 VGPRs of fragments -> at most 64 rows (two row groups per wave)
         if (M.mt <= 2) fh_body<NP, 2>(G, M, slice, rb, smem);

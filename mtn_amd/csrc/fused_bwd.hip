@@ -52,14 +52,31 @@ struct FbMember {
     float* ln_part;
     int lnK;
 };
+// The one development switch of this file: -DFB_TIMELINE (tools/fb_timeline.py, tools/fb_rounds.py) — 16 wall-clock stamps (100 MHz) per
+// workgroup of the launch selected with MTN_FB_TL_LAUNCH, slot 15 = where the workgroup ran (XCC_ID (hardware register 20) << 32 | HW_ID
+// (register 4: wave / SIMD / CU / SH / SE ids)); read back with mtn_fb_timeline_read().
 #ifdef FB_TIMELINE
-// development build (tools/fb_timeline.py): 16 wall-clock stamps (100 MHz) per workgroup of the launch selected with MTN_FB_TL_LAUNCH
 __device__ unsigned long long fb_timeline[1024 * 16];
 #define FB_STAMP(k) do { if (tl && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) fb_timeline[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
-// slot 15: where the workgroup ran — XCC_ID (hardware register 20) << 32 | HW_ID (register 4: wave / SIMD / CU / SH / SE ids)
 #define FB_WHERE() do { if (tl && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0) fb_timeline[(size_t)blockIdx.x * 16 + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | (unsigned)__builtin_amdgcn_s_getreg(0xF804); } while (0)
+#define FB_SELECT_LAUNCH(P) do { \
+        static int launch = 0; \
+        static const int want = [] { const char* e = getenv("MTN_FB_TL_LAUNCH"); return e ? atoi(e) : 0; }(); \
+        (P).G.tl = (launch++ == want); \
+        if ((P).G.tl) { \
+            fprintf(stderr, "fb timeline: launch %d, %d workgroups, %zu B LDS\n", want, (P).wgs, (P).lds); \
+            for (int i = 0; i < (P).G.count; ++i) \
+                fprintf(stderr, "  member %d: wgs %d..%d a=%d m=%d blk=%d mt=%d self=%d mask=%d\n", i, (P).G.wg_start[i], (P).G.wg_start[i + 1], (P).G.m[i].a, \
+                        (P).G.m[i].m, (P).G.m[i].blk, (P).G.m[i].mt, (P).G.m[i].self_attn, (P).G.m[i].mask != nullptr); \
+        } \
+    } while (0)
+extern "C" int mtn_fb_timeline_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_timeline), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? MTN_OK : MTN_ERR_LAUNCH;
+}
 #else
 #define FB_STAMP(k) do { } while (0)
+#define FB_WHERE() do { } while (0)
+#define FB_SELECT_LAUNCH(P) do { } while (0)
 #endif
 struct FbGroup {
     int count;
@@ -153,9 +170,7 @@ template <int MT, int NQB, bool RING>
 __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, const int rb, unsigned char* smem, const int stop, const int tl) {
     const int tid = threadIdx.x;
     FB_STAMP(0);
-#ifdef FB_TIMELINE
     FB_WHERE();
-#endif
     const int row0 = rb * M.rows_per_wg;
     const int R = (M.rows - row0) < M.rows_per_wg ? (M.rows - row0) : M.rows_per_wg;
     const int lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
@@ -270,17 +285,13 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
     // LDS-DMA images and weight fragments have landed once at most the FH_MASKB + 4 NQB + 1 loads issued behind them fly
     static_assert(FH_MASKB == 8 && (NQB == 1 || NQB == 2), "the counted waits below spell the number of younger loads out");
     // (MTN_SAFE_WAITS: the full-wait build the counted one is compared with bit for bit, tests/test_counted_waits_gpu.py)
-#ifdef MTN_SAFE_WAITS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
     if (mask_wide) {                                            // 2 (mask dwords) + 4 NQB (statistics) + 1 (fold value)
-        if constexpr (NQB == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        if constexpr (NQB == 1) FH_WAIT_VM(7);
+        else FH_WAIT_VM(11);
     } else {                                                    // 8 mask bytes instead
-        if constexpr (NQB == 1) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+        if constexpr (NQB == 1) FH_WAIT_VM(13);
+        else FH_WAIT_VM(17);
     }
-#endif
     __builtin_amdgcn_s_barrier();
     FB_STAMP(2);
     if (stop == 1) return;
@@ -435,12 +446,8 @@ __device__ __forceinline__ void fb_body(const FbMember& M, const int slice, cons
                 if ((it & 1) == 0) {
                     // key block it / 2 has landed in its slot: the only younger vector-memory operations of this wave are the 4 LDS-DMA
                     // instructions of the next block (loads return in order), if there is one
-#ifdef MTN_SAFE_WAITS
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-                    if ((it / 2 + 1) * FB_RING_KEYS < mk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+                    if ((it / 2 + 1) * FB_RING_KEYS < mk) FH_WAIT_VM(4);
+                    else FH_WAIT_VM(0);
                     __builtin_amdgcn_s_barrier();          // (raw barriers in this loop: __syncthreads() would drain the refill DMA in flight)
                 }
                 jimg = ((j0 / FB_RING_KEYS) & 1) * FB_RING_KEYS + (j0 & (FB_RING_KEYS - 1));
@@ -735,29 +742,9 @@ int fb_group_bwd_stage(int n_mha, const mtn_mha_args* mha, const FbIo* io, void*
         }
         attr = true;
     }
-#ifdef FB_TIMELINE
-    {
-        static int launch = 0;
-        static const int want = [] { const char* e = getenv("MTN_FB_TL_LAUNCH"); return e ? atoi(e) : 0; }();
-        P.G.tl = (launch++ == want);
-        if (P.G.tl) {
-            fprintf(stderr, "fb timeline: launch %d, %d workgroups, %zu B LDS\n", want, P.wgs, P.lds);
-            for (int i = 0; i < P.G.count; ++i)
-                fprintf(stderr, "  member %d: wgs %d..%d a=%d m=%d blk=%d mt=%d self=%d mask=%d\n", i, P.G.wg_start[i], P.G.wg_start[i + 1], P.G.m[i].a,
-                        P.G.m[i].m, P.G.m[i].blk, P.G.m[i].mt, P.G.m[i].self_attn, P.G.m[i].mask != nullptr);
-        }
-    }
-#endif
+    FB_SELECT_LAUNCH(P);
     if (P.wide) hipLaunchKernelGGL(fused_head_bwd_kernel<true>, dim3(P.wgs), dim3(FH_THREADS), P.lds, (hipStream_t)stream, P.G);
     else hipLaunchKernelGGL(fused_head_bwd_kernel<false>, dim3(P.wgs), dim3(FH_THREADS), P.lds, (hipStream_t)stream, P.G);
-#ifdef MTN_DBG_TWICE      // development probe (tools/twice_probe.py)
-    if (!P.wide) hipLaunchKernelGGL(fused_head_bwd_kernel<false>, dim3(P.wgs), dim3(FH_THREADS), P.lds, (hipStream_t)stream, P.G);
-#endif
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }
-#ifdef FB_TIMELINE
-extern "C" int mtn_fb_timeline_read(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_timeline), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? MTN_OK : MTN_ERR_LAUNCH;
-}
-#endif

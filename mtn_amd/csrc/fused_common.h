@@ -76,3 +76,13 @@ __device__ __forceinline__ uint4 fh_vfrag(const unsigned char* img, int row0, in
     return f;
 }
 
+// Counted waits of the fused kernels.  They wait with `s_waitcnt vmcnt(N)`, N = the vector-memory operations the compiler emits TODAY behind
+// the LDS-DMA images / row loads a stage needs (each site spells its count out and static_asserts what it depends on).  -DMTN_SAFE_WAITS
+// turns every one of them into a full wait: the twin library tests/test_counted_waits_gpu.py compares the shipped one with, bit for bit.
+#ifdef MTN_SAFE_WAITS
+#define FH_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define FH_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define FH_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define FH_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)" ::: "memory")
+#endif

@@ -246,9 +246,6 @@ __device__ __forceinline__ void epilogue4(const mtn_gemm_problem& P, const DropS
         if (vec) { const float4 q = pre ? pre_res : *(const float4*)rp; v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
         else for (int r = 0; r < nv; ++r) v[r] += rp[r];
     }
-#ifdef MTN_DBG_NO_STORE      // development ablation (tools/r04_ag_run.sh): the epilogue's stores never happen (timing only)
-    if (v[0] != 1.2345e33f) return;
-#endif
     if (P.out_f32) {
         if (vec) *(float4*)(P.out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
         else for (int r = 0; r < nv; ++r) P.out_f32[o + r] = v[r];
@@ -338,11 +335,7 @@ __device__ __forceinline__ void ln_consume_issue(const LnEpiSlot& E, LnConsumeLo
     }
     Q.p1 = Q.p2 = 0.f;
     const int pr = tile_row0 + (tid >> 3);
-#ifdef LNE_ABL_NO_PART
-    if (false) {
-#else
     if (pr < M && sums) {
-#endif
         const float2* pp = (const float2*)E.part + (size_t)pr * E.np;
         for (int k = tid & 7; k < E.np; k += 8) { const float2 t = pp[k]; Q.p1 += t.x; Q.p2 += t.y; }
     }
@@ -361,19 +354,12 @@ template <int RT, int CT, int BMT>
 __device__ __forceinline__ void ln_consume_epilogue(const LnEpiSlot& E, LnConsumeLoads<RT, CT>& Q, const f32x4_t (&acc)[RT][CT], const int M, const int N,
                                                     const int tile_row0, const int row_base, const int col_base, const int l15, const int lg, const int tid, float* lds) {
     const DropState nds = drop_init(E.dx_lp_drop);
-#ifdef LNE_ABL_NO_PART
-    const float p1 = Q.p1, p2 = Q.p2;
-#endif
     const float inv_d = 1.0f / (float)N;
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         const int row = row_base + 16 * i + l15, lr = row - tile_row0;
         const bool live = row < M;
-#ifdef LNE_ABL_NO_PART
-        const float S1 = p1 + lr, P2 = p2;
-#else
         const float S1 = lds[2 * lr], P2 = lds[2 * lr + 1];
-#endif
         const float r = Q.rs[i];
         const float std_u = fmaxf(1.0f / r - E.eps, 1e-30f);
         const float c1 = r * S1 * inv_d;
@@ -395,18 +381,10 @@ __device__ __forceinline__ void ln_consume_epilogue(const LnEpiSlot& E, LnConsum
                 ga[k] = live ? g[k] * e * r : 0.f;
                 gb[k] = live ? g[k] : 0.f;
             }
-#ifdef MTN_DBG_NO_STORE
-            if (live && o[0] == 1.2345e33f) {
-#else
             if (live) {
-#endif
                 const size_t eo = (size_t)row * N + col;
                 *(float4*)(E.dx + eo) = make_float4(o[0], o[1], o[2], o[3]);
-#ifdef LNE_ABL_NO_LP
-                if (false) {
-#else
                 if (E.dx_lp) {
-#endif
                     if (nds.on) {
                         const DropBase db = drop_base((uint64_t)eo);
 #pragma unroll
@@ -415,11 +393,7 @@ __device__ __forceinline__ void ln_consume_epilogue(const LnEpiSlot& E, LnConsum
                     store_lp4<bf16_t>((bf16_t*)E.dx_lp + eo, make_float4(o[0], o[1], o[2], o[3]));
                 }
             }
-#if defined(LNE_ABL_NO_COLPART) || defined(MTN_DBG_NO_STORE)
-            if (false) {
-#else
             if (E.colpart) {
-#endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { ga[k] = fh_row8_sum(ga[k]); gb[k] = fh_row8_sum(gb[k]); }
                 if ((l15 & 7) == 0 && pb * 8 < M) {
@@ -771,19 +745,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nstages = (K + BK - 1) / BK;
-#ifdef MTN_DBG_EMPTY
-    if (P.out_lp) { ((T*)P.out_lp)[(size_t)(row0 + (tid >> 2)) * P.ldc + col0 + (tid & 3)] = 0; }
-    return;
-#endif
     auto issue_stage = [&](int st) {
         unsigned char* dst = smem + (st & (NBUF - 1)) * STAGE_BYTES;
         dma_issue_tile<T, BM, DMA_ROWB, NW>(rA, dst, lda_b, M, K, row0, st * BK, wave, lane);
         issue_b(dst + A_BYTES, st * BK);
     };
-#ifndef MTN_DBG_NO_LOAD
     // prologue: NBUF = 2: up to two stages in flight; NBUF = 4: up to three (NDMA LDS-DMA instructions per wave per stage, always)
     for (int st = 0; st < (NBUF == 2 ? 2 : NBUF - 1) && st < nstages; ++st) issue_stage(st);
-#endif
     // LayerNorm epilogue (LNE): its loads go out right behind the first stages, so that their round trip hides under the contraction.
     // The counted waits below stay as they are: with these loads in the queue a wait for stage s also waits for the loads issued
     // before the stages behind s — at most a few instructions' worth of over-waiting in the first two iterations, exact afterwards.
@@ -854,18 +822,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
             }
         }
         __builtin_amdgcn_s_barrier();
-#ifndef MTN_DBG_NO_LOAD
         if constexpr (NBUF > 2) {                  // every wave is done with stage s-1: its buffer takes stage s + NBUF - 1
             if (s + NBUF - 1 < nstages) issue_stage(s + NBUF - 1);
         }
-#endif
         const unsigned char* sA = smem + (s & (NBUF - 1)) * STAGE_BYTES;
         const unsigned char* sB = sA + A_BYTES;
         const int kleft = K - s * BK;
         int ksteps = kleft >= BK ? DMA_ROWB / 64 : (kleft * (int)sizeof(T) + 63) / 64;   // 64-byte contraction steps holding data
-#ifdef MTN_DBG_NO_COMPUTE
-        ksteps = 0;
-#endif
         {
             // Every fragment read is INLINE ASM, for two reasons.  (1) The compiler puts s_waitcnt vmcnt(0) in front of any LDS read
             // it can see while LDS-DMA instructions are outstanding (it cannot tell the stage being read from the one being filled):
@@ -924,7 +887,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
                 }
             }
         }
-#ifndef MTN_DBG_NO_LOAD
         if constexpr (NBUF == 2) {
             if (s + 2 < nstages) {       // refill this buffer with stage s+2 once every wave is done reading it
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -932,7 +894,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_dma_kernel(const GemmGroup grp, 
                 issue_stage(s + 2);
             }
         }
-#endif
     }
 
     // ---- epilogue.  The MFMAs were issued with the operands swapped (acc = W-tile x X-tile^T), so a lane holds, for ONE
@@ -1222,12 +1183,8 @@ __device__ __forceinline__ void tt128_tile(const mtn_gemm_problem& P, const Adam
             }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-#ifdef MTN_TTB_NOPIPE
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
             if (ks == 0) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1806,9 +1763,6 @@ static int launch_dma_impl(const GemmGroup& grp, const typename LnArg<LNE>::type
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF, NW, LNE>), dim3(tiles), dim3(64 * NW), LDS, s, grp, lne);
-#ifdef MTN_DBG_TWICE      // development probe: every launch issued twice (results of in-place epilogues are WRONG; timing only — tools/twice_probe.py)
-    hipLaunchKernelGGL((gemm_dma_kernel<T, BM, BN, ROWB, BTR, NBUF, NW, LNE>), dim3(tiles), dim3(64 * NW), LDS, s, grp, lne);
-#endif
     MTN_CHECK_LAUNCH();
     return MTN_OK;
 }

@@ -38,11 +38,7 @@ __global__ __launch_bounds__(GK_THREADS) void gemm_k512_kernel(const GkGroup G) 
     {
         const unsigned ldab = (unsigned)P.lda * 2u;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)row0 * P.lda), 0, (R - 1) * ldab + FH_ROWB, 0x00020000);
-#ifdef GK_ABLATE_NO_X      // development (tools/k512_probe.py ablation builds): no x image traffic
-        for (int r = wave; r < 0; r += 8) {
-#else
         for (int r = wave; r < 128; r += 8) {
-#endif
             const unsigned vo = r < R ? (unsigned)r * ldab + (unsigned)((lane ^ (r & 15)) << 4) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (fh_lds_void_t*)(smem + r * FH_ROWB), 16, vo, 0, 0, 0);
         }
@@ -53,11 +49,7 @@ __global__ __launch_bounds__(GK_THREADS) void gemm_k512_kernel(const GkGroup G) 
         n = n < P.N ? n : P.N - 1;
         const bf16_t* wrow = P.B + (size_t)n * P.ldb + (lane & 3) * 8;
 #pragma unroll
-#ifdef GK_ABLATE_NO_W
-        for (int s = 0; s < 16; ++s) wf[s] = make_uint4((unsigned)(size_t)wrow + s, 1u, 2u, 3u);
-#else
         for (int s = 0; s < 16; ++s) wf[s] = *(const uint4*)(wrow + s * 32);
-#endif
     }
     const int colq = col0 + 16 * wave + 4 * lg;                  // this lane's four output columns
     float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -81,11 +73,7 @@ __global__ __launch_bounds__(GK_THREADS) void gemm_k512_kernel(const GkGroup G) 
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-#ifdef GK_ABLATE_NO_MFMA
-    for (int s = 0; s < 1; ++s)
-#else
     for (int s = 0; s < 16; ++s)
-#endif
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) mma16<bf16_t>(acc[mt], wf[s], fh_xfrag(smem, mt * 16 + l15, s * 4 + lg));
     __syncthreads();                                             // the x image is dead: it becomes the output staging area
@@ -101,11 +89,7 @@ __global__ __launch_bounds__(GK_THREADS) void gemm_k512_kernel(const GkGroup G) 
     for (int ps = 0; ps < 4; ++ps) {
         const int r = ps * 32 + (tid >> 4), c = tid & 15;
         const int col = col0 + c * 8;
-#ifdef GK_ABLATE_NO_STORE
-        if (r < R && col < P.N && acc[0][0] == 1.2345e33f)
-#else
         if (r < R && col < P.N)                                  // N % 8 == 0: the 8 columns are in or out together
-#endif
             *(uint4*)(P.out + (size_t)(row0 + r) * P.ldc + col) = *(const uint4*)(smem + r * GK_CPITCH + c * 16);
     }
 }
@@ -259,9 +243,6 @@ __global__ __launch_bounds__(GK_THREADS, 2) void gemm_k512p_kernel(const GkGroup
     const bool loader = wave < 4;
     auto issue_x = [&](const GpUnit& c, unsigned char* img) {
         if (!loader || c.p < 0) return;
-#ifdef GP_ABLATE_NO_DMA
-        if (c.tm >= 0) return;
-#endif
         const GkProblem& P = G.p[c.p];
         const int row0 = c.tm * GP_ROWS;
         const int R = (P.M - row0) < GP_ROWS ? (P.M - row0) : GP_ROWS;
@@ -333,10 +314,6 @@ __global__ __launch_bounds__(GK_THREADS, 2) void gemm_k512p_kernel(const GkGroup
         f32x4_t acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#ifndef GP_ABLATE_NO_MFMA
-#ifdef GP_ABLATE_MFMA_X2
-        for (int rep_ = 0; rep_ < 2; ++rep_)
-#endif
         {   // x fragments of step s+1 in flight under the MFMAs of step s (two register sets).  The reads are INLINE ASM on purpose:
             // the compiler puts s_waitcnt vmcnt(0) in front of any LDS read it can see while LDS-DMA instructions are outstanding
             // (it cannot tell the image being read from the one being filled) — which would drain the prefetched image before every
@@ -348,11 +325,7 @@ __global__ __launch_bounds__(GK_THREADS, 2) void gemm_k512p_kernel(const GkGroup
                 for (int mt = 0; mt < 4; ++mt) {
                     const int row = mt * 16 + l15;
                     const unsigned addr = ibase + row * FH_ROWB + (((s * 4 + lg) ^ (row & 15)) << 4);
-#ifdef GP_ABLATE_NO_LDS
-                    x[mt] = u32x4_t{addr, addr + 1, addr + 2, addr + 3};
-#else
                     asm volatile("ds_read_b128 %0, %1" : "=v"(x[mt]) : "v"(addr));
-#endif
                 }
             };
             auto landed = [&](u32x4_t* x) {                            // (MTN_LANDED: common.h)
@@ -378,7 +351,6 @@ __global__ __launch_bounds__(GK_THREADS, 2) void gemm_k512p_kernel(const GkGroup
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#endif
         GP_STAMP();                                                    // [5i+4] MFMAs issued
         // C[16 mt + l15][16 wave + 4 lg + k] -> staging rows (the storing waves took the previous tile out of it before this unit's first barrier)
 #pragma unroll
@@ -394,13 +366,9 @@ __global__ __launch_bounds__(GK_THREADS, 2) void gemm_k512p_kernel(const GkGroup
         const GpUnit nn = nxt.p >= 0 ? next_of(nxt) : GpUnit{-1, 0, 0};
         const bool new_w = nxt.p >= 0 && (nxt.p != cur.p || nxt.tn != cur.tn);
         if (new_w) load_w(nxt);                                        // (every wave is done with the old fragments; waits for image i+1 as well)
-#ifndef GP_STORES_AFTER_DMA
         // the tile's stores go into the CU's memory pipeline BEFORE the next image's 64 LDS-DMA instructions: behind them they sat
         // until the image had landed (the storing waves took 4-5 us per unit, timeline in profiles/r03_k512_persistent.txt)
         if (loader) { __builtin_amdgcn_s_barrier(); issue_x(nn.p >= 0 ? nn : GpUnit{-1, 0, 0}, smem + (i & 1) * GP_IMG); }
-#else
-        if (nn.p >= 0) issue_x(nn, smem + (i & 1) * GP_IMG);          // two units ahead, into the image just consumed
-#endif
         if (!loader) {                                                 // whole 256-byte row segments: 16 lanes per row, 16 rows per pass
             const GkProblem& P = G.p[cur.p];
             const int row0 = cur.tm * GP_ROWS, col0 = cur.tn * 128;
@@ -422,16 +390,10 @@ __global__ __launch_bounds__(GK_THREADS, 2) void gemm_k512p_kernel(const GkGroup
             for (int ps = 0; ps < 4; ++ps) {
                 const int r = ps * 16 + (t4 >> 4), c8 = t4 & 15;
                 const int col = col0 + c8 * 8;
-#ifdef GP_ABLATE_NO_STORE
-                if (r < R && col < P.N && o[ps].x == 0x12345678u)
-#else
                 if (r < R && col < P.N)
-#endif
                     *(uint4*)(P.out + (size_t)(row0 + r) * P.ldc + col) = as_uint4(o[ps]);
             }
-#ifndef GP_STORES_AFTER_DMA
             __builtin_amdgcn_s_barrier();
-#endif
         }
         if (nxt.p < 0) break;
         cur = nxt; nxt = nn;

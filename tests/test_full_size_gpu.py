@@ -236,8 +236,9 @@ def test_cfg2_loss_and_gradients_match_oracle_through_the_captured_step(case, wo
       fp32 mode: 3e-3 relative to max per tensor (Frobenius-relative for the ReLU-gated w_1 gradients), cosine >= 0.999999 overall;
       bf16 mode: cosine >= 0.9995 over all parameters against the fp32 oracle, and — the tight bar — per tensor against the oracle
       run in fp64 ON THE OPERANDS THE DEVICE SEES (weight matrices and features rounded to bf16: what is left is the path's own
-      rounding of activations and gradient operands): max error <= 8e-2 (matrices) / 1.5e-1 (vectors) / 0.25 (ReLU-gated) of the
-      larger of the tensor's own and its family's typical largest entry, cosine >= 0.998 — bars and measured values in the body.
+      rounding of activations and gradient operands): max error <= 7e-2 (matrices) / 1.5e-1 (vectors) / 0.25 (ReLU-gated) of the
+      larger of the tensor's own and its family's typical largest entry, cosine >= 0.998 (>= 0.93 for the tensors below 10 %
+      of their family's scale) and >= 96 % equal signs over each tensor's 256 largest entries — EVERY tensor; bars and measured values in the body.
     For B >= 32 the launch census of the tested step (kernel variant, grid, problem count and shape of every GEMM launch, in
     order; fused forward / backward group counts; LayerNorm-epilogue groups) must EQUAL the census of the step bench.py times
     (dropout on, bf16): selection in gemm.hip is by tile count and in the fused kernels by unit lists, so a 4-sample test would
@@ -303,13 +304,14 @@ def test_cfg2_loss_and_gradients_match_oracle_through_the_captured_step(case, wo
             # gradients of its query / key projections are 2-3 orders of magnitude below those of their siblings and are rounding noise
             # in bf16 whatever the kernel (measured: 0.3-0.55 of their own largest entry at 6 layers, fused kernels on or off); such a
             # tensor is held to the absolute size of its siblings' gradients, every other tensor to its own.
-            #   weight matrices                                    8e-2 (measured worst over the four cases 6.5e-2; VERDICT r4 hoped for 5e-2: the
+            #   weight matrices                                    7e-2 (measured worst over the four cases 6.5e-2; VERDICT r4 hoped for 5e-2: the
             #                                                      auto-encoder attentions' q / k projections of the top layers sit at 5-6.5e-2)
             #   vectors (biases, LayerNorm gains / biases)         1.5e-1: column sums of bf16-rounded rows over all rows of the batch (measured 6.6e-2
             #                                                      at batch 32 / 64, 1.1e-1 on a 2 048-wide w_1 bias at batch 4)
             #   Linears followed by a ReLU (w_1, feature encoder)  0.25: gate flips of units whose pre-activation rounds across zero (measured 0.15)
-            # and the cosine (0.998 / 0.997 gated; measured worst 0.9982) for every tensor that is not noise-dominated (own scale >= 10 % of its
-            # family's).  The overall cosine over all parameters (>= 0.9995, above) is the tight global statement.
+            # and the cosine (0.998 / 0.997 gated; measured worst 0.9982) for every tensor at >= 10 % of its family's scale, 0.93 for the smaller
+            # ones, plus the sign pattern of the largest entries (below).  The overall cosine over all parameters (>= 0.9995, above) is the tight
+            # global statement.
             fam = {}
             for k, v in sd64.items():
                 if v.grad is not None:
@@ -317,6 +319,7 @@ def test_cfg2_loss_and_gradients_match_oracle_through_the_captured_step(case, wo
             fam = {sh: sorted(vs)[len(vs) // 2] for sh, vs in fam.items()}
             worst = {"matrix": (0.0, None), "vector": (0.0, None), "gated": (0.0, None)}
             worst_own, bad = (0.0, None), []
+            small_cos, small_sign, big_cos = (2.0, None), (2.0, None), (2.0, None)
             for k, v in sd64.items():
                 ref = v.grad
                 if ref is None or float(ref.abs().max()) < 1e-9 or k.endswith("linears.1.bias"):
@@ -327,16 +330,34 @@ def test_cfg2_loss_and_gradients_match_oracle_through_the_captured_step(case, wo
                 e = e_abs / max(own, fs)
                 c64 = float((g64 * ref).sum() / (g64.norm() * ref.norm() + 1e-300))
                 cls = "gated" if (".w_1.weight" in k or (k.startswith("vid_encoder.") and k.endswith("weight"))) else ("matrix" if ref.dim() == 2 else "vector")
-                bar, cbar = {"matrix": (8e-2, 0.998), "vector": (1.5e-1, 0.998), "gated": (0.25, 0.997)}[cls]
+                bar, cbar = {"matrix": (7e-2, 0.998), "vector": (1.5e-1, 0.998), "gated": (0.25, 0.997)}[cls]
                 if e > worst[cls][0]:
                     worst[cls] = (e, k)
                 if e_abs / own > worst_own[0]:
                     worst_own = (e_abs / own, k, own / fs)
-                if not (e < bar and (c64 > cbar or own < 0.1 * fs)):
-                    bad.append((k, cls, round(e, 4), round(c64, 5), round(own / fs, 4)))
+                # the sign pattern of the (up to) 256 largest reference entries: what Adam's first step sees of this tensor
+                top = ref.abs().flatten().topk(min(256, ref.numel())).indices
+                sign_ok = float((torch.sign(g64.flatten()[top]) == torch.sign(ref.flatten()[top])).double().mean())
+                small = own < 0.1 * fs
+                if small:
+                    if c64 < small_cos[0]:
+                        small_cos = (c64, k, own / fs)
+                    if sign_ok < small_sign[0]:
+                        small_sign = (sign_ok, k, own / fs)
+                elif c64 < big_cos[0]:
+                    big_cos = (c64, k)
+                # EVERY tensor is held to a cosine and to the sign pattern of its largest entries (round 6; until round 5 the tensors below 10 % of
+                # their family's scale — the upper layers' self-attention q / k projections — were only held to "not larger than their siblings"):
+                # at >= 10 % of the family scale the cosine bar of the class; below it 0.93 (measured worst 0.950 over the four cases: these
+                # gradients are 100x smaller than their siblings' and sit at the bf16 noise floor of a 6-layer chain); signs of the 256 largest
+                # reference entries agree for >= 96 % (measured worst 0.9805)
+                if not (e < bar and c64 > (0.93 if small else cbar) and sign_ok >= 0.96):
+                    bad.append((k, cls, round(e, 4), round(c64, 5), round(sign_ok, 4), round(own / fs, 4)))
             print(f"{case}: bf16 gradients vs fp64 oracle on rounded operands, worst error / max(own, family median) scale: " +
                   "; ".join(f"{c} {w[0]:.2e} ({w[1]})" for c, w in worst.items()) +
-                  f"; worst relative to the tensor's OWN largest entry {worst_own[0]:.2e} ({worst_own[1]}, whose scale is {worst_own[2]:.1e} of its family's)")
+                  f"; worst relative to the tensor's OWN largest entry {worst_own[0]:.2e} ({worst_own[1]}, whose scale is {worst_own[2]:.1e} of its family's)"
+                  f"; worst cosine of a tensor at >= 10 % of its family's scale {big_cos[0]:.5f} ({big_cos[1]}); of the smaller ones {small_cos[0]:.4f} ({small_cos[1]}, scale {small_cos[2] if small_cos[1] else 0:.1e})"
+                  f", their worst sign agreement over the 256 largest reference entries {small_sign[0]:.4f} ({small_sign[1]})")
             assert not bad, (case, bad[:8])
             if B >= 32:
                 # same launches as the benchmark's step?  (the optimiser is separate here: compare everything but the table launch)
@@ -359,7 +380,7 @@ def test_cfg2_two_fused_steps_match_oracle_adam(dtype, B, ragged):
     p2 - p0 of every weight matrix is compared: cosine >= 0.999 per tensor, and the loss of the second step within 1e-3.
     bf16 mode (bf16 operands, fp32 master weights / moments — the benchmark's arithmetic, fused forward and backward kernels on):
     second-step loss within 1e-2; update cosine >= 0.99 over all weight matrices together (measured 0.9941, the same with the
-    fused kernels off: it is what bf16 operands do to Adam's normalised step) and >= 0.85 per tensor (measured worst 0.90: the
+    fused kernels off: it is what bf16 operands do to Adam's normalised step) and >= 0.88 per tensor (measured worst 0.90: the
     query projection of the top layer's target self-attention, whose gradient over 80 target tokens is tiny and is then
     normalised by Adam).  B = 32 (unpadded and ragged) is the benchmark's batch: the bf16 leg's launch census must equal the census
     of the step bench.py times, table launch with its optimiser epilogue included."""
@@ -402,7 +423,7 @@ def test_cfg2_two_fused_steps_match_oracle_adam(dtype, B, ragged):
             continue
         du_w, du_g = (w.detach() - p0[k]).double().flatten(), (got[k] - p0[k]).double().flatten()
         cos = float(torch.dot(du_w, du_g) / (du_w.norm() * du_g.norm() + 1e-30))
-        assert cos > (0.999 if f32 else 0.85), (k, cos)
+        assert cos > (0.999 if f32 else 0.88), (k, cos)
         if cos < worst:
             worst, worst_k = cos, k
         dot += float(torch.dot(du_w, du_g)); n1 += float(du_w.norm()) ** 2; n2 += float(du_g.norm()) ** 2

@@ -2,7 +2,7 @@
 # Same-box A/B of the train step under environment variants, inside ONE gpurun call (box-to-box spread on the pool is +-4 %):
 #   gpurun -- 'bash tools/ab_run.sh OUT.txt [--workload cfgN ...] -- "VAR=1" "VAR=0 OTHER=2" ...'
 # Every variant is run twice, interleaved; one line per run: variant, ms/step of the timed window, median of five windows, average
-# duration of the dominant kernel.  (The rounds' one-off scripts that produced profiles/r03_* and r04_* are under tools/attic/runs/:
+# duration of the dominant kernel.  (The rounds' one-off scripts that produced profiles/r03_* and r04_* were under tools/attic/runs/ until round 6 — tools/attic/INDEX.md lists them:
 # they name switches of their own round's library.)
 OUT=$1; shift
 ARGS=()

@@ -1,7 +1,7 @@
 # Builds tools/libmtn_hip_<name>.so = the library with extra compile flags on ONE source (SRC=gemm by default; the other objects
 # are taken from mtn_amd/build): same-box A/B of a compile-time choice through MTN_HIP_LIB.
-#   bash tools/build_variant.sh nopipe -DMTN_TTB_NOPIPE && MTN_HIP_LIB=tools/libmtn_hip_nopipe.so python bench.py ...
-#   SRC=gemm_k512 bash tools/build_variant.sh k_nomfma -DGP_ABLATE_NO_MFMA
+#   SRC=fused_bwd bash tools/build_variant.sh fbtl -DFB_TIMELINE && MTN_HIP_LIB=tools/libmtn_hip_fbtl.so python tools/fb_timeline.py
+#   (the ablation switches of rounds 3-5 — MTN_TTB_NOPIPE, GP_ABLATE_*, LNE_ABL_*, ... — left the sources in round 6: tools/attic/INDEX.md)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
