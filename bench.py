@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4"],
+    ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4", "avsd32"],
                     help="default: cfg2 (batch 32) on one GPU, cfg3 (batch 64 per GPU) on several")
     ap.add_argument("--batch-per-gpu", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -846,8 +846,8 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        gflop = SURVEY_GFLOP_PER_SAMPLE.get(args.workload)
         gflop_formula = flops_per_sample(**cfg) / 1e9
+        gflop = SURVEY_GFLOP_PER_SAMPLE.get(args.workload, round(gflop_formula, 2))
         step_tf = value * gflop / 1e3                                 # whole job
         peak = (PEAK_BF16_TFLOPS if lp == torch.bfloat16 else PEAK_FP32_TFLOPS) * world
         ev_ms = ev_total_ms / args.steps

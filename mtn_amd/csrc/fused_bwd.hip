@@ -627,11 +627,13 @@ __global__ __launch_bounds__(FH_THREADS) void fused_head_bwd_kernel(const FbGrou
         if (M.ring) {                                           // one sample per workgroup, a <= 64 (host)
             if (M.a <= 32) fb_body<2, 1, true>(M, slice, rb, smem, G.stop, G.tl);
             else if (M.mt == 3) fb_body<3, 2, true>(M, slice, rb, smem, G.stop, G.tl);
+            else if (M.mt == 4) fb_body<4, 2, true>(M, slice, rb, smem, G.stop, G.tl);
             else fb_body<5, 2, true>(M, slice, rb, smem, G.stop, G.tl);
             return;
         }
         if (M.a > 32) {                                         // query blocks of 32: 2 (at least 3 row tiles)
             if (M.mt == 3) fb_body<3, 2, false>(M, slice, rb, smem, G.stop, G.tl);
+            else if (M.mt == 4) fb_body<4, 2, false>(M, slice, rb, smem, G.stop, G.tl);
             else fb_body<5, 2, false>(M, slice, rb, smem, G.stop, G.tl);
             return;
         }
@@ -655,7 +657,12 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
     memset(&G, 0, sizeof(G));
     { static const int stop = [] { const char* e = getenv("MTN_FB_STOP"); return e ? atoi(e) : 0; }(); G.stop = stop; }
     const int budget = 256 / n_mha > 8 ? 256 / n_mha : 8;
-    const int mts[3] = {2, 3, 5};
+    // row tiles (16 rows) per workgroup: 2, 3 or 5 — and, for members with more than 32 query rows per sample (the two-block bodies), 4: a
+    // 49..64-row sample then takes a 64 KB dy image instead of 80, which is what lets an AVSD-length answer (56 tokens) attend a long history
+    // (>= 160 keys: the key ring) inside the fused kernel at all (round 6: that member — and with it its whole lockstep group — fell back to
+    // attn_bwd_mfma + a separate dO GEMM + LayerNorm backward launches, 8 % of the step at the ragged corpus' commonest shape:
+    // profiles/r06_avsd32_one_step_breakdown_before.txt).  Members of <= 32 query rows keep {2, 3, 5}: the benchmark's launches are unchanged.
+    const int mts_all[4] = {2, 3, 4, 5};
     int wgs = 0;
     size_t lds = 0;
     P.wide = false;
@@ -670,8 +677,8 @@ static bool fb_plan(int n_mha, const mtn_mha_args* mha, const FbIo* io, FbLaunch
         int blk = 0, mt = 0, l = 0, ring = 0;
         for (int b = 1; b <= A.B; ++b) {
             int t = 0;
-            for (int c = 0; c < 3; ++c)
-                if (mts[c] * 16 >= b * A.a) { t = mts[c]; break; }
+            for (int c = 0; c < 4; ++c)
+                if (mts_all[c] * 16 >= b * A.a && (mts_all[c] != 4 || A.a > 32)) { t = mts_all[c]; break; }
             if (!t) break;
             if (A.mask && b * qa * m > FH_THREADS * FH_MASKB) break;
             int need = fb_lds_map(t, self ? t * 16 : b * m, b * qa * m).total;

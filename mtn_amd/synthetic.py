@@ -16,6 +16,9 @@ CONFIGS = {
     "cfg2": dict(vocab=3000, N=6, d_model=512, d_ff=2048, h=8, ft_sizes=[2048, 128], B=32, Q=20, H=128, C=40, T=20, frames=[32, 32]),
     "cfg3": dict(vocab=3000, N=6, d_model=512, d_ff=2048, h=8, ft_sizes=[2048, 128], B=64, Q=20, H=128, C=40, T=20, frames=[32, 32]),
     "cfg4": dict(vocab=3000, N=6, d_model=512, d_ff=2048, h=8, ft_sizes=[2048, 128], B=8, Q=20, H=512, C=40, T=20, frames=[256, 256]),
+    # not a BASELINE config: the commonest padded shape of the ragged-corpus loop at AVSD lengths (tools/corpus_loop_probe.py: answers up to 56
+    # tokens, questions 48, 40 frames) — what a real epoch's step looks like next to cfg2's 20-token targets; used for profiling only
+    "avsd32": dict(vocab=3000, N=6, d_model=512, d_ff=2048, h=8, ft_sizes=[2048, 128], B=32, Q=48, H=192, C=40, T=56, frames=[40, 40]),
 }
 
 

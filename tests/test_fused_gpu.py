@@ -180,7 +180,8 @@ def _dev_leaves(host, dev):
     return dl
 
 
-@pytest.mark.parametrize("T,H", [(20, 37), (31, 37), (40, 37), (54, 37), (64, 37), (20, 300), (20, 520), (40, 520), (20, 576)])
+@pytest.mark.parametrize("T,H", [(20, 37), (31, 37), (40, 37), (54, 37), (64, 37), (20, 300), (20, 520), (40, 520), (20, 576),
+                                 (56, 192), (56, 472), (64, 300), (50, 160)])
 def test_fused_group_backward_matches_oracle_directly(dev, T, H):
     """ONE lockstep group through mtn_sublayer_group_fwd / _bwd with the fused kernels on (csrc/fused.hip, fused_bwd.hip), d_model
     512 / 8 heads, three attention members of the three kinds the kernels serve, each with its own free input:
@@ -194,7 +195,9 @@ def test_fused_group_backward_matches_oracle_directly(dev, T, H):
     four-launch path).  T = 40 / 54 / 64 are AVSD's longer targets: 2 query blocks of 32 in the backward kernel.
     H = 300 / 520 / 576 are long histories (BASELINE configs[3] has 512 tokens; data_handler.py:182 lets them grow): the forward
     kernel puts the V image over the dead xn image and splits the keys over its 8 waves, the backward kernel streams K / V
-    through its two-slot key ring."""
+    through its two-slot key ring.  T = 50 / 56 / 64 WITH H >= 160 (round 6) are the ragged corpus' own shapes — an AVSD-length answer
+    attending a long history: four row tiles per workgroup (a 64 KB dy image) beside the key ring; until round 5 that member, and with it
+    its whole group, left the fused backward kernel."""
     from mtn_amd import lib, ops
     c = dict(vocab=80, N=1, d_model=512, d_ff=2048, h=8, ft_sizes=[64, 32], B=5, Q=13, H=H, C=29, T=T, frames=[17, 9],
              diff_encoder=True, diff_embed=False, diff_gen=False, auto_encoder_ft="query")
