@@ -25,7 +25,7 @@ for l in range(6):
     plists = nxt
 torch.cuda.synchronize()
 st = sess._dbg.view(-1, 4).cpu().numpy().astype("int64")
-names = ["EMBED", "SELF_QKV", "SELF_ATT", "OUT", "CROSS", "FFN1", "FFN2", "FINAL"]
+names = ["EMBED", "SELF_QKV", "SELF_ATT", "OUT", "CROSS", "FFN1", "FFN2", "FINAL", "CROSS_P", "SELF_ATT_P", "XSUM"]
 import ctypes as C
 from mtn_amd import lib as L
 raw = bytes(sess._stages_dev.cpu().numpy())
