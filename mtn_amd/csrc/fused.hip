@@ -685,6 +685,7 @@ __global__ __launch_bounds__(FH_THREADS) void fused_head_fwd_kernel(const FhGrou
     } else {
         if (M.mt <= 2) fh_body<NP, 2>(G, M, slice, rb, smem);
         else if (M.mt == 3) fh_body<NP, 3>(G, M, slice, rb, smem);
+        else if (M.mt == 4) fh_body<NP, 4>(G, M, slice, rb, smem);       // (round 6: samples of 49..64 rows — AVSD-length answers; host: fh_plan_mha_at)
         else fh_body<NP, 5>(G, M, slice, rb, smem);
     }
 }
@@ -704,8 +705,9 @@ static bool fh_env_off() {
 int fh_is_enabled() { return fh_env_off() ? 0 : 1; }
 
 static constexpr int FH_LDS_MAX = 160 * 1024;
-// row tiles a workgroup may have: {2, 3, 5} in the 1- and 3-block kernels, {2, 4} in the 4-block kernel
-static const int fh_mt_sets[2][3] = {{2, 3, 5}, {2, 4, 4}};
+// row tiles a workgroup may have: {2, 3, 5} in the 1- and 3-block kernels — plus 4 for members of more than 32 rows per sample (round 6: a 56-row
+// answer took an 80-row tile; members of <= 32 rows keep {2, 3, 5}, so the benchmark's launches are unchanged) —, {2, 4} in the 4-block kernel
+static const int fh_mt_sets[2][4] = {{2, 3, 4, 5}, {2, 4, 4, 4}};
 
 struct FhPlan { int blk, mt, lds, late_v; };
 static int fh_member_lds(const mtn_mha_args& A, int blk, int mt, bool late_v = false) {
@@ -725,8 +727,8 @@ static FhPlan fh_plan_mha_at(const mtn_mha_args& A, int np, int blk) {
     FhPlan none = {0, 0, 0, 0};
     const int R = blk * A.a, Rm = blk * m;
     int mt = 0;
-    for (int c = 0; c < 3; ++c)
-        if (fh_mt_choices[c] * 16 >= R && (!raw || fh_mt_choices[c] * 16 >= Rm)) { mt = fh_mt_choices[c]; break; }
+    for (int c = 0; c < 4; ++c)
+        if (fh_mt_choices[c] * 16 >= R && (!raw || fh_mt_choices[c] * 16 >= Rm) && (np == 4 || fh_mt_choices[c] != 4 || A.a > 32)) { mt = fh_mt_choices[c]; break; }
     if (!mt) return none;
     if (A.mask && blk * qa * m > FH_THREADS * FH_MASKB) return none;
     int lds = fh_member_lds(A, blk, mt), late = 0;
