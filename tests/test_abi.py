@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     h = lib.load()
     for name in declared:
         assert getattr(h, name) is not None
-    assert h.mtn_version() >= 112
+    assert h.mtn_version() >= 113
 
 
 def test_struct_layouts_match_c(tmp_path):
@@ -66,3 +66,27 @@ def test_ops_refuse_cpu_tensors():
     from mtn_amd import ops
     with pytest.raises(Exception):
         ops.layer_norm(torch.randn(4, 64), torch.ones(64), torch.zeros(64))
+
+
+def test_bench_line_is_terse_enough_for_the_drivers_record():
+    """bench.py prints the terse form of its record: the driver keeps an 8 KB tail of stdout, so the WHOLE line must fit in it (< 7 KB) and still
+    carry the contract's keys plus every secondary figure README.md quotes.  Checked on a committed verbose record of a real run
+    (profiles/r06_bench_full.json, written by `bench.py --full-record`)."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_full.json")))
+    line = bench.terse_line(full)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 7000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    assert "workload" in line["config"] and "model" not in line["config"]
+    sec = line["secondary"]
+    assert {"batch64_one_gpu", "dp_schedule_one_rank", "batch_sweep", "cfg4_long_context", "corpus_loop", "decode"} <= set(sec)
+    assert sec["batch64_one_gpu"]["samples_per_s"] > 0 and sec["decode"]["beam"]["hypothesis_tokens_per_s"] > 0
+    assert list(line)[-1] == "secondary", "the secondary figures go last: the driver's record keeps the TAIL of the line"
