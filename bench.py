@@ -12,7 +12,8 @@ batch already resident in HBM: forward -> generator + label-smoothed loss (main 
 (d_model=512, 6 layers, 8 heads, d_ff=2048, |V|=3000, Q/H/C/T=20/128/40/20, 32 I3D(2048)+32 VGGish(128) frames); N = 1:
 32 samples (cfg2 = BASELINE configs[1], the configuration the metric is quoted on); N > 1: 64 samples PER GPU (cfg3 = BASELINE
 configs[2], weak scaling); bf16 compute with fp32 master weights / residual stream / statistics, dropout 0.1 on (in-kernel),
-random-init weights, synthetic data.  Rank 0 prints ONE JSON line.  `value` comes from EXACTLY --steps steps between two
+random-init weights, synthetic data.  Rank 0 prints ONE JSON line — the TERSE form of the record (< 7 KB: the driver keeps an 8 KB tail of
+stdout; keys explained in README.md "Reading the bench line"; `--full-record PATH` writes the verbose form).  `value` comes from EXACTLY --steps steps between two
 barrier + synchronize brackets; four more windows of the same length are timed afterwards and reported beside it
 (config.window_ms_per_step, median) because one window of a 4-5 ms step is a short sample.
 """
